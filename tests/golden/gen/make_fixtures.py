@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE.
+
+Run in the build container only (needs /root/reference, which does not exist on
+the GPU box):
+
+    python tests/golden/gen/make_fixtures.py
+
+What it does
+------------
+1. compiles ``emu.cpp`` (the reference's own ``convolution.cu`` #included by
+   path behind a host prelude) into a temp dir,
+2. puts ``cupy_shim`` (NumPy-backed stand-in for the absent CuPy) and
+   ``/root/reference/src`` on ``sys.path`` and imports the reference,
+3. calls the reference's own functions on seeded inputs and stores inputs and
+   outputs as ``.npz`` (data only; no reference source is stored),
+4. re-encodes the data files the reference's own tests hold
+   (``tests/data/ptycho_setup.pickle.lzma``, ``ptycho_gaussian.pickle.lzma``,
+   ``tests/ptycho/ortho-{in,out}.mat``) as ``.npz``.
+"""
+import lzma
+import os
+import pickle
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.dirname(HERE)
+REF = "/root/reference"
+
+tmp = tempfile.mkdtemp(prefix="tike_ref_emu_")
+lib = os.path.join(tmp, "libemu.so")
+subprocess.check_call(
+    ["g++", "-O2", "-shared", "-fPIC", "-o", lib,
+     os.path.join(HERE, "emu.cpp")])
+os.environ["TIKE_REF_EMU_LIB"] = lib
+sys.path.insert(0, os.path.join(HERE, "cupy_shim"))
+sys.path.insert(0, os.path.join(REF, "src"))
+
+import cupy as cp  # noqa: E402  (the shim)
+import tike.linalg  # noqa: E402
+import tike.operators  # noqa: E402
+import tike.opt  # noqa: E402
+import tike.ptycho  # noqa: E402
+import tike.ptycho.solvers.lstsq as ref_lstsq  # noqa: E402
+import tike.random  # noqa: E402
+from tike.ptycho.solvers._preconditioner import (  # noqa: E402
+    _probe_preconditioner, _psi_preconditioner)
+
+PHYS = dict(probe_wavelength=1e-10, probe_FOV_lengths=(1e-5, 1e-5),
+            multislice_propagation_distance=1e-8)
+
+
+def rc(rng, *shape):
+    """uniform [-0.5, 0.5) complex64 like tike.random.numpy_complex."""
+    return (rng.random((*shape, 2), dtype=np.float32) - 0.5).view(
+        np.complex64)[..., 0]
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def A(x):
+    return cp.asarray(x)
+
+
+# ---- 4. reference-held data files ----------------------------------------
+with lzma.open(f"{REF}/tests/data/ptycho_setup.pickle.lzma", "rb") as f:
+    data, scan, probe, original = pickle.load(f)
+save("ref_ptycho_setup.npz", data=data, scan=scan, probe=probe,
+     original=original)
+with lzma.open(f"{REF}/tests/data/ptycho_gaussian.pickle.lzma", "rb") as f:
+    save("ref_ptycho_gaussian.npz", weights=pickle.load(f))
+import scipy.io  # noqa: E402
+
+_in = scipy.io.loadmat(f"{REF}/tests/ptycho/ortho-in.mat")
+_out = scipy.io.loadmat(f"{REF}/tests/ptycho/ortho-out.mat")
+save("ref_ortho.npz", modes=np.rollaxis(_in["modes"], -1, 0),
+     pr=np.rollaxis(_out["pr"], -1, 0))
+
+# check: reference simulate() reproduces its own fixture under the shim
+sim = tike.ptycho.simulate(detector_shape=data.shape[-1], probe=probe,
+                           scan=scan, psi=original, **PHYS)
+err = np.abs(np.sqrt(sim) - np.sqrt(data)).max()
+print("reference simulate vs its fixture: max|sqrt diff| =", err)
+assert err < 1e-6
+
+# ---- operators -------------------------------------------------------------
+rng = np.random.default_rng(20241008)
+
+# Patch (tests/operators/test_patch.py shapes, scaled down)
+ntheta, nscan, H, W, pw = 3, 7, 48, 40, 12
+images = rc(rng, ntheta, H, W)
+positions = (rng.random((ntheta, nscan, 2), dtype=np.float32) *
+             np.array([H - pw - 2, W - pw - 2], dtype=np.float32))
+patches_in = rc(rng, ntheta, nscan, pw, pw)
+with tike.operators.Patch() as op:
+    fwd1 = op.fwd(images=A(images), positions=A(positions), patch_width=pw)
+    padded = cp.zeros((ntheta, nscan * 2, pw + 6, pw + 6), dtype=np.complex64)
+    fwd2 = op.fwd(images=A(images), positions=A(positions), patches=padded,
+                  patch_width=pw, nrepeat=2)
+    adj1 = op.adj(positions=A(positions), patches=A(patches_in),
+                  patch_width=pw, height=H, width=W)
+    padded_in = rc(rng, ntheta, nscan * 2, pw + 6, pw + 6)
+    adj2 = op.adj(positions=A(positions), patches=A(padded_in),
+                  patch_width=pw, height=H, width=W, nrepeat=2)
+    # K = 1 broadcast (the psi-preconditioner call shape).  Single image only:
+    # with nimage > 1 the reference kernel's image_offset assumes N*nrepeat
+    # patches per image and reads out of bounds (convolution.cu:96).
+    bcast_in = rc(rng, 1, pw, pw)
+    adj3 = op.adj(positions=A(positions[0]), patches=A(bcast_in),
+                  patch_width=pw, height=H, width=W, nrepeat=1)
+save("op_patch.npz", images=images, positions=positions, pw=pw,
+     patches_in=patches_in, fwd1=fwd1, fwd2=fwd2, adj1=adj1,
+     padded_in=padded_in, adj2=adj2, bcast_in=bcast_in, adj3=adj3)
+
+# Ptycho (tests/operators/test_ptycho.py: pw=15, det=45, nprobe=3, psi 128^2)
+for tag, (nscan, pw, det, S, HW, shared) in {
+        "odd": (11, 15, 45, 3, 128, False),
+        "pow2": (9, 16, 32, 2, 64, True),
+        "full": (6, 32, 32, 2, 80, False),
+}.items():
+    scan_ = (rng.random((nscan, 2), dtype=np.float32) * (HW - pw - 3) +
+             1).astype(np.float32)
+    probe_ = rc(rng, 1 if shared else nscan, 1, S, pw, pw)
+    psi_ = rc(rng, 1, HW, HW)
+    far_ = rc(rng, nscan, 1, S, det, det)
+    with tike.operators.Ptycho(nscan=nscan, probe_shape=pw, detector_shape=det,
+                               nz=HW, n=HW, **PHYS) as op:
+        fwd = op.fwd(probe=A(probe_), scan=A(scan_), psi=A(psi_))
+        bprobe = np.broadcast_to(probe_, (nscan, 1, S, pw, pw)).copy()
+        psi_adj, probe_adj = op.adj(farplane=A(far_), probe=A(bprobe),
+                                    scan=A(scan_), psi=A(psi_))
+        inten, _ = op._compute_intensity(None, A(psi_), A(scan_), A(probe_))
+        data_ = (rng.random((nscan, det, det), dtype=np.float32) *
+                 np.asarray(inten).max())
+        cost_g = op.cost(A(data_), A(psi_), A(scan_), A(probe_),
+                         model="gaussian")
+        cost_p = op.cost(A(data_), A(psi_), A(scan_), A(probe_),
+                         model="poisson")
+        gg = tike.operators.gaussian_grad(A(data_), fwd, inten)
+        pg = tike.operators.poisson_grad(A(data_), fwd, inten)
+        ge = tike.operators.gaussian_each_pattern(A(data_), inten)
+        pe = tike.operators.poisson_each_pattern(A(data_), inten)
+    save(f"op_ptycho_{tag}.npz", scan=scan_, probe=probe_, psi=psi_,
+         farplane_in=far_, fwd=fwd, psi_adj=psi_adj, probe_adj=probe_adj,
+         intensity=inten, data=data_, cost_gaussian=cost_g,
+         cost_poisson=cost_p, gaussian_grad=gg, poisson_grad=pg,
+         gaussian_each=ge, poisson_each=pe, det=det)
+
+
+# ---- synthetic ptychography problem ---------------------------------------
+def make_problem(rng, N, pw, det, S, pitch=3.0, eigen=0):
+    side = int(np.ceil(np.sqrt(N)))
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
+                              indexing="ij"), -1).reshape(-1, 2)[:N]
+    scan = (2 + pitch * ij + rng.random((N, 2))).astype(np.float32)
+    HW = int(np.ceil(pitch * (side - 1) + pw + 6))
+    psi_true = ((0.75 + 0.25 * rng.random((1, HW, HW))) * np.exp(
+        1j * np.pi * (rng.random((1, HW, HW)) - 0.5))).astype(np.complex64)
+    w = tike.ptycho.probe.gaussian(pw, rin=0.6, rout=1.0)
+    probe = np.stack([
+        w * np.exp(1j * np.pi * rng.random((pw, pw))) / (m + 1)
+        for m in range(S)
+    ])[None, None].astype(np.complex64)
+    data = tike.ptycho.simulate(detector_shape=det, probe=probe, scan=scan,
+                                psi=psi_true, **PHYS)
+    psi0 = np.full((1, HW, HW), 0.5 + 0j, dtype=np.complex64)
+    probe0 = (probe * (1 + 0.1 * rc(rng, *probe.shape))).astype(np.complex64)
+    eigen_probe = eigen_weights = None
+    if eigen > 0:
+        np.random.seed(int(rng.integers(1 << 30)))
+        tike.random.randomizer_np = np.random.default_rng(
+            int(rng.integers(1 << 30)))
+        eigen_probe, eigen_weights = tike.ptycho.probe.init_varying_probe(
+            scan, probe0, num_eigen_probes=eigen + 1, probes_with_modes=1)
+    return dict(scan=scan, psi_true=psi_true, probe_true=probe, data=data,
+                psi0=psi0, probe0=probe0, eigen_probe=eigen_probe,
+                eigen_weights=eigen_weights, det=det)
+
+
+# ---- lstsq pieces: one minibatch through the reference internals ----------
+def lstsq_parts(tag, N, pw, det, S, eigen):
+    p = make_problem(rng, N, pw, det, S, eigen=eigen)
+    HW = p["psi0"].shape[-1]
+    psi = (p["psi0"] * (1 + 0.2 * rc(rng, 1, HW, HW))).astype(np.complex64)
+    measured = np.ones((det, det), dtype=bool)
+    params = tike.ptycho.PtychoParameters(
+        probe=p["probe0"].copy(), psi=psi.copy(), scan=p["scan"].copy(),
+        eigen_probe=None if p["eigen_probe"] is None else
+        p["eigen_probe"].copy(),
+        eigen_weights=None if p["eigen_weights"] is None else
+        p["eigen_weights"].copy(),
+        algorithm_options=tike.ptycho.LstsqOptions(num_batch=2),
+        probe_options=tike.ptycho.ProbeOptions(),
+        object_options=tike.ptycho.ObjectOptions(),
+        exitwave_options=tike.ptycho.ExitWaveOptions(measured_pixels=measured),
+    ).copy_to_device()
+    batches = np.array_split(np.arange(N), 2)
+    with tike.operators.Ptycho(probe_shape=pw, detector_shape=det, nz=HW,
+                               n=HW, **PHYS) as op:
+        psi_pre = _psi_preconditioner(params, [], operator=op)
+        probe_pre = _probe_preconditioner(params, [], operator=op)
+        out = {}
+        bi = 1
+        (chi, uprobe, probe_update, object_upd_sum, m_probe_update, costs,
+         patches, _, _, _) = ref_lstsq._get_nearplane_gradients(
+             p["data"], params.psi, params.scan, params.probe,
+             params.eigen_probe, params.eigen_weights, batches, None, None,
+             None, [], cp.asarray(measured), psi_pre, batch_index=bi,
+             num_batch=2, op=op, recover_psi=True, recover_probe=True,
+             recover_positions=False,
+             exitwave_options=params.exitwave_options)
+        out.update(chi=chi, unique_probe=uprobe, probe_update=probe_update,
+                   object_upd_sum=object_upd_sum,
+                   m_probe_update=m_probe_update, costs=costs,
+                   patches=patches)
+        if params.eigen_weights is not None:
+            ep, ew = ref_lstsq._update_nearplane(
+                chi, probe_update, m_probe_update, params.probe,
+                None if params.eigen_probe is None else
+                params.eigen_probe.copy(), params.eigen_weights.copy(),
+                patches, batches, batch_index=bi, num_batch=2)
+            out.update(eigen_probe_out=ep, eigen_weights_out=ew)
+        precond, beta_o, beta_p = ref_lstsq._precondition_nearplane_gradients(
+            chi, params.scan, uprobe, params.probe, object_upd_sum,
+            m_probe_update, psi_pre, patches, batches, batch_index=bi, op=op,
+            m=0, recover_psi=True, recover_probe=True,
+            probe_options=params.probe_options)
+        out.update(object_update_precond=precond, beta_object=beta_o,
+                   beta_probe=beta_p)
+    extra = {}
+    if p["eigen_probe"] is not None:
+        extra["eigen_probe"] = p["eigen_probe"]
+    if p["eigen_weights"] is not None:
+        extra["eigen_weights"] = p["eigen_weights"]
+    save(f"lstsq_parts_{tag}.npz", data=p["data"], psi=psi,
+         probe=p["probe0"], scan=p["scan"], det=det, batch_lo=batches[bi][0],
+         batch_hi=batches[bi][-1] + 1, psi_precond=psi_pre,
+         probe_precond=probe_pre, **extra, **out)
+
+
+lstsq_parts("plain", N=24, pw=16, det=16, S=2, eigen=0)
+lstsq_parts("eigen", N=24, pw=16, det=24, S=3, eigen=2)
+
+
+# ---- full reconstructions (3 epochs, called twice like ReconstructTwice) ---
+def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
+          adaptive=False, orth=False):
+    p = make_problem(rng, N, pw, det, S, eigen=eigen)
+    np.random.seed(7)
+    tike.random.randomizer_np = np.random.default_rng(11)
+    measured = np.ones((det, det), dtype=bool)
+    params = tike.ptycho.PtychoParameters(
+        probe=p["probe0"].copy(), psi=p["psi0"].copy(),
+        scan=p["scan"].copy(),
+        eigen_probe=None if p["eigen_probe"] is None else
+        p["eigen_probe"].copy(),
+        eigen_weights=None if p["eigen_weights"] is None else
+        p["eigen_weights"].copy(),
+        algorithm_options=tike.ptycho.LstsqOptions(
+            num_batch=num_batch, batch_method=batch_method, num_iter=epochs),
+        probe_options=tike.ptycho.ProbeOptions(
+            force_orthogonality=orth, use_adaptive_moment=adaptive),
+        object_options=tike.ptycho.ObjectOptions(
+            use_adaptive_moment=adaptive),
+        exitwave_options=tike.ptycho.ExitWaveOptions(measured_pixels=measured),
+    )
+    # record the batches the reference's clustering chooses (host-side,
+    # out of scope): one worker => order = concatenated batches
+    with tike.ptycho.Reconstruction(p["data"], params, 1, False) as ctx:
+        order = np.asarray(ctx.comm.order[0])
+        batches = [np.asarray(b) for b in ctx.batches[0]]
+        perms = []
+        orig_perm = tike.random.randomizer_np.permutation
+        ctx.iterate(epochs)
+        r1 = ctx.get_result()
+    # second call continues from r1 (state round trip), as ReconstructTwice
+    np.random.seed(7)
+    r2 = tike.ptycho.reconstruct(p["data"], r1, 1, False)
+    extra = {}
+    for k in ("eigen_probe", "eigen_weights"):
+        if p[k] is not None:
+            extra[k] = p[k]
+            extra[k + "_1"] = getattr(r1, k)
+    save(f"lstsq_recon_{tag}.npz", data=p["data"], psi0=p["psi0"],
+         probe0=p["probe0"], scan=p["scan"], det=det, order=order,
+         batch_sizes=np.array([len(b) for b in batches]),
+         num_batch=num_batch, batch_method=batch_method, epochs=epochs,
+         adaptive=adaptive, orth=orth, psi_1=r1.psi, probe_1=r1.probe,
+         costs_1=np.array(r1.algorithm_options.costs[:epochs]),
+         costs_2=np.array(r2.algorithm_options.costs), psi_2=r2.psi,
+         probe_2=r2.probe, **extra)
+    print(tag, "costs:", np.array(r2.algorithm_options.costs).ravel())
+
+
+recon("compact", N=48, pw=24, det=32, S=2, eigen=0, num_batch=2,
+      batch_method="compact", epochs=3, adaptive=True, orth=True)
+recon("wobbly_eigen", N=40, pw=32, det=32, S=3, eigen=2, num_batch=2,
+      batch_method="wobbly_center", epochs=3, orth=True)
+
+# ---- cgrad composition (absent as a solver) ---------------
+p = make_problem(rng, 36, 16, 16, 1)
+HW = p["psi0"].shape[-1]
+with tike.operators.Ptycho(probe_shape=16, detector_shape=16, nz=HW, n=HW,
+                           **PHYS) as op:
+    probe = A(p["probe_true"])
+    scan = A(p["scan"])
+    data = A(p["data"])
+
+    def cost_function(psi):
+        return float(op.cost(data, psi, scan, probe, model="gaussian"))
+
+    def grad(psi):
+        inten, far = op._compute_intensity(data, psi, scan, probe)
+        g = tike.operators.gaussian_grad(data, far, inten)
+        bp = cp.asarray(
+            np.broadcast_to(probe, (len(scan), *probe.shape[1:])).copy())
+        return [op.adj(farplane=g, probe=bp, scan=scan, psi=psi)[0]]
+
+    def dir_multi(d):
+        return d[0]
+
+    psi = A(p["psi0"])
+    costs, psis = [cost_function(psi)], []
+    for _ in range(3):
+        psi, c = tike.opt.conjugate_gradient(
+            cp, x=psi, cost_function=cost_function, grad=grad,
+            dir_multi=dir_multi, num_iter=4, step_length=1.0)
+        psi = cp.asarray(psi, dtype=np.complex64)
+        costs.append(float(c))
+        psis.append(np.asarray(psi).copy())
+save("cgrad.npz", data=p["data"], psi0=p["psi0"], probe=p["probe_true"],
+     scan=p["scan"], det=16, costs=np.array(costs), psis=np.stack(psis))
+print("cgrad costs", costs)
