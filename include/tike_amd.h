@@ -1,0 +1,114 @@
+/* tike_amd.h -- C ABI of the MI355X-native ptychography hot path.
+ *
+ * Drop-in boundary for the tike.operators / tike.ptycho.solvers hot path
+ * (reference: AdvancedPhotonSource/tike @ 2024_10_08; file:line citations are
+ * relative to the reference tree).  The reference has no FFI for this path:
+ * its operators are Python classes over CuPy, one JIT-compiled CUDA source
+ * (src/tike/operators/cupy/convolution.cu) and cuFFT.  These entry points are
+ * what a ctypes binding of those operators calls instead.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on the calling thread's current HIP
+ *     device; complex64 arrays are interleaved (re, im) float32, C-contiguous;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     calls are asynchronous on that stream, allocate nothing and never
+ *     synchronise (tike_init, called once per device, is the exception);
+ *   - return value: 0 on success, a hipError_t (> 0) from the runtime, or
+ *     TIKE_ERR_ARG / TIKE_ERR_UNSUPPORTED for violated shape relations -- the
+ *     Python layer raises ValueError / RuntimeError from these, mirroring the
+ *     reference's assert / ValueError behaviour;
+ *   - scan positions are float32 (y, x) of the patch's minimum corner
+ *     (reference patch.py:102-106).
+ */
+#ifndef TIKE_AMD_H
+#define TIKE_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TIKE_ERR_ARG 1000001
+#define TIKE_ERR_UNSUPPORTED 1000002
+
+/* Create the per-device constant tables (FFT twiddles).  Allocates; call once
+ * per device before capturing graphs.  Every other call does it lazily. */
+int tike_init(void);
+
+/* ---- Patch: replaces fwd_patch / adj_patch<float2,float2,float>
+ * (convolution.cu:146-165 as launched by operators/cupy/patch.py:79-188).
+ * images (nimage,H,W) c64; positions (nimage,nscan,2) f32;
+ * fwd: patches (nimage, nscan*nrepeat, padded, padded) -- only the centred
+ * patch_width window is written; adj: images += scatter(patches), patches
+ * (nimage, npatch, padded, padded) with (nscan*nrepeat) % npatch == 0 and
+ * npatch >= nrepeat (broadcast, patch.py:155). */
+int tike_patch_fwd(const void* images, void* patches, const float* positions, int nimage, int H,
+                   int W, int nscan, int nrepeat, int patch_width, int padded_width,
+                   void* stream);
+int tike_patch_adj(void* images, const void* patches, const float* positions, int nimage, int H,
+                   int W, int nscan, int nrepeat, int patch_width, int padded_width, int npatch,
+                   void* stream);
+
+/* ---- Convolution (operators/cupy/convolution.py:58-154), single image.
+ * psi (H,W); scan (nscan,2); probe (1|nscan, S, pw, pw) selected by
+ * probe_per_scan; nearplane (nscan, S, det, det).
+ * conv_adj accumulates into psi; conv_adj_probe writes (nscan,S,pw,pw). */
+int tike_conv_fwd(const void* psi, const float* scan, const void* probe, int probe_per_scan,
+                  void* nearplane, int nscan, int S, int pw, int det, int H, int W, void* stream);
+int tike_conv_adj(const void* nearplane, const float* scan, const void* probe,
+                  int probe_per_scan, void* psi, int nscan, int S, int pw, int det, int H, int W,
+                  void* stream);
+int tike_conv_adj_probe(const void* nearplane, const float* scan, const void* psi,
+                        void* probe_adj, int nscan, int S, int pw, int det, int H, int W,
+                        void* stream);
+
+/* ---- Propagation: replaces cuFFT behind CachedFFT._fft2/_ifft2
+ * (operators/cupy/propagation.py:43-73, cache.py:66-82).
+ * ntile tiles of n x n c64; out may alias in (overwrite); every element is
+ * multiplied by `scale` (norm='ortho' -> 1/n both ways). n <= 1024. */
+int tike_fft2(const void* in, void* out, long ntile, int n, int inverse, float scale,
+              void* stream);
+
+/* ---- Ptycho.fwd fused (operators/cupy/ptycho.py:114-129):
+ * farplane[n][s] = scale * FFT2( pad( patch_n(psi) * probe_n[s] ) ).
+ * The probe at position n is probe[n|0][s] or, when eigen_weights != NULL,
+ * weights[n][0][s]*probe[0][s] + sum_c weights[n][c+1][s]*eigen[c][s]
+ * (ptycho/probe.py:272-303); eigen_probe (num_eigen, eigen_modes, pw, pw),
+ * eigen_weights (nscan, num_eigen+1, S) f32. farplane (nscan,S,det,det). */
+int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe, int probe_per_scan,
+                    const void* eigen_probe, const float* eigen_weights, int num_eigen,
+                    int eigen_modes, void* farplane, int nscan, int S, int pw, int det, int H,
+                    int W, float scale, void* stream);
+
+/* ---- IFFT2 + crop to the probe window (propagation.py:59-73 followed by
+ * lstsq.py:506-507 / convolution.py:108-110 crop).  work (ntile,det,det) holds
+ * the intermediate and may alias farplane; chi (ntile,pw,pw) may alias work
+ * only when pw == det. */
+int tike_ifft2_crop(const void* farplane, void* work, void* chi, long ntile, int det, int pw,
+                    float scale, void* stream);
+
+/* ---- intensity, per-pattern cost and far-plane gradient in one pass
+ * (ptycho.py:18-23; objective.py:11-124; lstsq.py:444-502).
+ * model 0 = gaussian, 1 = poisson.  measured (det,det) uint8 mask or NULL
+ * (all measured); num_measured = number of non-zero mask pixels.
+ * intensity (nscan,det,det) and costs (nscan) are optional outputs (NULL to
+ * skip).  With apply_gradient the farplane is overwritten by
+ *   -grad on measured pixels, (unmeasured_scaling-1)*farplane elsewhere. */
+int tike_farplane_gradient(void* farplane, const float* data, const unsigned char* measured,
+                           float* intensity, float* costs, int nscan, int S, int det, int model,
+                           int apply_gradient, float unmeasured_scaling, long num_measured,
+                           void* stream);
+
+/* ---- stand-alone objective helpers (operators/cupy/objective.py:18-124,
+ * ptycho.py:18-23 _intensity_from_farplane).  farplane (nscan,S,npix) c64,
+ * data / intensity (nscan,npix) f32, costs (nscan) = mean over npix. */
+int tike_intensity(const void* farplane, float* intensity, long nscan, int S, long npix,
+                   void* stream);
+int tike_cost_each_pattern(const float* data, const float* intensity, float* costs, long nscan,
+                           long npix, int model, void* stream);
+int tike_objective_grad(const float* data, const void* farplane, const float* intensity,
+                        void* out, long nscan, int S, long npix, int model, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIKE_AMD_H */

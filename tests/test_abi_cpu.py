@@ -1,0 +1,40 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/tike_amd.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import tike_amd._lib as L
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    names = L.declared_symbols()
+    assert len(names) >= 10
+    lib = ctypes.CDLL(L.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_every_declared_symbol_has_a_python_prototype():
+    assert sorted(L._PROTOTYPES) == L.declared_symbols()
+
+
+def test_prototype_arity_matches_header():
+    text = open(L.HEADER_PATH).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, args in L._PROTOTYPES.items():
+        m = re.search(rf"int\s+{name}\s*\(([^)]*)\)", text)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else len(params.split(","))
+        assert n == len(args), (name, n, len(args))
+
+
+def test_no_product_module_imports_the_oracle():
+    root = os.path.join(os.path.dirname(L.__file__))
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src,
+                                     flags=re.M), os.path.join(dirpath, f)

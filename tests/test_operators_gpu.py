@@ -1,0 +1,352 @@
+"""GPU parity tests of the operator layer: HIP kernels (through the C ABI and
+the tike-compatible Python classes) vs the CPU oracle, the reference-run
+fixtures, and the reference's own known-answer / adjoint-identity tests."""
+import numpy as np
+import pytest
+
+from util import assert_close, relerr, COST_RTOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import tike_amd.operators as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import operators as o
+    return o
+
+
+def rc(rng, *shape):
+    return (rng.random((*shape, 2), dtype=np.float32) - 0.5).view(
+        np.complex64)[..., 0]
+
+
+def inner(x, y):
+    return np.sum(x * np.conj(y))
+
+
+# ---------------------------------------------------------------- Patch
+def test_patch_correctness(ops):
+    """reference tests/operators/test_patch.py:64-133 (atol 1e-6)."""
+    size, win = 256, 8
+    rng = np.random.default_rng(0)
+    fov = rc(rng, size, size)
+    sub = 0.12346789
+    positions = np.array([[0, 0], [0, size - win], [size - win, 0],
+                          [size - win, size - win],
+                          [size // 2 - win // 2, size // 2 - win // 2],
+                          [sub, 3]], dtype=np.float32)
+    truth = np.stack((
+        fov[:win, :win], fov[:win, -win:], fov[-win:, :win], fov[-win:, -win:],
+        fov[size // 2 - win // 2:size // 2 + win // 2,
+            size // 2 - win // 2:size // 2 + win // 2],
+        (1.0 - sub) * fov[0:win, 3:3 + win] + sub * fov[1:1 + win, 3:3 + win],
+    ), axis=0)
+    with ops.Patch() as op:
+        patches = op.fwd(images=fov, positions=positions, patch_width=win)
+    np.testing.assert_allclose(patches, truth, atol=1e-6)
+
+
+def test_patch_correctness_adjoint(ops):
+    """reference tests/operators/test_patch.py:136-206 (atol 1e-6)."""
+    size, win = 8, 2
+    positions = np.array([[0, 0], [0, size - win], [size - win, 0],
+                          [size - win, size - win],
+                          [size // 2 - win // 2, size // 2 - win // 2],
+                          [0.123, 3], [3, 0.123], [5.5, 3.5]],
+                         dtype=np.float32)
+    fov = np.zeros((size, size), dtype=np.complex64)
+    fov[:win, :win] += 1
+    fov[:win, -win:] += 1
+    fov[-win:, :win] += 1
+    fov[-win:, -win:] += 1
+    fov[3:5, 3:5] += 1
+    fov[0:win, 3:3 + win] += (1 - 0.123)
+    fov[1:1 + win, 3:3 + win] += 0.123
+    fov[3:3 + win, 0:win] += (1 - 0.123)
+    fov[3:3 + win, 1:1 + win] += 0.123
+    fov[5:5 + win, 3:3 + win] += 0.25
+    fov[6:6 + win, 3:3 + win] += 0.25
+    fov[5:5 + win, 4:4 + win] += 0.25
+    fov[6:6 + win, 4:4 + win] += 0.25
+    with ops.Patch() as op:
+        combined = op.adj(
+            patches=np.ones((len(positions), win, win), dtype=np.complex64),
+            positions=positions, patch_width=win,
+            images=np.zeros((size, size), dtype=np.complex64))
+    np.testing.assert_allclose(combined, fov, atol=1e-6)
+
+
+def test_patch_vs_reference_fixture(ops, golden):
+    g = golden("op_patch.npz")
+    pw = int(g["pw"])
+    H, W = g["images"].shape[-2:]
+    with ops.Patch() as op:
+        assert_close(op.fwd(g["images"], g["positions"], patch_width=pw),
+                     g["fwd1"], what="fwd1")
+        assert_close(
+            op.fwd(g["images"], g["positions"], np.zeros_like(g["fwd2"]),
+                   patch_width=pw, nrepeat=2), g["fwd2"], what="fwd2")
+        assert_close(
+            op.adj(g["positions"], g["patches_in"], patch_width=pw, height=H,
+                   width=W), g["adj1"], what="adj1")
+        assert_close(
+            op.adj(g["positions"], g["padded_in"], patch_width=pw, height=H,
+                   width=W, nrepeat=2), g["adj2"], what="adj2")
+        assert_close(
+            op.adj(g["positions"][0], g["bcast_in"], patch_width=pw, height=H,
+                   width=W), g["adj3"], what="adj3 (K=1 broadcast)")
+
+
+def test_patch_adjoint_identity(ops):
+    """reference tests/operators/test_patch.py:19-61 via util.py:42-54."""
+    rng = np.random.default_rng(0)
+    ntheta, nscan, pw = 3, 7, 16
+    scan = (rng.random((ntheta, nscan, 2)) * (256 - pw - 2)).astype(np.float32)
+    m = rc(rng, ntheta, 256, 256)
+    d = rc(rng, ntheta, nscan, pw, pw)
+    with ops.Patch() as op:
+        Fm = op.fwd(images=m, positions=scan, patch_width=pw, height=256,
+                    width=256)
+        Fd = op.adj(patches=d, positions=scan, patch_width=pw, height=256,
+                    width=256)
+    a, b = inner(Fm, d), inner(m, Fd)
+    np.testing.assert_allclose([a.real, a.imag], [b.real, b.imag], rtol=1e-3)
+
+
+def test_patch_empty(ops):
+    with ops.Patch() as op:
+        out = op.fwd(images=np.zeros((8, 8), np.complex64),
+                     positions=np.zeros((0, 2), np.float32), patch_width=2)
+    assert out.shape == (0, 2, 2)
+
+
+# ---------------------------------------------------------- Convolution
+def test_convolution_adjoint_identities(ops, oracle):
+    """reference tests/operators/test_convolution.py:20-103."""
+    rng = np.random.default_rng(0)
+    ntheta, nscan, S, pw, det, HW = 3, 27, 3, 15, 45, 128
+    scan = (rng.random((ntheta, nscan, 2)) * (HW - pw - 2) + 1).astype(
+        np.float32)
+    psi = rc(rng, ntheta, HW, HW)
+    probe = rc(rng, ntheta, nscan, S, pw, pw)
+    near = rc(rng, ntheta, nscan, S, det, det)
+    with ops.Convolution(ntheta=ntheta, nscan=nscan, nz=HW, n=HW,
+                         probe_shape=pw, nprobe=S, detector_shape=det) as op:
+        d = op.fwd(psi=psi, scan=scan, probe=probe)
+        m = op.adj(nearplane=near, scan=scan, probe=probe)
+        mp = op.adj_probe(nearplane=near, scan=scan, psi=psi)
+    assert d.shape == near.shape and m.shape == psi.shape
+    assert mp.shape == probe.shape
+    a, b, c = inner(d, near), inner(psi, m), inner(probe, mp)
+    np.testing.assert_allclose([a.real, a.imag], [b.real, b.imag], rtol=1e-3)
+    np.testing.assert_allclose([a.real, a.imag], [c.real, c.imag], rtol=1e-3)
+    for i in range(ntheta):
+        assert_close(d[i], oracle.convolution_fwd(psi[i], scan[i], probe[i],
+                                                  det), what="conv fwd")
+        assert_close(m[i], oracle.convolution_adj(near[i], scan[i], probe[i],
+                                                  HW, HW), what="conv adj")
+        assert_close(mp[i], oracle.convolution_adj_probe(near[i], scan[i],
+                                                         psi[i], pw),
+                     what="conv adj_probe")
+
+
+# ---------------------------------------------------------- Propagation
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 127, 45, 24, 7])
+@pytest.mark.parametrize("norm", ["ortho", "forward", "backward"])
+def test_propagation_vs_numpy(ops, n, norm):
+    rng = np.random.default_rng(n)
+    batch = 3 if n >= 512 else 13
+    x = rc(rng, batch, n, n)
+    with ops.Propagation(detector_shape=n, norm=norm) as op:
+        f = op.fwd(nearplane=x)
+        b = op.adj(farplane=x)
+    assert_close(f, np.fft.fft2(x.astype(np.complex128), norm=norm),
+                 normwise=2e-6, maxabs=2e-5, what=f"fft2 n={n}")
+    assert_close(b, np.fft.ifft2(x.astype(np.complex128), norm=norm),
+                 normwise=2e-6, maxabs=2e-5, what=f"ifft2 n={n}")
+
+
+@pytest.mark.parametrize("n", [127, 64])
+def test_propagation_adjoint_and_scaled(ops, n):
+    """reference tests/operators/test_propagation.py:16-36 (13 waves of 127^2):
+    <F m, d> = <m, F* d> and |F* F m| = |m| (rtol 1e-3)."""
+    rng = np.random.default_rng(0)
+    m, d = rc(rng, 13, n, n), rc(rng, 13, n, n)
+    with ops.Propagation(nwaves=13, detector_shape=n) as op:
+        Fm = op.fwd(nearplane=m)
+        Fd = op.adj(farplane=d)
+        FFm = op.adj(farplane=Fm)
+    a, b = inner(Fm, d), inner(m, Fd)
+    np.testing.assert_allclose([a.real, a.imag], [b.real, b.imag], rtol=1e-3)
+    np.testing.assert_allclose(inner(FFm, FFm).real, inner(m, m).real,
+                               rtol=1e-3)
+
+
+def test_propagation_overwrite_and_errors(ops):
+    import torch
+    rng = np.random.default_rng(1)
+    x = rc(rng, 5, 64, 64)
+    with ops.Propagation(detector_shape=64) as op:
+        t = op.asarray(x)
+        out = op.fwd(nearplane=t, overwrite=True)
+        assert out.data_ptr() == t.data_ptr()
+        assert_close(out.cpu().numpy(), np.fft.fft2(x, norm="ortho"),
+                     normwise=2e-6, maxabs=2e-5)
+        with pytest.raises(ValueError):
+            op.fwd(nearplane=np.zeros((2, 32, 32), np.complex64))
+
+
+# --------------------------------------------------------------- Ptycho
+@pytest.mark.parametrize("tag", ["odd", "pow2", "full"])
+def test_ptycho_vs_reference_fixture(ops, golden, tag):
+    g = golden(f"op_ptycho_{tag}.npz")
+    det = int(g["det"])
+    N = len(g["scan"])
+    pw = g["probe"].shape[-1]
+    HW = g["psi"].shape[-1]
+    with ops.Ptycho(nscan=N, probe_shape=pw, detector_shape=det, nz=HW,
+                    n=HW) as op:
+        fwd = op.fwd(probe=g["probe"], scan=g["scan"], psi=g["psi"])
+        assert_close(fwd, g["fwd"], what="fwd")
+        bprobe = np.broadcast_to(g["probe"], (N, *g["probe"].shape[1:])).copy()
+        psi_adj, probe_adj = op.adj(farplane=g["farplane_in"], probe=bprobe,
+                                    scan=g["scan"], psi=g["psi"])
+        assert_close(psi_adj, g["psi_adj"], what="psi_adj")
+        assert_close(probe_adj, g["probe_adj"], what="probe_adj")
+        inten, far = op._compute_intensity(None, g["psi"], g["scan"],
+                                           g["probe"])
+        assert_close(inten, g["intensity"], what="intensity")
+        d = g["data"]
+        np.testing.assert_allclose(
+            float(op.cost(d, g["psi"], g["scan"], g["probe"],
+                          model="gaussian")), g["cost_gaussian"],
+            rtol=COST_RTOL)
+        np.testing.assert_allclose(
+            float(op.cost(d, g["psi"], g["scan"], g["probe"],
+                          model="poisson")), g["cost_poisson"], rtol=COST_RTOL)
+    assert_close(ops.gaussian_grad(d, g["fwd"], g["intensity"]),
+                 g["gaussian_grad"], what="gaussian_grad")
+    assert_close(ops.poisson_grad(d, g["fwd"], g["intensity"]),
+                 g["poisson_grad"], normwise=1e-4, maxabs=1e-3,
+                 what="poisson_grad")
+    np.testing.assert_allclose(ops.gaussian_each_pattern(d, g["intensity"]),
+                               g["gaussian_each"], rtol=COST_RTOL)
+    np.testing.assert_allclose(ops.poisson_each_pattern(d, g["intensity"]),
+                               g["poisson_each"], rtol=COST_RTOL)
+
+
+def test_ptycho_adjoint_identity_reference_shapes(ops):
+    """reference tests/operators/test_ptycho.py:18-75."""
+    rng = np.random.default_rng(0)
+    nscan, pw, S, det = 27, 15, 3, 45
+    scan = (rng.random((nscan, 2), dtype=np.float32) * (127 - 16))
+    scan = np.maximum(scan, 1).astype(np.float32)
+    probe, psi = rc(rng, nscan, 1, S, pw, pw), rc(rng, 1, 128, 128)
+    far = rc(rng, nscan, 1, S, det, det)
+    with ops.Ptycho(nscan=nscan, probe_shape=pw, detector_shape=det, nz=128,
+                    n=128) as op:
+        d = op.fwd(scan=scan, probe=probe, psi=psi)
+        assert d.shape == far.shape
+        m0, m1 = op.adj(farplane=far, scan=scan, probe=probe, psi=psi)
+        assert m0.shape == psi.shape and m1.shape == probe.shape
+    a, b, c = inner(d, far), inner(psi, m0), inner(probe, m1)
+    np.testing.assert_allclose([a.real, a.imag], [b.real, b.imag], rtol=1e-3)
+    np.testing.assert_allclose([a.real, a.imag], [c.real, c.imag], rtol=1e-3)
+
+
+@pytest.mark.parametrize("det,pw,S,shared", [(64, 64, 2, True),
+                                             (128, 96, 3, False),
+                                             (256, 256, 1, True),
+                                             (64, 40, 2, True)])
+def test_ptycho_fused_vs_oracle(ops, oracle, det, pw, S, shared):
+    rng = np.random.default_rng(det + pw)
+    N = 5
+    HW = pw + 40
+    scan = (rng.random((N, 2)) * 36 + 1.5).astype(np.float32)
+    probe = rc(rng, 1 if shared else N, 1, S, pw, pw)
+    psi = rc(rng, 1, HW, HW)
+    far = rc(rng, N, 1, S, det, det)
+    with ops.Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+        fwd = op.fwd(probe=probe, scan=scan, psi=psi)
+        bprobe = np.broadcast_to(probe, (N, 1, S, pw, pw)).copy()
+        psi_adj, probe_adj = op.adj(farplane=far, probe=bprobe, scan=scan,
+                                    psi=psi)
+    assert_close(fwd, oracle.ptycho_fwd(probe, scan, psi, det), what="fwd")
+    o_psi, o_probe = oracle.ptycho_adj(far, bprobe, scan, psi)
+    assert_close(psi_adj, o_psi, what="psi_adj")
+    assert_close(probe_adj, o_probe, what="probe_adj")
+
+
+def test_ptycho_fwd_eigen_probe_on_the_fly(ops):
+    """Varying probe synthesised inside the kernel == get_varying_probe."""
+    from oracle import solvers as sol
+    from oracle import operators as oo
+    import torch
+    rng = np.random.default_rng(3)
+    N, S, C, Sm, pw, det, HW = 6, 3, 2, 1, 32, 64, 80
+    scan = (rng.random((N, 2)) * 40 + 2).astype(np.float32)
+    probe, psi = rc(rng, 1, 1, S, pw, pw), rc(rng, 1, HW, HW)
+    eigen = rc(rng, 1, C, Sm, pw, pw)
+    w = rng.standard_normal((N, C + 1, S)).astype(np.float32)
+    uprobe = sol.get_varying_probe(probe, eigen, w)
+    want = oo.ptycho_fwd(uprobe, scan, psi, det)
+    with ops.Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+        got = op.fwd_device(op.asarray(probe), op.asarray(scan),
+                            op.asarray(psi), op.asarray(eigen), op.asarray(w))
+    assert_close(got.cpu().numpy(), want, what="fwd with eigen probes")
+
+
+def test_farplane_gradient_fused(ops, oracle):
+    """tike_farplane_gradient vs objective.py + lstsq.py:444-502, with a mask
+    whose unmeasured pixels hold NaN data (reference tests put NaN there)."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import lib, check
+    rng = np.random.default_rng(5)
+    N, S, det = 7, 3, 48
+    far = rc(rng, N, 1, S, det, det)
+    inten = oracle.intensity_from_farplane(far)
+    data = (rng.random((N, det, det), dtype=np.float32) * inten.max())
+    mask = rng.random((det, det)) > 0.2
+    data_nan = data.copy()
+    data_nan[:, ~mask] = np.nan
+    for model in ("gaussian", "poisson"):
+        want = far.copy()
+        grad = getattr(oracle, f"{model}_grad")(data, far, inten)
+        want[..., mask] = -grad[..., mask]
+        want[..., ~mask] *= np.float32(0.7 - 1.0)
+        costs = getattr(oracle, f"{model}_each_pattern")(
+            data[:, mask][:, None, :], inten[:, mask][:, None, :])
+        f = A.to_device(far, np.complex64)
+        I = torch.empty((N, det, det), dtype=torch.float32, device=f.device)
+        c = torch.empty(N, dtype=torch.float32, device=f.device)
+        check(lib.tike_farplane_gradient(
+            A.ptr(f), A.ptr(A.to_device(data_nan, np.float32)),
+            A.ptr(A.to_device(mask.astype(np.uint8))), A.ptr(I), A.ptr(c), N,
+            S, det, 0 if model == "gaussian" else 1, 1, 0.7, int(mask.sum()),
+            A.stream_ptr()))
+        assert_close(f.cpu().numpy(), want, normwise=1e-4, maxabs=1e-3,
+                     what=f"{model} gradient")
+        assert_close(I.cpu().numpy(), inten, what="intensity")
+        np.testing.assert_allclose(c.cpu().numpy(), costs, rtol=COST_RTOL)
+
+
+def test_full_size_roundtrip_property(ops):
+    """BASELINE size (256^2): F* F = identity on the probe window and
+    Parseval, properties the oracle need not be run for."""
+    import torch
+    rng = np.random.default_rng(9)
+    x = rc(rng, 64, 256, 256)
+    with ops.Propagation(detector_shape=256) as op:
+        t = op.asarray(x)
+        f = op.fwd(nearplane=t)
+        np.testing.assert_allclose(
+            float((f.abs()**2).sum()), float((t.abs()**2).sum()), rtol=1e-5)
+        back = op.adj(farplane=f)
+    assert relerr(back.cpu().numpy(), x) < 2e-6

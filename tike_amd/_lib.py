@@ -1,0 +1,71 @@
+"""ctypes binding of the C ABI declared in include/tike_amd.h.
+
+The shared library is built in-tree (``tike_amd/csrc/libtike_amd.so``) by
+``tike_amd/csrc/Makefile`` (``__graft_entry__.build()``).  There is no CPU
+fallback: if the library is missing, importing this module raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtike_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
+
+ERR_ARG = 1000001
+ERR_UNSUPPORTED = 1000002
+
+if not os.path.isfile(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build the HIP library first "
+        "(`make -C tike_amd/csrc` or `python -c 'import __graft_entry__ as g; "
+        "g.build()'`). tike_amd has no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_long
+_f = ctypes.c_float
+
+_PROTOTYPES = {
+    "tike_init": [],
+    "tike_patch_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "tike_patch_adj": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "tike_conv_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "tike_conv_adj": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
+    "tike_conv_adj_probe": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "tike_fft2": [_p, _p, _l, _i, _i, _f, _p],
+    "tike_ptycho_fwd": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i,
+                        _i, _i, _f, _p],
+    "tike_ifft2_crop": [_p, _p, _p, _l, _i, _i, _f, _p],
+    "tike_farplane_gradient": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _l,
+                               _p],
+    "tike_intensity": [_p, _p, _l, _i, _l, _p],
+    "tike_cost_each_pattern": [_p, _p, _p, _l, _l, _i, _p],
+    "tike_objective_grad": [_p, _p, _p, _p, _l, _i, _l, _i, _p],
+}
+
+
+def declared_symbols():
+    """Names of every function declared in include/tike_amd.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"^int\s+(tike_\w+)\s*\(", text, flags=re.M)))
+
+
+for _name, _args in _PROTOTYPES.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_int
+
+
+def check(rc, what=""):
+    """Translate a C-ABI return code into the reference's error behaviour."""
+    if rc == 0:
+        return
+    if rc == ERR_ARG:
+        raise ValueError(f"{what}: incompatible shapes / arguments")
+    if rc == ERR_UNSUPPORTED:
+        raise ValueError(f"{what}: unsupported size for the HIP path")
+    raise RuntimeError(f"{what}: HIP error {rc}")

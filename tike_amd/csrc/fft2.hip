@@ -1,0 +1,167 @@
+// Batched 2-D complex64 FFT for gfx950: replaces cuFFT behind
+// tike.operators.Propagation (reference propagation.py:43-73, cache.py:66-82).
+//
+// Power-of-two n in [32, 1024]: one workgroup owns one n x n tile and runs
+// both passes (rows, then columns in place on the output tile) through the
+// register/LDS engine of fft_engine.h.  Any other n <= 1024: direct O(n^2)
+// DFT per line (correctness path for the reference's 45/127-sized tests).
+#include <cmath>
+#include <mutex>
+
+#include "fft_engine.h"
+#include "tike_amd.h"
+
+// ---------------------------------------------------------------- twiddles
+static cf* g_tw_dev[64] = {nullptr};
+static std::mutex g_tw_mutex;
+
+const cf* tk_twiddles() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_tw_mutex);
+  if (g_tw_dev[dev]) return g_tw_dev[dev];
+  static cf host[2048];
+  for (int n = 32; n <= 1024; n *= 2)
+    for (int k = 0; k < n; ++k) {
+      const double a = -2.0 * M_PI * (double)k / (double)n;
+      host[n + k] = mk((float)std::cos(a), (float)std::sin(a));
+    }
+  cf* d = nullptr;
+  if (hipMalloc((void**)&d, sizeof(host)) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  g_tw_dev[dev] = d;
+  return d;
+}
+
+extern "C" int tike_init(void) { return tk_twiddles() ? TK_OK : (int)hipErrorNotInitialized; }
+
+// ------------------------------------------------------------ pow2 kernel
+template <int N, bool INV>
+__global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void fft2_pow2_kernel(
+    const cf* in, cf* out, long ntile, float scale, const cf* __restrict__ twtab) {
+  using G = FftGeom<N>;
+  __shared__ cf lds[G::LDS_ELEMS];
+  FftTw<N> tw;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const cf* src = in + tile * (long)N * N;
+    cf* dst = out + tile * (long)N * N;
+    const FftLane<N, false> row = fft_lane<N, false>();
+    tw.init(twtab, row.j);
+    for (int g = 0; g < N; g += G::L) {
+      fft_lines<N, INV, false>(
+          lds, row, tw, [&](int line, int e) { return src[(g + line) * N + e]; },
+          [&](int line, int e, cf v) { dst[(g + line) * N + e] = v; });
+    }
+    __syncthreads();  // row pass results visible to the whole workgroup
+    const FftLane<N, true> col = fft_lane<N, true>();
+    tw.init(twtab, col.j);
+    for (int g = 0; g < N; g += G::L) {
+      fft_lines<N, INV, true>(
+          lds, col, tw, [&](int line, int e) { return dst[e * N + g + line]; },
+          [&](int line, int e, cf v) { dst[e * N + g + line] = v * scale; });
+    }
+    __syncthreads();
+  }
+}
+
+// --------------------------------------------------------- generic kernel
+// One workgroup per tile, n <= 1024.  LDS: twiddle table (n) + one line (n).
+template <bool INV>
+__global__ __launch_bounds__(256) void dft2_generic_kernel(const cf* in, cf* out, int n,
+                                                           long ntile, float scale) {
+  __shared__ cf tw[1024];
+  __shared__ cf line[1024];
+  for (int k = threadIdx.x; k < n; k += blockDim.x) {
+    double s, c;
+    sincospi(2.0 * (double)k / (double)n, &s, &c);
+    tw[k] = mk((float)c, INV ? (float)s : (float)-s);
+  }
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const cf* src = in + tile * (long)n * n;
+    cf* dst = out + tile * (long)n * n;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int l = 0; l < n; ++l) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += blockDim.x)
+          line[e] = pass == 0 ? src[(long)l * n + e] : dst[(long)e * n + l];
+        __syncthreads();
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+          float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
+          int m = 0;  // (j * k) mod n
+          int j = 0;
+          for (; j + 1 < n; j += 2) {
+            cf w0 = tw[m];
+            m += k;
+            if (m >= n) m -= n;
+            cf w1 = tw[m];
+            m += k;
+            if (m >= n) m -= n;
+            cf x0 = line[j], x1 = line[j + 1];
+            ax += x0.x * w0.x - x0.y * w0.y;
+            ay += x0.x * w0.y + x0.y * w0.x;
+            bx += x1.x * w1.x - x1.y * w1.y;
+            by += x1.x * w1.y + x1.y * w1.x;
+          }
+          if (j < n) {
+            cf w0 = tw[m];
+            cf x0 = line[j];
+            ax += x0.x * w0.x - x0.y * w0.y;
+            ay += x0.x * w0.y + x0.y * w0.x;
+          }
+          cf r = mk(ax + bx, ay + by);
+          if (pass == 0)
+            dst[(long)l * n + k] = r;
+          else
+            dst[(long)k * n + l] = r * scale;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int N>
+static int launch_pow2(const cf* in, cf* out, long ntile, int inverse, float scale,
+                       hipStream_t stream) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  const int grid = tk_grid(ntile, N >= 512 ? 2 : 4);
+  if (inverse)
+    hipLaunchKernelGGL((fft2_pow2_kernel<N, true>), dim3(grid), dim3(FftPlan<N>::NT), 0, stream,
+                       in, out, ntile, scale, tw);
+  else
+    hipLaunchKernelGGL((fft2_pow2_kernel<N, false>), dim3(grid), dim3(FftPlan<N>::NT), 0,
+                       stream, in, out, ntile, scale, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+int tk_fft2(const cf* in, cf* out, long ntile, int n, int inverse, float scale,
+            hipStream_t stream) {
+  TK_CHECK_ARG(in && out && n >= 1 && ntile >= 0);
+  if (ntile == 0) return TK_OK;
+  switch (n) {
+    case 32: return launch_pow2<32>(in, out, ntile, inverse, scale, stream);
+    case 64: return launch_pow2<64>(in, out, ntile, inverse, scale, stream);
+    case 128: return launch_pow2<128>(in, out, ntile, inverse, scale, stream);
+    case 256: return launch_pow2<256>(in, out, ntile, inverse, scale, stream);
+    case 512: return launch_pow2<512>(in, out, ntile, inverse, scale, stream);
+    case 1024: return launch_pow2<1024>(in, out, ntile, inverse, scale, stream);
+    default: break;
+  }
+  if (n > 1024) return TK_ERR_UNSUPPORTED;
+  const int grid = tk_grid(ntile, 8);
+  if (inverse)
+    hipLaunchKernelGGL((dft2_generic_kernel<true>), dim3(grid), dim3(256), 0, stream, in, out, n,
+                       ntile, scale);
+  else
+    hipLaunchKernelGGL((dft2_generic_kernel<false>), dim3(grid), dim3(256), 0, stream, in, out,
+                       n, ntile, scale);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_fft2(const void* in, void* out, long ntile, int n, int inverse, float scale,
+                         void* stream) {
+  return tk_fft2((const cf*)in, (cf*)out, ntile, n, inverse, scale, (hipStream_t)stream);
+}

@@ -1,0 +1,368 @@
+// Fused ptychography forward / adjoint kernels for gfx950.
+//
+//   tike_ptycho_fwd      bilinear patch gather * probe -> zero pad -> FFT2
+//                        (reference ptycho.py:114-129 = convolution.py:58-101
+//                        + propagation.py:43-57) in ONE kernel: no patch
+//                        array, no memset, no separate multiply pass.
+//   tike_ifft2_crop      IFFT2 -> crop to the probe window
+//                        (propagation.py:59-73 + lstsq.py:504-507).
+//   tike_farplane_gradient  intensity, per-pattern cost and the far-plane
+//                        gradient in one pass (ptycho.py:18-23,
+//                        objective.py:11-124, lstsq.py:444-502).
+//
+// One workgroup owns one (position, mode) tile and runs the row pass and the
+// column pass back to back; the intermediate lives in the tile's own output
+// (L2 / Infinity Cache resident between the passes).
+#include "fft_engine.h"
+#include "internal.h"
+#include "tike_amd.h"
+
+// --------------------------------------------------------------- forward
+template <int N>
+__global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ptycho_fwd_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    cf* __restrict__ farplane, long ntile, int S, int pw, int H, int W, float scale,
+    const cf* __restrict__ twtab) {
+  using G = FftGeom<N>;
+  __shared__ cf lds[G::LDS_ELEMS];
+  FftTw<N> tw;
+  const int pad = (N - pw) / 2;
+  const int end = pad + pw;
+  const long total = (long)H * W;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long n = tile / S;
+    const int s = (int)(tile % S);
+    const TkCorner c = tk_corner(scan, n);
+    cf* __restrict__ dst = farplane + tile * (long)N * N;
+    const FftLane<N, false> row = fft_lane<N, false>();
+    tw.init(twtab, row.j);
+    for (int g = 0; g < N; g += G::L) {
+      if (g + G::L <= pad || g >= end) {
+        // rows entirely inside the zero padding transform to zero
+        for (int i = threadIdx.x; i < G::L * N; i += G::NT) dst[g * N + i] = mk(0.f, 0.f);
+        continue;
+      }
+      fft_lines<N, false, false, 4>(
+          lds, row, tw,
+          [&](int line, int e) {
+            const int py = g + line - pad, px = e - pad;
+            const int y = c.sy + py, x = c.sx + px;
+            if (py < 0 || py >= pw || px < 0 || px >= pw || y < 0 || y >= H || x < 0 || x >= W)
+              return mk(0.f, 0.f);
+            const cf o = tk_gather(psi, (long)y * W + x, W, total, c);
+            return o * probe.at(n, s, (long)py * pw + px);
+          },
+          [&](int line, int e, cf v) { dst[(g + line) * N + e] = v; });
+    }
+    __syncthreads();
+    const FftLane<N, true> col = fft_lane<N, true>();
+    tw.init(twtab, col.j);
+    for (int g = 0; g < N; g += G::L) {
+      fft_lines<N, false, true>(
+          lds, col, tw, [&](int line, int e) { return dst[e * N + g + line]; },
+          [&](int line, int e, cf v) { dst[e * N + g + line] = v * scale; });
+    }
+    __syncthreads();
+  }
+}
+
+template <int N>
+static int launch_fwd(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
+                      long ntile, int S, int pw, int H, int W, float scale, hipStream_t stream) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  hipLaunchKernelGGL((ptycho_fwd_kernel<N>), dim3(tk_grid(ntile, N >= 512 ? 2 : 4)),
+                     dim3(FftPlan<N>::NT), 0, stream, psi, scan, probe, farplane, ntile, S, pw, H,
+                     W, scale, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe,
+                               int probe_per_scan, const void* eigen_probe,
+                               const float* eigen_weights, int num_eigen, int eigen_modes,
+                               void* farplane, int nscan, int S, int pw, int det, int H, int W,
+                               float scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(psi && scan && probe && farplane);
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
+  if (nscan == 0) return TK_OK;
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw);
+  const long ntile = (long)nscan * S;
+  const cf* psi_ = (const cf*)psi;
+  cf* far = (cf*)farplane;
+  switch (det) {
+    case 32: return launch_fwd<32>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+    case 64: return launch_fwd<64>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+    case 128: return launch_fwd<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+    case 256: return launch_fwd<256>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+    case 512: return launch_fwd<512>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+    case 1024: return launch_fwd<1024>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+    default: break;
+  }
+  // any other detector size: unfused gather*probe, then the generic DFT in place
+  int rc = tk_conv_fwd(psi_, scan, P, far, nscan, S, pw, det, H, W, stream);
+  if (rc) return rc;
+  return tk_fft2(far, far, ntile, det, 0, scale, stream);
+}
+
+// ------------------------------------------------------- inverse + crop
+template <int N>
+__global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_kernel(
+    const cf* farplane, cf* work, cf* chi, long ntile,
+    int pw, float scale, const cf* __restrict__ twtab) {
+  using G = FftGeom<N>;
+  __shared__ cf lds[G::LDS_ELEMS];
+  FftTw<N> tw;
+  const int pad = (N - pw) / 2;
+  const int end = pad + pw;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const cf* src = farplane + tile * (long)N * N;
+    cf* mid = work + tile * (long)N * N;
+    cf* dst = chi + tile * (long)pw * pw;
+    const FftLane<N, false> row = fft_lane<N, false>();
+    tw.init(twtab, row.j);
+    for (int g = 0; g < N; g += G::L) {
+      fft_lines<N, true, false>(
+          lds, row, tw, [&](int line, int e) { return src[(g + line) * N + e]; },
+          [&](int line, int e, cf v) { mid[(g + line) * N + e] = v; });
+    }
+    __syncthreads();
+    const FftLane<N, true> col = fft_lane<N, true>();
+    tw.init(twtab, col.j);
+    for (int g = 0; g < N; g += G::L) {
+      if (g + G::L <= pad || g >= end) continue;  // columns outside the crop
+      fft_lines<N, true, true>(
+          lds, col, tw, [&](int line, int e) { return mid[e * N + g + line]; },
+          [&](int line, int e, cf v) {
+            const int py = e - pad, px = g + line - pad;
+            if (py >= 0 && py < pw && px >= 0 && px < pw) dst[py * pw + px] = v * scale;
+          });
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void crop_kernel(const cf* __restrict__ src,
+                                                   cf* __restrict__ dst, long ntile, int det,
+                                                   int pw) {
+  const int pad = (det - pw) / 2;
+  const long nrow = ntile * pw;
+  for (long r = blockIdx.x; r < nrow; r += gridDim.x) {
+    const long t = r / pw;
+    const int py = (int)(r % pw);
+    for (int px = threadIdx.x; px < pw; px += blockDim.x)
+      dst[(t * pw + py) * pw + px] = src[(t * det + pad + py) * (long)det + pad + px];
+  }
+}
+
+template <int N>
+static int launch_icrop(const cf* far, cf* work, cf* chi, long ntile, int pw, float scale,
+                        hipStream_t stream) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  hipLaunchKernelGGL((ifft2_crop_kernel<N>), dim3(tk_grid(ntile, N >= 512 ? 2 : 4)),
+                     dim3(FftPlan<N>::NT), 0, stream, far, work, chi, ntile, pw, scale, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// work: (ntile, det, det) scratch for the intermediate; may alias farplane
+// (overwrite) and, when pw == det, chi may alias work.
+extern "C" int tike_ifft2_crop(const void* farplane, void* work, void* chi, long ntile, int det,
+                               int pw, float scale, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(farplane && work && chi && ntile >= 0 && pw >= 1 && det >= pw);
+  TK_CHECK_ARG(!(chi == work && pw != det));
+  if (ntile == 0) return TK_OK;
+  const cf* far = (const cf*)farplane;
+  cf* wk = (cf*)work;
+  cf* out = (cf*)chi;
+  switch (det) {
+    case 32: return launch_icrop<32>(far, wk, out, ntile, pw, scale, stream);
+    case 64: return launch_icrop<64>(far, wk, out, ntile, pw, scale, stream);
+    case 128: return launch_icrop<128>(far, wk, out, ntile, pw, scale, stream);
+    case 256: return launch_icrop<256>(far, wk, out, ntile, pw, scale, stream);
+    case 512: return launch_icrop<512>(far, wk, out, ntile, pw, scale, stream);
+    case 1024: return launch_icrop<1024>(far, wk, out, ntile, pw, scale, stream);
+    default: break;
+  }
+  int rc = tk_fft2(far, wk, ntile, det, 1, scale, stream);
+  if (rc) return rc;
+  if (out == wk) return TK_OK;
+  hipLaunchKernelGGL(crop_kernel, dim3(tk_grid(ntile * pw, 16)), dim3(256), 0, stream, wk, out,
+                     ntile, det, pw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// ------------------------------------------- intensity / cost / gradient
+// One workgroup per position.  For every detector pixel: I = sum_s |F_s|^2;
+// cost contribution on measured pixels; F_s *= g with
+//   gaussian: g = -(1 - sqrt(d) / (sqrt(I) + 1e-9))       (objective.py:31-44)
+//   poisson:  g = -(1 - d / (I + 1e-9))                   (objective.py:97-109)
+// on measured pixels and g = (unmeasured_scaling - 1) elsewhere
+// (lstsq.py:491-502).  Unmeasured pixels are selected by the mask and their
+// data values (possibly NaN) are never read into the arithmetic.
+template <int MODEL, bool GRAD>
+__global__ __launch_bounds__(256) void farplane_gradient_kernel(
+    cf* __restrict__ farplane, const float* __restrict__ data,
+    const unsigned char* __restrict__ mask, float* __restrict__ intensity,
+    float* __restrict__ costs, int nscan, int S, int det, float unmeasured_scaling,
+    float inv_nmeasured) {
+  __shared__ float red[4];
+  const long npix = (long)det * det;
+  for (long n = blockIdx.x; n < nscan; n += gridDim.x) {
+    cf* __restrict__ F = farplane + n * S * npix;
+    const float* __restrict__ d = data + n * npix;
+    float cost = 0.f;
+    for (long p = threadIdx.x; p < npix; p += blockDim.x) {
+      float I = 0.f;
+      for (int s = 0; s < S; ++s) I += norm2(F[s * npix + p]);
+      if (intensity) intensity[n * npix + p] = I;
+      const bool measured = mask ? mask[p] != 0 : true;
+      float g;
+      if (measured) {
+        const float dv = d[p];
+        if (MODEL == 0) {
+          const float sI = sqrtf(I), sd = sqrtf(dv);
+          const float diff = sI - sd;
+          cost += diff * diff;
+          g = -(1.0f - sd / (sI + 1e-9f));
+        } else {
+          cost += I - dv * logf(I + 1e-9f);
+          g = -(1.0f - dv / (I + 1e-9f));
+        }
+      } else {
+        g = unmeasured_scaling - 1.0f;
+      }
+      if (GRAD)
+        for (int s = 0; s < S; ++s) F[s * npix + p] = F[s * npix + p] * g;
+    }
+    cost = tk_block_sum256(cost, red);
+    if (costs && threadIdx.x == 0) costs[n] = cost * inv_nmeasured;
+  }
+}
+
+extern "C" int tike_farplane_gradient(void* farplane, const float* data,
+                                      const unsigned char* measured, float* intensity,
+                                      float* costs, int nscan, int S, int det, int model,
+                                      int apply_gradient, float unmeasured_scaling,
+                                      long num_measured, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(farplane && data && nscan >= 0 && S >= 1 && det >= 1);
+  TK_CHECK_ARG(model == 0 || model == 1);
+  TK_CHECK_ARG(num_measured > 0);
+  if (nscan == 0) return TK_OK;
+  const float inv = 1.0f / (float)num_measured;
+  const dim3 grid(tk_grid(nscan, 16)), block(256);
+#define TK_FG(M, G)                                                                          \
+  hipLaunchKernelGGL((farplane_gradient_kernel<M, G>), grid, block, 0, stream, (cf*)farplane, \
+                     data, measured, intensity, costs, nscan, S, det, unmeasured_scaling, inv)
+  if (model == 0 && apply_gradient) TK_FG(0, true);
+  if (model == 0 && !apply_gradient) TK_FG(0, false);
+  if (model == 1 && apply_gradient) TK_FG(1, true);
+  if (model == 1 && !apply_gradient) TK_FG(1, false);
+#undef TK_FG
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// ------------------------------------------------ stand-alone objective ops
+// The free functions tike.operators.{gaussian,poisson}{_each_pattern,_grad}
+// (objective.py:18-124) and _intensity_from_farplane (ptycho.py:18-23).
+__global__ __launch_bounds__(256) void intensity_kernel(const cf* __restrict__ F,
+                                                        float* __restrict__ I, long nscan, int S,
+                                                        long npix) {
+  const long total = nscan * npix;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long n = i / npix, p = i % npix;
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += norm2(F[(n * S + s) * npix + p]);
+    I[i] = a;
+  }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void cost_each_kernel(const float* __restrict__ data,
+                                                        const float* __restrict__ I,
+                                                        float* __restrict__ costs, long nscan,
+                                                        long npix) {
+  __shared__ float red[4];
+  for (long n = blockIdx.x; n < nscan; n += gridDim.x) {
+    float c = 0.f;
+    for (long p = threadIdx.x; p < npix; p += blockDim.x) {
+      const float d = data[n * npix + p], iv = I[n * npix + p];
+      if (MODEL == 0) {
+        const float diff = sqrtf(iv) - sqrtf(d);
+        c += diff * diff;
+      } else {
+        c += iv - d * logf(iv + 1e-9f);
+      }
+    }
+    c = tk_block_sum256(c, red);
+    if (threadIdx.x == 0) costs[n] = c / (float)npix;
+  }
+}
+
+template <int MODEL>
+__global__ __launch_bounds__(256) void objective_grad_kernel(const float* __restrict__ data,
+                                                             const cf* __restrict__ F,
+                                                             const float* __restrict__ I,
+                                                             cf* __restrict__ out, long nscan,
+                                                             int S, long npix) {
+  const long total = nscan * npix;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long n = i / npix, p = i % npix;
+    const float d = data[i], iv = I[i];
+    const float g = MODEL == 0 ? 1.0f - sqrtf(d) / (sqrtf(iv) + 1e-9f) : 1.0f - d / (iv + 1e-9f);
+    for (int s = 0; s < S; ++s) out[(n * S + s) * npix + p] = F[(n * S + s) * npix + p] * g;
+  }
+}
+
+extern "C" int tike_intensity(const void* farplane, float* intensity, long nscan, int S,
+                              long npix, void* stream) {
+  TK_CHECK_ARG(farplane && intensity && nscan >= 0 && S >= 1 && npix >= 1);
+  if (nscan == 0) return TK_OK;
+  hipLaunchKernelGGL(intensity_kernel, dim3(tk_grid((nscan * npix + 255) / 256, 16)), dim3(256),
+                     0, (hipStream_t)stream, (const cf*)farplane, intensity, nscan, S, npix);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_cost_each_pattern(const float* data, const float* intensity, float* costs,
+                                      long nscan, long npix, int model, void* stream) {
+  TK_CHECK_ARG(data && intensity && costs && nscan >= 0 && npix >= 1);
+  TK_CHECK_ARG(model == 0 || model == 1);
+  if (nscan == 0) return TK_OK;
+  const dim3 grid(tk_grid(nscan, 16)), block(256);
+  if (model == 0)
+    hipLaunchKernelGGL((cost_each_kernel<0>), grid, block, 0, (hipStream_t)stream, data,
+                       intensity, costs, nscan, npix);
+  else
+    hipLaunchKernelGGL((cost_each_kernel<1>), grid, block, 0, (hipStream_t)stream, data,
+                       intensity, costs, nscan, npix);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_objective_grad(const float* data, const void* farplane,
+                                   const float* intensity, void* out, long nscan, int S,
+                                   long npix, int model, void* stream) {
+  TK_CHECK_ARG(data && farplane && intensity && out && nscan >= 0 && S >= 1 && npix >= 1);
+  TK_CHECK_ARG(model == 0 || model == 1);
+  if (nscan == 0) return TK_OK;
+  const dim3 grid(tk_grid((nscan * npix + 255) / 256, 16)), block(256);
+  if (model == 0)
+    hipLaunchKernelGGL((objective_grad_kernel<0>), grid, block, 0, (hipStream_t)stream, data,
+                       (const cf*)farplane, intensity, (cf*)out, nscan, S, npix);
+  else
+    hipLaunchKernelGGL((objective_grad_kernel<1>), grid, block, 0, (hipStream_t)stream, data,
+                       (const cf*)farplane, intensity, (cf*)out, nscan, S, npix);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
