@@ -16,6 +16,11 @@
     if (!(cond)) return TK_ERR_ARG; \
   } while (0)
 
+// hipGetLastError() is per-thread state shared with every other HIP user in the
+// process (PyTorch included): clear stale errors on entry so that a launch
+// check only ever reports this library's own launches.
+#define TK_ENTER() (void)hipGetLastError()
+
 #define TK_LAUNCH_CHECK()                   \
   do {                                      \
     hipError_t e__ = hipGetLastError();     \

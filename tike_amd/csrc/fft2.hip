@@ -163,5 +163,6 @@ int tk_fft2(const cf* in, cf* out, long ntile, int n, int inverse, float scale,
 
 extern "C" int tike_fft2(const void* in, void* out, long ntile, int n, int inverse, float scale,
                          void* stream) {
+  TK_ENTER();
   return tk_fft2((const cf*)in, (cf*)out, ntile, n, inverse, scale, (hipStream_t)stream);
 }

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void patch_kernel(cf* __restrict__ images,
 extern "C" int tike_patch_fwd(const void* images, void* patches, const float* positions,
                               int nimage, int H, int W, int nscan, int nrepeat, int patch_width,
                               int padded_width, void* stream) {
+  TK_ENTER();
   TK_CHECK_ARG(images && patches && positions);
   TK_CHECK_ARG(nimage >= 1 && H >= 1 && W >= 1 && nscan >= 0 && nrepeat >= 1);
   TK_CHECK_ARG(patch_width >= 1 && patch_width <= padded_width);
@@ -82,6 +83,7 @@ extern "C" int tike_patch_fwd(const void* images, void* patches, const float* po
 extern "C" int tike_patch_adj(void* images, const void* patches, const float* positions,
                               int nimage, int H, int W, int nscan, int nrepeat, int patch_width,
                               int padded_width, int npatch, void* stream) {
+  TK_ENTER();
   TK_CHECK_ARG(images && patches && positions);
   TK_CHECK_ARG(nimage >= 1 && H >= 1 && W >= 1 && nscan >= 0 && nrepeat >= 1);
   TK_CHECK_ARG(patch_width >= 1 && patch_width <= padded_width);
@@ -242,6 +244,7 @@ int tk_conv_adj_probe(const cf* nearplane, const float* scan, const cf* psi, cf*
 extern "C" int tike_conv_fwd(const void* psi, const float* scan, const void* probe,
                              int probe_per_scan, void* nearplane, int nscan, int S, int pw,
                              int det, int H, int W, void* stream) {
+  TK_ENTER();
   return tk_conv_fwd((const cf*)psi, scan,
                      tk_make_probe(probe, probe_per_scan, nullptr, nullptr, 0, 0, S, pw),
                      (cf*)nearplane, nscan, S, pw, det, H, W, (hipStream_t)stream);
@@ -250,6 +253,7 @@ extern "C" int tike_conv_fwd(const void* psi, const float* scan, const void* pro
 extern "C" int tike_conv_adj(const void* nearplane, const float* scan, const void* probe,
                              int probe_per_scan, void* psi, int nscan, int S, int pw, int det,
                              int H, int W, void* stream) {
+  TK_ENTER();
   return tk_conv_adj((const cf*)nearplane, scan,
                      tk_make_probe(probe, probe_per_scan, nullptr, nullptr, 0, 0, S, pw),
                      (cf*)psi, nscan, S, pw, det, H, W, (hipStream_t)stream);
@@ -258,6 +262,7 @@ extern "C" int tike_conv_adj(const void* nearplane, const float* scan, const voi
 extern "C" int tike_conv_adj_probe(const void* nearplane, const float* scan, const void* psi,
                                    void* probe_adj, int nscan, int S, int pw, int det, int H,
                                    int W, void* stream) {
+  TK_ENTER();
   return tk_conv_adj_probe((const cf*)nearplane, scan, (const cf*)psi, (cf*)probe_adj, nscan, S,
                            pw, det, H, W, (hipStream_t)stream);
 }

@@ -83,6 +83,7 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
                                const float* eigen_weights, int num_eigen, int eigen_modes,
                                void* farplane, int nscan, int S, int pw, int det, int H, int W,
                                float scale, void* stream_) {
+  TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(psi && scan && probe && farplane);
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
@@ -173,6 +174,7 @@ static int launch_icrop(const cf* far, cf* work, cf* chi, long ntile, int pw, fl
 // (overwrite) and, when pw == det, chi may alias work.
 extern "C" int tike_ifft2_crop(const void* farplane, void* work, void* chi, long ntile, int det,
                                int pw, float scale, void* stream_) {
+  TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(farplane && work && chi && ntile >= 0 && pw >= 1 && det >= pw);
   TK_CHECK_ARG(!(chi == work && pw != det));
@@ -251,6 +253,7 @@ extern "C" int tike_farplane_gradient(void* farplane, const float* data,
                                       float* costs, int nscan, int S, int det, int model,
                                       int apply_gradient, float unmeasured_scaling,
                                       long num_measured, void* stream_) {
+  TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(farplane && data && nscan >= 0 && S >= 1 && det >= 1);
   TK_CHECK_ARG(model == 0 || model == 1);
@@ -326,6 +329,7 @@ __global__ __launch_bounds__(256) void objective_grad_kernel(const float* __rest
 
 extern "C" int tike_intensity(const void* farplane, float* intensity, long nscan, int S,
                               long npix, void* stream) {
+  TK_ENTER();
   TK_CHECK_ARG(farplane && intensity && nscan >= 0 && S >= 1 && npix >= 1);
   if (nscan == 0) return TK_OK;
   hipLaunchKernelGGL(intensity_kernel, dim3(tk_grid((nscan * npix + 255) / 256, 16)), dim3(256),
@@ -336,6 +340,7 @@ extern "C" int tike_intensity(const void* farplane, float* intensity, long nscan
 
 extern "C" int tike_cost_each_pattern(const float* data, const float* intensity, float* costs,
                                       long nscan, long npix, int model, void* stream) {
+  TK_ENTER();
   TK_CHECK_ARG(data && intensity && costs && nscan >= 0 && npix >= 1);
   TK_CHECK_ARG(model == 0 || model == 1);
   if (nscan == 0) return TK_OK;
@@ -353,6 +358,7 @@ extern "C" int tike_cost_each_pattern(const float* data, const float* intensity,
 extern "C" int tike_objective_grad(const float* data, const void* farplane,
                                    const float* intensity, void* out, long nscan, int S,
                                    long npix, int model, void* stream) {
+  TK_ENTER();
   TK_CHECK_ARG(data && farplane && intensity && out && nscan >= 0 && S >= 1 && npix >= 1);
   TK_CHECK_ARG(model == 0 || model == 1);
   if (nscan == 0) return TK_OK;

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks (HIP events) for the FFT-bearing kernels.
+
+python tools/kbench.py [--det 256] [--tiles 2048] [--reps 10]
+"""
+import argparse
+import sys
+import os
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tike_amd._arrays as A  # noqa: E402
+from tike_amd._lib import lib, check  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
+        enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--det", type=int, default=256)
+    p.add_argument("--tiles", type=int, default=2048)
+    p.add_argument("--reps", type=int, default=10)
+    p.add_argument("--modes", type=int, default=1)
+    a = p.parse_args()
+    n, T, S = a.det, a.tiles, a.modes
+    dev = torch.device("cuda", 0)
+    x = torch.randn(T, n, n, dtype=torch.complex64, device=dev)
+    y = torch.empty_like(x)
+    st = A.stream_ptr()
+    tile_bytes = n * n * 8
+    rows = []
+
+    ms = timeit(lambda: check(lib.tike_fft2(x.data_ptr(), y.data_ptr(), T, n, 0,
+                                            1.0 / n, st)), a.reps)
+    rows.append(("fft2 out-of-place", ms, 2 * T * tile_bytes))
+    ms = timeit(lambda: check(lib.tike_fft2(y.data_ptr(), y.data_ptr(), T, n, 1,
+                                            1.0 / n, st)), a.reps)
+    rows.append(("ifft2 in-place", ms, 2 * T * tile_bytes))
+    ms = timeit(lambda: check(lib.tike_ifft2_crop(y.data_ptr(), y.data_ptr(),
+                                                  y.data_ptr(), T, n, n,
+                                                  1.0 / n, st)), a.reps)
+    rows.append(("ifft2_crop in-place", ms, 2 * T * tile_bytes))
+    ms = timeit(lambda: y.copy_(x), a.reps)
+    rows.append(("torch copy (HBM ref)", ms, 2 * T * tile_bytes))
+
+    N = T // S
+    side = int(np.ceil(np.sqrt(N)))
+    HW = 8 * side + n + 8
+    rng = np.random.default_rng(0)
+    scan = torch.tensor(1 + rng.random((N, 2)) * (HW - n - 3),
+                        dtype=torch.float32, device=dev)
+    psi = torch.randn(1, HW, HW, dtype=torch.complex64, device=dev)
+    probe = torch.randn(1, 1, S, n, n, dtype=torch.complex64, device=dev)
+    far = y[:N * S]
+    ms = timeit(lambda: check(lib.tike_ptycho_fwd(
+        psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0, None, None, 0, 0,
+        far.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st)), a.reps)
+    rows.append((f"ptycho_fwd S={S}", ms, N * S * tile_bytes + N * tile_bytes))
+    for name, ms, nbytes in rows:
+        print(f"{name:28s} {ms:8.3f} ms  {T / ms / 1e3:8.3f} Mtile/s  "
+              f"{nbytes / ms / 1e6:8.1f} GB/s (algorithmic)")
+
+
+if __name__ == "__main__":
+    main()
