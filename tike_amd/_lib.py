@@ -8,6 +8,12 @@ import ctypes
 import os
 import re
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so).  It must
+# be loaded BEFORE libtike_amd.so so that both bind to the same runtime: with
+# the opposite order the process holds two runtimes and every launch from
+# this library fails with hipErrorNoDevice (100).
+import torch  # noqa: F401  (load order matters, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libtike_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
