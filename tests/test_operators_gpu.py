@@ -326,9 +326,10 @@ def test_farplane_gradient_fused(ops, oracle):
         f = A.to_device(far, np.complex64)
         I = torch.empty((N, det, det), dtype=torch.float32, device=f.device)
         c = torch.empty(N, dtype=torch.float32, device=f.device)
+        d_dev = A.to_device(data_nan, np.float32)  # keep alive over the call
+        m_dev = A.to_device(mask.astype(np.uint8))
         check(lib.tike_farplane_gradient(
-            A.ptr(f), A.ptr(A.to_device(data_nan, np.float32)),
-            A.ptr(A.to_device(mask.astype(np.uint8))), A.ptr(I), A.ptr(c), N,
+            A.ptr(f), A.ptr(d_dev), A.ptr(m_dev), A.ptr(I), A.ptr(c), N,
             S, det, 0 if model == "gaussian" else 1, 1, 0.7, int(mask.sum()),
             A.stream_ptr()))
         assert_close(f.cpu().numpy(), want, normwise=1e-4, maxabs=1e-3,

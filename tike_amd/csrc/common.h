@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "fft_radix.h"
 
@@ -32,7 +33,12 @@ static inline bool tk_is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // Number of persistent workgroups for grid-stride kernels: enough to fill
 // 256 CUs several times over, capped by the amount of work.
 static inline int tk_grid(long work_items, int per_cu = 8) {
-  long cap = 256L * per_cu;
+  // TIKE_GRID_CAP: tuning/experiment override of the workgroup cap
+  static const long env_cap = [] {
+    const char* e = getenv("TIKE_GRID_CAP");
+    return e ? atol(e) : 0L;
+  }();
+  long cap = env_cap > 0 ? env_cap : 256L * per_cu;
   long g = work_items < cap ? work_items : cap;
   return (int)(g < 1 ? 1 : g);
 }

@@ -68,11 +68,11 @@ extern "C" int tike_patch_fwd(const void* images, void* patches, const float* po
                               int nimage, int H, int W, int nscan, int nrepeat, int patch_width,
                               int padded_width, void* stream) {
   TK_ENTER();
-  TK_CHECK_ARG(images && patches && positions);
   TK_CHECK_ARG(nimage >= 1 && H >= 1 && W >= 1 && nscan >= 0 && nrepeat >= 1);
   TK_CHECK_ARG(patch_width >= 1 && patch_width <= padded_width);
   const long nrow = (long)nimage * nscan * patch_width;
   if (nrow == 0) return TK_OK;
+  TK_CHECK_ARG(images && patches && positions);
   hipLaunchKernelGGL((patch_kernel<false>), dim3(tk_grid(nrow, 16)), dim3(256), 0,
                      (hipStream_t)stream, (cf*)images, (cf*)patches, positions, nimage, H, W,
                      nscan, nrepeat, patch_width, padded_width, nscan * nrepeat);
@@ -84,12 +84,12 @@ extern "C" int tike_patch_adj(void* images, const void* patches, const float* po
                               int nimage, int H, int W, int nscan, int nrepeat, int patch_width,
                               int padded_width, int npatch, void* stream) {
   TK_ENTER();
-  TK_CHECK_ARG(images && patches && positions);
   TK_CHECK_ARG(nimage >= 1 && H >= 1 && W >= 1 && nscan >= 0 && nrepeat >= 1);
   TK_CHECK_ARG(patch_width >= 1 && patch_width <= padded_width);
-  TK_CHECK_ARG(npatch >= nrepeat && ((long)nscan * nrepeat) % npatch == 0);
   const long nrow = (long)nimage * nscan * patch_width;
   if (nrow == 0) return TK_OK;
+  TK_CHECK_ARG(images && patches && positions);
+  TK_CHECK_ARG(npatch >= nrepeat && ((long)nscan * nrepeat) % npatch == 0);
   hipLaunchKernelGGL((patch_kernel<true>), dim3(tk_grid(nrow, 16)), dim3(256), 0,
                      (hipStream_t)stream, (cf*)images, (cf*)patches, positions, nimage, H, W,
                      nscan, nrepeat, patch_width, padded_width, npatch);
