@@ -170,9 +170,13 @@ struct FftStage {
 // LOAD_CHUNK > 0 fences the scheduler every LOAD_CHUNK elements of the load
 // phase: for expensive loaders (bilinear gather * probe) this bounds the
 // loads in flight per thread and with it the register footprint.
+// sync_after_load: the loader reads the LDS line buffers themselves (inputs
+// staged there by the caller), so a barrier must separate those reads from
+// the first inter-stage write.
 template <int N, bool INV, bool COL, int LOAD_CHUNK = 0, class Load, class Store>
 __device__ __forceinline__ void fft_lines(cf* __restrict__ lds, const FftLane<N, COL>& ln,
-                                          const FftTw<N>& tw, Load&& load, Store&& store) {
+                                          const FftTw<N>& tw, Load&& load, Store&& store,
+                                          bool sync_after_load = false) {
   using G = FftGeom<N>;
   cf v[G::E];
 #pragma unroll
@@ -181,6 +185,7 @@ __device__ __forceinline__ void fft_lines(cf* __restrict__ lds, const FftLane<N,
     if (LOAD_CHUNK > 0 && (i % (LOAD_CHUNK > 0 ? LOAD_CHUNK : 1)) == LOAD_CHUNK - 1)
       __builtin_amdgcn_sched_barrier(0);
   }
+  if (sync_after_load) __syncthreads();
   FftStage<N, INV, 0>::run(v, lds + ln.line * G::LS, ln.j, tw);
 #pragma unroll
   for (int i = 0; i < G::E; ++i) store(ln.line, ln.j + i * G::T, v[i]);

@@ -42,17 +42,58 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ptycho_fwd_k
         for (int i = threadIdx.x; i < G::L * N; i += G::NT) dst[g * N + i] = mk(0.f, 0.f);
         continue;
       }
-      fft_lines<N, false, false, 4>(
+      // Stage the L input rows (patch * probe, zero padded) into the LDS line
+      // buffers with row-contiguous, fully coalesced loads: thread -> column,
+      // loop over rows, re-using the lower taps of one row as the upper taps
+      // of the next (2 new object loads per pixel instead of 4).
+      for (int x0 = 0; x0 < N; x0 += G::NT) {
+        const int dx = x0 + threadIdx.x;
+        const int px = dx - pad;
+        const int x = c.sx + px;
+        const bool col_ok = dx < N && px >= 0 && px < pw && x >= 0 && x < W;
+        cf t0 = mk(0.f, 0.f), t1 = mk(0.f, 0.f);  // taps of the current object row
+        bool have = false;
+#pragma unroll 4
+        for (int line = 0; line < G::L; ++line) {
+          const int py = g + line - pad;
+          const int y = c.sy + py;
+          cf o = mk(0.f, 0.f);
+          if (col_ok && py >= 0 && py < pw && y >= 0 && y < H) {
+            const long ii = (long)y * W + x;
+            if (!have) {
+              t0 = psi[ii];
+              t1 = (ii + 1 < total) ? psi[ii + 1] : mk(0.f, 0.f);
+            }
+            cf b0 = mk(0.f, 0.f), b1 = mk(0.f, 0.f);
+            // lower taps are loaded whenever they lie inside the allocation
+            // (they become the next row's upper taps); a zero weight makes
+            // their contribution exactly zero, as in the reference kernel.
+            if (ii + W < total) {
+              b0 = psi[ii + W];
+              if (ii + W + 1 < total) b1 = psi[ii + W + 1];
+            }
+            cf v = mk(t0.x * c.w00, t0.y * c.w00);
+            v.x += t1.x * c.w01;
+            v.y += t1.y * c.w01;
+            v.x += b0.x * c.w10;
+            v.y += b0.y * c.w10;
+            v.x += b1.x * c.w11;
+            v.y += b1.y * c.w11;
+            o = v * probe.at(n, s, (long)py * pw + px);
+            t0 = b0;
+            t1 = b1;
+            have = true;
+          } else {
+            have = false;
+          }
+          if (dx < N) lds[line * G::LS + tk_pad16(dx)] = o;
+        }
+      }
+      __syncthreads();
+      fft_lines<N, false, false>(
           lds, row, tw,
-          [&](int line, int e) {
-            const int py = g + line - pad, px = e - pad;
-            const int y = c.sy + py, x = c.sx + px;
-            if (py < 0 || py >= pw || px < 0 || px >= pw || y < 0 || y >= H || x < 0 || x >= W)
-              return mk(0.f, 0.f);
-            const cf o = tk_gather(psi, (long)y * W + x, W, total, c);
-            return o * probe.at(n, s, (long)py * pw + px);
-          },
-          [&](int line, int e, cf v) { dst[(g + line) * N + e] = v; });
+          [&](int line, int e) { return lds[line * G::LS + tk_pad16(e)]; },
+          [&](int line, int e, cf v) { dst[(g + line) * N + e] = v; }, /*sync_after_load=*/true);
     }
     __syncthreads();
     const FftLane<N, true> col = fft_lane<N, true>();
