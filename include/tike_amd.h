@@ -108,6 +108,44 @@ int tike_cost_each_pattern(const float* data, const float* intensity, float* cos
 int tike_objective_grad(const float* data, const void* farplane, const float* intensity,
                         void* out, long nscan, int S, long npix, int model, void* stream);
 
+/* ==== lstsq_grad update loop (ptycho/solvers/lstsq.py), one minibatch ====
+ * chi (nscan,S,pw,pw): exit-wave update = tike_ifft2_crop of the far-plane
+ * gradient.  The probe arguments select P_n,s as in tike_ptycho_fwd. */
+
+/* object_upd_sum (H,W) += scatter_n( sum_s conj(P_n,s) * chi_n,s )
+ * (lstsq.py:510-520 = conj multiply + Patch.adj with nrepeat = S). */
+int tike_object_grad(const void* chi, const float* scan, const void* probe, int probe_per_scan,
+                     const void* eigen_probe, const float* eigen_weights, int num_eigen,
+                     int eigen_modes, void* object_upd_sum, int nscan, int S, int pw, int H,
+                     int W, void* stream);
+
+/* m_probe_update (S,pw,pw) += sum_n conj(patch_n(psi)) * chi_n,s
+ * (lstsq.py:524-539); patches (nscan,pw,pw), if not NULL, receives
+ * patch_n(psi) (the reference's bpatches).  S <= 16. */
+int tike_probe_grad(const void* chi, const float* scan, const void* psi, void* patches,
+                    void* m_probe_update, int nscan, int S, int pw, int H, int W, void* stream);
+
+/* out (pw,pw) c64: real part += sum_n |patch_n(psi)|^2
+ * (solvers/_preconditioner.py:116-167). */
+int tike_probe_preconditioner(const float* scan, const void* psi, void* out, int nscan, int pw,
+                              int H, int W, void* stream);
+
+/* Per-position sums of the 2x2 step-size normal equations for mode 0
+ * (lstsq.py:619-718) and of the eigen-probe intensity coefficients
+ * (lstsq.py:721-738): stats (nscan, 8) f32 =
+ * { sum|dOP|^2, sum|dPO|^2, Re/Im sum dOP conj(dPO), sum Re(conj(dOP) chi0),
+ *   sum Re(conj(dPO) chi0), sum Re(conj(O P_0) chi0), sum|O P_0|^2 },
+ * dOP = patch_n(object_update_precond) * P_n,0, dPO = m_probe_update[0] * O_n,
+ * O_n = patch_n(psi), P_0 = shared probe mode 0.  object_update_precond and
+ * m_probe_update may be NULL (that direction is then zero).  chi is laid out
+ * (nscan, chi_modes, pw, pw) and only its mode 0 is read (chi_modes = 1 when
+ * the caller kept just that mode). */
+int tike_lstsq_step_stats(const void* chi, const float* scan, const void* psi,
+                          const void* object_update_precond, const void* probe,
+                          const void* eigen_probe, const float* eigen_weights, int num_eigen,
+                          int eigen_modes, const void* m_probe_update, float* stats, int nscan,
+                          int S, int chi_modes, int pw, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,204 @@
+"""GPU parity of the update loop: HIP kernels + host driver vs fixtures
+recorded from the reference (tests/golden/gen/make_fixtures.py) and vs the
+oracle."""
+import numpy as np
+import pytest
+
+from util import (assert_close, relerr, COST_RTOL, SOLVER_NORMWISE)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tp():
+    import tike_amd.ptycho as m
+    return m
+
+
+def test_simulate_matches_reference_fixture(tp, golden):
+    """reference tests/ptycho/test_ptycho.py:191-203 (atol 1e-6 on sqrt I)."""
+    g = golden("ref_ptycho_setup.npz")
+    data = tp.simulate(detector_shape=g["data"].shape[-1], probe=g["probe"],
+                       scan=g["scan"], psi=g["original"])
+    assert data.dtype == np.float32 and data.shape == g["data"].shape
+    np.testing.assert_allclose(np.sqrt(data), np.sqrt(g["data"]), atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["plain", "eigen"])
+def test_lstsq_minibatch_kernels_vs_reference(tp, golden, tag):
+    """One minibatch through the HIP kernels == the reference's
+    _get_nearplane_gradients / _precondition_nearplane_gradients /
+    _update_nearplane outputs."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd.communicators import Comm
+    from tike_amd.operators import Ptycho
+    from tike_amd.ptycho.solvers import lstsq as L
+    from tike_amd.ptycho.solvers._preconditioner import (
+        _psi_preconditioner, _probe_preconditioner)
+    g = golden(f"lstsq_parts_{tag}.npz")
+    det = int(g["det"])
+    lo, hi = int(g["batch_lo"]), int(g["batch_hi"])
+    psi, probe, scan = (A.to_device(g[k]) for k in ("psi", "probe", "scan"))
+    data = A.to_device(g["data"], np.float32)
+    ep = A.to_device(g["eigen_probe"]) if "eigen_probe" in g else None
+    ew = A.to_device(g["eigen_weights"]) if "eigen_weights" in g else None
+    params = tp.PtychoParameters(
+        probe=probe, psi=psi, scan=scan, eigen_probe=ep, eigen_weights=ew,
+        algorithm_options=tp.LstsqOptions(num_batch=2),
+        probe_options=tp.ProbeOptions(), object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)).copy_to_device())
+    comm = Comm()
+    HW = psi.shape[-1]
+    with Ptycho(probe_shape=probe.shape[-1], detector_shape=det, nz=HW,
+                n=HW) as op:
+        assert_close(_psi_preconditioner(params, op).cpu().numpy(),
+                     g["psi_precond"], what="psi preconditioner")
+        assert_close(_probe_preconditioner(params, op).cpu().numpy(),
+                     g["probe_precond"], what="probe preconditioner")
+        out = L._get_nearplane_gradients(
+            data, psi, scan, probe, ep, ew, lo, hi, comm, num_batch=2,
+            exitwave_options=params.exitwave_options, op=op, recover_psi=True,
+            recover_probe=True)
+        assert_close(out["object_upd_sum"].cpu().numpy(), g["object_upd_sum"],
+                     normwise=2e-5, what="object_upd_sum")
+        assert_close(out["m_probe_update"].cpu().numpy(), g["m_probe_update"],
+                     normwise=2e-5, what="m_probe_update")
+        assert_close(out["chi0"].cpu().numpy(), g["chi"][:, 0, 0],
+                     normwise=2e-5, what="chi mode 0")
+        np.testing.assert_allclose(float(out["cost"]), g["costs"].mean(),
+                                   rtol=COST_RTOL)
+        if out["patches"] is not None:
+            assert_close(out["patches"].cpu().numpy(), g["patches"][:, 0, 0],
+                         what="patches")
+        precond = L._precondition_object_update(
+            out["object_upd_sum"], A.to_device(g["psi_precond"]))
+        assert_close(precond.cpu().numpy(), g["object_update_precond"],
+                     normwise=2e-5, what="object_update_precond")
+        stats = L._step_stats(out, psi, scan, probe, ep, precond, lo, hi,
+                              op=op)
+        if ew is not None:
+            ep2, ew2 = L._update_nearplane(out, stats, probe, ep.clone(),
+                                           ew.clone(), lo, hi, comm,
+                                           num_batch=2)
+            assert_close(ep2.cpu().numpy(), g["eigen_probe_out"],
+                         normwise=1e-4, maxabs=1e-3, what="eigen_probe")
+            assert_close(ew2.cpu().numpy(), g["eigen_weights_out"],
+                         normwise=1e-4, maxabs=1e-3, what="eigen_weights")
+        bo, bp = L._solve_steps(stats, out["count"], comm,
+                                pw=probe.shape[-1], recover_psi=True,
+                                recover_probe=True)
+        np.testing.assert_allclose(float(bo), g["beta_object"].ravel()[0],
+                                   rtol=1e-3)
+        np.testing.assert_allclose(float(bp), g["beta_probe"].ravel()[0],
+                                   rtol=1e-3)
+
+
+def _reconstruct_like_reference(tp, g, second):
+    import tike_amd.random
+    det = int(g["det"])
+    sizes = g["batch_sizes"]
+    ends = np.cumsum(sizes)
+    batches = [np.arange(e - s, e) for s, e in zip(sizes, ends)]
+    tike_amd.random.randomizer_np = np.random.default_rng(11)
+    adaptive, orth = bool(g["adaptive"]), bool(g["orth"])
+    params = tp.PtychoParameters(
+        probe=g["probe0"].copy(), psi=g["psi0"].copy(), scan=g["scan"].copy(),
+        eigen_probe=g["eigen_probe"].copy() if "eigen_probe" in g else None,
+        eigen_weights=g["eigen_weights"].copy()
+        if "eigen_weights" in g else None,
+        algorithm_options=tp.LstsqOptions(
+            num_batch=int(g["num_batch"]),
+            batch_method=str(g["batch_method"]), num_iter=int(g["epochs"])),
+        probe_options=tp.ProbeOptions(force_orthogonality=orth,
+                                      use_adaptive_moment=adaptive),
+        object_options=tp.ObjectOptions(use_adaptive_moment=adaptive),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    results = []
+    for _ in range(2 if second else 1):
+        with tp.Reconstruction(g["data"], params, order=g["order"],
+                               batches=batches) as ctx:
+            ctx.iterate(int(g["epochs"]))
+            params = ctx.get_result()
+        results.append(params)
+    return results
+
+
+@pytest.mark.parametrize("tag", ["compact", "wobbly_eigen"])
+def test_lstsq_reconstruct_twice_vs_reference(tp, golden, tag):
+    """The reference's ReconstructTwice template (tests/ptycho/templates.py:
+    115-129), asserted against the reference's own iterates."""
+    g = golden(f"lstsq_recon_{tag}.npz")
+    r1, r2 = _reconstruct_like_reference(tp, g, second=True)
+    epochs = int(g["epochs"])
+    np.testing.assert_allclose(
+        np.array(r1.algorithm_options.costs[:epochs]), g["costs_1"],
+        rtol=1e-3)
+    assert_close(r1.psi, g["psi_1"], normwise=SOLVER_NORMWISE, maxabs=1e-2,
+                 what="psi after call 1")
+    assert_close(r1.probe, g["probe_1"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe after call 1")
+    if "eigen_weights" in g:
+        assert_close(r1.eigen_weights, g["eigen_weights_1"], normwise=5e-3,
+                     maxabs=5e-2, what="eigen_weights after call 1")
+        assert_close(r1.eigen_probe, g["eigen_probe_1"], normwise=5e-3,
+                     maxabs=5e-2, what="eigen_probe after call 1")
+    np.testing.assert_allclose(np.array(r2.algorithm_options.costs),
+                               g["costs_2"], rtol=5e-3)
+    assert_close(r2.psi, g["psi_2"], normwise=5e-3, maxabs=5e-2,
+                 what="psi after call 2")
+    assert_close(r2.probe, g["probe_2"], normwise=5e-3, maxabs=5e-2,
+                 what="probe after call 2")
+
+
+def test_cgrad_vs_reference_composition(tp, golden):
+    g = golden("cgrad.npz")
+    det = int(g["det"])
+    N = len(g["scan"])
+    params = tp.PtychoParameters(
+        probe=g["probe"].copy(), psi=g["psi0"].copy(), scan=g["scan"].copy(),
+        algorithm_options=tp.CgradOptions(num_batch=1, cg_iter=4, num_iter=1,
+                                          batch_method="contiguous"),
+        probe_options=None, object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    for i in range(3):
+        params = tp.reconstruct(g["data"], params)
+        np.testing.assert_allclose(params.algorithm_options.costs[-1][0],
+                                   g["costs"][i + 1], rtol=2e-3)
+        assert relerr(params.psi, g["psis"][i]) < 2e-3
+
+
+def test_lstsq_converges_and_resumes(tp):
+    """Cost decreases monotonically on a clean synthetic problem and state
+    round-trips through PtychoParameters (larger, pow-2 sizes)."""
+    rng = np.random.default_rng(0)
+    N, S, pw = 100, 2, 64
+    side = 10
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
+                              indexing="ij"), -1).reshape(-1, 2)
+    scan = (2 + 6.0 * ij + rng.random((N, 2))).astype(np.float32)
+    HW = 6 * (side - 1) + pw + 8
+    psi_true = ((0.75 + 0.25 * rng.random((1, HW, HW))) * np.exp(
+        1j * np.pi * (rng.random((1, HW, HW)) - 0.5))).astype(np.complex64)
+    w = tp.gaussian(pw, rin=0.6)
+    probe = np.stack([w * np.exp(1j * np.pi * rng.random((pw, pw))) / (m + 1)
+                      for m in range(S)])[None, None].astype(np.complex64)
+    data = tp.simulate(pw, probe, scan, psi_true)
+    params = tp.PtychoParameters(
+        probe=probe * (1 + 0.05 * rng.standard_normal(probe.shape)).astype(
+            np.float32), psi=np.full_like(psi_true, 0.5), scan=scan,
+        algorithm_options=tp.LstsqOptions(num_batch=4, num_iter=4,
+                                          batch_method="compact"),
+        probe_options=tp.ProbeOptions(force_orthogonality=True),
+        object_options=tp.ObjectOptions())
+    np.random.seed(0)
+    params = tp.reconstruct(data, params)
+    np.random.seed(0)
+    params = tp.reconstruct(data, params)
+    costs = [c[0] for c in params.algorithm_options.costs]
+    assert len(costs) == 8 and len(params.algorithm_options.times) == 8
+    assert all(np.isfinite(costs))
+    assert costs[-1] < 0.5 * costs[0], costs

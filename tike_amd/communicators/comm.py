@@ -1,0 +1,65 @@
+"""Collectives for the one-process-per-GPU design.
+
+The reference runs one Python thread per GPU and implements its
+"collectives" as serial peer copies + adds onto one device
+(src/tike/communicators/pool.py:300-395, comm.py:96-136).  Here every rank is
+its own process bound to one GPU (torchrun) and the only collective the hot
+path needs is a sum all-reduce, executed by RCCL over xGMI through
+``torch.distributed`` (backend "nccl"; "gloo" on CPU for the tests).
+With a single rank every call is the identity.
+"""
+import torch
+import torch.distributed as dist
+
+
+class Comm:
+    """All-reduce helper bound to a process group (or to a single rank)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.enabled = dist.is_available() and dist.is_initialized()
+        self.size = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, type, value, traceback):
+        pass
+
+    def Allreduce(self, *tensors):
+        """Sum the tensors across ranks IN PLACE; complex tensors are reduced
+        as interleaved float32.  Several tensors are packed into one flat
+        buffer so that a minibatch costs one collective."""
+        if self.size == 1:
+            return tensors if len(tensors) != 1 else tensors[0]
+        views = [
+            torch.view_as_real(t) if t.is_complex() else t for t in tensors
+        ]
+        if len(views) == 1 and views[0].is_contiguous():
+            dist.all_reduce(views[0], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            flat = torch.cat([v.reshape(-1).to(torch.float32) for v in views])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            off = 0
+            for v in views:
+                n = v.numel()
+                v.copy_(flat[off:off + n].reshape(v.shape))
+                off += n
+        return tensors if len(tensors) != 1 else tensors[0]
+
+    def Allreduce_scalars(self, values, device):
+        """Sum a short list of Python/0-d values across ranks -> float64
+        tensor on `device` (one tiny collective)."""
+        t = torch.stack([
+            v.detach().to(device=device, dtype=torch.float64).reshape(())
+            if isinstance(v, torch.Tensor) else torch.tensor(
+                float(v), dtype=torch.float64, device=device) for v in values
+        ])
+        if self.size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def barrier(self):
+        if self.size > 1:
+            dist.barrier(group=self.group)

@@ -1,0 +1,19 @@
+"""Ptychography solvers and helpers (mirror of ``tike.ptycho``)."""
+from .exitwave import ExitWaveOptions
+from .object import (ObjectOptions, get_padded_object, positivity_constraint,
+                     remove_object_ambiguity, smoothness_constraint)
+from .position import PositionOptions, check_allowed_positions
+from .probe import (ProbeOptions, add_modes_random_phase, adjust_probe_power,
+                    constrain_variable_probe, gaussian, get_varying_probe,
+                    init_varying_probe, orthogonalize_eig)
+from .ptycho import Reconstruction, reconstruct, simulate
+from .solvers import (CgradOptions, LstsqOptions, PtychoParameters,
+                      RpieOptions, cgrad, lstsq_grad, update_preconditioners)
+from . import probe, object, position, exitwave, solvers  # noqa: F401,A004
+
+__all__ = [
+    "CgradOptions", "ExitWaveOptions", "LstsqOptions", "ObjectOptions",
+    "PositionOptions", "ProbeOptions", "PtychoParameters", "Reconstruction",
+    "RpieOptions", "cgrad", "check_allowed_positions", "lstsq_grad",
+    "reconstruct", "simulate", "update_preconditioners",
+]

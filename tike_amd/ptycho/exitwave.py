@@ -1,0 +1,49 @@
+"""Exit-wave options (reference src/tike/ptycho/exitwave.py:22-119)."""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+from .. import _arrays as A
+
+
+@dataclasses.dataclass
+class ExitWaveOptions:
+    """Settings of the exit-wave (far-plane) update; same fields and defaults
+    as the reference."""
+
+    measured_pixels: np.ndarray
+    """Boolean (det, det) mask: True = measured pixel, False = bad pixel."""
+
+    noise_model: str = "gaussian"
+    """'gaussian' or 'poisson'."""
+
+    step_length_weight: float = 0.5
+    step_length_usemodes: str = "all_modes"
+    step_length_start: float = 0.5
+
+    unmeasured_pixels_scaling: float = 1.00
+    """Scaling of the far-plane in unmeasured regions; 1.0 = none."""
+
+    propagation_normalization: str = "ortho"
+    """'ortho', 'forward' or 'backward' FFT scaling of the forward model."""
+
+    def _copy(self, measured_pixels):
+        return ExitWaveOptions(
+            measured_pixels=measured_pixels,
+            noise_model=self.noise_model,
+            propagation_normalization=self.propagation_normalization,
+            step_length_start=self.step_length_start,
+            step_length_usemodes=self.step_length_usemodes,
+            step_length_weight=self.step_length_weight,
+            unmeasured_pixels_scaling=self.unmeasured_pixels_scaling,
+        )
+
+    def copy_to_device(self) -> "ExitWaveOptions":
+        return self._copy(A.to_device(np.asarray(A.to_host(
+            self.measured_pixels), dtype=bool)))
+
+    def copy_to_host(self) -> "ExitWaveOptions":
+        return self._copy(np.asarray(A.to_host(self.measured_pixels),
+                                     dtype=bool))

@@ -1,0 +1,110 @@
+"""Object (psi) options and constraints
+(reference src/tike/ptycho/object.py)."""
+from __future__ import annotations
+
+import copy
+import dataclasses
+import typing
+
+import numpy as np
+import torch
+
+from .. import _arrays as A
+from .. import linalg, precision
+
+
+def _to_dev(x):
+    if x is None:
+        return None
+    h = A.to_host(x) if not A.is_device(x) else None
+    if A.is_device(x):
+        return x
+    return A.to_device(h, np.complex64 if np.iscomplexobj(h) else np.float32)
+
+
+@dataclasses.dataclass
+class ObjectOptions:
+    """Settings and state of the object update; same fields and defaults as
+    the reference (object.py:25-81)."""
+
+    convergence_tolerance: float = 0
+    update_mnorm: typing.List[float] = dataclasses.field(init=False,
+                                                         default_factory=list)
+    positivity_constraint: float = 0
+    smoothness_constraint: float = 0
+    use_adaptive_moment: bool = False
+    vdecay: float = 0.999
+    mdecay: float = 0.9
+    v: typing.Any = dataclasses.field(init=False, default=None)
+    m: typing.Any = dataclasses.field(init=False, default=None)
+    preconditioner: typing.Any = dataclasses.field(init=False, default=None)
+    clip_magnitude: bool = False
+    multislice_propagation_distance: float = 1.0e-9
+
+    def _copy(self, f):
+        o = ObjectOptions(
+            convergence_tolerance=self.convergence_tolerance,
+            positivity_constraint=self.positivity_constraint,
+            smoothness_constraint=self.smoothness_constraint,
+            use_adaptive_moment=self.use_adaptive_moment,
+            vdecay=self.vdecay,
+            mdecay=self.mdecay,
+            clip_magnitude=self.clip_magnitude,
+            multislice_propagation_distance=self.
+            multislice_propagation_distance,
+        )
+        o.update_mnorm = copy.copy(self.update_mnorm)
+        o.v, o.m = f(self.v), f(self.m)
+        o.preconditioner = f(self.preconditioner)
+        return o
+
+    def copy_to_device(self) -> "ObjectOptions":
+        return self._copy(_to_dev)
+
+    def copy_to_host(self) -> "ObjectOptions":
+        return self._copy(lambda x: None if x is None else A.to_host(x))
+
+
+def positivity_constraint(x, r):
+    """r*|x| + (1-r)*x (object.py:207-223)."""
+    if r > 0:
+        if r > 1:
+            raise ValueError(
+                f"Positivity constraint must be in the range [0, 1] not {r}.")
+        return r * x.abs() + (1 - r) * x
+    return x
+
+
+def smoothness_constraint(x, a):
+    """3x3 averaging kernel with centre 1-8a, 'nearest' edges
+    (object.py:226-253)."""
+    if 0 <= a and a < 1.0 / 8.0:
+        w = torch.full((1, 1, 3, 3), a, dtype=torch.float32, device=x.device)
+        w[..., 1, 1] = 1.0 - 8.0 * a
+
+        def conv(p):
+            p = torch.nn.functional.pad(p[:, None], (1, 1, 1, 1),
+                                        mode="replicate")
+            return torch.nn.functional.conv2d(p, w)[:, 0]
+
+        return torch.complex(conv(x.real), conv(x.imag))
+    raise ValueError(
+        f"Smoothness constraint must be in range [0, 1/8) not {a}.")
+
+
+def get_padded_object(scan, probe, extra: int = 0):
+    """Ones-initialised (0.5+0j) object and shifted scan (object.py:256-274)."""
+    int_scan = scan // 1
+    min_corner = np.min(int_scan, axis=-2)
+    max_corner = np.max(int_scan, axis=-2)
+    span = max_corner - min_corner + probe.shape[-1] + 2 + 2 * extra
+    return np.full(span.astype(precision.integer), 0.5 + 0j,
+                   dtype=precision.cfloating), scan + 1 - min_corner + extra
+
+
+def remove_object_ambiguity(psi, probe, preconditioner):
+    """Normalise the object / probe scaling ambiguity (object.py:324-335)."""
+    W = preconditioner.real
+    W = W / linalg.mnorm(W)
+    object_norm = 2 * torch.sqrt(torch.mean(torch.square(psi.abs()) * W))
+    return psi / object_norm, probe * object_norm

@@ -1,0 +1,11 @@
+"""Solver implementations (mirror of ``tike.ptycho.solvers``)."""
+from ._preconditioner import update_preconditioners
+from .cgrad import cgrad
+from .lstsq import lstsq_grad
+from .options import (CgradOptions, IterativeOptions, LstsqOptions,
+                      PtychoParameters, RpieOptions)
+
+__all__ = [
+    "cgrad", "CgradOptions", "IterativeOptions", "lstsq_grad", "LstsqOptions",
+    "PtychoParameters", "RpieOptions", "update_preconditioners",
+]

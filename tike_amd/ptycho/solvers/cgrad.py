@@ -1,0 +1,125 @@
+"""Conjugate-gradient ptychography solver.
+
+The reference snapshot ships no ptychography ``cgrad``; it is
+composed here, as BASELINE's configs ask, from the reference's own pieces:
+``tike.opt.conjugate_gradient`` (opt.py:312-380: Dai-Yuan direction,
+backtracking line search), the gaussian cost ``Ptycho.cost`` (ptycho.py:193-204)
+and the gradient ``Ptycho.adj(gaussian_grad(...))`` (objective.py:31-44),
+following the multi-GPU pattern of lamino/solvers/cgrad.py:58-92: the cost and
+the gradient are summed over ranks, every rank then takes the same step.
+"""
+import numpy as np
+import torch
+
+from ... import _arrays as A
+from ... import opt
+from ..._lib import check, lib
+from ...operators.propagation import fft_scales
+from .lstsq import _workspace, chunk_positions, mask_info
+
+
+def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
+                   want_grad):
+    """Global gaussian cost (mean over all positions and pixels) and,
+    optionally, d cost / d psi and d cost / d probe (unnormalised adjoints)."""
+    dev = psi.device
+    N = scan.shape[0]
+    S, pw = probe.shape[-3], probe.shape[-1]
+    det = op.detector_shape
+    H, W = psi.shape[-2:]
+    ws = _workspace(op)
+    st = A.stream_ptr()
+    inv_scale = fft_scales(det, op.norm)[1]
+    chunk = chunk_positions(S, det)
+    far = ws.get("far", (min(chunk, max(N, 1)), 1, S, det, det),
+                 torch.complex64, dev)
+    chi_ws = None if pw == det else ws.get(
+        "chi", (min(chunk, max(N, 1)), 1, S, pw, pw), torch.complex64, dev)
+    costs = ws.get("costs", (max(N, 1),), torch.float32, dev)
+    gpsi = torch.zeros_like(psi) if (want_grad and want_psi) else None
+    gprobe = torch.zeros_like(probe) if (want_grad and want_probe) else None
+    for lo in range(0, N, chunk):
+        hi = min(N, lo + chunk)
+        n = hi - lo
+        op.fwd_device(probe, scan[lo:hi], psi, out=far[:n])
+        # gaussian cost per pattern; with the gradient requested the farplane
+        # becomes -grad (sign flipped back below)
+        check(
+            lib.tike_farplane_gradient(A.ptr(far), A.ptr(data[lo:hi]), None,
+                                       None, A.ptr(costs[lo:hi]), n, S, det, 0,
+                                       int(want_grad), 1.0, det * det, st),
+            "cgrad cost")
+        if not want_grad:
+            continue
+        chi = far if chi_ws is None else chi_ws
+        check(
+            lib.tike_ifft2_crop(A.ptr(far), A.ptr(far), A.ptr(chi), n * S, det,
+                                pw, inv_scale, st), "cgrad ifft2")
+        if gpsi is not None:
+            check(
+                lib.tike_object_grad(A.ptr(chi), A.ptr(scan[lo:hi]),
+                                     A.ptr(probe), 0, None, None, 0, 0,
+                                     A.ptr(gpsi), n, S, pw, H, W, st),
+                "cgrad object gradient")
+        if gprobe is not None:
+            check(
+                lib.tike_probe_grad(A.ptr(chi), A.ptr(scan[lo:hi]), A.ptr(psi),
+                                    None, A.ptr(gprobe), n, S, pw, H, W, st),
+                "cgrad probe gradient")
+    tot = comm.Allreduce_scalars([costs[:N].sum(), N], dev)
+    cost = float((tot[0] / tot[1]).item())
+    grads = [t for t in (gpsi, gprobe) if t is not None]
+    if grads and comm.size > 1:
+        comm.Allreduce(*grads)
+    if gpsi is not None:
+        gpsi = -gpsi
+    if gprobe is not None:
+        gprobe = -gprobe
+    return cost, gpsi, gprobe
+
+
+def cgrad(parameters, data, batches, comm, *, op, epoch):
+    """One epoch: for every minibatch, `cg_iter` CG iterations on psi and
+    then (when probe recovery is on) on the probe."""
+    o = parameters.algorithm_options
+    if parameters.eigen_probe is not None or parameters.eigen_weights is not None:
+        raise NotImplementedError("cgrad does not support eigen probes")
+    recover_psi = parameters.object_options is not None
+    recover_probe = (parameters.probe_options is not None
+                     and epoch >= parameters.probe_options.update_start)
+    psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
+    batch_cost = []
+    for b in batches:
+        lo = int(b[0]) if len(b) else 0
+        hi = lo + len(b)
+        d, s = data[lo:hi], scan[lo:hi]
+        cost = None
+        if recover_psi:
+            psi, cost = opt.conjugate_gradient(
+                torch, x=psi,
+                cost_function=lambda x: _cost_and_grad(
+                    op, comm, d, x, s, probe, want_psi=True, want_probe=False,
+                    want_grad=False)[0],
+                grad=lambda x: [_cost_and_grad(
+                    op, comm, d, x, s, probe, want_psi=True, want_probe=False,
+                    want_grad=True)[1]],
+                dir_multi=lambda x: x[0], num_iter=o.cg_iter,
+                step_length=o.step_length)
+        if recover_probe:
+            probe, cost = opt.conjugate_gradient(
+                torch, x=probe,
+                cost_function=lambda x: _cost_and_grad(
+                    op, comm, d, psi, s, x, want_psi=False, want_probe=True,
+                    want_grad=False)[0],
+                grad=lambda x: [_cost_and_grad(
+                    op, comm, d, psi, s, x, want_psi=False, want_probe=True,
+                    want_grad=True)[2]],
+                dir_multi=lambda x: x[0], num_iter=o.cg_iter,
+                step_length=o.step_length)
+        if cost is None:
+            cost = _cost_and_grad(op, comm, d, psi, s, probe, want_psi=False,
+                                  want_probe=False, want_grad=False)[0]
+        batch_cost.append(cost)
+    o.costs.append([float(np.mean(batch_cost))])
+    parameters.psi, parameters.probe = psi, probe
+    return parameters

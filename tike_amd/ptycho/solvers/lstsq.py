@@ -1,0 +1,422 @@
+"""Least-squares + gradient solver (Odstrcil 2018 LSQ-ML)
+(reference src/tike/ptycho/solvers/lstsq.py:25-858).
+
+One call = one epoch over this rank's share of every minibatch.  All
+per-position x per-pixel work runs in the HIP kernels of ``tike_amd/csrc``
+(fused forward, far-plane gradient, IFFT2+crop, object scatter, probe
+gradient, step-size normal equations); the arrays left to torch are psi-,
+probe- and (positions,)-sized.
+
+Differences from the reference that do not change the mathematics:
+  * the per-position ("unique") probe is never materialised: kernels
+    synthesise ``w0*probe + sum_c w_c*eigen_c`` on the fly;
+  * a minibatch is processed in chunks sized for the GPU, and only mode 0 of
+    the exit-wave update ``chi`` survives a chunk (the step-size and
+    eigen-probe passes need nothing else);
+  * positions are sharded over ranks: every sum / mean over positions is
+    completed by an RCCL all-reduce (``comm``), so P GPUs follow the 1-GPU
+    iterates up to summation order.
+"""
+import logging
+
+import numpy as np
+import torch
+
+from ... import _arrays as A
+from ... import linalg
+from ... import opt
+from ... import random as trandom
+from ..._lib import check, lib
+from ...operators.propagation import fft_scales
+
+logger = logging.getLogger(__name__)
+
+_MODELS = {"gaussian": 0, "poisson": 1}
+
+
+class _Workspace:
+    """Device buffers reused across minibatches (keyed on the operator)."""
+
+    def __init__(self):
+        self.buffers = {}
+
+    def get(self, name, shape, dtype, device):
+        n = int(np.prod(shape))
+        buf = self.buffers.get(name)
+        if (buf is None or buf.numel() < n or buf.dtype != dtype
+                or buf.device != device):
+            buf = torch.empty(n, dtype=dtype, device=device)
+            self.buffers[name] = buf
+        return buf[:n].view(*shape)
+
+
+def _workspace(op):
+    ws = getattr(op, "_tike_amd_workspace", None)
+    if ws is None:
+        ws = op._tike_amd_workspace = _Workspace()
+    return ws
+
+
+def chunk_positions(S, det):
+    """Positions per kernel launch: enough (position, mode) tiles to fill the
+    chip several times over while bounding the far-plane workspace."""
+    tiles = max(2048, (1 << 28) // (det * det * 8))  # >= 2048 tiles or 256 MiB
+    return max(64, tiles // max(S, 1))
+
+
+def mask_info(exitwave_options):
+    """(number of measured pixels, uint8 device mask or None when every pixel
+    is measured); computed once and cached on the options object."""
+    info = exitwave_options.__dict__.get("_mask_info")
+    if info is None:
+        mask = exitwave_options.measured_pixels
+        mask = mask if A.is_device(mask) else A.to_device(
+            np.asarray(mask, dtype=bool))
+        n = int(mask.sum().item())
+        info = (n, None if n == mask.numel() else mask.to(
+            torch.uint8).contiguous())
+        exitwave_options.__dict__["_mask_info"] = info
+    return info
+
+
+def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
+    """Advance psi / probe / eigen probes by one epoch (lstsq.py:25-294)."""
+    scan = parameters.scan
+    psi = parameters.psi
+    probe = parameters.probe
+    algorithm_options = parameters.algorithm_options
+    eigen_weights = parameters.eigen_weights
+    eigen_probe = parameters.eigen_probe
+    exitwave_options = parameters.exitwave_options
+    object_options = parameters.object_options
+    probe_options = parameters.probe_options
+    if parameters.position_options is not None:
+        raise NotImplementedError(
+            "position correction is not accelerated yet (DESIGN.md: next)")
+    if exitwave_options.noise_model != "gaussian":
+        raise NotImplementedError(
+            "only the gaussian noise model is accelerated (DESIGN.md: next)")
+    recover_probe = (probe_options is not None
+                     and epoch >= probe_options.update_start)
+    recover_psi = object_options is not None
+    num_batch = algorithm_options.num_batch
+    compact = algorithm_options.batch_method == "compact"
+    order = (range(num_batch) if compact else
+             trandom.randomizer_np.permutation(num_batch))
+
+    object_combined_update = torch.zeros_like(psi)
+    probe_combined_update = torch.zeros_like(probe)
+    batch_cost = torch.zeros(num_batch, dtype=torch.float32, device=psi.device)
+    beta_object, beta_probe = [], []
+
+    for batch_index in order:
+        lo = int(batches[batch_index][0]) if len(batches[batch_index]) else 0
+        hi = lo + len(batches[batch_index])
+        g = _get_nearplane_gradients(
+            data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi, comm,
+            num_batch=num_batch, exitwave_options=exitwave_options, op=op,
+            recover_psi=recover_psi, recover_probe=recover_probe)
+
+        object_update_precond = None
+        if recover_psi:
+            object_update_precond = _precondition_object_update(
+                g["object_upd_sum"], object_options.preconditioner)
+        stats = _step_stats(g, psi, scan, probe, eigen_probe,
+                            object_update_precond, lo, hi, op=op)
+
+        if recover_probe and eigen_weights is not None:
+            eigen_probe, eigen_weights = _update_nearplane(
+                g, stats, probe, eigen_probe, eigen_weights, lo, hi, comm,
+                num_batch=num_batch)
+
+        bbeta_object, bbeta_probe = _solve_steps(
+            stats, g["count"], comm, pw=probe.shape[-1],
+            recover_psi=recover_psi, recover_probe=recover_probe)
+
+        if recover_psi:
+            if not compact:
+                dpsi = bbeta_object * object_update_precond
+                if object_options.use_adaptive_moment:
+                    dpsi, object_options.v, object_options.m = opt.momentum(
+                        g=dpsi, v=object_options.v, m=object_options.m,
+                        vdecay=object_options.vdecay,
+                        mdecay=object_options.mdecay)
+                psi = psi + dpsi
+            else:
+                object_combined_update += g["object_upd_sum"]
+            beta_object.append(bbeta_object)
+
+        if recover_probe:
+            dprobe = bbeta_probe * g["m_probe_update"]
+            probe_combined_update += dprobe / num_batch
+            probe += dprobe
+            beta_probe.append(bbeta_probe)
+
+        batch_cost[batch_index] = g["cost"]
+
+    algorithm_options.costs.append([float(batch_cost.mean().item())])
+
+    if recover_psi and compact:
+        object_update_precond = _precondition_object_update(
+            object_combined_update, object_options.preconditioner)
+        bo = torch.mean(torch.stack(beta_object))
+        dpsi = bo * object_update_precond
+        psi = psi + dpsi
+        if object_options.use_adaptive_moment:
+            dpsi, object_options.v, object_options.m = _momentum_checked(
+                g=dpsi, v=object_options.v, m=object_options.m,
+                mdecay=object_options.mdecay,
+                errors=[float(x[0]) for x in algorithm_options.costs[-3:]],
+                beta=bo, memory_length=3)
+            weight = object_options.preconditioner
+            weight = weight / (0.1 * weight.real.max() + weight)
+            psi = psi + weight * dpsi
+
+    if recover_probe and probe_options.use_adaptive_moment:
+        bp = torch.mean(torch.stack(beta_probe))
+        dprobe = probe_combined_update
+        if probe_options.v is None:
+            probe_options.v = torch.zeros((3, *dprobe.shape),
+                                          dtype=dprobe.dtype,
+                                          device=dprobe.device)
+        if probe_options.m is None:
+            probe_options.m = torch.zeros_like(dprobe)
+        mode = 0  # ptychoshelves only applies momentum to the main probe
+        (d, probe_options.v[..., mode, :, :],
+         probe_options.m[..., mode, :, :]) = _momentum_checked(
+             g=dprobe[..., mode, :, :], v=probe_options.v[..., mode, :, :],
+             m=probe_options.m[..., mode, :, :], mdecay=probe_options.mdecay,
+             errors=[float(x[0]) for x in algorithm_options.costs[-3:]],
+             beta=bp, memory_length=3)
+        probe[..., mode, :, :] = probe[..., mode, :, :] + d
+
+    parameters.scan = scan
+    parameters.psi = psi
+    parameters.probe = probe
+    parameters.eigen_weights = eigen_weights
+    parameters.eigen_probe = eigen_probe
+    return parameters
+
+
+def _eigen_args(eigen_probe, weights):
+    """(eigen ptr, weights tensor, C, Sm) for the on-the-fly varying probe."""
+    if weights is None:
+        return None, None, 0, 0
+    C = Sm = 0
+    if eigen_probe is not None:
+        C, Sm = eigen_probe.shape[-4], eigen_probe.shape[-3]
+    assert weights.shape[1] == C + 1, (weights.shape, C)
+    return eigen_probe, weights, C, Sm
+
+
+def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
+                             eigen_weights, lo, hi, comm, *, num_batch,
+                             exitwave_options, op, recover_psi, recover_probe):
+    """Object / probe gradients of one minibatch (lstsq.py:367-602)."""
+    dev = psi.device
+    B = hi - lo
+    S, pw = probe.shape[-3], probe.shape[-1]
+    det = op.detector_shape
+    H, W = psi.shape[-2:]
+    ws = _workspace(op)
+    st = A.stream_ptr()
+    fwd_scale, inv_scale = fft_scales(det, op.norm)
+    nmeasured, mask_u8 = mask_info(exitwave_options)
+
+    # old weights: the step-size pass must see the probe this gradient used
+    w_old = None
+    if eigen_weights is not None:
+        w_old = eigen_weights[lo:hi].clone()
+    ep, _, C, Sm = _eigen_args(eigen_probe, w_old)
+
+    object_upd_sum = torch.zeros_like(psi) if recover_psi else None
+    m_probe_update = torch.zeros_like(probe) if recover_probe else None
+    chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
+    patches = None
+    if recover_probe and eigen_weights is not None:
+        patches = ws.get("patches", (max(B, 1), pw, pw), torch.complex64, dev)
+    costs = ws.get("costs", (max(B, 1),), torch.float32, dev)
+    chunk = chunk_positions(S, det)
+    far = ws.get("far", (min(chunk, max(B, 1)), 1, S, det, det),
+                 torch.complex64, dev)
+    chi_ws = None
+    if pw != det:
+        chi_ws = ws.get("chi", (min(chunk, max(B, 1)), 1, S, pw, pw),
+                        torch.complex64, dev)
+
+    for clo in range(lo, hi, chunk):
+        chi_hi = min(hi, clo + chunk)
+        n = chi_hi - clo
+        blo = clo - lo
+        w_c = None if w_old is None else w_old[blo:blo + n]
+        op.fwd_device(probe, scan[clo:chi_hi], psi, eigen_probe, w_c,
+                      out=far[:n])
+        check(
+            lib.tike_farplane_gradient(
+                A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), None,
+                A.ptr(costs[blo:blo + n]), n, S, det,
+                _MODELS[exitwave_options.noise_model], 1,
+                float(exitwave_options.unmeasured_pixels_scaling), nmeasured,
+                st), "farplane gradient")
+        chi = far if chi_ws is None else chi_ws
+        check(
+            lib.tike_ifft2_crop(A.ptr(far), A.ptr(far), A.ptr(chi), n * S, det,
+                                pw, inv_scale, st), "ifft2 + crop")
+        if recover_psi:
+            check(
+                lib.tike_object_grad(A.ptr(chi), A.ptr(scan[clo:chi_hi]),
+                                     A.ptr(probe), 0, A.ptr(ep), A.ptr(w_c), C,
+                                     Sm, A.ptr(object_upd_sum), n, S, pw, H, W,
+                                     st), "object gradient")
+        if recover_probe:
+            check(
+                lib.tike_probe_grad(
+                    A.ptr(chi), A.ptr(scan[clo:chi_hi]), A.ptr(psi),
+                    None if patches is None else A.ptr(patches[blo:blo + n]),
+                    A.ptr(m_probe_update), n, S, pw, H, W, st),
+                "probe gradient")
+        chi0[blo:blo + n] = chi[:n, 0, 0]
+
+    # complete the sums over positions across ranks
+    cost_sum = costs[:B].sum() if B > 0 else torch.zeros((), device=dev)
+    reduced = [t for t in (object_upd_sum, m_probe_update) if t is not None]
+    if comm.size > 1:
+        comm.Allreduce(*reduced)
+    tot = comm.Allreduce_scalars([cost_sum, B], dev)
+    if recover_probe:
+        m_probe_update = m_probe_update / num_batch
+    return dict(chi0=chi0[:B], w_old=w_old, patches=None if patches is None
+                else patches[:B], object_upd_sum=object_upd_sum,
+                m_probe_update=m_probe_update,
+                cost=(tot[0] / tot[1]).to(torch.float32), count=tot[1],
+                local_count=B)
+
+
+def _precondition_object_update(object_upd_sum, psi_update_denominator,
+                                alpha=0.05):
+    """g / sqrt(((1-a) P)^2 + (a max P)^2) (lstsq.py:605-616)."""
+    pmax = torch.amax(psi_update_denominator.real, dim=(-2, -1), keepdim=True)
+    return object_upd_sum / torch.sqrt(
+        torch.square((1 - alpha) * psi_update_denominator) +
+        torch.square(alpha * pmax))
+
+
+def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
+                hi, *, op):
+    """Per-position sums of the normal equations (HIP; lstsq.py:652-694)."""
+    B = hi - lo
+    dev = psi.device
+    S, pw = probe.shape[-3], probe.shape[-1]
+    stats = _workspace(op).get("stats", (max(B, 1), 8), torch.float32, dev)
+    ep, w_old, C, Sm = _eigen_args(eigen_probe, g["w_old"])
+    check(
+        lib.tike_lstsq_step_stats(
+            A.ptr(g["chi0"]), A.ptr(scan[lo:hi]), A.ptr(psi),
+            A.ptr(object_update_precond), A.ptr(probe), A.ptr(ep),
+            A.ptr(w_old), C, Sm, A.ptr(g["m_probe_update"]), A.ptr(stats), B,
+            S, 1, pw, psi.shape[-2], psi.shape[-1], A.stream_ptr()),
+        "step-size statistics")
+    return stats[:B]
+
+
+def _solve_steps(stats, count, comm, *, pw, recover_psi, recover_probe):
+    """2x2 least-squares step sizes, averaged over the minibatch
+    (lstsq.py:641-718).  Means over positions are global (all ranks)."""
+    dev = stats.device
+    eps_total = np.float32(np.float32(1e-9) / (pw * pw)) * (pw * pw)
+    A1 = stats[:, 0] + eps_total
+    A4 = stats[:, 1] + eps_total
+    sums = comm.Allreduce_scalars([A1.sum(), A4.sum()], dev)
+    A1 = A1 + (0.5 * sums[0] / count).to(torch.float32)
+    A4 = A4 + (0.5 * sums[1] / count).to(torch.float32)
+    b1, b2 = stats[:, 4], stats[:, 5]
+    x1 = x2 = None
+    if recover_psi and recover_probe:
+        A2 = torch.complex(stats[:, 2], stats[:, 3])
+        A3 = A2.conj()
+        determinant = A1 * A4 - A2 * A3
+        x1 = -torch.conj(A2 * b2 - A4 * b1) / determinant
+        x2 = torch.conj(A1 * b2 - A3 * b1) / determinant
+    elif recover_psi:
+        x1 = b1 / A1
+    elif recover_probe:
+        x2 = b2 / A4
+    zero = torch.zeros((), dtype=torch.float32, device=dev)
+    so = (0.9 * torch.clamp(x1.real, min=0)).sum() if recover_psi else zero
+    sp = (0.9 * torch.clamp(x2.real, min=0)).sum() if recover_probe else zero
+    tot = comm.Allreduce_scalars([so, sp], dev)
+    beta_object = (tot[0] / count).to(torch.float32) if recover_psi else None
+    beta_probe = (tot[1] / count).to(torch.float32) if recover_probe else None
+    return beta_object, beta_probe
+
+
+def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
+                      comm, *, num_batch):
+    """Eigen-probe ("OPR") update for mode 0 (lstsq.py:297-364, 721-761;
+    probe.py:362-476).  Means over positions are global."""
+    m = 0
+    dev = probe.device
+    count = g["count"]
+    # (lstsq.py:721-738) weights of the shared probe
+    eigen_weights[lo:hi, 0, m] += 0.1 * stats[:, 6] / stats[:, 7]
+    if eigen_weights.shape[-2] <= 1 or eigen_probe is None:
+        return eigen_probe, eigen_weights
+    if m >= eigen_probe.shape[-3]:
+        return eigen_probe, eigen_weights
+    assert eigen_weights.shape[-2] == eigen_probe.shape[-4] + 1
+    chi0, patches = g["chi0"], g["patches"]
+    probe_update0 = patches.conj() * chi0  # (B, pw, pw)
+    R = probe_update0 - g["m_probe_update"][0, 0, m]
+    beta = min(0.1, 1.0 / num_batch)
+    P = R.shape[-1] * R.shape[-2]
+    for c in range(1, eigen_probe.shape[-4] + 1):
+        E = eigen_probe[0, c - 1, m]
+        w = eigen_weights[lo:hi, c, m]
+        norm_weights = comm.Allreduce_scalars([torch.sum(w * w)], dev)[0].to(
+            torch.float32)
+        # a batch whose weights are all zero would divide by zero; the
+        # reference raises ValueError after a host sync (probe.py:426) --
+        # here the check is deferred to the end of the epoch (NaN costs).
+        proj_mean = (torch.sum((R.conj() * E).real, dim=(-2, -1)) / P +
+                     w) / norm_weights
+        update = torch.sum(R * proj_mean[:, None, None], dim=0)
+        if comm.size > 1:
+            comm.Allreduce(update)
+        update = update / count.to(torch.float32)
+        E = E + beta * update / linalg.mnorm(update)
+        E = E / linalg.mnorm(E)
+        eigen_probe[0, c - 1, m] = E
+        # new weights for the updated eigen probe
+        phi = patches * E
+        n = torch.mean((chi0 * phi.conj()).real, dim=(-1, -2))
+        d = torch.mean(torch.square(phi.abs()), dim=(-1, -2))
+        d_mean = (comm.Allreduce_scalars([d.sum()], dev)[0] / count).to(
+            torch.float32)
+        eigen_weights[lo:hi, c, m] += n / (d + 0.1 * d_mean)
+        if c + 1 < eigen_weights.shape[-2]:
+            # remove the projection of R onto the updated eigen probe
+            coef = torch.sum(R * E.conj(), dim=(-2, -1),
+                             keepdim=True) / torch.sum(E * E.conj())
+            R = R - coef * E
+    return eigen_probe, eigen_weights
+
+
+def _momentum_checked(g, v, m, mdecay, errors, beta=1.0, memory_length=3):
+    """Momentum only while the cost trends downward and the recent update
+    directions agree (lstsq.py:809-858)."""
+    m = torch.zeros_like(g) if m is None else m
+    previous_g = (torch.zeros((memory_length, *g.shape), dtype=g.dtype,
+                              device=g.device) if v is None else v)
+    previous_g = torch.roll(previous_g, shifts=-1, dims=0)
+    previous_g[-1] = g / linalg.norm(g) * beta
+    if (len(errors) > 2
+            and max(errors[-3], errors[-2]) > min(errors[-2], errors[-1])):
+        corr = linalg.inner(previous_g[:-1], previous_g[-1],
+                            axis=(-2, -1)).real.flatten().cpu().numpy()
+        if np.all(corr > 0):
+            friction, _ = opt.fit_line_least_squares(
+                x=np.arange(len(corr) + 1), y=[0] + np.log(corr).tolist())
+            friction = 0.5 * max(-friction, 0)
+            m = (1 - friction) * m + g
+            return mdecay * m, previous_g, m
+    return torch.zeros_like(g), previous_g, m / 2
