@@ -125,6 +125,13 @@ int tike_object_grad(const void* chi, const float* scan, const void* probe, int 
 int tike_probe_grad(const void* chi, const float* scan, const void* psi, void* patches,
                     void* m_probe_update, int nscan, int S, int pw, int H, int W, void* stream);
 
+/* out (H,W) c64: real part += scatter_n( sum_s |probe_s|^2 ), the object
+ * preconditioner (solvers/_preconditioner.py:48-104 = Patch.adj of one
+ * broadcast patch).  probe (S,pw,pw) shared.  Positions must satisfy
+ * check_allowed_positions (position.py:600-628); so must tike_object_grad's. */
+int tike_psi_preconditioner(const void* probe, const float* scan, void* out, int nscan, int S,
+                            int pw, int H, int W, void* stream);
+
 /* out (pw,pw) c64: real part += sum_n |patch_n(psi)|^2
  * (solvers/_preconditioner.py:116-167). */
 int tike_probe_preconditioner(const float* scan, const void* psi, void* out, int nscan, int pw,

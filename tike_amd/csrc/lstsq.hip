@@ -12,7 +12,89 @@
 #include "internal.h"
 #include "tike_amd.h"
 
+// ------------------------------------------------- footprint scatter-add
+// Adjoint of the bilinear patch gather with ONE atomic per object pixel and
+// position instead of four per patch pixel: the patch value v[y][x] reaches
+// the (pw+1)^2 object pixels (sy+y', sx+x') with
+//   f[y'][x'] = (1-fy) u[y'][x'] + fy u[y'-1][x'],
+//   u[y'][x'] = (1-fx) v[y'][x'] + fx v[y'][x'-1]          (v = 0 outside)
+// which expands to the reference's four products w00..w11 (convolution.cu:
+// 130-135).  A workgroup owns a strip of rows of one position; a thread owns
+// a column, walks down the strip keeping u[y'-1] in registers and takes its
+// left neighbour's v by wave shuffle.  Requires positions that keep the patch
+// inside the image (check_allowed_positions, position.py:600-628); pixels
+// falling outside are dropped.
+constexpr int TK_STRIP = 32;
+
+template <bool REAL_ONLY, class ValueFn>
+__device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorner& c,
+                                                  float fx, float fy, float* __restrict__ imf,
+                                                  int pw, int H, int W, int strip) {
+  const int r0 = strip * TK_STRIP;
+  const int r1 = min(pw + 1, r0 + TK_STRIP);  // rows y' in [r0, r1)
+  for (int x0 = 0; x0 < pw; x0 += blockDim.x) {
+    const int xp = x0 + threadIdx.x;  // column x' (also the patch column)
+    const bool active = xp < pw;
+    cf uprev = mk(0.f, 0.f), uprev_last = mk(0.f, 0.f);
+    for (int yp = max(r0 - 1, 0); yp < r1; ++yp) {
+      cf v = mk(0.f, 0.f);
+      if (active && yp < pw) v = value(yp, xp);
+      // left neighbour v[yp][xp-1]
+      cf left = mk(__shfl_up(v.x, 1, 64), __shfl_up(v.y, 1, 64));
+      if ((threadIdx.x & 63) == 0)
+        left = (active && xp > 0 && yp < pw) ? value(yp, xp - 1) : mk(0.f, 0.f);
+      const cf u = mk((1.0f - fx) * v.x + fx * left.x, (1.0f - fx) * v.y + fx * left.y);
+      // the thread owning the last patch column also produces column x' = pw
+      const cf ulast = mk(fx * v.x, fx * v.y);
+      if (yp >= r0 && active) {
+        const int Y = c.sy + yp;
+        if (Y >= 0 && Y < H) {
+          const int X = c.sx + xp;
+          if (X >= 0 && X < W) {
+            const long ii = (long)Y * W + X;
+            unsafeAtomicAdd(&imf[2 * ii], (1.0f - fy) * u.x + fy * uprev.x);
+            if (!REAL_ONLY) unsafeAtomicAdd(&imf[2 * ii + 1], (1.0f - fy) * u.y + fy * uprev.y);
+          }
+          if (xp == pw - 1 && X + 1 >= 0 && X + 1 < W) {
+            const long ii = (long)Y * W + X + 1;
+            unsafeAtomicAdd(&imf[2 * ii], (1.0f - fy) * ulast.x + fy * uprev_last.x);
+            if (!REAL_ONLY)
+              unsafeAtomicAdd(&imf[2 * ii + 1], (1.0f - fy) * ulast.y + fy * uprev_last.y);
+          }
+        }
+      }
+      uprev = u;
+      uprev_last = ulast;
+    }
+  }
+}
+
 // ----------------------------------------------------------- object gradient
+// object_upd_sum += scatter_n( sum_s conj(P_n,s) chi_n,s )   (lstsq.py:510-520)
+__global__ __launch_bounds__(256) void object_grad_kernel(const cf* __restrict__ chi,
+                                                          const float* __restrict__ scan,
+                                                          const TkProbe probe,
+                                                          float* __restrict__ imf, int nscan,
+                                                          int S, int pw, int H, int W) {
+  const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
+  const long P = (long)pw * pw;
+  for (long w = blockIdx.x; w < (long)nscan * nstrip; w += gridDim.x) {
+    const long n = w / nstrip;
+    const int strip = (int)(w % nstrip);
+    const TkCorner c = tk_corner(scan, n);
+    const float fy = scan[2 * n] - floorf(scan[2 * n]);
+    const float fx = scan[2 * n + 1] - floorf(scan[2 * n + 1]);
+    scatter_footprint<false>(
+        [&](int y, int x) {
+          const long p = (long)y * pw + x;
+          cf v = mk(0.f, 0.f);
+          for (int s = 0; s < S; ++s) v = v + conjf(probe.at(n, s, p)) * chi[(n * S + s) * P + p];
+          return v;
+        },
+        c, fx, fy, imf, pw, H, W, strip);
+  }
+}
+
 extern "C" int tike_object_grad(const void* chi, const float* scan, const void* probe,
                                 int probe_per_scan, const void* eigen_probe,
                                 const float* eigen_weights, int num_eigen, int eigen_modes,
@@ -20,10 +102,57 @@ extern "C" int tike_object_grad(const void* chi, const float* scan, const void* 
                                 void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
-  return tk_conv_adj((const cf*)chi, scan,
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && H >= 1 && W >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(chi && scan && probe && object_upd_sum);
+  const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
+  hipLaunchKernelGGL(object_grad_kernel, dim3(tk_grid((long)nscan * nstrip, 16)), dim3(256), 0,
+                     (hipStream_t)stream, (const cf*)chi, scan,
                      tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
                                    eigen_modes, S, pw),
-                     (cf*)object_upd_sum, nscan, S, pw, pw, H, W, (hipStream_t)stream);
+                     (float*)object_upd_sum, nscan, S, pw, H, W);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// ------------------------------------------------------ psi preconditioner
+// out (H,W) complex: real part += scatter_n( sum_s |probe_s|^2 )
+// (solvers/_preconditioner.py:48-104: Patch.adj of one broadcast patch).
+__global__ __launch_bounds__(256) void psi_precond_kernel(const cf* __restrict__ probe,
+                                                          const float* __restrict__ scan,
+                                                          float* __restrict__ imf, int nscan,
+                                                          int S, int pw, int H, int W) {
+  const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
+  const long P = (long)pw * pw;
+  for (long w = blockIdx.x; w < (long)nscan * nstrip; w += gridDim.x) {
+    const long n = w / nstrip;
+    const int strip = (int)(w % nstrip);
+    const TkCorner c = tk_corner(scan, n);
+    const float fy = scan[2 * n] - floorf(scan[2 * n]);
+    const float fx = scan[2 * n + 1] - floorf(scan[2 * n + 1]);
+    scatter_footprint<true>(
+        [&](int y, int x) {
+          const long p = (long)y * pw + x;
+          float a = 0.f;
+          for (int s = 0; s < S; ++s) a += norm2(probe[s * P + p]);
+          return mk(a, 0.f);
+        },
+        c, fx, fy, imf, pw, H, W, strip);
+  }
+}
+
+extern "C" int tike_psi_preconditioner(const void* probe, const float* scan, void* out,
+                                       int nscan, int S, int pw, int H, int W, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && H >= 1 && W >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(probe && scan && out);
+  const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
+  hipLaunchKernelGGL(psi_precond_kernel, dim3(tk_grid((long)nscan * nstrip, 16)), dim3(256), 0,
+                     (hipStream_t)stream, (const cf*)probe, scan, (float*)out, nscan, S, pw, H,
+                     W);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
 }
 
 // ------------------------------------------------------------ probe gradient

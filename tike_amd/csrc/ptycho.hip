@@ -249,6 +249,10 @@ extern "C" int tike_ifft2_crop(const void* farplane, void* work, void* chi, long
 // on measured pixels and g = (unmeasured_scaling - 1) elsewhere
 // (lstsq.py:491-502).  Unmeasured pixels are selected by the mask and their
 // data values (possibly NaN) are never read into the arithmetic.
+// Grid: (pixel blocks, positions); a workgroup covers TK_FG_PIX pixels of one
+// position and adds its share of the cost with one atomic.
+constexpr int TK_FG_PIX = 1024;
+
 template <int MODEL, bool GRAD>
 __global__ __launch_bounds__(256) void farplane_gradient_kernel(
     cf* __restrict__ farplane, const float* __restrict__ data,
@@ -257,35 +261,38 @@ __global__ __launch_bounds__(256) void farplane_gradient_kernel(
     float inv_nmeasured) {
   __shared__ float red[4];
   const long npix = (long)det * det;
-  for (long n = blockIdx.x; n < nscan; n += gridDim.x) {
-    cf* __restrict__ F = farplane + n * S * npix;
-    const float* __restrict__ d = data + n * npix;
-    float cost = 0.f;
-    for (long p = threadIdx.x; p < npix; p += blockDim.x) {
-      float I = 0.f;
-      for (int s = 0; s < S; ++s) I += norm2(F[s * npix + p]);
-      if (intensity) intensity[n * npix + p] = I;
-      const bool measured = mask ? mask[p] != 0 : true;
-      float g;
-      if (measured) {
-        const float dv = d[p];
-        if (MODEL == 0) {
-          const float sI = sqrtf(I), sd = sqrtf(dv);
-          const float diff = sI - sd;
-          cost += diff * diff;
-          g = -(1.0f - sd / (sI + 1e-9f));
-        } else {
-          cost += I - dv * logf(I + 1e-9f);
-          g = -(1.0f - dv / (I + 1e-9f));
-        }
+  const long n = blockIdx.y;
+  cf* __restrict__ F = farplane + n * S * npix;
+  const float* __restrict__ d = data + n * npix;
+  float cost = 0.f;
+  const long p0 = (long)blockIdx.x * TK_FG_PIX;
+  const long p1 = p0 + TK_FG_PIX < npix ? p0 + TK_FG_PIX : npix;
+  for (long p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    float I = 0.f;
+    for (int s = 0; s < S; ++s) I += norm2(F[s * npix + p]);
+    if (intensity) intensity[n * npix + p] = I;
+    const bool measured = mask ? mask[p] != 0 : true;
+    float g;
+    if (measured) {
+      const float dv = d[p];
+      if (MODEL == 0) {
+        const float sI = sqrtf(I), sd = sqrtf(dv);
+        const float diff = sI - sd;
+        cost += diff * diff;
+        g = -(1.0f - sd / (sI + 1e-9f));
       } else {
-        g = unmeasured_scaling - 1.0f;
+        cost += I - dv * logf(I + 1e-9f);
+        g = -(1.0f - dv / (I + 1e-9f));
       }
-      if (GRAD)
-        for (int s = 0; s < S; ++s) F[s * npix + p] = F[s * npix + p] * g;
+    } else {
+      g = unmeasured_scaling - 1.0f;
     }
+    if (GRAD)
+      for (int s = 0; s < S; ++s) F[s * npix + p] = F[s * npix + p] * g;
+  }
+  if (costs) {
     cost = tk_block_sum256(cost, red);
-    if (costs && threadIdx.x == 0) costs[n] = cost * inv_nmeasured;
+    if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
   }
 }
 
@@ -296,12 +303,18 @@ extern "C" int tike_farplane_gradient(void* farplane, const float* data,
                                       long num_measured, void* stream_) {
   TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
-  TK_CHECK_ARG(farplane && data && nscan >= 0 && S >= 1 && det >= 1);
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1);
   TK_CHECK_ARG(model == 0 || model == 1);
   TK_CHECK_ARG(num_measured > 0);
   if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(farplane && data);
+  if (costs) {
+    hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
+    if (e != hipSuccess) return (int)e;
+  }
   const float inv = 1.0f / (float)num_measured;
-  const dim3 grid(tk_grid(nscan, 16)), block(256);
+  const long npix = (long)det * det;
+  const dim3 grid((unsigned)((npix + TK_FG_PIX - 1) / TK_FG_PIX), (unsigned)nscan), block(256);
 #define TK_FG(M, G)                                                                          \
   hipLaunchKernelGGL((farplane_gradient_kernel<M, G>), grid, block, 0, stream, (cf*)farplane, \
                      data, measured, intensity, costs, nscan, S, det, unmeasured_scaling, inv)

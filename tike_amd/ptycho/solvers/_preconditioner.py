@@ -1,8 +1,8 @@
 """Object / probe illumination preconditioners
 (reference src/tike/ptycho/solvers/_preconditioner.py:48-209).
 
-Device work: ``tike_patch_adj`` with a single broadcast patch (K = 1) and
-``tike_probe_preconditioner``.  Unlike the reference (whose all-reduce is
+Device work: ``tike_psi_preconditioner`` (one atomic per object pixel and
+position) and ``tike_probe_preconditioner``.  Unlike the reference (whose all-reduce is
 commented out, :185,201, because every GPU owns a spatial stripe) positions
 are sharded across ranks here, so both preconditioners are summed over ranks.
 """
@@ -17,12 +17,12 @@ def _psi_preconditioner(parameters, operator):
     psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
     assert psi.shape[0] == 1, "single-slice objects only"
     out = torch.zeros_like(psi)
-    probe_amp = torch.sum(probe * probe.conj(), dim=-3)[:, 0].contiguous()
     pw = probe.shape[-1]
     check(
-        lib.tike_patch_adj(A.ptr(out), A.ptr(probe_amp), A.ptr(scan), 1,
-                           psi.shape[-2], psi.shape[-1], scan.shape[0], 1, pw,
-                           pw, 1, A.stream_ptr()), "psi preconditioner")
+        lib.tike_psi_preconditioner(A.ptr(probe), A.ptr(scan), A.ptr(out),
+                                    scan.shape[0], probe.shape[-3], pw,
+                                    psi.shape[-2], psi.shape[-1],
+                                    A.stream_ptr()), "psi preconditioner")
     return out
 
 
