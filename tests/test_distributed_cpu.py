@@ -1,0 +1,107 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU plumbing: the packed
+all-reduce of `Comm`, the scalar all-reduce, and the position sharding of
+`Reconstruction._shard` (every global minibatch split contiguously over ranks,
+every position owned exactly once)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), fn, ret), nprocs=world,
+             join=True)
+    return [ret[r] for r in range(world)]
+
+
+def _allreduce(rank, world):
+    from tike_amd.communicators import Comm
+    comm = Comm()
+    a = torch.full((3, 4), rank + 1.0) * (1 + 2j)
+    a = a.to(torch.complex64)
+    b = torch.arange(5, dtype=torch.float32) * (rank + 1)
+    comm.Allreduce(a, b)
+    s = comm.Allreduce_scalars([rank + 1, torch.tensor(2.0 * rank)], "cpu")
+    single = comm.Allreduce(torch.ones(2, dtype=torch.complex64) * (rank + 1))
+    return (a.numpy(), b.numpy(), s.numpy(), single.numpy(), comm.size,
+            comm.rank)
+
+
+def test_comm_allreduce_gloo():
+    out = _run(_allreduce)
+    for r, (a, b, s, single, size, rank) in enumerate(out):
+        assert size == 2 and rank == r
+        np.testing.assert_allclose(a, np.full((3, 4), 3 * (1 + 2j)))
+        np.testing.assert_allclose(b, np.arange(5) * 3.0)
+        np.testing.assert_allclose(s, [3.0, 2.0])
+        np.testing.assert_allclose(single, [3, 3])
+
+
+def _shard(rank, world):
+    import tike_amd.ptycho as tp
+    from tike_amd.communicators import Comm
+    rng = np.random.default_rng(0)
+    N, pw = 50, 8
+    scan = (rng.random((N, 2)) * 20 + 2).astype(np.float32)
+    params = tp.PtychoParameters(
+        probe=np.ones((1, 1, 1, pw, pw), np.complex64),
+        psi=np.ones((1, 40, 40), np.complex64), scan=scan,
+        algorithm_options=tp.LstsqOptions(num_batch=3,
+                                          batch_method="wobbly_center"))
+    rec = tp.Reconstruction.__new__(tp.Reconstruction)
+    rec._parameters_in = params
+    rec._presharded = False
+    rec._order_in = rec._batches_in = None
+    rec.comm = Comm()
+    order, local, batches = rec._shard(N)
+    return order, local, [b.tolist() for b in batches]
+
+
+def test_position_sharding_covers_every_position_once():
+    out = _run(_shard)
+    (order0, local0, b0), (order1, local1, b1) = out
+    np.testing.assert_array_equal(order0, order1)  # same global clustering
+    both = np.concatenate([local0, local1])
+    assert sorted(both.tolist()) == list(range(50))
+    # local batches are contiguous ranges of the local arrays and every
+    # global batch is split (nearly) evenly
+    for batches, local in ((b0, local0), (b1, local1)):
+        flat = [i for b in batches for i in b]
+        assert flat == list(range(len(local)))
+    for x, y in zip(b0, b1):
+        assert abs(len(x) - len(y)) <= 1
+
+
+def test_single_rank_comm_is_identity():
+    from tike_amd.communicators import Comm
+    comm = Comm()
+    assert comm.size == 1 and comm.rank == 0
+    t = torch.ones(3)
+    assert comm.Allreduce(t) is t
+    np.testing.assert_allclose(
+        comm.Allreduce_scalars([1.5, torch.tensor(2.0)], "cpu").numpy(),
+        [1.5, 2.0])

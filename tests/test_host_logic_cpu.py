@@ -1,0 +1,171 @@
+"""CPU tests of the host-side logic around the hot path: option validation
+(reference options.py:141-168, ptycho.py:306-323), batch clustering
+invariants (reference tests/test_random.py), probe helpers against the
+oracle and the reference's golden files, linalg / opt helpers
+(reference tests/test_linalg.py, tests/test_opt.py)."""
+import numpy as np
+import pytest
+import torch
+
+import tike_amd.cluster as cluster
+import tike_amd.linalg as linalg
+import tike_amd.opt as opt
+import tike_amd.ptycho as tp
+from oracle import solvers as osol
+
+
+def rc(rng, *shape):
+    return (rng.random((*shape, 2), dtype=np.float32) - 0.5).view(
+        np.complex64)[..., 0]
+
+
+def test_check_allowed_positions():
+    """reference tests/ptycho/test_ptycho.py:92-100."""
+    psi = np.empty((1, 4, 9))
+    probe = np.empty((8, 2, 2))
+    scan = np.array([[1, 1], [1, 6.9], [1.1, 1], [1.9, 5.5]])
+    tp.check_allowed_positions(scan, psi, probe.shape)
+    for bad in np.array([[1, 7], [1, 0.9], [0.9, 1], [1, 0]]):
+        with pytest.raises(ValueError):
+            tp.check_allowed_positions(bad[None], psi, probe.shape)
+
+
+def test_parameters_validation():
+    good = dict(probe=np.ones((1, 1, 2, 8, 8), np.complex64),
+                psi=np.ones((1, 32, 32), np.complex64),
+                scan=np.full((5, 2), 4, np.float32))
+    p = tp.PtychoParameters(**good)
+    assert p.exitwave_options.measured_pixels.shape == (8, 8)
+    with pytest.raises(ValueError):
+        tp.PtychoParameters(**{**good, "scan": np.zeros((5, 3), np.float32)})
+    with pytest.raises(ValueError):
+        tp.PtychoParameters(**{**good,
+                               "probe": np.ones((1, 2, 8, 8), np.complex64)})
+    with pytest.raises(ValueError):
+        tp.PtychoParameters(**{**good, "psi": np.ones((1, 8, 8),
+                                                      np.complex64)})
+    with pytest.raises(ValueError):  # positions outside the field of view
+        tp.PtychoParameters(**{**good, "scan": np.full((5, 2), 30,
+                                                       np.float32)})
+
+
+def test_options_defaults_match_reference():
+    o = tp.LstsqOptions()
+    assert (o.name, o.num_batch, o.batch_method, o.rescale_period) == (
+        "lstsq_grad", 1, "wobbly_center", 10)
+    po = tp.ProbeOptions()
+    assert po.init_rescale_from_measurements and not po.force_orthogonality
+    assert po.recover_probe(3) and not tp.ProbeOptions(
+        update_start=5).recover_probe(3)
+    eo = tp.ExitWaveOptions(measured_pixels=np.ones((4, 4), bool))
+    assert (eo.noise_model, eo.propagation_normalization,
+            eo.unmeasured_pixels_scaling) == ("gaussian", "ortho", 1.0)
+
+
+@pytest.mark.parametrize("method", ["wobbly_center", "compact", "contiguous"])
+def test_cluster_partitions(method):
+    """Every index in exactly one cluster, sizes differ by <= 1
+    (reference tests/test_random.py invariants)."""
+    rng = np.random.default_rng(0)
+    np.random.seed(0)
+    pop = rng.random((97, 2))
+    order, batches = cluster.batches_contiguous(pop, method, 5)
+    assert sorted(order.tolist()) == list(range(97))
+    sizes = [len(b) for b in batches]
+    assert sum(sizes) == 97 and max(sizes) - min(sizes) <= 1
+    assert np.concatenate(batches).tolist() == list(range(97))
+
+
+def test_gaussian_probe_bit_exact(golden):
+    g = golden("ref_ptycho_gaussian.npz")
+    np.testing.assert_array_equal(tp.gaussian(15, rin=0.8, rout=1.0),
+                                  g["weights"])
+
+
+def test_orthogonalize_eig_reference_mat(golden):
+    """reference tests/ptycho/test_probe.py:138-158."""
+    g = golden("ref_ortho.npz")
+    out, power = tp.orthogonalize_eig(g["modes"])
+    np.testing.assert_allclose(np.abs(out), np.abs(g["pr"]), rtol=1e-4)
+    assert np.all(np.diff(power) <= 0)
+
+
+def test_probe_helpers_match_oracle():
+    rng = np.random.default_rng(1)
+    N, C, S, pw = 12, 2, 3, 8
+    probe, eigen = rc(rng, 1, 1, S, pw, pw), rc(rng, 1, C, 1, pw, pw)
+    w = rng.standard_normal((N, C + 1, S)).astype(np.float32)
+    np.testing.assert_allclose(tp.get_varying_probe(probe, eigen, w),
+                               osol.get_varying_probe(probe, eigen, w),
+                               rtol=1e-6)
+    e1, w1 = tp.constrain_variable_probe(eigen.copy(), w.copy())
+    e2, w2 = osol.constrain_variable_probe(eigen.copy(), w.copy())
+    np.testing.assert_allclose(e1, e2, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(w1, w2, rtol=1e-4, atol=1e-6)
+    psi = rc(rng, 1, 20, 20)
+    pre = rng.random((1, 20, 20)).astype(np.complex64)
+    a, b = tp.remove_object_ambiguity(torch.from_numpy(psi),
+                                      torch.from_numpy(probe),
+                                      torch.from_numpy(pre))
+    c, d = osol.remove_object_ambiguity(psi, probe, pre)
+    np.testing.assert_allclose(a.numpy(), c, rtol=1e-5)
+    np.testing.assert_allclose(b.numpy(), d, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["numpy", "torch"])
+def test_linalg(kind):
+    """reference tests/test_linalg.py: norm, projection, lstsq, GS."""
+    rng = np.random.default_rng(2)
+    x, y = rc(rng, 4, 5, 6), rc(rng, 4, 5, 6)
+    conv = (lambda a: a) if kind == "numpy" else torch.from_numpy
+    back = (lambda a: a) if kind == "numpy" else (lambda a: a.numpy())
+    np.testing.assert_allclose(back(linalg.norm(conv(x), axis=(-2, -1))),
+                               np.sqrt((np.abs(x)**2).sum((-2, -1))),
+                               rtol=1e-5)
+    np.testing.assert_allclose(back(linalg.mnorm(conv(x))),
+                               np.sqrt((np.abs(x)**2).mean()), rtol=1e-5)
+    np.testing.assert_allclose(back(linalg.inner(conv(x), conv(y))),
+                               (x * y.conj()).sum(), rtol=1e-4)
+    p = back(linalg.projection(conv(x), conv(y), axis=(-2, -1)))
+    resid = x - p
+    np.testing.assert_allclose((resid * y.conj()).sum((-2, -1)), 0, atol=1e-5)
+    u = back(linalg.orthogonalize_gs(conv(x), axis=(-2, -1)))
+    for i in range(4):  # vectors run along the first axis not in `axis`
+        for j in range(i):
+            np.testing.assert_allclose((u[i] * u[j].conj()).sum(), 0,
+                                       atol=1e-5)
+    a = rng.standard_normal((3, 7, 2)).astype(np.float32)
+    xs = rng.standard_normal((3, 2, 1)).astype(np.float32)
+    np.testing.assert_allclose(back(linalg.lstsq(conv(a), conv(a @ xs))), xs,
+                               rtol=1e-3, atol=1e-4)
+
+
+def test_opt_helpers():
+    """reference tests/test_opt.py: line fit; CG converges on a quadratic."""
+    s, i = opt.fit_line_least_squares(y=[1, 3, 5, 7], x=[0, 1, 2, 3])
+    np.testing.assert_allclose([s, i], [2, 1])
+    A_ = np.array([[3.0, 1.0], [1.0, 2.0]])
+    b = np.array([1.0, -1.0])
+    cost = lambda x: float(0.5 * x @ A_ @ x - b @ x)
+    x, c = opt.conjugate_gradient(np, np.zeros(2), cost,
+                                  lambda x: [A_ @ x - b],
+                                  dir_multi=lambda d: d[0], num_iter=20)
+    np.testing.assert_allclose(x, np.linalg.solve(A_, b), atol=1e-3)
+    m, _, m2 = opt.momentum(np.ones(3), None, None, mdecay=0.9)
+    np.testing.assert_allclose(m, 0.1 * np.ones(3))
+
+
+def test_unsupported_features_fail_loudly():
+    params = tp.PtychoParameters(
+        probe=np.ones((1, 1, 1, 8, 8), np.complex64),
+        psi=np.ones((1, 32, 32), np.complex64),
+        scan=np.full((4, 2), 4, np.float32),
+        algorithm_options=tp.RpieOptions())
+    with pytest.raises(NotImplementedError):
+        tp.Reconstruction(np.ones((4, 8, 8), np.float32), params)
+    with pytest.raises(ValueError):
+        tp.Reconstruction(np.ones((3, 8, 8), np.float32),
+                          tp.PtychoParameters(
+                              probe=params.probe, psi=params.psi,
+                              scan=params.scan,
+                              algorithm_options=tp.LstsqOptions()))
