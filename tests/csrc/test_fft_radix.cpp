@@ -36,6 +36,8 @@ int main() {
   e = std::fmax(e, check<8, true>());
   e = std::fmax(e, check<16, false>());
   e = std::fmax(e, check<16, true>());
+  e = std::fmax(e, check<32, false>());
+  e = std::fmax(e, check<32, true>());
   printf("max err %.3e\n", e);
   return e < 5e-6 ? 0 : 1;
 }

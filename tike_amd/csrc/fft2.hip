@@ -8,7 +8,7 @@
 #include <cmath>
 #include <mutex>
 
-#include "fft_engine.h"
+#include "fft_engine2.h"
 #include "tike_amd.h"
 
 // ---------------------------------------------------------------- twiddles
@@ -62,6 +62,49 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void fft2_pow2_ke
     }
     __syncthreads();
   }
+}
+
+// ------------------------------------------------ v2 kernel (out of place)
+// One workgroup (N threads) per tile: RB pass-1 iterations of 16 strided rows
+// each, then 16 barrier-free pass-2 iterations in place on the output tile
+// (fft_engine2.h).  Requires in != out.
+template <int N, bool INV>
+__global__ __launch_bounds__(N, TK_V2_MINW(N)) void fft2_v2_kernel(
+    const cf* __restrict__ in, cf* __restrict__ out, long ntile, float scale,
+    const cf* __restrict__ twtab) {
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS];
+  FftTw<N> tw;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const cf* __restrict__ src = in + tile * (long)N * N;
+    cf* __restrict__ dst = out + tile * (long)N * N;
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    tw.init(twtab, j);
+    for (int r = 0; r < G2::RB; ++r)
+      fft2_pass1<N, INV>(lds, twtab, tw, line, j, r,
+                         [&](int y, int e) { return src[y * N + e]; }, dst);
+    __syncthreads();
+    for (int k1 = 0; k1 < 16; ++k1)
+      fft2_pass2<N, INV>(dst, k1, [&](int ky, int t, cf v) { dst[ky * N + t] = v * scale; });
+    __syncthreads();
+  }
+}
+
+template <int N>
+static int launch_v2(const cf* in, cf* out, long ntile, int inverse, float scale,
+                     hipStream_t stream) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  const int grid = tk_grid(ntile, 4);
+  if (inverse)
+    hipLaunchKernelGGL((fft2_v2_kernel<N, true>), dim3(grid), dim3(N), 0, stream, in, out, ntile,
+                       scale, tw);
+  else
+    hipLaunchKernelGGL((fft2_v2_kernel<N, false>), dim3(grid), dim3(N), 0, stream, in, out,
+                       ntile, scale, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
 }
 
 // --------------------------------------------------------- generic kernel
@@ -140,6 +183,15 @@ int tk_fft2(const cf* in, cf* out, long ntile, int n, int inverse, float scale,
             hipStream_t stream) {
   TK_CHECK_ARG(in && out && n >= 1 && ntile >= 0);
   if (ntile == 0) return TK_OK;
+  static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
+  if (use_v2 && in != out) {
+    switch (n) {
+      case 128: return launch_v2<128>(in, out, ntile, inverse, scale, stream);
+      case 256: return launch_v2<256>(in, out, ntile, inverse, scale, stream);
+      case 512: return launch_v2<512>(in, out, ntile, inverse, scale, stream);
+      default: break;
+    }
+  }
   switch (n) {
     case 32: return launch_pow2<32>(in, out, ntile, inverse, scale, stream);
     case 64: return launch_pow2<64>(in, out, ntile, inverse, scale, stream);

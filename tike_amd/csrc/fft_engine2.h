@@ -1,0 +1,134 @@
+// Tile-level 2-D FFT, version 2: strided two-pass decomposition of the
+// column transform (N = 16 * RB, N in {128, 256, 512}).
+//
+// With y = r + RB*y2 (r < RB, y2 < 16) and ky = k1 + 16*k2 (k1 < 16, k2 < RB)
+//   w_N^(y*ky) = w_16^(y2*k1) * w_N^(r*k1) * w_RB^(r*k2),
+// so the column DFT splits into
+//   pass 1 (fixed r):  the 16 rows {r + RB*y2} get their row FFTs (length N,
+//       radix-16 Stockham in registers, the inter-stage exchange stays inside
+//       a wave), are transposed through LDS so that one thread owns one column
+//       of those 16 rows, take a radix-16 DFT over y2 and the twiddle
+//       w_N^(r*k1) (uniform per workgroup iteration -> scalar registers), and
+//       are stored as the 16 CONSECUTIVE rows 16*r + k1 of the intermediate;
+//   pass 2 (fixed k1): one thread per column loads rows {16*r + k1}, does a
+//       radix-RB DFT over r in registers and stores rows {k1 + 16*k2} -- the
+//       same set of rows, so pass 2 runs in place; no LDS, no barriers.
+// Every global access of both passes is a whole contiguous row (N*8 bytes
+// per workgroup), one workgroup barrier pair per 16 rows instead of four.
+// Pass 1 is NOT in place (it reads rows r + RB*y2 and writes rows 16*r + k1).
+#pragma once
+
+#include "fft_engine.h"
+
+// minimum waves per SIMD requested from the register allocator for the v2
+// kernels (N threads per workgroup): tunable at build time.
+#ifndef TK_V2_WAVES
+#define TK_V2_WAVES 4
+#endif
+#define TK_V2_MINW(N) ((N) <= 256 ? TK_V2_WAVES : 2)
+
+template <int N>
+struct Fft2Geom {
+  using G = FftGeom<N>;
+  static constexpr int RA = 16;      // rows per pass-1 iteration
+  static constexpr int RB = N / 16;  // radix of pass 2
+  static constexpr int NT = N;       // one thread per column
+  static constexpr int T = N / 16;   // threads per row in the row FFT
+  static constexpr int LS = N + N / 16 + 1;
+  static constexpr int LDS_ELEMS = RA * LS;
+  static_assert(N == 128 || N == 256 || N == 512, "unsupported size");
+  static_assert(FftPlan<N>::E == 16, "row plan must hold 16 elements per thread");
+};
+
+// Row-FFT stage with wave-level synchronisation: a line's T <= 32 threads
+// always sit in one wave (lanes j = tid % T), LDS instructions of a wave
+// execute in order, so no workgroup barrier is needed between the stages.
+template <int N, bool INV, int S>
+struct FftStageWave {
+  using G = FftGeom<N>;
+  using P = FftPlan<N>;
+  static constexpr int T = N / 16;
+  static __device__ __forceinline__ void run(cf (&v)[16], cf* __restrict__ lbase, int j,
+                                             const FftTw<N>& tw) {
+    constexpr int R = P::R[S];
+    constexpr int B = 16 / R;
+    constexpr int Ns = G::ns(S);
+    constexpr bool LAST = (S == P::NST - 1);
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+      cf u[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        u[r] = v[b + r * B];
+        if (S > 0 && r > 0) u[r] = mul_tw<INV>(u[r], tw.w[S][b + r * B]);
+      }
+      Dft<R, INV>::run(u);
+      if (LAST) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[b + r * B] = u[r];
+      } else {
+        const int jj = j + b * T;
+        const int k = jj & (Ns - 1);
+        const int j0 = (jj - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) lbase[tk_pad16(j0 + r * Ns)] = u[r];
+      }
+    }
+    if constexpr (!LAST) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = lbase[tk_pad16(j + i * T)];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      FftStageWave<N, INV, S + 1>::run(v, lbase, j, tw);
+    }
+  }
+};
+
+// Pass 1 for the 16 rows {r + RB*y2}.  `load(y, e)` returns input element e
+// of row y; results go to rows 16*r + k1 of `mid` (row-major N x N tile).
+// Contains two workgroup barriers; every thread of the NT = N workgroup calls.
+template <int N, bool INV, class Load>
+__device__ __forceinline__ void fft2_pass1(cf* __restrict__ lds, const cf* __restrict__ twtab,
+                                           const FftTw<N>& tw, int line, int j, int r,
+                                           Load&& load, cf* __restrict__ mid) {
+  using G2 = Fft2Geom<N>;
+  cf v[16];
+  const int y = r + G2::RB * line;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = load(y, j + i * G2::T);
+  cf* lbase = lds + line * G2::LS;
+  FftStageWave<N, INV, 0>::run(v, lbase, j, tw);
+  // natural-order row spectrum -> LDS [line][e]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lbase[tk_pad16(j + i * G2::T)] = v[i];
+  __syncthreads();
+  // thread t owns column t of the 16 rows
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int y2 = 0; y2 < 16; ++y2) v[y2] = lds[y2 * G2::LS + tk_pad16(t)];
+  __syncthreads();
+  Dft<16, INV>::run(v);
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) {
+    cf o = v[k1];
+    if (k1 > 0) o = mul_tw<INV>(o, twtab[N + r * k1]);  // uniform address -> scalar load
+    mid[(16 * r + k1) * N + t] = o;
+  }
+}
+
+// Pass 2 for one k1: in-place radix-RB over rows {16*r + k1} -> {k1 + 16*k2}.
+// `store(ky, t, value)` receives the final element of row ky, column t.
+template <int N, bool INV, class Store>
+__device__ __forceinline__ void fft2_pass2(const cf* __restrict__ mid, int k1, Store&& store) {
+  using G2 = Fft2Geom<N>;
+  const int t = threadIdx.x;
+  cf u[G2::RB];
+#pragma unroll
+  for (int r = 0; r < G2::RB; ++r) u[r] = mid[(16 * r + k1) * N + t];
+  Dft<G2::RB, INV>::run(u);
+#pragma unroll
+  for (int k2 = 0; k2 < G2::RB; ++k2) store(k1 + 16 * k2, t, u[k2]);
+}

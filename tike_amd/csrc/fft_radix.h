@@ -125,3 +125,27 @@ struct Dft<16, INV> {
     }
   }
 };
+
+template <bool INV>
+struct Dft<32, INV> {
+  static TK_HD void run(cf* v) {
+    // X[k] = E[k] + w32^k O[k], X[k+16] = E[k] - w32^k O[k]
+    const float c[16] = {1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654757f, 0.55557023301960229f, 0.38268343236508984f, 0.19509032201612833f, 0.0f, -0.19509032201612819f, -0.38268343236508973f, -0.55557023301960196f, -0.70710678118654746f, -0.83146961230254535f, -0.92387953251128674f, -0.98078528040323043f};
+    const float s[16] = {0.0f, 0.19509032201612825f, 0.38268343236508978f, 0.55557023301960218f, 0.70710678118654746f, 0.83146961230254524f, 0.92387953251128674f, 0.98078528040323043f, 1.0f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254546f, 0.70710678118654757f, 0.55557023301960218f, 0.38268343236508989f, 0.19509032201612861f};
+    cf e[16], o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      e[i] = v[2 * i];
+      o[i] = v[2 * i + 1];
+    }
+    Dft<16, INV>::run(e);
+    Dft<16, INV>::run(o);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const cf w = mk(c[k], -s[k]);  // forward twiddle exp(-2 pi i k / 32)
+      const cf t = mul_tw<INV>(o[k], w);
+      v[k] = e[k] + t;
+      v[k + 16] = e[k] - t;
+    }
+  }
+};
