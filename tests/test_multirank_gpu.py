@@ -1,0 +1,106 @@
+"""Two ranks (one process each, gloo, sharing cuda:0 on the single-GPU test
+box) reconstruct the same problem as one rank: with all-reduced gradients the
+P-rank iterates equal the 1-rank iterates up to summation order
+(DESIGN.md section 5)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem(eigen):
+    import tike_amd.ptycho as tp
+    import tike_amd.random
+    rng = np.random.default_rng(3)
+    N, S, pw, side = 64, 2, 32, 8
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
+                              indexing="ij"), -1).reshape(-1, 2)
+    scan = (2 + 5.0 * ij + rng.random((N, 2))).astype(np.float32)
+    HW = 5 * (side - 1) + pw + 8
+    psi_true = ((0.75 + 0.25 * rng.random((1, HW, HW))) * np.exp(
+        1j * np.pi * (rng.random((1, HW, HW)) - 0.5))).astype(np.complex64)
+    w = tp.gaussian(pw, rin=0.6)
+    probe = np.stack([w * np.exp(1j * np.pi * rng.random((pw, pw))) / (m + 1)
+                      for m in range(S)])[None, None].astype(np.complex64)
+    data = tp.simulate(pw, probe, scan, psi_true)
+    ep = ew = None
+    if eigen:
+        np.random.seed(5)
+        tike_amd.random.randomizer_np = np.random.default_rng(6)
+        ep, ew = tp.init_varying_probe(scan, probe, 2, 1)
+    return data, scan, probe, np.full_like(psi_true, 0.5), ep, ew
+
+
+def _reconstruct(eigen, method):
+    import tike_amd.ptycho as tp
+    import tike_amd.random
+    data, scan, probe, psi0, ep, ew = _problem(eigen)
+    np.random.seed(1)
+    tike_amd.random.randomizer_np = np.random.default_rng(2)
+    params = tp.PtychoParameters(
+        probe=probe.copy(), psi=psi0.copy(), scan=scan.copy(), eigen_probe=ep,
+        eigen_weights=ew,
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=3,
+                                          batch_method=method),
+        probe_options=tp.ProbeOptions(force_orthogonality=True),
+        object_options=tp.ObjectOptions())
+    return tp.reconstruct(data, params)
+
+
+def _worker(rank, world, port, eigen, method, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r = _reconstruct(eigen, method)
+        ret[rank] = (r.psi, r.probe, r.eigen_weights, r.scan,
+                     np.array(r.algorithm_options.costs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("eigen,method", [(False, "compact"),
+                                          (True, "wobbly_center")])
+def test_two_ranks_match_one_rank(eigen, method):
+    import torch.multiprocessing as mp
+    single = _reconstruct(eigen, method)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker,
+                         args=(r, 2, port, eigen, method, ret))
+             for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for rank in range(2):
+        psi, probe, ew, scan, costs = ret[rank]
+        np.testing.assert_allclose(
+            costs, np.array(single.algorithm_options.costs), rtol=1e-3)
+        assert_close(psi, single.psi, normwise=1e-3, maxabs=1e-2,
+                     what=f"psi rank {rank}")
+        assert_close(probe, single.probe, normwise=1e-3, maxabs=1e-2,
+                     what=f"probe rank {rank}")
+        np.testing.assert_array_equal(scan, single.scan)
+        if eigen:
+            assert_close(ew, single.eigen_weights, normwise=5e-3, maxabs=5e-2,
+                         what=f"eigen weights rank {rank}")
