@@ -13,7 +13,7 @@
 // One workgroup owns one (position, mode) tile and runs the row pass and the
 // column pass back to back; the intermediate lives in the tile's own output
 // (L2 / Infinity Cache resident between the passes).
-#include "fft_engine.h"
+#include "fft_engine2.h"
 #include "internal.h"
 #include "tike_amd.h"
 
@@ -107,6 +107,63 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ptycho_fwd_k
   }
 }
 
+// v2 structure (fft_engine2.h): N threads per workgroup, thread = column.
+template <int N>
+__global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    cf* __restrict__ farplane, long ntile, int S, int pw, int H, int W, float scale,
+    const cf* __restrict__ twtab) {
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS];
+  FftTw<N> tw;
+  const int pad = (N - pw) / 2;
+  const long total = (long)H * W;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long n = tile / S;
+    const int s = (int)(tile % S);
+    const TkCorner c = tk_corner(scan, n);
+    cf* __restrict__ dst = farplane + tile * (long)N * N;
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    tw.init(twtab, j);
+    const int t = threadIdx.x;
+    const int px = t - pad;
+    const int x = c.sx + px;
+    const bool col_ok = px >= 0 && px < pw && x >= 0 && x < W;
+    for (int r = 0; r < G2::RB; ++r) {
+      // stage the 16 rows {r + RB*l} of patch * probe (zero padded) into LDS
+#pragma unroll 4
+      for (int l = 0; l < 16; ++l) {
+        const int py = r + G2::RB * l - pad;
+        const int y = c.sy + py;
+        cf o = mk(0.f, 0.f);
+        if (col_ok && py >= 0 && py < pw && y >= 0 && y < H)
+          o = tk_gather(psi, (long)y * W + x, W, total, c) * probe.at(n, s, (long)py * pw + px);
+        lds[l * G2::LS + tk_pad16(t)] = o;
+      }
+      __syncthreads();
+      fft2_pass1<N, false>(lds, twtab, tw, line, j, r,
+                           [&](int y, int e) { return lds[line * G2::LS + tk_pad16(e)]; }, dst);
+    }
+    __syncthreads();
+    for (int k1 = 0; k1 < 16; ++k1)
+      fft2_pass2<N, false>(dst, k1, [&](int ky, int tt, cf v) { dst[ky * N + tt] = v * scale; });
+    __syncthreads();
+  }
+}
+
+template <int N>
+static int launch_fwd_v2(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
+                         long ntile, int S, int pw, int H, int W, float scale,
+                         hipStream_t stream) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  hipLaunchKernelGGL((ptycho_fwd_v2_kernel<N>), dim3(tk_grid(ntile, 4)), dim3(N), 0, stream, psi,
+                     scan, probe, farplane, ntile, S, pw, H, W, scale, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 template <int N>
 static int launch_fwd(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                       long ntile, int S, int pw, int H, int W, float scale, hipStream_t stream) {
@@ -135,6 +192,15 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
   const long ntile = (long)nscan * S;
   const cf* psi_ = (const cf*)psi;
   cf* far = (cf*)farplane;
+  static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
+  if (use_v2) {
+    switch (det) {
+      case 128: return launch_fwd_v2<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+      case 256: return launch_fwd_v2<256>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+      case 512: return launch_fwd_v2<512>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
+      default: break;
+    }
+  }
   switch (det) {
     case 32: return launch_fwd<32>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
     case 64: return launch_fwd<64>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
@@ -187,6 +253,46 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_k
   }
 }
 
+// v2: pass 1 farplane -> work (must not alias), pass 2 in place / cropped.
+template <int N>
+__global__ __launch_bounds__(N, TK_V2_MINW(N)) void ifft2_crop_v2_kernel(
+    const cf* __restrict__ farplane, cf* work, cf* chi, long ntile, int pw, float scale,
+    const cf* __restrict__ twtab) {
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS];
+  FftTw<N> tw;
+  const int pad = (N - pw) / 2;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const cf* __restrict__ src = farplane + tile * (long)N * N;
+    cf* mid = work + tile * (long)N * N;
+    cf* dst = chi + tile * (long)pw * pw;
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    tw.init(twtab, j);
+    for (int r = 0; r < G2::RB; ++r)
+      fft2_pass1<N, true>(lds, twtab, tw, line, j, r,
+                          [&](int y, int e) { return src[y * N + e]; }, mid);
+    __syncthreads();
+    for (int k1 = 0; k1 < 16; ++k1)
+      fft2_pass2<N, true>(mid, k1, [&](int ky, int t, cf v) {
+        const int py = ky - pad, px = t - pad;
+        if (py >= 0 && py < pw && px >= 0 && px < pw) dst[py * pw + px] = v * scale;
+      });
+    __syncthreads();
+  }
+}
+
+template <int N>
+static int launch_icrop_v2(const cf* far, cf* work, cf* chi, long ntile, int pw, float scale,
+                           hipStream_t stream) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  hipLaunchKernelGGL((ifft2_crop_v2_kernel<N>), dim3(tk_grid(ntile, 4)), dim3(N), 0, stream, far,
+                     work, chi, ntile, pw, scale, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 __global__ __launch_bounds__(256) void crop_kernel(const cf* __restrict__ src,
                                                    cf* __restrict__ dst, long ntile, int det,
                                                    int pw) {
@@ -223,6 +329,15 @@ extern "C" int tike_ifft2_crop(const void* farplane, void* work, void* chi, long
   const cf* far = (const cf*)farplane;
   cf* wk = (cf*)work;
   cf* out = (cf*)chi;
+  static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
+  if (use_v2 && (const cf*)wk != far) {
+    switch (det) {
+      case 128: return launch_icrop_v2<128>(far, wk, out, ntile, pw, scale, stream);
+      case 256: return launch_icrop_v2<256>(far, wk, out, ntile, pw, scale, stream);
+      case 512: return launch_icrop_v2<512>(far, wk, out, ntile, pw, scale, stream);
+      default: break;
+    }
+  }
   switch (det) {
     case 32: return launch_icrop<32>(far, wk, out, ntile, pw, scale, stream);
     case 64: return launch_icrop<64>(far, wk, out, ntile, pw, scale, stream);

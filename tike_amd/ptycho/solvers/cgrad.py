@@ -33,7 +33,8 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
     chunk = chunk_positions(S, det)
     far = ws.get("far", (min(chunk, max(N, 1)), 1, S, det, det),
                  torch.complex64, dev)
-    chi_ws = None if pw == det else ws.get(
+    mid = ws.get("mid", tuple(far.shape), torch.complex64, dev)
+    chi_ws = mid if pw == det else ws.get(
         "chi", (min(chunk, max(N, 1)), 1, S, pw, pw), torch.complex64, dev)
     costs = ws.get("costs", (max(N, 1),), torch.float32, dev)
     gpsi = torch.zeros_like(psi) if (want_grad and want_psi) else None
@@ -51,9 +52,9 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
             "cgrad cost")
         if not want_grad:
             continue
-        chi = far if chi_ws is None else chi_ws
+        chi = chi_ws
         check(
-            lib.tike_ifft2_crop(A.ptr(far), A.ptr(far), A.ptr(chi), n * S, det,
+            lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S, det,
                                 pw, inv_scale, st), "cgrad ifft2")
         if gpsi is not None:
             check(

@@ -239,7 +239,10 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     chunk = chunk_positions(S, det)
     far = ws.get("far", (min(chunk, max(B, 1)), 1, S, det, det),
                  torch.complex64, dev)
-    chi_ws = None
+    # the inverse transform is out of place (far -> mid); chi is the cropped
+    # result and aliases mid when the probe fills the detector
+    mid = ws.get("mid", tuple(far.shape), torch.complex64, dev)
+    chi_ws = mid
     if pw != det:
         chi_ws = ws.get("chi", (min(chunk, max(B, 1)), 1, S, pw, pw),
                         torch.complex64, dev)
@@ -258,9 +261,9 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                 _MODELS[exitwave_options.noise_model], 1,
                 float(exitwave_options.unmeasured_pixels_scaling), nmeasured,
                 st), "farplane gradient")
-        chi = far if chi_ws is None else chi_ws
+        chi = chi_ws
         check(
-            lib.tike_ifft2_crop(A.ptr(far), A.ptr(far), A.ptr(chi), n * S, det,
+            lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S, det,
                                 pw, inv_scale, st), "ifft2 + crop")
         if recover_psi:
             check(
