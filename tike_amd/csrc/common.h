@@ -86,23 +86,25 @@ __device__ __forceinline__ TkCorner tk_corner(const float* __restrict__ scan, lo
 // allocation starting at img.  Caller guarantees the leading tap is in bounds.
 __device__ __forceinline__ cf tk_gather(const cf* __restrict__ img, long ii, int W, long total,
                                         const TkCorner& c) {
-  cf a = img[ii];
+  // Branch-free: the four loads are issued back to back (a branch per tap
+  // serialises four memory latencies).  Taps outside the allocation are read
+  // from a clamped address and weighted by exactly zero; zero-weight taps
+  // inside the allocation contribute exactly zero, as in the reference.
+  const long last = total - 1;
+  const long i1 = ii + 1 <= last ? ii + 1 : last;
+  const long i2 = ii + W <= last ? ii + W : last;
+  const long i3 = ii + W + 1 <= last ? ii + W + 1 : last;
+  const float w1 = ii + 1 <= last ? c.w01 : 0.0f;
+  const float w2 = ii + W <= last ? c.w10 : 0.0f;
+  const float w3 = ii + W + 1 <= last ? c.w11 : 0.0f;
+  const cf a = img[ii], b = img[i1], d = img[i2], e = img[i3];
   cf r = mk(a.x * c.w00, a.y * c.w00);
-  if (c.w01 != 0.0f && ii + 1 < total) {
-    cf b = img[ii + 1];
-    r.x += b.x * c.w01;
-    r.y += b.y * c.w01;
-  }
-  if (c.w10 != 0.0f && ii + W < total) {
-    cf b = img[ii + W];
-    r.x += b.x * c.w10;
-    r.y += b.y * c.w10;
-  }
-  if (c.w11 != 0.0f && ii + W + 1 < total) {
-    cf b = img[ii + W + 1];
-    r.x += b.x * c.w11;
-    r.y += b.y * c.w11;
-  }
+  r.x += b.x * w1;
+  r.y += b.y * w1;
+  r.x += d.x * w2;
+  r.y += d.y * w2;
+  r.x += e.x * w3;
+  r.y += e.y * w3;
   return r;
 }
 

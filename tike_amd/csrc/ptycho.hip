@@ -130,16 +130,22 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
     const int px = t - pad;
     const int x = c.sx + px;
     const bool col_ok = px >= 0 && px < pw && x >= 0 && x < W;
+    // clamped coordinates: every load is unconditional and in bounds, the
+    // padding / out-of-image pixels are zeroed by a select afterwards
+    const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+    const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
     for (int r = 0; r < G2::RB; ++r) {
       // stage the 16 rows {r + RB*l} of patch * probe (zero padded) into LDS
-#pragma unroll 4
+#pragma unroll 8
       for (int l = 0; l < 16; ++l) {
         const int py = r + G2::RB * l - pad;
         const int y = c.sy + py;
-        cf o = mk(0.f, 0.f);
-        if (col_ok && py >= 0 && py < pw && y >= 0 && y < H)
-          o = tk_gather(psi, (long)y * W + x, W, total, c) * probe.at(n, s, (long)py * pw + px);
-        lds[l * G2::LS + tk_pad16(t)] = o;
+        const bool ok = col_ok && py >= 0 && py < pw && y >= 0 && y < H;
+        const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
+        const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
+        const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c) *
+                     probe.at(n, s, (long)pyc * pw + pxc);
+        lds[l * G2::LS + tk_pad16(t)] = ok ? o : mk(0.f, 0.f);
       }
       __syncthreads();
       fft2_pass1<N, false>(lds, twtab, tw, line, j, r,
