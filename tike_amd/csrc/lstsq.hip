@@ -36,35 +36,58 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
     const int xp = x0 + threadIdx.x;  // column x' (also the patch column)
     const bool active = xp < pw;
     cf uprev = mk(0.f, 0.f), uprev_last = mk(0.f, 0.f);
-    for (int yp = max(r0 - 1, 0); yp < r1; ++yp) {
-      cf v = mk(0.f, 0.f);
-      if (active && yp < pw) v = value(yp, xp);
-      // left neighbour v[yp][xp-1]
-      cf left = mk(__shfl_up(v.x, 1, 64), __shfl_up(v.y, 1, 64));
-      if ((threadIdx.x & 63) == 0)
-        left = (active && xp > 0 && yp < pw) ? value(yp, xp - 1) : mk(0.f, 0.f);
-      const cf u = mk((1.0f - fx) * v.x + fx * left.x, (1.0f - fx) * v.y + fx * left.y);
-      // the thread owning the last patch column also produces column x' = pw
-      const cf ulast = mk(fx * v.x, fx * v.y);
-      if (yp >= r0 && active) {
-        const int Y = c.sy + yp;
-        if (Y >= 0 && Y < H) {
-          const int X = c.sx + xp;
-          if (X >= 0 && X < W) {
-            const long ii = (long)Y * W + X;
-            unsafeAtomicAdd(&imf[2 * ii], (1.0f - fy) * u.x + fy * uprev.x);
-            if (!REAL_ONLY) unsafeAtomicAdd(&imf[2 * ii + 1], (1.0f - fy) * u.y + fy * uprev.y);
-          }
-          if (xp == pw - 1 && X + 1 >= 0 && X + 1 < W) {
-            const long ii = (long)Y * W + X + 1;
-            unsafeAtomicAdd(&imf[2 * ii], (1.0f - fy) * ulast.x + fy * uprev_last.x);
-            if (!REAL_ONLY)
-              unsafeAtomicAdd(&imf[2 * ii + 1], (1.0f - fy) * ulast.y + fy * uprev_last.y);
-          }
+    constexpr int RG = 4;  // rows whose loads are issued together
+    for (int yb = max(r0 - 1, 0); yb < r1; yb += RG) {
+      cf vv[RG], ll[RG];
+#pragma unroll
+      for (int k = 0; k < RG; ++k) {
+        const int yp = yb + k;
+        const int ypc = yp < pw ? yp : pw - 1;  // clamped: loads stay unconditional
+        const int xpc = active ? xp : pw - 1;
+        vv[k] = value(ypc, xpc);
+      }
+      // left neighbour for lane 0 of each wave (the others take it by shuffle)
+      if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < RG; ++k) {
+          const int yp = yb + k;
+          const int ypc = yp < pw ? yp : pw - 1;
+          const int xpc = active ? xp : pw - 1;
+          ll[k] = value(ypc, xpc > 0 ? xpc - 1 : 0);
         }
       }
-      uprev = u;
-      uprev_last = ulast;
+#pragma unroll
+      for (int k = 0; k < RG; ++k) {
+        const int yp = yb + k;
+        if (yp >= r1) break;
+        cf v = (active && yp < pw) ? vv[k] : mk(0.f, 0.f);
+        cf left = mk(__shfl_up(v.x, 1, 64), __shfl_up(v.y, 1, 64));
+        if ((threadIdx.x & 63) == 0)
+          left = (active && xp > 0 && yp < pw) ? ll[k] : mk(0.f, 0.f);
+        const cf u = mk((1.0f - fx) * v.x + fx * left.x, (1.0f - fx) * v.y + fx * left.y);
+        // the thread owning the last patch column also produces column x' = pw
+        const cf ulast = mk(fx * v.x, fx * v.y);
+        if (yp >= r0 && active) {
+          const int Y = c.sy + yp;
+          if (Y >= 0 && Y < H) {
+            const int X = c.sx + xp;
+            if (X >= 0 && X < W) {
+              const long ii = (long)Y * W + X;
+              unsafeAtomicAdd(&imf[2 * ii], (1.0f - fy) * u.x + fy * uprev.x);
+              if (!REAL_ONLY)
+                unsafeAtomicAdd(&imf[2 * ii + 1], (1.0f - fy) * u.y + fy * uprev.y);
+            }
+            if (xp == pw - 1 && X + 1 >= 0 && X + 1 < W) {
+              const long ii = (long)Y * W + X + 1;
+              unsafeAtomicAdd(&imf[2 * ii], (1.0f - fy) * ulast.x + fy * uprev_last.x);
+              if (!REAL_ONLY)
+                unsafeAtomicAdd(&imf[2 * ii + 1], (1.0f - fy) * ulast.y + fy * uprev_last.y);
+            }
+          }
+        }
+        uprev = u;
+        uprev_last = ulast;
+      }
     }
   }
 }
