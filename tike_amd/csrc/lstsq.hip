@@ -37,25 +37,30 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
     const bool active = xp < pw;
     cf uprev = mk(0.f, 0.f), uprev_last = mk(0.f, 0.f);
     constexpr int RG = 4;  // rows whose loads are issued together
-    for (int yb = max(r0 - 1, 0); yb < r1; yb += RG) {
-      cf vv[RG], ll[RG];
+    // Software pipeline: the loads of row group g+1 are issued BEFORE the
+    // atomics of group g.  vmcnt retires in issue order, so a load issued
+    // after an atomic would wait for that atomic's full round trip.
+    cf vv[RG], ll[RG], nv[RG], nl[RG];
+    auto load_group = [&](int yb, cf (&a)[RG], cf (&b)[RG]) {
+      const int xpc = active ? xp : pw - 1;
 #pragma unroll
       for (int k = 0; k < RG; ++k) {
-        const int yp = yb + k;
-        const int ypc = yp < pw ? yp : pw - 1;  // clamped: loads stay unconditional
-        const int xpc = active ? xp : pw - 1;
-        vv[k] = value(ypc, xpc);
+        const int ypc = yb + k < pw ? yb + k : pw - 1;  // clamped, unconditional
+        a[k] = value(ypc, xpc);
       }
       // left neighbour for lane 0 of each wave (the others take it by shuffle)
       if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < RG; ++k) {
-          const int yp = yb + k;
-          const int ypc = yp < pw ? yp : pw - 1;
-          const int xpc = active ? xp : pw - 1;
-          ll[k] = value(ypc, xpc > 0 ? xpc - 1 : 0);
+          const int ypc = yb + k < pw ? yb + k : pw - 1;
+          b[k] = value(ypc, xpc > 0 ? xpc - 1 : 0);
         }
       }
+    };
+    const int ystart = max(r0 - 1, 0);
+    load_group(ystart, vv, ll);
+    for (int yb = ystart; yb < r1; yb += RG) {
+      if (yb + RG < r1) load_group(yb + RG, nv, nl);
 #pragma unroll
       for (int k = 0; k < RG; ++k) {
         const int yp = yb + k;
@@ -87,6 +92,11 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
         }
         uprev = u;
         uprev_last = ulast;
+      }
+#pragma unroll
+      for (int k = 0; k < RG; ++k) {
+        vv[k] = nv[k];
+        ll[k] = nl[k];
       }
     }
   }
