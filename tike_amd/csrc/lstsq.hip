@@ -25,6 +25,11 @@
 // inside the image (check_allowed_positions, position.py:600-628); pixels
 // falling outside are dropped.
 constexpr int TK_STRIP = 32;
+#ifdef TK_DBG_NO_ATOMIC
+#define TK_ATOMIC_ADD(p, v) asm volatile("" ::"v"(p), "v"(v))
+#else
+#define TK_ATOMIC_ADD(p, v) unsafeAtomicAdd(p, v)
+#endif
 
 template <bool REAL_ONLY, class ValueFn>
 __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorner& c,
@@ -78,15 +83,15 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
             const int X = c.sx + xp;
             if (X >= 0 && X < W) {
               const long ii = (long)Y * W + X;
-              unsafeAtomicAdd(&imf[2 * ii], (1.0f - fy) * u.x + fy * uprev.x);
+              TK_ATOMIC_ADD(&imf[2 * ii], (1.0f - fy) * u.x + fy * uprev.x);
               if (!REAL_ONLY)
-                unsafeAtomicAdd(&imf[2 * ii + 1], (1.0f - fy) * u.y + fy * uprev.y);
+                TK_ATOMIC_ADD(&imf[2 * ii + 1], (1.0f - fy) * u.y + fy * uprev.y);
             }
             if (xp == pw - 1 && X + 1 >= 0 && X + 1 < W) {
               const long ii = (long)Y * W + X + 1;
-              unsafeAtomicAdd(&imf[2 * ii], (1.0f - fy) * ulast.x + fy * uprev_last.x);
+              TK_ATOMIC_ADD(&imf[2 * ii], (1.0f - fy) * ulast.x + fy * uprev_last.x);
               if (!REAL_ONLY)
-                unsafeAtomicAdd(&imf[2 * ii + 1], (1.0f - fy) * ulast.y + fy * uprev_last.y);
+                TK_ATOMIC_ADD(&imf[2 * ii + 1], (1.0f - fy) * ulast.y + fy * uprev_last.y);
             }
           }
         }
