@@ -49,8 +49,10 @@ class Comm:
         return tensors if len(tensors) != 1 else tensors[0]
 
     def Allreduce_scalars(self, values, device):
-        """Sum a short list of Python/0-d values across ranks -> float64
-        tensor on `device` (one tiny collective)."""
+        """Sum a short list of 0-d DEVICE tensors across ranks -> float64
+        tensor on `device` (one tiny collective, no host synchronisation).
+        Python numbers are accepted but cost a blocking host-to-device copy:
+        keep them out of per-minibatch code (see `Allreduce_count`)."""
         t = torch.stack([
             v.detach().to(device=device, dtype=torch.float64).reshape(())
             if isinstance(v, torch.Tensor) else torch.tensor(
@@ -59,6 +61,17 @@ class Comm:
         if self.size > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def Allreduce_count(self, n: int) -> float:
+        """Sum of a host integer over ranks, returned as a host float
+        (used once per run for the global minibatch sizes)."""
+        if self.size == 1:
+            return float(n)
+        t = torch.tensor([float(n)], dtype=torch.float64)
+        if dist.get_backend(self.group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item())
 
     def barrier(self):
         if self.size > 1:

@@ -122,8 +122,16 @@ def constrain_variable_probe(variable_probe, weights):
         w[..., 1:, i] = w[..., 1 + order, i]
         vp[..., :, i, :, :] = vp[..., order, i, :, :]
     aevol = w.abs()
-    limit = 1.5 * torch.quantile(aevol.to(torch.float64), 0.95, dim=-3,
-                                 keepdim=True).to(w.dtype)
+    # 95th percentile over positions with linear interpolation (what
+    # cp.percentile / np.percentile compute); a sort, not torch.quantile,
+    # which is two orders of magnitude slower on ROCm for this shape.
+    srt = torch.sort(aevol, dim=-3).values
+    npos = aevol.shape[-3]
+    pos = 0.95 * (npos - 1)
+    lo, hi = int(np.floor(pos)), int(np.ceil(pos))
+    frac = float(pos - lo)
+    limit = 1.5 * (srt[..., lo:lo + 1, :, :] * (1.0 - frac) +
+                   srt[..., hi:hi + 1, :, :] * frac)
     w = torch.minimum(aevol, limit) * torch.sign(w)
     return _back(vp, was), _back(w, was)
 

@@ -15,7 +15,7 @@ from ... import _arrays as A
 from ... import opt
 from ..._lib import check, lib
 from ...operators.propagation import fft_scales
-from .lstsq import _workspace, chunk_positions, mask_info
+from .lstsq import _workspace, chunk_positions, global_count, mask_info
 
 
 def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
@@ -67,8 +67,8 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
                 lib.tike_probe_grad(A.ptr(chi), A.ptr(scan[lo:hi]), A.ptr(psi),
                                     None, A.ptr(gprobe), n, S, pw, H, W, st),
                 "cgrad probe gradient")
-    tot = comm.Allreduce_scalars([costs[:N].sum(), N], dev)
-    cost = float((tot[0] / tot[1]).item())
+    tot = comm.Allreduce_scalars([costs[:N].sum()], dev)
+    cost = float((tot[0] / global_count(comm, op, 0, N)).item())
     grads = [t for t in (gpsi, gprobe) if t is not None]
     if grads and comm.size > 1:
         comm.Allreduce(*grads)

@@ -64,6 +64,17 @@ def chunk_positions(S, det):
     return max(64, tiles // max(S, 1))
 
 
+def global_count(comm, op, lo, hi):
+    """Number of positions of the minibatch [lo, hi) over all ranks, as a
+    host float; minibatch sizes are static, so this is all-reduced once and
+    cached on the operator."""
+    cache = op.__dict__.setdefault("_tike_amd_counts", {})
+    key = (lo, hi, comm.size)
+    if key not in cache:
+        cache[key] = comm.Allreduce_count(hi - lo)
+    return cache[key]
+
+
 def mask_info(exitwave_options):
     """(number of measured pixels, uint8 device mask or None when every pixel
     is measured); computed once and cached on the options object."""
@@ -154,6 +165,7 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
 
         batch_cost[batch_index] = g["cost"]
 
+    # one device->host scalar per epoch, as in the reference (lstsq.py:222)
     algorithm_options.costs.append([float(batch_cost.mean().item())])
 
     if recover_psi and compact:
@@ -285,13 +297,14 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     reduced = [t for t in (object_upd_sum, m_probe_update) if t is not None]
     if comm.size > 1:
         comm.Allreduce(*reduced)
-    tot = comm.Allreduce_scalars([cost_sum, B], dev)
+    count = global_count(comm, op, lo, hi)
+    tot = comm.Allreduce_scalars([cost_sum], dev)
     if recover_probe:
         m_probe_update = m_probe_update / num_batch
     return dict(chi0=chi0[:B], w_old=w_old, patches=None if patches is None
                 else patches[:B], object_upd_sum=object_upd_sum,
                 m_probe_update=m_probe_update,
-                cost=(tot[0] / tot[1]).to(torch.float32), count=tot[1],
+                cost=(tot[0] / count).to(torch.float32), count=count,
                 local_count=B)
 
 
@@ -385,7 +398,7 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
         update = torch.sum(R * proj_mean[:, None, None], dim=0)
         if comm.size > 1:
             comm.Allreduce(update)
-        update = update / count.to(torch.float32)
+        update = update / count
         E = E + beta * update / linalg.mnorm(update)
         E = E / linalg.mnorm(E)
         eigen_probe[0, c - 1, m] = E
