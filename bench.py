@@ -162,10 +162,10 @@ def algorithmic_bytes(name, n, S, det, pw, C):
         return n * (2 * T + 4 * det * det + 4)
     if name == "tike_ifft2_crop":
         return n * (T + 8 * S * pw * pw)
-    if name == "tike_object_grad":
+    if name == "tike_lstsq_gradients":
         return n * (8 * S * pw * pw + 2 * 8 * pw * pw)
-    if name == "tike_probe_grad":
-        return n * (8 * S * pw * pw + 2 * 8 * pw * pw)
+    if name == "tike_scatter_patches":
+        return n * (8 * pw * pw + 8 * (pw + 1) * (pw + 1))
     if name == "tike_lstsq_step_stats":
         return n * (3 * 8 * pw * pw + 32)
     return 0
@@ -190,8 +190,9 @@ def main():
 
     timers = KernelTimers(lib, [
         "tike_ptycho_fwd", "tike_farplane_gradient", "tike_ifft2_crop",
-        "tike_object_grad", "tike_probe_grad", "tike_lstsq_step_stats",
-        "tike_patch_adj", "tike_probe_preconditioner", "tike_intensity"
+        "tike_lstsq_gradients", "tike_scatter_patches",
+        "tike_lstsq_step_stats", "tike_psi_preconditioner",
+        "tike_probe_preconditioner", "tike_intensity"
     ])
     cpu = None
     C = 0

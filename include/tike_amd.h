@@ -112,12 +112,22 @@ int tike_objective_grad(const float* data, const void* farplane, const float* in
  * chi (nscan,S,pw,pw): exit-wave update = tike_ifft2_crop of the far-plane
  * gradient.  The probe arguments select P_n,s as in tike_ptycho_fwd. */
 
-/* object_upd_sum (H,W) += scatter_n( sum_s conj(P_n,s) * chi_n,s )
- * (lstsq.py:510-520 = conj multiply + Patch.adj with nrepeat = S). */
-int tike_object_grad(const void* chi, const float* scan, const void* probe, int probe_per_scan,
-                     const void* eigen_probe, const float* eigen_weights, int num_eigen,
-                     int eigen_modes, void* object_upd_sum, int nscan, int S, int pw, int H,
-                     int W, void* stream);
+/* One pass over chi for both gradients (lstsq.py:506-539):
+ *   m_probe_update (S,pw,pw) += sum_n conj(patch_n(psi)) * chi_n,s
+ *   objproj (nscan,pw,pw)     = sum_s conj(P_n,s) * chi_n,s
+ *   patches (nscan,pw,pw)     = patch_n(psi)            (the reference's bpatches)
+ * any of the three outputs may be NULL.  S <= 16. */
+int tike_lstsq_gradients(const void* chi, const float* scan, const void* psi, const void* probe,
+                         const void* eigen_probe, const float* eigen_weights, int num_eigen,
+                         int eigen_modes, void* patches, void* m_probe_update, void* objproj,
+                         int nscan, int S, int pw, int H, int W, void* stream);
+
+/* acc (2,H,W) f32, PLANAR (real plane, imaginary plane) += scatter_n( objproj_n ):
+ * the adjoint of the bilinear patch gather (Patch.adj, patch.py:132-188) with
+ * one atomic per object pixel and position.  Positions must satisfy
+ * check_allowed_positions (position.py:600-628). */
+int tike_scatter_patches(const void* objproj, const float* scan, float* acc, int nscan, int pw,
+                         int H, int W, void* stream);
 
 /* m_probe_update (S,pw,pw) += sum_n conj(patch_n(psi)) * chi_n,s
  * (lstsq.py:524-539); patches (nscan,pw,pw), if not NULL, receives
@@ -125,10 +135,10 @@ int tike_object_grad(const void* chi, const float* scan, const void* probe, int 
 int tike_probe_grad(const void* chi, const float* scan, const void* psi, void* patches,
                     void* m_probe_update, int nscan, int S, int pw, int H, int W, void* stream);
 
-/* out (H,W) c64: real part += scatter_n( sum_s |probe_s|^2 ), the object
+/* out (H,W) f32 += scatter_n( sum_s |probe_s|^2 ), the (real-valued) object
  * preconditioner (solvers/_preconditioner.py:48-104 = Patch.adj of one
  * broadcast patch).  probe (S,pw,pw) shared.  Positions must satisfy
- * check_allowed_positions (position.py:600-628); so must tike_object_grad's. */
+ * check_allowed_positions (position.py:600-628). */
 int tike_psi_preconditioner(const void* probe, const float* scan, void* out, int nscan, int S,
                             int pw, int H, int W, void* stream);
 

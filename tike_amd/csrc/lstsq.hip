@@ -1,8 +1,8 @@
 // Kernels of the least-squares + gradient update loop (lstsq_grad) for gfx950.
 //
 // Reference: src/tike/ptycho/solvers/lstsq.py (one minibatch):
-//   :506-520  object gradient  sum_s conj(P_n,s) chi_n,s scattered   -> tike_object_grad
-//   :524-539  probe gradient   sum_n conj(O_n) chi_n,s               -> tike_probe_grad
+//   :506-520  object gradient  sum_s conj(P_n,s) chi_n,s scattered   -> tike_lstsq_gradients + tike_scatter_patches
+//   :524-539  probe gradient   sum_n conj(O_n) chi_n,s               -> tike_lstsq_gradients (tike_probe_grad)
 //   :619-718  step-size normal equations, per position               -> tike_lstsq_step_stats
 //   :721-738  eigen-probe intensity coefficients                     -> (same kernel)
 //   solvers/_preconditioner.py:116-167 probe preconditioner          -> tike_probe_preconditioner
@@ -31,10 +31,14 @@ constexpr int TK_STRIP = 32;
 #define TK_ATOMIC_ADD(p, v) unsafeAtomicAdd(p, v)
 #endif
 
+// The accumulation image is PLANAR (all real parts, then all imaginary parts):
+// one atomic wave-instruction then covers 256 contiguous bytes, the shape that
+// runs at the full atomic rate (interleaved complex halves it).
 template <bool REAL_ONLY, class ValueFn>
 __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorner& c,
-                                                  float fx, float fy, float* __restrict__ imf,
-                                                  int pw, int H, int W, int strip) {
+                                                  float fx, float fy, float* __restrict__ re,
+                                                  float* __restrict__ im, int pw, int H, int W,
+                                                  int strip) {
   const int r0 = strip * TK_STRIP;
   const int r1 = min(pw + 1, r0 + TK_STRIP);  // rows y' in [r0, r1)
   for (int x0 = 0; x0 < pw; x0 += blockDim.x) {
@@ -83,15 +87,14 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
             const int X = c.sx + xp;
             if (X >= 0 && X < W) {
               const long ii = (long)Y * W + X;
-              TK_ATOMIC_ADD(&imf[2 * ii], (1.0f - fy) * u.x + fy * uprev.x);
-              if (!REAL_ONLY)
-                TK_ATOMIC_ADD(&imf[2 * ii + 1], (1.0f - fy) * u.y + fy * uprev.y);
+              TK_ATOMIC_ADD(&re[ii], (1.0f - fy) * u.x + fy * uprev.x);
+              if (!REAL_ONLY) TK_ATOMIC_ADD(&im[ii], (1.0f - fy) * u.y + fy * uprev.y);
             }
             if (xp == pw - 1 && X + 1 >= 0 && X + 1 < W) {
               const long ii = (long)Y * W + X + 1;
-              TK_ATOMIC_ADD(&imf[2 * ii], (1.0f - fy) * ulast.x + fy * uprev_last.x);
+              TK_ATOMIC_ADD(&re[ii], (1.0f - fy) * ulast.x + fy * uprev_last.x);
               if (!REAL_ONLY)
-                TK_ATOMIC_ADD(&imf[2 * ii + 1], (1.0f - fy) * ulast.y + fy * uprev_last.y);
+                TK_ATOMIC_ADD(&im[ii], (1.0f - fy) * ulast.y + fy * uprev_last.y);
             }
           }
         }
@@ -108,57 +111,47 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
 }
 
 // ----------------------------------------------------------- object gradient
-// object_upd_sum += scatter_n( sum_s conj(P_n,s) chi_n,s )   (lstsq.py:510-520)
-__global__ __launch_bounds__(256) void object_grad_kernel(const cf* __restrict__ chi,
-                                                          const float* __restrict__ scan,
-                                                          const TkProbe probe,
-                                                          float* __restrict__ imf, int nscan,
-                                                          int S, int pw, int H, int W) {
+// acc (2,H,W) planar f32 += scatter_n( objproj_n ),  objproj (nscan,pw,pw) c64 =
+// sum_s conj(P_n,s) chi_n,s  computed by tike_lstsq_gradients
+// (lstsq.py:510-520 = conj multiply + Patch.adj with nrepeat = S).
+__global__ __launch_bounds__(256) void scatter_patches_kernel(const cf* __restrict__ proj,
+                                                              const float* __restrict__ scan,
+                                                              float* __restrict__ acc, int nscan,
+                                                              int pw, int H, int W) {
   const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
   const long P = (long)pw * pw;
+  float* __restrict__ re = acc;
+  float* __restrict__ im = acc + (long)H * W;
   for (long w = blockIdx.x; w < (long)nscan * nstrip; w += gridDim.x) {
     const long n = w / nstrip;
     const int strip = (int)(w % nstrip);
     const TkCorner c = tk_corner(scan, n);
     const float fy = scan[2 * n] - floorf(scan[2 * n]);
     const float fx = scan[2 * n + 1] - floorf(scan[2 * n + 1]);
-    scatter_footprint<false>(
-        [&](int y, int x) {
-          const long p = (long)y * pw + x;
-          cf v = mk(0.f, 0.f);
-          for (int s = 0; s < S; ++s) v = v + conjf(probe.at(n, s, p)) * chi[(n * S + s) * P + p];
-          return v;
-        },
-        c, fx, fy, imf, pw, H, W, strip);
+    scatter_footprint<false>([&](int y, int x) { return proj[n * P + (long)y * pw + x]; }, c, fx,
+                             fy, re, im, pw, H, W, strip);
   }
 }
 
-extern "C" int tike_object_grad(const void* chi, const float* scan, const void* probe,
-                                int probe_per_scan, const void* eigen_probe,
-                                const float* eigen_weights, int num_eigen, int eigen_modes,
-                                void* object_upd_sum, int nscan, int S, int pw, int H, int W,
-                                void* stream) {
+extern "C" int tike_scatter_patches(const void* objproj, const float* scan, float* acc,
+                                    int nscan, int pw, int H, int W, void* stream) {
   TK_ENTER();
-  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
-  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && H >= 1 && W >= 1);
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
-  TK_CHECK_ARG(chi && scan && probe && object_upd_sum);
+  TK_CHECK_ARG(objproj && scan && acc);
   const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
-  hipLaunchKernelGGL(object_grad_kernel, dim3(tk_grid((long)nscan * nstrip, 16)), dim3(256), 0,
-                     (hipStream_t)stream, (const cf*)chi, scan,
-                     tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
-                                   eigen_modes, S, pw),
-                     (float*)object_upd_sum, nscan, S, pw, H, W);
+  hipLaunchKernelGGL(scatter_patches_kernel, dim3(tk_grid((long)nscan * nstrip, 16)), dim3(256),
+                     0, (hipStream_t)stream, (const cf*)objproj, scan, acc, nscan, pw, H, W);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
 
 // ------------------------------------------------------ psi preconditioner
-// out (H,W) complex: real part += scatter_n( sum_s |probe_s|^2 )
+// out (H,W) float32 += scatter_n( sum_s |probe_s|^2 )
 // (solvers/_preconditioner.py:48-104: Patch.adj of one broadcast patch).
 __global__ __launch_bounds__(256) void psi_precond_kernel(const cf* __restrict__ probe,
                                                           const float* __restrict__ scan,
-                                                          float* __restrict__ imf, int nscan,
+                                                          float* __restrict__ out, int nscan,
                                                           int S, int pw, int H, int W) {
   const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
   const long P = (long)pw * pw;
@@ -175,7 +168,7 @@ __global__ __launch_bounds__(256) void psi_precond_kernel(const cf* __restrict__
           for (int s = 0; s < S; ++s) a += norm2(probe[s * P + p]);
           return mk(a, 0.f);
         },
-        c, fx, fy, imf, pw, H, W, strip);
+        c, fx, fy, out, out, pw, H, W, strip);
   }
 }
 
@@ -202,8 +195,8 @@ constexpr int TK_MAX_MODES = 16;
 template <bool WITH_CHI>
 __global__ __launch_bounds__(256) void probe_grad_kernel(
     const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
-    cf* __restrict__ patches, float* __restrict__ out, int nscan, int S, int pw, int H, int W,
-    int chunk) {
+    cf* __restrict__ patches, float* __restrict__ out, const TkProbe probe,
+    cf* __restrict__ objproj, int nscan, int S, int pw, int H, int W, int chunk) {
   const long P = (long)pw * pw;
   const long total = (long)H * W;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,20 +215,28 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
     if (patches) patches[b * P + p] = o;
     if (WITH_CHI) {
       const cf oc = conjf(o);
+      cf proj = mk(0.f, 0.f);
 #pragma unroll
       for (int s = 0; s < TK_MAX_MODES; ++s)
-        if (s < S) acc[s] = acc[s] + oc * chi[((long)b * S + s) * P + p];
+        if (s < S) {
+          const cf x = chi[((long)b * S + s) * P + p];
+          if (out) acc[s] = acc[s] + oc * x;
+          if (objproj) proj = proj + conjf(probe.at(b, s, p)) * x;
+        }
+      if (objproj) objproj[b * P + p] = proj;
     } else {
       acc[0].x += norm2(o);
     }
   }
   if (WITH_CHI) {
+    if (out) {
 #pragma unroll
-    for (int s = 0; s < TK_MAX_MODES; ++s)
-      if (s < S) {
-        unsafeAtomicAdd(&out[2 * (s * P + p)], acc[s].x);
-        unsafeAtomicAdd(&out[2 * (s * P + p) + 1], acc[s].y);
-      }
+      for (int s = 0; s < TK_MAX_MODES; ++s)
+        if (s < S) {
+          unsafeAtomicAdd(&out[2 * (s * P + p)], acc[s].x);
+          unsafeAtomicAdd(&out[2 * (s * P + p) + 1], acc[s].y);
+        }
+    }
   } else {
     unsafeAtomicAdd(&out[2 * p], acc[0].x);
   }
@@ -259,7 +260,33 @@ extern "C" int tike_probe_grad(const void* chi, const float* scan, const void* p
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
   hipLaunchKernelGGL((probe_grad_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream,
                      (const cf*)chi, scan, (const cf*)psi, (cf*)patches, (float*)m_probe_update,
-                     nscan, S, pw, H, W, chunk);
+                     tk_make_probe(psi, 0, nullptr, nullptr, 0, 0, S, pw), (cf*)nullptr, nscan, S,
+                     pw, H, W, chunk);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// One pass over chi for BOTH gradients (lstsq.py:506-539):
+//   m_probe_update (S,pw,pw) += sum_n conj(O_n) chi_n,s          (may be NULL)
+//   objproj (nscan,pw,pw)     = sum_s conj(P_n,s) chi_n,s        (may be NULL)
+//   patches (nscan,pw,pw)     = O_n = patch_n(psi)               (may be NULL)
+extern "C" int tike_lstsq_gradients(const void* chi, const float* scan, const void* psi,
+                                    const void* probe, const void* eigen_probe,
+                                    const float* eigen_weights, int num_eigen, int eigen_modes,
+                                    void* patches, void* m_probe_update, void* objproj,
+                                    int nscan, int S, int pw, int H, int W, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && S <= TK_MAX_MODES && pw >= 1 && H >= 1 && W >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(chi && scan && psi && probe);
+  const long P = (long)pw * pw;
+  const int chunk = probe_chunk(nscan);
+  dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
+  hipLaunchKernelGGL((probe_grad_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream,
+                     (const cf*)chi, scan, (const cf*)psi, (cf*)patches, (float*)m_probe_update,
+                     tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
+                                   S, pw),
+                     (cf*)objproj, nscan, S, pw, H, W, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -276,8 +303,9 @@ extern "C" int tike_probe_preconditioner(const float* scan, const void* psi, voi
   const int chunk = probe_chunk(nscan);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
   hipLaunchKernelGGL((probe_grad_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream,
-                     (const cf*)nullptr, scan, (const cf*)psi, (cf*)nullptr, (float*)out, nscan,
-                     1, pw, H, W, chunk);
+                     (const cf*)nullptr, scan, (const cf*)psi, (cf*)nullptr, (float*)out,
+                     tk_make_probe(psi, 0, nullptr, nullptr, 0, 0, 1, pw), (cf*)nullptr, nscan, 1,
+                     pw, H, W, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -16,7 +16,7 @@ def _psi_preconditioner(parameters, operator):
     """sum_s |probe_s|^2 scattered at every position (:48-104)."""
     psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
     assert psi.shape[0] == 1, "single-slice objects only"
-    out = torch.zeros_like(psi)
+    out = torch.zeros(tuple(psi.shape), dtype=torch.float32, device=psi.device)
     pw = probe.shape[-1]
     check(
         lib.tike_psi_preconditioner(A.ptr(probe), A.ptr(scan), A.ptr(out),
@@ -43,8 +43,10 @@ def _probe_preconditioner(parameters, operator):
 def update_preconditioners(comm, parameters, operator):
     """Refresh both preconditioners once per epoch (:170-209)."""
     if parameters.object_options:
+        # accumulated as float32 (real-valued), stored complex64 like the
+        # reference's array (object.py:69-72)
         parameters.object_options.preconditioner = comm.Allreduce(
-            _psi_preconditioner(parameters, operator))
+            _psi_preconditioner(parameters, operator)).to(torch.complex64)
     if parameters.probe_options:
         parameters.probe_options.preconditioner = comm.Allreduce(
             _probe_preconditioner(parameters, operator))

@@ -37,8 +37,11 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
     chi_ws = mid if pw == det else ws.get(
         "chi", (min(chunk, max(N, 1)), 1, S, pw, pw), torch.complex64, dev)
     costs = ws.get("costs", (max(N, 1),), torch.float32, dev)
-    gpsi = torch.zeros_like(psi) if (want_grad and want_psi) else None
+    gacc = (torch.zeros((2, H, W), dtype=torch.float32, device=dev)
+            if (want_grad and want_psi) else None)
     gprobe = torch.zeros_like(probe) if (want_grad and want_probe) else None
+    objproj = (ws.get("objproj", (min(chunk, max(N, 1)), pw, pw),
+                      torch.complex64, dev) if gacc is not None else None)
     for lo in range(0, N, chunk):
         hi = min(N, lo + chunk)
         n = hi - lo
@@ -56,24 +59,24 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
         check(
             lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S, det,
                                 pw, inv_scale, st), "cgrad ifft2")
-        if gpsi is not None:
+        check(
+            lib.tike_lstsq_gradients(A.ptr(chi), A.ptr(scan[lo:hi]), A.ptr(psi),
+                                     A.ptr(probe), None, None, 0, 0, None,
+                                     A.ptr(gprobe), A.ptr(objproj), n, S, pw,
+                                     H, W, st), "cgrad gradients")
+        if gacc is not None:
             check(
-                lib.tike_object_grad(A.ptr(chi), A.ptr(scan[lo:hi]),
-                                     A.ptr(probe), 0, None, None, 0, 0,
-                                     A.ptr(gpsi), n, S, pw, H, W, st),
-                "cgrad object gradient")
-        if gprobe is not None:
-            check(
-                lib.tike_probe_grad(A.ptr(chi), A.ptr(scan[lo:hi]), A.ptr(psi),
-                                    None, A.ptr(gprobe), n, S, pw, H, W, st),
-                "cgrad probe gradient")
+                lib.tike_scatter_patches(A.ptr(objproj), A.ptr(scan[lo:hi]),
+                                         A.ptr(gacc), n, pw, H, W, st),
+                "cgrad object scatter")
     tot = comm.Allreduce_scalars([costs[:N].sum()], dev)
     cost = float((tot[0] / global_count(comm, op, 0, N)).item())
-    grads = [t for t in (gpsi, gprobe) if t is not None]
+    grads = [t for t in (gacc, gprobe) if t is not None]
     if grads and comm.size > 1:
         comm.Allreduce(*grads)
-    if gpsi is not None:
-        gpsi = -gpsi
+    gpsi = None
+    if gacc is not None:
+        gpsi = -torch.complex(gacc[0], gacc[1])[None]
     if gprobe is not None:
         gprobe = -gprobe
     return cost, gpsi, gprobe

@@ -241,7 +241,10 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         w_old = eigen_weights[lo:hi].clone()
     ep, _, C, Sm = _eigen_args(eigen_probe, w_old)
 
-    object_upd_sum = torch.zeros_like(psi) if recover_psi else None
+    # planar (real plane, imaginary plane) float32 accumulator of the object
+    # gradient: the shape float atomics run fastest on; recombined below
+    obj_acc = (torch.zeros((2, H, W), dtype=torch.float32, device=dev)
+               if recover_psi else None)
     m_probe_update = torch.zeros_like(probe) if recover_probe else None
     chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
     patches = None
@@ -249,6 +252,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         patches = ws.get("patches", (max(B, 1), pw, pw), torch.complex64, dev)
     costs = ws.get("costs", (max(B, 1),), torch.float32, dev)
     chunk = chunk_positions(S, det)
+    objproj = ws.get("objproj", (min(chunk, max(B, 1)), pw, pw),
+                     torch.complex64, dev)
     far = ws.get("far", (min(chunk, max(B, 1)), 1, S, det, det),
                  torch.complex64, dev)
     # the inverse transform is out of place (far -> mid); chi is the cropped
@@ -277,26 +282,29 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         check(
             lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S, det,
                                 pw, inv_scale, st), "ifft2 + crop")
+        # one pass over chi: probe gradient, object projection, patches
+        check(
+            lib.tike_lstsq_gradients(
+                A.ptr(chi), A.ptr(scan[clo:chi_hi]), A.ptr(psi), A.ptr(probe),
+                A.ptr(ep), A.ptr(w_c), C, Sm,
+                None if patches is None else A.ptr(patches[blo:blo + n]),
+                A.ptr(m_probe_update), A.ptr(objproj) if recover_psi else None,
+                n, S, pw, H, W, st), "probe gradient + object projection")
         if recover_psi:
             check(
-                lib.tike_object_grad(A.ptr(chi), A.ptr(scan[clo:chi_hi]),
-                                     A.ptr(probe), 0, A.ptr(ep), A.ptr(w_c), C,
-                                     Sm, A.ptr(object_upd_sum), n, S, pw, H, W,
-                                     st), "object gradient")
-        if recover_probe:
-            check(
-                lib.tike_probe_grad(
-                    A.ptr(chi), A.ptr(scan[clo:chi_hi]), A.ptr(psi),
-                    None if patches is None else A.ptr(patches[blo:blo + n]),
-                    A.ptr(m_probe_update), n, S, pw, H, W, st),
-                "probe gradient")
+                lib.tike_scatter_patches(A.ptr(objproj),
+                                         A.ptr(scan[clo:chi_hi]),
+                                         A.ptr(obj_acc), n, pw, H, W, st),
+                "object scatter")
         chi0[blo:blo + n] = chi[:n, 0, 0]
 
     # complete the sums over positions across ranks
     cost_sum = costs[:B].sum() if B > 0 else torch.zeros((), device=dev)
-    reduced = [t for t in (object_upd_sum, m_probe_update) if t is not None]
+    reduced = [t for t in (obj_acc, m_probe_update) if t is not None]
     if comm.size > 1:
         comm.Allreduce(*reduced)
+    object_upd_sum = (torch.complex(obj_acc[0], obj_acc[1])[None]
+                      if recover_psi else None)
     count = global_count(comm, op, lo, hi)
     tot = comm.Allreduce_scalars([cost_sum], dev)
     if recover_probe:
