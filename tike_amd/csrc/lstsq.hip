@@ -192,11 +192,16 @@ extern "C" int tike_psi_preconditioner(const void* probe, const float* scan, voi
 // Optionally stores the object patches (B, pw, pw) for later passes.
 constexpr int TK_MAX_MODES = 16;
 
-template <bool WITH_CHI>
+// SC = compile-time number of modes (0: runtime S <= TK_MAX_MODES).  With SC
+// known the mode loop has no branches, so all S loads of a position are in
+// flight together instead of one memory latency per mode.
+template <bool WITH_CHI, int SC>
 __global__ __launch_bounds__(256) void probe_grad_kernel(
     const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
     cf* __restrict__ patches, float* __restrict__ out, const TkProbe probe,
-    cf* __restrict__ objproj, int nscan, int S, int pw, int H, int W, int chunk) {
+    cf* __restrict__ objproj, int nscan, int S_rt, int pw, int H, int W, int chunk) {
+  constexpr int SM = SC > 0 ? SC : TK_MAX_MODES;
+  const int S = SC > 0 ? SC : S_rt;
   const long P = (long)pw * pw;
   const long total = (long)H * W;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,24 +209,32 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
   const int b1 = min(nscan, b0 + chunk);
   if (p >= P) return;
   const int py = (int)(p / pw), px = (int)(p % pw);
-  cf acc[TK_MAX_MODES];
+  cf acc[SM];
 #pragma unroll
-  for (int s = 0; s < TK_MAX_MODES; ++s) acc[s] = mk(0.f, 0.f);
+  for (int s = 0; s < SM; ++s) acc[s] = mk(0.f, 0.f);
   for (int b = b0; b < b1; ++b) {
     const TkCorner c = tk_corner(scan, b);
     const int y = c.sy + py, x = c.sx + px;
-    cf o = mk(0.f, 0.f);
-    if (y >= 0 && y < H && x >= 0 && x < W) o = tk_gather(psi, (long)y * W + x, W, total, c);
+    const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+    const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+    const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+    cf xs[SM];
+    if (WITH_CHI) {
+#pragma unroll
+      for (int s = 0; s < SM; ++s)
+        if (SC > 0 || s < S) xs[s] = chi[((long)b * S + s) * P + p];
+    }
+    cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
+    if (!ok) o = mk(0.f, 0.f);
     if (patches) patches[b * P + p] = o;
     if (WITH_CHI) {
       const cf oc = conjf(o);
       cf proj = mk(0.f, 0.f);
 #pragma unroll
-      for (int s = 0; s < TK_MAX_MODES; ++s)
-        if (s < S) {
-          const cf x = chi[((long)b * S + s) * P + p];
-          if (out) acc[s] = acc[s] + oc * x;
-          if (objproj) proj = proj + conjf(probe.at(b, s, p)) * x;
+      for (int s = 0; s < SM; ++s)
+        if (SC > 0 || s < S) {
+          if (out) acc[s] = acc[s] + oc * xs[s];
+          if (objproj) proj = proj + conjf(probe.at(b, s, p)) * xs[s];
         }
       if (objproj) objproj[b * P + p] = proj;
     } else {
@@ -231,8 +244,8 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
   if (WITH_CHI) {
     if (out) {
 #pragma unroll
-      for (int s = 0; s < TK_MAX_MODES; ++s)
-        if (s < S) {
+      for (int s = 0; s < SM; ++s)
+        if (SC > 0 || s < S) {
           unsafeAtomicAdd(&out[2 * (s * P + p)], acc[s].x);
           unsafeAtomicAdd(&out[2 * (s * P + p) + 1], acc[s].y);
         }
@@ -240,6 +253,26 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
   } else {
     unsafeAtomicAdd(&out[2 * p], acc[0].x);
   }
+}
+
+template <bool WITH_CHI>
+static void launch_probe_grad(dim3 grid, hipStream_t stream, const cf* chi, const float* scan,
+                              const cf* psi, cf* patches, float* out, const TkProbe& probe,
+                              cf* objproj, int nscan, int S, int pw, int H, int W, int chunk) {
+#define TK_PG(SC)                                                                              \
+  hipLaunchKernelGGL((probe_grad_kernel<WITH_CHI, SC>), grid, dim3(256), 0, stream, chi, scan, \
+                     psi, patches, out, probe, objproj, nscan, S, pw, H, W, chunk)
+  switch (WITH_CHI ? S : 1) {
+    case 1: TK_PG(1); break;
+    case 2: TK_PG(2); break;
+    case 3: TK_PG(3); break;
+    case 4: TK_PG(4); break;
+    case 5: TK_PG(5); break;
+    case 6: TK_PG(6); break;
+    case 8: TK_PG(8); break;
+    default: TK_PG(0); break;
+  }
+#undef TK_PG
 }
 
 static int probe_chunk(int nscan) {
@@ -258,10 +291,10 @@ extern "C" int tike_probe_grad(const void* chi, const float* scan, const void* p
   const long P = (long)pw * pw;
   const int chunk = probe_chunk(nscan);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
-  hipLaunchKernelGGL((probe_grad_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream,
-                     (const cf*)chi, scan, (const cf*)psi, (cf*)patches, (float*)m_probe_update,
-                     tk_make_probe(psi, 0, nullptr, nullptr, 0, 0, S, pw), (cf*)nullptr, nscan, S,
-                     pw, H, W, chunk);
+  launch_probe_grad<true>(grid, (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,
+                          (cf*)patches, (float*)m_probe_update,
+                          tk_make_probe(psi, 0, nullptr, nullptr, 0, 0, S, pw), (cf*)nullptr,
+                          nscan, S, pw, H, W, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -282,11 +315,11 @@ extern "C" int tike_lstsq_gradients(const void* chi, const float* scan, const vo
   const long P = (long)pw * pw;
   const int chunk = probe_chunk(nscan);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
-  hipLaunchKernelGGL((probe_grad_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream,
-                     (const cf*)chi, scan, (const cf*)psi, (cf*)patches, (float*)m_probe_update,
-                     tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
-                                   S, pw),
-                     (cf*)objproj, nscan, S, pw, H, W, chunk);
+  launch_probe_grad<true>(grid, (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,
+                          (cf*)patches, (float*)m_probe_update,
+                          tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen,
+                                        eigen_modes, S, pw),
+                          (cf*)objproj, nscan, S, pw, H, W, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -302,10 +335,10 @@ extern "C" int tike_probe_preconditioner(const float* scan, const void* psi, voi
   const long P = (long)pw * pw;
   const int chunk = probe_chunk(nscan);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
-  hipLaunchKernelGGL((probe_grad_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream,
-                     (const cf*)nullptr, scan, (const cf*)psi, (cf*)nullptr, (float*)out,
-                     tk_make_probe(psi, 0, nullptr, nullptr, 0, 0, 1, pw), (cf*)nullptr, nscan, 1,
-                     pw, H, W, chunk);
+  launch_probe_grad<false>(grid, (hipStream_t)stream, (const cf*)nullptr, scan,
+                           (const cf*)psi, (cf*)nullptr, (float*)out,
+                           tk_make_probe(psi, 0, nullptr, nullptr, 0, 0, 1, pw), (cf*)nullptr,
+                           nscan, 1, pw, H, W, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
