@@ -134,18 +134,60 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
     // padding / out-of-image pixels are zeroed by a select afterwards
     const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
     const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
+    // Fast path (every position that passes check_allowed_positions): all four
+    // taps of every patch pixel lie inside the image, so rows are addressed as
+    // uniform row offset + per-thread column with no clamping, and the probe
+    // weights of this (position, mode) are hoisted into scalars.
+    const bool interior = c.sy >= 0 && c.sx >= 0 && c.sy + pw < H && c.sx + pw < W;
+    const long PP = (long)pw * pw;
+    const cf* __restrict__ Pn = probe.probe + n * probe.pos_stride + s * PP;
+    float w0 = 1.0f;
+    int nE = 0;
+    if (probe.weights != nullptr) {
+      w0 = probe.weights[n * (long)(probe.C + 1) * probe.S + s];
+      if (probe.eigen != nullptr && s < probe.Sm) nE = probe.C;
+    }
     for (int r = 0; r < G2::RB; ++r) {
       // stage the 16 rows {r + RB*l} of patch * probe (zero padded) into LDS
+      if (interior) {
 #pragma unroll 8
-      for (int l = 0; l < 16; ++l) {
-        const int py = r + G2::RB * l - pad;
-        const int y = c.sy + py;
-        const bool ok = col_ok && py >= 0 && py < pw && y >= 0 && y < H;
-        const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
-        const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
-        const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c) *
-                     probe.at(n, s, (long)pyc * pw + pxc);
-        lds[l * G2::LS + tk_pad16(t)] = ok ? o : mk(0.f, 0.f);
+        for (int l = 0; l < 16; ++l) {
+          const int py = r + G2::RB * l - pad;           // uniform
+          const bool row_ok = py >= 0 && py < pw;        // uniform
+          const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
+          const cf* __restrict__ q = psi + (long)(c.sy + pyc) * W + c.sx + pxc;
+          const cf a = q[0], b = q[1], d = q[W], e = q[W + 1];
+          const long pi = (long)pyc * pw + pxc;
+          cf pr = Pn[pi] * w0;
+          for (int k = 0; k < nE; ++k) {
+            const cf ev = probe.eigen[((long)k * probe.Sm + s) * PP + pi];
+            const float wk =
+                probe.weights[n * (long)(probe.C + 1) * probe.S + (k + 1) * probe.S + s];
+            pr.x += wk * ev.x;
+            pr.y += wk * ev.y;
+          }
+          cf o = mk(a.x * c.w00, a.y * c.w00);
+          o.x += b.x * c.w01;
+          o.y += b.y * c.w01;
+          o.x += d.x * c.w10;
+          o.y += d.y * c.w10;
+          o.x += e.x * c.w11;
+          o.y += e.y * c.w11;
+          o = o * pr;
+          lds[l * G2::LS + tk_pad16(t)] = (row_ok && col_ok) ? o : mk(0.f, 0.f);
+        }
+      } else {
+#pragma unroll 4
+        for (int l = 0; l < 16; ++l) {
+          const int py = r + G2::RB * l - pad;
+          const int y = c.sy + py;
+          const bool ok = col_ok && py >= 0 && py < pw && y >= 0 && y < H;
+          const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
+          const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
+          const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c) *
+                       probe.at(n, s, (long)pyc * pw + pxc);
+          lds[l * G2::LS + tk_pad16(t)] = ok ? o : mk(0.f, 0.f);
+        }
       }
       __syncthreads();
       fft2_pass1<N, false>(lds, twtab, tw, line, j, r,
@@ -156,109 +198,6 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
       fft2_pass2<N, false>(dst, k1, [&](int ky, int tt, cf v) { dst[ky * N + tt] = v * scale; });
     __syncthreads();
   }
-}
-
-// v3: producer / consumer split of the v2 forward.  Threads [0, N) run the
-// FFT of 16-row group r out of one LDS buffer while threads [N, 2N) gather
-// patch * probe for group r+1 into the other buffer, so the gather's memory
-// latency overlaps the butterflies instead of preceding them.  Same two
-// barriers per row group as v2.
-template <int N>
-__global__ __launch_bounds__(2 * N, (N <= 128 ? 4 : (N == 256 ? 4 : 2))) void ptycho_fwd_v3_kernel(
-    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
-    cf* __restrict__ farplane, long ntile, int S, int pw, int H, int W, float scale,
-    const cf* __restrict__ twtab) {
-  using G2 = Fft2Geom<N>;
-  __shared__ cf lds[2 * G2::LDS_ELEMS];
-  FftTw<N> tw;
-  const int pad = (N - pw) / 2;
-  const long total = (long)H * W;
-  // wave-uniform role (N is a multiple of 64): scalar branches, and the register
-  // allocator sees the two roles as alternatives rather than as one live set
-  const bool producer = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= N)) != 0;
-  const int t = producer ? threadIdx.x - N : threadIdx.x;  // column owned
-  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const long n = tile / S;
-    const int s = (int)(tile % S);
-    const TkCorner c = tk_corner(scan, n);
-    cf* __restrict__ dst = farplane + tile * (long)N * N;
-    int line = t / G2::T, j = t % G2::T;
-    asm volatile("" : "+v"(line), "+v"(j));
-    if (!producer) tw.init(twtab, j);
-    const int px = t - pad;
-    const int x = c.sx + px;
-    const bool col_ok = px >= 0 && px < pw && x >= 0 && x < W;
-    const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
-    const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
-    auto stage = [&](int r, cf* __restrict__ buf) {
-#pragma unroll 4
-      for (int l = 0; l < 16; ++l) {
-        const int py = r + G2::RB * l - pad;
-        const int y = c.sy + py;
-        const bool ok = col_ok && py >= 0 && py < pw && y >= 0 && y < H;
-        const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
-        const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
-        const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c) *
-                     probe.at(n, s, (long)pyc * pw + pxc);
-        buf[l * G2::LS + tk_pad16(t)] = ok ? o : mk(0.f, 0.f);
-      }
-    };
-    if (producer) stage(0, lds);
-    __syncthreads();
-    for (int r = 0; r < G2::RB; ++r) {
-      cf* __restrict__ cur = lds + (r & 1) * G2::LDS_ELEMS;
-      cf* __restrict__ nxt = lds + ((r + 1) & 1) * G2::LDS_ELEMS;
-      cf v[16];
-      if (producer) {
-        if (r + 1 < G2::RB) stage(r + 1, nxt);
-      } else {
-        cf* lbase = cur + line * G2::LS;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = lbase[tk_pad16(j + i * G2::T)];
-        FftStageWave<N, false, 0>::run(v, lbase, j, tw);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) lbase[tk_pad16(j + i * G2::T)] = v[i];
-      }
-      __syncthreads();
-      if (!producer) {
-#pragma unroll
-        for (int y2 = 0; y2 < 16; ++y2) v[y2] = cur[y2 * G2::LS + tk_pad16(t)];
-      }
-      __syncthreads();
-      if (!producer) {
-        Dft<16, false>::run(v);
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) {
-          cf o = v[k1];
-          if (k1 > 0) o = mul_tw<false>(o, twtab[N + r * k1]);
-          dst[(16 * r + k1) * N + t] = o;
-        }
-      }
-    }
-    __syncthreads();
-    // pass 2: both halves of the workgroup share the 16 k1 iterations
-    for (int k1 = producer ? 1 : 0; k1 < 16; k1 += 2) {
-      cf u[G2::RB];
-#pragma unroll
-      for (int rr = 0; rr < G2::RB; ++rr) u[rr] = dst[(16 * rr + k1) * N + t];
-      Dft<G2::RB, false>::run(u);
-#pragma unroll
-      for (int k2 = 0; k2 < G2::RB; ++k2) dst[(k1 + 16 * k2) * N + t] = u[k2] * scale;
-    }
-    __syncthreads();
-  }
-}
-
-template <int N>
-static int launch_fwd_v3(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
-                         long ntile, int S, int pw, int H, int W, float scale,
-                         hipStream_t stream) {
-  const cf* tw = tk_twiddles();
-  if (!tw) return (int)hipErrorNotInitialized;
-  hipLaunchKernelGGL((ptycho_fwd_v3_kernel<N>), dim3(tk_grid(ntile, 2)), dim3(2 * N), 0, stream,
-                     psi, scan, probe, farplane, ntile, S, pw, H, W, scale, tw);
-  TK_LAUNCH_CHECK();
-  return TK_OK;
 }
 
 template <int N>
@@ -302,14 +241,6 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
   const cf* psi_ = (const cf*)psi;
   cf* far = (cf*)farplane;
   static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
-  static const bool use_v3 = getenv("TIKE_FWD_V2") == nullptr;
-  if (use_v2 && use_v3) {
-    switch (det) {
-      case 128: return launch_fwd_v3<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
-      case 256: return launch_fwd_v3<256>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
-      default: break;
-    }
-  }
   if (use_v2) {
     switch (det) {
       case 128: return launch_fwd_v2<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
