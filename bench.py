@@ -158,6 +158,12 @@ def algorithmic_bytes(name, n, S, det, pw, C):
     T = 8 * S * det * det  # one position's far-plane, bytes
     if name == "tike_ptycho_fwd":
         return n * (T + 8 * pw * pw + 8) + 8 * (S + C) * pw * pw
+    if name == "tike_ptycho_fwd_intensity":
+        return n * (T + 8 * pw * pw + 4 * det * det + 8) + 8 * (S + C) * pw * pw
+    if name == "tike_ifft2_crop_scaled":
+        return n * (T + 8 * S * pw * pw + 4 * det * det)
+    if name == "tike_gradient_scale":
+        return n * 3 * 4 * det * det
     if name == "tike_farplane_gradient":
         return n * (2 * T + 4 * det * det + 4)
     if name == "tike_ifft2_crop":
@@ -190,6 +196,8 @@ def main():
 
     timers = KernelTimers(lib, [
         "tike_ptycho_fwd", "tike_farplane_gradient", "tike_ifft2_crop",
+        "tike_ptycho_fwd_intensity", "tike_gradient_scale",
+        "tike_ifft2_crop_scaled",
         "tike_lstsq_gradients", "tike_scatter_patches",
         "tike_lstsq_step_stats", "tike_psi_preconditioner",
         "tike_probe_preconditioner", "tike_intensity"
@@ -260,7 +268,8 @@ def main():
             ctx.iterate(1)
 
         units = N
-        launch_n = min(chunk_positions(S, det), N // num_batch)
+        launch_n = min(chunk_positions(S, det, det in (128, 256)),
+                       N // num_batch)
         dominant = None
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_epoch(p, data, S, det)

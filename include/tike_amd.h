@@ -79,6 +79,33 @@ int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe, int p
                     int eigen_modes, void* farplane, int nscan, int S, int pw, int det, int H,
                     int W, float scale, void* stream);
 
+/* ---- Ptycho.fwd + intensity, position-major (one workgroup per position
+ * walks all S modes): same far-plane as tike_ptycho_fwd plus
+ * intensity[n] = sum_s |farplane[n][s]|^2 (ptycho.py:18-23) accumulated in
+ * registers, so the far-plane is not re-read to form it.  det in {128, 256}
+ * (TIKE_ERR_UNSUPPORTED otherwise: use tike_ptycho_fwd + tike_intensity).
+ * intensity (nscan,det,det) f32 may be NULL. */
+int tike_ptycho_fwd_intensity(const void* psi, const float* scan, const void* probe,
+                              int probe_per_scan, const void* eigen_probe,
+                              const float* eigen_weights, int num_eigen, int eigen_modes,
+                              void* farplane, float* intensity, int nscan, int S, int pw, int det,
+                              int H, int W, float scale, void* stream);
+
+/* ---- far-plane gradient factor from the intensity (objective.py:31-44,97-109;
+ * lstsq.py:491-502): gscale[n][p] = -(1 - sqrt(d)/(sqrt(I)+1e-9)) (gaussian) or
+ * -(1 - d/(I+1e-9)) (poisson) on measured pixels, (unmeasured_scaling - 1)
+ * elsewhere; costs[n] (optional) = per-pattern cost over measured pixels. */
+int tike_gradient_scale(const float* intensity, const float* data, const unsigned char* measured,
+                        float* gscale, float* costs, int nscan, int det, int model,
+                        float unmeasured_scaling, long num_measured, void* stream);
+
+/* ---- IFFT2 + crop of (farplane * gscale): the far-plane gradient is applied
+ * while the rows are loaded (no separate read-modify-write pass).  gscale
+ * (ntile / S, det, det) f32 is shared by the S modes of a position; work must
+ * not alias farplane; det in {128, 256, 512}. */
+int tike_ifft2_crop_scaled(const void* farplane, const float* gscale, int S, void* work,
+                           void* chi, long ntile, int det, int pw, float scale, void* stream);
+
 /* ---- IFFT2 + crop to the probe window (propagation.py:59-73 followed by
  * lstsq.py:506-507 / convolution.py:108-110 crop).  work (ntile,det,det) holds
  * the intermediate and may alias farplane; chi (ntile,pw,pw) may alias work

@@ -351,3 +351,64 @@ def test_full_size_roundtrip_property(ops):
             float((f.abs()**2).sum()), float((t.abs()**2).sum()), rtol=1e-5)
         back = op.adj(farplane=f)
     assert relerr(back.cpu().numpy(), x) < 2e-6
+
+
+@pytest.mark.parametrize("det,pw,S", [(128, 128, 3), (256, 256, 2),
+                                      (128, 96, 2)])
+def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
+    """tike_ptycho_fwd_intensity -> tike_gradient_scale ->
+    tike_ifft2_crop_scaled == oracle fwd, intensity, per-pattern cost and
+    cropped IFFT2 of the far-plane gradient (lstsq.py:441-507), with eigen
+    probes and a mask whose unmeasured pixels hold NaN."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import lib, check
+    from oracle import solvers as sol
+    rng = np.random.default_rng(det + S)
+    N, C, HW = 5, 1, pw + 40
+    scan = (rng.random((N, 2)) * 36 + 1.5).astype(np.float32)
+    probe, psi = rc(rng, 1, 1, S, pw, pw), rc(rng, 1, HW, HW)
+    eigen = rc(rng, 1, C, 1, pw, pw)
+    w = (1 + 0.1 * rng.standard_normal((N, C + 1, S))).astype(np.float32)
+    uprobe = sol.get_varying_probe(probe, eigen, w)
+    want_far = oracle.ptycho_fwd(uprobe, scan, psi, det)
+    want_I = oracle.intensity_from_farplane(want_far)
+    data = (rng.random((N, det, det), dtype=np.float32) * want_I.max())
+    mask = rng.random((det, det)) > 0.1
+    data_nan = data.copy()
+    data_nan[:, ~mask] = np.nan
+    grad = want_far.copy()
+    grad[..., mask] = -oracle.gaussian_grad(data, want_far, want_I)[..., mask]
+    grad[..., ~mask] *= np.float32(0.5 - 1.0)
+    pad = (det - pw) // 2
+    want_chi = oracle.propagation_adj(grad)[..., pad:pad + pw, pad:pad + pw]
+    want_cost = oracle.gaussian_each_pattern(
+        data[:, mask][:, None, :], want_I[:, mask][:, None, :])
+    dev = A.current_device()
+    t = lambda x, dt=None: A.to_device(x, dt)
+    psi_d, scan_d, probe_d, eig_d, w_d = (t(psi), t(scan), t(probe), t(eigen),
+                                          t(w))
+    far = torch.empty((N, 1, S, det, det), dtype=torch.complex64, device=dev)
+    I = torch.empty((N, det, det), dtype=torch.float32, device=dev)
+    st = A.stream_ptr()
+    check(lib.tike_ptycho_fwd_intensity(
+        A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, A.ptr(eig_d),
+        A.ptr(w_d), C, 1, A.ptr(far), A.ptr(I), N, S, pw, det, HW, HW,
+        1.0 / det, st))
+    assert_close(far.cpu().numpy(), want_far, what="farplane")
+    assert_close(I.cpu().numpy(), want_I, what="intensity")
+    d_d, m_d = t(data_nan, np.float32), t(mask.astype(np.uint8))
+    g = torch.empty_like(I)
+    costs = torch.empty(N, dtype=torch.float32, device=dev)
+    check(lib.tike_gradient_scale(A.ptr(I), A.ptr(d_d), A.ptr(m_d), A.ptr(g),
+                                  A.ptr(costs), N, det, 0, 0.5,
+                                  int(mask.sum()), st))
+    np.testing.assert_allclose(costs.cpu().numpy(), want_cost, rtol=COST_RTOL)
+    mid = torch.empty_like(far)
+    chi = mid if pw == det else torch.empty((N, 1, S, pw, pw),
+                                            dtype=torch.complex64, device=dev)
+    check(lib.tike_ifft2_crop_scaled(A.ptr(far), A.ptr(g), S, A.ptr(mid),
+                                     A.ptr(chi), N * S, det, pw, 1.0 / det,
+                                     st))
+    assert_close(chi.cpu().numpy(), want_chi, normwise=1e-4, maxabs=1e-3,
+                 what="chi")

@@ -45,6 +45,10 @@ _PROTOTYPES = {
     "tike_ptycho_fwd": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i,
                         _i, _i, _f, _p],
     "tike_ifft2_crop": [_p, _p, _p, _l, _i, _i, _f, _p],
+    "tike_ptycho_fwd_intensity": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _i,
+                                  _i, _i, _i, _i, _i, _f, _p],
+    "tike_gradient_scale": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _l, _p],
+    "tike_ifft2_crop_scaled": [_p, _p, _i, _p, _p, _l, _i, _i, _f, _p],
     "tike_farplane_gradient": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _l,
                                _p],
     "tike_intensity": [_p, _p, _l, _i, _l, _p],

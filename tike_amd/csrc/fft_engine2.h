@@ -43,13 +43,48 @@ struct Fft2Geom {
 // Row-FFT stage with wave-level synchronisation: a line's T <= 32 threads
 // always sit in one wave (lanes j = tid % T), LDS instructions of a wave
 // execute in order, so no workgroup barrier is needed between the stages.
+// Inter-stage twiddles kept in LDS instead of registers: they depend only on
+// (stage, slot, j), i.e. are the same for every tile and every line, so one
+// table per workgroup ((NST-1)*16*T entries) filled once per kernel replaces
+// 30-46 VGPRs per thread.  Reads are conflict-free (consecutive j) and
+// broadcast across the lines of a wave.
+template <int N>
+struct FftTwLds {
+  static constexpr int T = N / 16;
+  static constexpr int ELEMS = (FftPlan<N>::NST - 1) * 16 * T;
+  const cf* tab;  // LDS
+  int j;
+  __device__ __forceinline__ cf get(int s, int i) const { return tab[((s - 1) * 16 + i) * T + j]; }
+  // fill (all threads of the workgroup), caller barriers afterwards
+  static __device__ __forceinline__ void fill(cf* tab, const cf* __restrict__ g_tw) {
+    using G = FftGeom<N>;
+    using P = FftPlan<N>;
+    for (int idx = threadIdx.x; idx < ELEMS; idx += blockDim.x) {
+      const int jj = idx % T;
+      const int i = (idx / T) % 16;
+      const int s = idx / (16 * T) + 1;
+      const int R = P::R[s], B = 16 / R, Ns = G::ns(s);
+      const int b = i % B, r = i / B;
+      const int k = (jj + b * T) & (Ns - 1);
+      tab[idx] = g_tw[N + k * r * (N / (Ns * R))];
+    }
+  }
+};
+
+template <int N>
+struct FftTwReg {
+  const FftTw<N>& tw;
+  __device__ __forceinline__ cf get(int s, int i) const { return tw.w[s][i]; }
+};
+
 template <int N, bool INV, int S>
 struct FftStageWave {
   using G = FftGeom<N>;
   using P = FftPlan<N>;
   static constexpr int T = N / 16;
+  template <class Tw>
   static __device__ __forceinline__ void run(cf (&v)[16], cf* __restrict__ lbase, int j,
-                                             const FftTw<N>& tw) {
+                                             const Tw& tw) {
     constexpr int R = P::R[S];
     constexpr int B = 16 / R;
     constexpr int Ns = G::ns(S);
@@ -60,7 +95,7 @@ struct FftStageWave {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         u[r] = v[b + r * B];
-        if (S > 0 && r > 0) u[r] = mul_tw<INV>(u[r], tw.w[S][b + r * B]);
+        if (S > 0 && r > 0) u[r] = mul_tw<INV>(u[r], tw.get(S, b + r * B));
       }
       Dft<R, INV>::run(u);
       if (LAST) {
@@ -90,10 +125,10 @@ struct FftStageWave {
 // Pass 1 for the 16 rows {r + RB*y2}.  `load(y, e)` returns input element e
 // of row y; results go to rows 16*r + k1 of `mid` (row-major N x N tile).
 // Contains two workgroup barriers; every thread of the NT = N workgroup calls.
-template <int N, bool INV, class Load>
+template <int N, bool INV, class Tw, class Load>
 __device__ __forceinline__ void fft2_pass1(cf* __restrict__ lds, const cf* __restrict__ twtab,
-                                           const FftTw<N>& tw, int line, int j, int r,
-                                           Load&& load, cf* __restrict__ mid) {
+                                           const Tw& tw, int line, int j, int r, Load&& load,
+                                           cf* __restrict__ mid) {
   using G2 = Fft2Geom<N>;
   cf v[16];
   const int y = r + G2::RB * line;

@@ -156,9 +156,15 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
           const bool row_ok = py >= 0 && py < pw;        // uniform
           const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
           const cf* __restrict__ q = psi + (long)(c.sy + pyc) * W + c.sx + pxc;
+#ifdef TK_DBG_FWD_NOLOAD
+          const cf a = mk(1.f, 0.f), b = a, d = a, e = a;
+          const long pi = (long)pyc * pw + pxc;
+          cf pr = mk(w0, (float)pi);
+#else
           const cf a = q[0], b = q[1], d = q[W], e = q[W + 1];
           const long pi = (long)pyc * pw + pxc;
           cf pr = Pn[pi] * w0;
+#endif
           for (int k = 0; k < nE; ++k) {
             const cf ev = probe.eigen[((long)k * probe.Sm + s) * PP + pi];
             const float wk =
@@ -190,13 +196,151 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
         }
       }
       __syncthreads();
-      fft2_pass1<N, false>(lds, twtab, tw, line, j, r,
+      fft2_pass1<N, false>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
                            [&](int y, int e) { return lds[line * G2::LS + tk_pad16(e)]; }, dst);
     }
     __syncthreads();
+#ifndef TK_DBG_FWD_NOPASS2
     for (int k1 = 0; k1 < 16; ++k1)
       fft2_pass2<N, false>(dst, k1, [&](int ky, int tt, cf v) { dst[ky * N + tt] = v * scale; });
     __syncthreads();
+#endif
+  }
+}
+
+// Position-major forward: one workgroup owns ALL S modes of a position, so the
+// bilinear patch is gathered once per 16-row group (registers) and re-used by
+// every mode, and the intensity sum_s |F_s|^2 accumulates in registers during
+// pass 2 -- the far-plane is never re-read to form it (ptycho.py:18-23,
+// lstsq.py:444-447).
+#ifndef TK_POS_WAVES
+#define TK_POS_WAVES 3
+#endif
+template <int N>
+__global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_pos_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    cf* __restrict__ farplane, float* __restrict__ intensity, int nscan, int S, int pw, int H,
+    int W, float scale, const cf* __restrict__ twtab) {
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int pad = (N - pw) / 2;
+  const long total = (long)H * W;
+  const long PP = (long)pw * pw;
+  for (long n = blockIdx.x; n < nscan; n += gridDim.x) {
+    const TkCorner c = tk_corner(scan, n);
+    cf* __restrict__ dst0 = farplane + n * S * (long)N * N;
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    const int t = threadIdx.x;
+    const int px = t - pad;
+    const int x = c.sx + px;
+    const bool col_ok = px >= 0 && px < pw && x >= 0 && x < W;
+    const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+    const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
+    for (int r = 0; r < G2::RB; ++r) {
+      cf pv[16];
+#pragma unroll 8
+      for (int l = 0; l < 16; ++l) {
+        const int py = r + G2::RB * l - pad;
+        const int y = c.sy + py;
+        const bool ok = col_ok && py >= 0 && py < pw && y >= 0 && y < H;
+        const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
+        const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
+        const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
+        pv[l] = ok ? o : mk(0.f, 0.f);
+      }
+      for (int s = 0; s < S; ++s) {
+        // probe of this (position, mode): hoisted scalars + one load per pixel
+        const cf* __restrict__ Pn = probe.probe + n * probe.pos_stride + s * PP;
+        float w0 = 1.0f;
+        int nE = 0;
+        if (probe.weights != nullptr) {
+          w0 = probe.weights[n * (long)(probe.C + 1) * probe.S + s];
+          if (probe.eigen != nullptr && s < probe.Sm) nE = probe.C;
+        }
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+          const int py = r + G2::RB * l - pad;
+          const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
+          const long pi = (long)pyc * pw + pxc;
+          cf pr = Pn[pi] * w0;
+          for (int k = 0; k < nE; ++k) {
+            const cf ev = probe.eigen[((long)k * probe.Sm + s) * PP + pi];
+            const float wk =
+                probe.weights[n * (long)(probe.C + 1) * probe.S + (k + 1) * probe.S + s];
+            pr.x += wk * ev.x;
+            pr.y += wk * ev.y;
+          }
+          lds[l * G2::LS + tk_pad16(t)] = pv[l] * pr;
+        }
+        __syncthreads();
+        fft2_pass1<N, false>(lds, twtab, tw, line, j, r,
+                             [&](int y, int e) { return lds[line * G2::LS + tk_pad16(e)]; },
+                             dst0 + s * (long)N * N);
+      }
+    }
+    __syncthreads();
+    for (int k1 = 0; k1 < 16; ++k1) {
+      float I[G2::RB];
+#pragma unroll
+      for (int k2 = 0; k2 < G2::RB; ++k2) I[k2] = 0.f;
+      for (int s = 0; s < S; ++s) {
+        cf* __restrict__ dst = dst0 + s * (long)N * N;
+        fft2_pass2<N, false>(dst, k1, [&](int ky, int tt, cf v) {
+          const cf o = v * scale;
+          dst[ky * N + tt] = o;
+          I[(ky - k1) >> 4] += norm2(o);
+        });
+      }
+      if (intensity) {
+#pragma unroll
+        for (int k2 = 0; k2 < G2::RB; ++k2)
+          intensity[n * (long)N * N + (k1 + 16 * k2) * N + t] = I[k2];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int N>
+static int launch_fwd_pos(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
+                          float* intensity, int nscan, int S, int pw, int H, int W, float scale,
+                          hipStream_t stream) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  hipLaunchKernelGGL((ptycho_fwd_pos_kernel<N>), dim3(tk_grid(nscan, 4)), dim3(N), 0, stream,
+                     psi, scan, probe, farplane, intensity, nscan, S, pw, H, W, scale, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, const void* probe,
+                                         int probe_per_scan, const void* eigen_probe,
+                                         const float* eigen_weights, int num_eigen,
+                                         int eigen_modes, void* farplane, float* intensity,
+                                         int nscan, int S, int pw, int det, int H, int W,
+                                         float scale, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(psi && scan && probe && farplane);
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw);
+  switch (det) {
+    case 128:
+      return launch_fwd_pos<128>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
+                                 H, W, scale, stream);
+    case 256:
+      return launch_fwd_pos<256>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
+                                 H, W, scale, stream);
+    default:
+      return TK_ERR_UNSUPPORTED;
   }
 }
 
@@ -305,7 +449,7 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_k
 template <int N>
 __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ifft2_crop_v2_kernel(
     const cf* __restrict__ farplane, cf* work, cf* chi, long ntile, int pw, float scale,
-    const cf* __restrict__ twtab) {
+    const cf* __restrict__ twtab, const float* __restrict__ gscale, int S) {
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS];
   FftTw<N> tw;
@@ -317,9 +461,17 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ifft2_crop_v2_kernel(
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
     tw.init(twtab, j);
-    for (int r = 0; r < G2::RB; ++r)
-      fft2_pass1<N, true>(lds, twtab, tw, line, j, r,
-                          [&](int y, int e) { return src[y * N + e]; }, mid);
+    if (gscale) {
+      // far-plane gradient applied on the fly: F_s * g, g per (position, pixel)
+      const float* __restrict__ gs = gscale + (tile / S) * (long)N * N;
+      for (int r = 0; r < G2::RB; ++r)
+        fft2_pass1<N, true>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
+                            [&](int y, int e) { return src[y * N + e] * gs[y * N + e]; }, mid);
+    } else {
+      for (int r = 0; r < G2::RB; ++r)
+        fft2_pass1<N, true>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
+                            [&](int y, int e) { return src[y * N + e]; }, mid);
+    }
     __syncthreads();
     for (int k1 = 0; k1 < 16; ++k1)
       fft2_pass2<N, true>(mid, k1, [&](int ky, int t, cf v) {
@@ -332,11 +484,11 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ifft2_crop_v2_kernel(
 
 template <int N>
 static int launch_icrop_v2(const cf* far, cf* work, cf* chi, long ntile, int pw, float scale,
-                           hipStream_t stream) {
+                           hipStream_t stream, const float* gscale = nullptr, int S = 1) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   hipLaunchKernelGGL((ifft2_crop_v2_kernel<N>), dim3(tk_grid(ntile, 4)), dim3(N), 0, stream, far,
-                     work, chi, ntile, pw, scale, tw);
+                     work, chi, ntile, pw, scale, tw, gscale, S);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -488,6 +640,99 @@ extern "C" int tike_farplane_gradient(void* farplane, const float* data,
 #undef TK_FG
   TK_LAUNCH_CHECK();
   return TK_OK;
+}
+
+// ------------------------------------------------ gradient scale from intensity
+// gscale[n][p] = -(1 - sqrt(d)/(sqrt(I)+1e-9))  (gaussian; poisson: -(1 - d/(I+1e-9)))
+// on measured pixels, (unmeasured_scaling - 1) elsewhere; costs[n] = mean over
+// measured pixels of the per-pixel cost (objective.py:11-124, lstsq.py:444-502).
+template <int MODEL>
+__global__ __launch_bounds__(256) void gradient_scale_kernel(
+    const float* __restrict__ intensity, const float* __restrict__ data,
+    const unsigned char* __restrict__ mask, float* __restrict__ gscale,
+    float* __restrict__ costs, int det, float unmeasured_scaling, float inv_nmeasured) {
+  __shared__ float red[4];
+  const long npix = (long)det * det;
+  const long n = blockIdx.y;
+  float cost = 0.f;
+  const long p0 = (long)blockIdx.x * TK_FG_PIX;
+  const long p1 = p0 + TK_FG_PIX < npix ? p0 + TK_FG_PIX : npix;
+  for (long p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    const float I = intensity[n * npix + p];
+    const bool measured = mask ? mask[p] != 0 : true;
+    float g;
+    if (measured) {
+      const float dv = data[n * npix + p];
+      if (MODEL == 0) {
+        const float sI = sqrtf(I), sd = sqrtf(dv);
+        const float diff = sI - sd;
+        cost += diff * diff;
+        g = -(1.0f - sd / (sI + 1e-9f));
+      } else {
+        cost += I - dv * logf(I + 1e-9f);
+        g = -(1.0f - dv / (I + 1e-9f));
+      }
+    } else {
+      g = unmeasured_scaling - 1.0f;
+    }
+    gscale[n * npix + p] = g;
+  }
+  if (costs) {
+    cost = tk_block_sum256(cost, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+  }
+}
+
+extern "C" int tike_gradient_scale(const float* intensity, const float* data,
+                                   const unsigned char* measured, float* gscale, float* costs,
+                                   int nscan, int det, int model, float unmeasured_scaling,
+                                   long num_measured, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && det >= 1 && (model == 0 || model == 1) && num_measured > 0);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(intensity && data && gscale);
+  if (costs) {
+    hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  const float inv = 1.0f / (float)num_measured;
+  const long npix = (long)det * det;
+  const dim3 grid((unsigned)((npix + TK_FG_PIX - 1) / TK_FG_PIX), (unsigned)nscan), block(256);
+  if (model == 0)
+    hipLaunchKernelGGL((gradient_scale_kernel<0>), grid, block, 0, stream, intensity, data,
+                       measured, gscale, costs, det, unmeasured_scaling, inv);
+  else
+    hipLaunchKernelGGL((gradient_scale_kernel<1>), grid, block, 0, stream, intensity, data,
+                       measured, gscale, costs, det, unmeasured_scaling, inv);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// IFFT2 + crop of (farplane * gscale): gscale (ntile / S, det, det) f32 is
+// shared by the S modes of a position.  work must not alias farplane.
+extern "C" int tike_ifft2_crop_scaled(const void* farplane, const float* gscale, int S,
+                                      void* work, void* chi, long ntile, int det, int pw,
+                                      float scale, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && S >= 1 && pw >= 1 && det >= pw);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(farplane && gscale && work && chi && work != farplane && ntile % S == 0);
+  TK_CHECK_ARG(!(chi == work && pw != det));
+  switch (det) {
+    case 128:
+      return launch_icrop_v2<128>((const cf*)farplane, (cf*)work, (cf*)chi, ntile, pw, scale,
+                                  stream, gscale, S);
+    case 256:
+      return launch_icrop_v2<256>((const cf*)farplane, (cf*)work, (cf*)chi, ntile, pw, scale,
+                                  stream, gscale, S);
+    case 512:
+      return launch_icrop_v2<512>((const cf*)farplane, (cf*)work, (cf*)chi, ntile, pw, scale,
+                                  stream, gscale, S);
+    default:
+      return TK_ERR_UNSUPPORTED;
+  }
 }
 
 // ------------------------------------------------ stand-alone objective ops

@@ -57,10 +57,18 @@ def _workspace(op):
     return ws
 
 
-def chunk_positions(S, det):
-    """Positions per kernel launch: enough (position, mode) tiles to fill the
-    chip several times over while bounding the far-plane workspace."""
+POSITION_MAJOR_SIZES = (128, 256)
+"""Detector sizes served by the position-major forward kernel
+(tike_ptycho_fwd_intensity) and the gradient-scaled inverse."""
+
+
+def chunk_positions(S, det, position_major=False):
+    """Positions per kernel launch: enough workgroups to fill the chip several
+    times over while bounding the far-plane workspace.  The position-major
+    kernels run one workgroup per position (not per tile)."""
     tiles = max(2048, (1 << 28) // (det * det * 8))  # >= 2048 tiles or 256 MiB
+    if position_major:
+        return max(1024, tiles // max(S, 1))
     return max(64, tiles // max(S, 1))
 
 
@@ -251,7 +259,14 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     if recover_probe and eigen_weights is not None:
         patches = ws.get("patches", (max(B, 1), pw, pw), torch.complex64, dev)
     costs = ws.get("costs", (max(B, 1),), torch.float32, dev)
-    chunk = chunk_positions(S, det)
+    pos_major = det in POSITION_MAJOR_SIZES
+    chunk = chunk_positions(S, det, pos_major)
+    inten = gscale = None
+    if pos_major:
+        inten = ws.get("intensity", (min(chunk, max(B, 1)), det, det),
+                       torch.float32, dev)
+        gscale = ws.get("gscale", (min(chunk, max(B, 1)), det, det),
+                        torch.float32, dev)
     objproj = ws.get("objproj", (min(chunk, max(B, 1)), pw, pw),
                      torch.complex64, dev)
     far = ws.get("far", (min(chunk, max(B, 1)), 1, S, det, det),
@@ -269,19 +284,39 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         n = chi_hi - clo
         blo = clo - lo
         w_c = None if w_old is None else w_old[blo:blo + n]
-        op.fwd_device(probe, scan[clo:chi_hi], psi, eigen_probe, w_c,
-                      out=far[:n])
-        check(
-            lib.tike_farplane_gradient(
-                A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), None,
-                A.ptr(costs[blo:blo + n]), n, S, det,
-                _MODELS[exitwave_options.noise_model], 1,
-                float(exitwave_options.unmeasured_pixels_scaling), nmeasured,
-                st), "farplane gradient")
         chi = chi_ws
-        check(
-            lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S, det,
-                                pw, inv_scale, st), "ifft2 + crop")
+        model = _MODELS[exitwave_options.noise_model]
+        unmeasured = float(exitwave_options.unmeasured_pixels_scaling)
+        if pos_major:
+            # forward + intensity in one kernel; the gradient factor is a
+            # per-pixel table applied while the inverse transform loads rows
+            check(
+                lib.tike_ptycho_fwd_intensity(
+                    A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
+                    A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(far), A.ptr(inten), n,
+                    S, pw, det, H, W, fwd_scale, st), "forward + intensity")
+            check(
+                lib.tike_gradient_scale(A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                                        A.ptr(mask_u8), A.ptr(gscale),
+                                        A.ptr(costs[blo:blo + n]), n, det,
+                                        model, unmeasured, nmeasured, st),
+                "gradient scale")
+            check(
+                lib.tike_ifft2_crop_scaled(A.ptr(far), A.ptr(gscale), S,
+                                           A.ptr(mid), A.ptr(chi), n * S, det,
+                                           pw, inv_scale, st),
+                "scaled ifft2 + crop")
+        else:
+            op.fwd_device(probe, scan[clo:chi_hi], psi, eigen_probe, w_c,
+                          out=far[:n])
+            check(
+                lib.tike_farplane_gradient(
+                    A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), None,
+                    A.ptr(costs[blo:blo + n]), n, S, det, model, 1, unmeasured,
+                    nmeasured, st), "farplane gradient")
+            check(
+                lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S,
+                                    det, pw, inv_scale, st), "ifft2 + crop")
         # one pass over chi: probe gradient, object projection, patches
         check(
             lib.tike_lstsq_gradients(
