@@ -214,7 +214,7 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
 // pass 2 -- the far-plane is never re-read to form it (ptycho.py:18-23,
 // lstsq.py:444-447).
 #ifndef TK_POS_WAVES
-#define TK_POS_WAVES 3
+#define TK_POS_WAVES 4
 #endif
 template <int N>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_pos_kernel(
