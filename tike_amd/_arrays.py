@@ -74,7 +74,11 @@ def like_input(t, reference_input):
 
 
 def ptr(t):
-    return None if t is None else t.data_ptr()
+    """Raw device pointer of a C-contiguous tensor (None passes through)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C-ABI arguments must be C-contiguous"
+    return t.data_ptr()
 
 
 def stream_ptr():

@@ -412,3 +412,126 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
+
+// ------------------------------------------------------- eigen-probe update
+// Residual probe update of position n for eigen probe index c (mode 0):
+//   R_n = conj(O_n) chi_n,0 - mpu_0 - sum_{c' < c} coef[n][c'] E_c'
+// (lstsq.py:740-761 _get_residuals/_update_residuals; probe.py:362-476).
+// O_n = patches[n], chi_n,0 = chi0[n]; eigen (C, Sm, pw, pw) holds the CURRENT
+// eigen probes (mode 0 slice used), coefs (nscan, C) complex the projections
+// already removed.  Never materialised: every pass recomputes it.
+struct TkResidual {
+  const cf* patches;
+  const cf* chi0;
+  const cf* mpu0;
+  const cf* eigen;
+  const cf* coefs;
+  int C, Sm, c;
+  long P;
+  __device__ __forceinline__ cf at(long n, long p) const {
+    cf r = conjf(patches[n * P + p]) * chi0[n * P + p] - mpu0[p];
+    for (int k = 0; k < c; ++k) r = r - coefs[n * C + k] * eigen[((long)k * Sm) * P + p];
+    return r;
+  }
+};
+
+// sums[n] = { sum Re(conj(R) E_c), sum Re(chi0 conj(O E_c)), sum |O E_c|^2,
+//             Re sum R conj(E_c), Im sum R conj(E_c) }
+__global__ __launch_bounds__(256) void eigen_position_sums_kernel(const TkResidual R,
+                                                                  float* __restrict__ sums,
+                                                                  int nscan) {
+  __shared__ float red[4];
+  const cf* __restrict__ E = R.eigen + ((long)R.c * R.Sm) * R.P;
+  for (int n = blockIdx.x; n < nscan; n += gridDim.x) {
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long p = threadIdx.x; p < R.P; p += blockDim.x) {
+      const cf e = E[p];
+      const cf r = R.at(n, p);
+      const cf phi = R.patches[n * R.P + p] * e;
+      const cf x = R.chi0[n * R.P + p];
+      a[0] += r.x * e.x + r.y * e.y;
+      a[1] += x.x * phi.x + x.y * phi.y;
+      a[2] += norm2(phi);
+      const cf re = r * conjf(e);
+      a[3] += re.x;
+      a[4] += re.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float v = tk_block_sum256(a[k], red);
+      if (threadIdx.x == 0) sums[(long)n * 5 + k] = v;
+    }
+  }
+}
+
+// update[p] += sum_n R_n[p] * pm[n]      (probe.py:432-436 before the mean)
+__global__ __launch_bounds__(256) void eigen_pixel_update_kernel(const TkResidual R,
+                                                                 const float* __restrict__ pm,
+                                                                 float* __restrict__ update,
+                                                                 int nscan, int chunk) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= R.P) return;
+  const int b0 = blockIdx.y * chunk;
+  const int b1 = min(nscan, b0 + chunk);
+  cf acc = mk(0.f, 0.f);
+  for (int n = b0; n < b1; ++n) {
+    const cf r = R.at(n, p);
+    const float w = pm[n];
+    acc.x += r.x * w;
+    acc.y += r.y * w;
+  }
+  unsafeAtomicAdd(&update[2 * p], acc.x);
+  unsafeAtomicAdd(&update[2 * p + 1], acc.y);
+}
+
+static TkResidual make_residual(const void* patches, const void* chi0, const void* mpu0,
+                                const void* eigen, const void* coefs, int C, int Sm, int c,
+                                int pw) {
+  TkResidual R;
+  R.patches = (const cf*)patches;
+  R.chi0 = (const cf*)chi0;
+  R.mpu0 = (const cf*)mpu0;
+  R.eigen = (const cf*)eigen;
+  R.coefs = (const cf*)coefs;
+  R.C = C;
+  R.Sm = Sm;
+  R.c = c;
+  R.P = (long)pw * pw;
+  return R;
+}
+
+extern "C" int tike_eigen_position_sums(const void* patches, const void* chi0, const void* mpu0,
+                                        const void* eigen_probe, const void* coefs,
+                                        int num_eigen, int eigen_modes, int c, float* sums,
+                                        int nscan, int pw, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && num_eigen >= 1 && c >= 0 && c < num_eigen);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(patches && chi0 && mpu0 && eigen_probe && sums && (c == 0 || coefs));
+  hipLaunchKernelGGL(eigen_position_sums_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
+                     (hipStream_t)stream,
+                     make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
+                                   eigen_modes, c, pw),
+                     sums, nscan);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_eigen_pixel_update(const void* patches, const void* chi0, const void* mpu0,
+                                       const void* eigen_probe, const void* coefs,
+                                       int num_eigen, int eigen_modes, int c, const float* pm,
+                                       void* update, int nscan, int pw, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && num_eigen >= 1 && c >= 0 && c < num_eigen);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(patches && chi0 && mpu0 && eigen_probe && pm && update && (c == 0 || coefs));
+  const long P = (long)pw * pw;
+  const int chunk = probe_chunk(nscan);
+  dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
+  hipLaunchKernelGGL(eigen_pixel_update_kernel, grid, dim3(256), 0, (hipStream_t)stream,
+                     make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
+                                   eigen_modes, c, pw),
+                     pm, (float*)update, nscan, chunk);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}

@@ -337,6 +337,7 @@ def _apply_probe_constraints(parameters, *, epoch):
                 "ProbeOptions.force_sparsity is outside the accelerated scope")
         if po.force_orthogonality:
             parameters.probe, pwr = orthogonalize_eig(parameters.probe)
+            parameters.probe = parameters.probe.contiguous()
         else:
             pwr = probe_power(parameters.probe)
         po.power.append(A.to_host(pwr))
@@ -347,9 +348,10 @@ def _apply_probe_constraints(parameters, *, epoch):
             parameters.probe, Nphotons=po.probe_photons,
             probe_power_fraction=None)
     if parameters.eigen_probe is not None and po.recover_probe(epoch):
-        (parameters.eigen_probe,
-         parameters.eigen_weights) = constrain_variable_probe(
-             parameters.eigen_probe, parameters.eigen_weights)
+        eigen_probe, eigen_weights = constrain_variable_probe(
+            parameters.eigen_probe, parameters.eigen_weights)
+        parameters.eigen_probe = eigen_probe.contiguous()
+        parameters.eigen_weights = eigen_weights.contiguous()
     return parameters
 
 

@@ -424,39 +424,58 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
         return eigen_probe, eigen_weights
     assert eigen_weights.shape[-2] == eigen_probe.shape[-4] + 1
     chi0, patches = g["chi0"], g["patches"]
-    probe_update0 = patches.conj() * chi0  # (B, pw, pw)
-    R = probe_update0 - g["m_probe_update"][0, 0, m]
+    mpu0 = g["m_probe_update"][0, 0, m].contiguous()
+    B = hi - lo
+    C, Sm, pw = eigen_probe.shape[-4], eigen_probe.shape[-3], probe.shape[-1]
+    P = pw * pw
     beta = min(0.1, 1.0 / num_batch)
-    P = R.shape[-1] * R.shape[-2]
-    for c in range(1, eigen_probe.shape[-4] + 1):
-        E = eigen_probe[0, c - 1, m]
+    st = A.stream_ptr()
+    sums = torch.empty((max(B, 1), 5), dtype=torch.float32, device=dev)
+    coefs = torch.zeros((max(B, 1), C), dtype=torch.complex64, device=dev)
+    ep = eigen_probe  # (1, C, Sm, pw, pw), updated in place, read by kernels
+
+    def position_sums(c):
+        check(
+            lib.tike_eigen_position_sums(A.ptr(patches), A.ptr(chi0),
+                                         A.ptr(mpu0), A.ptr(ep), A.ptr(coefs),
+                                         C, Sm, c, A.ptr(sums), B, pw, st),
+            "eigen position sums")
+        return sums[:B]
+
+    for c in range(1, C + 1):
         w = eigen_weights[lo:hi, c, m]
         norm_weights = comm.Allreduce_scalars([torch.sum(w * w)], dev)[0].to(
             torch.float32)
         # a batch whose weights are all zero would divide by zero; the
         # reference raises ValueError after a host sync (probe.py:426) --
-        # here the check is deferred to the end of the epoch (NaN costs).
-        proj_mean = (torch.sum((R.conj() * E).real, dim=(-2, -1)) / P +
-                     w) / norm_weights
-        update = torch.sum(R * proj_mean[:, None, None], dim=0)
+        # here the symptom is deferred to the epoch cost (NaN).
+        s = position_sums(c - 1)
+        proj_mean = ((s[:, 0] / P + w) / norm_weights).contiguous()
+        update = torch.zeros((pw, pw), dtype=torch.complex64, device=dev)
+        check(
+            lib.tike_eigen_pixel_update(A.ptr(patches), A.ptr(chi0),
+                                        A.ptr(mpu0), A.ptr(ep), A.ptr(coefs),
+                                        C, Sm, c - 1, A.ptr(proj_mean),
+                                        A.ptr(update), B, pw, st),
+            "eigen pixel update")
         if comm.size > 1:
             comm.Allreduce(update)
         update = update / count
+        E = ep[0, c - 1, m]
         E = E + beta * update / linalg.mnorm(update)
         E = E / linalg.mnorm(E)
-        eigen_probe[0, c - 1, m] = E
-        # new weights for the updated eigen probe
-        phi = patches * E
-        n = torch.mean((chi0 * phi.conj()).real, dim=(-1, -2))
-        d = torch.mean(torch.square(phi.abs()), dim=(-1, -2))
+        ep[0, c - 1, m] = E
+        # new weights for the updated eigen probe (and the projection of the
+        # residual onto it, removed before the next eigen probe)
+        s = position_sums(c - 1)
+        n = s[:, 1] / P
+        d = s[:, 2] / P
         d_mean = (comm.Allreduce_scalars([d.sum()], dev)[0] / count).to(
             torch.float32)
         eigen_weights[lo:hi, c, m] += n / (d + 0.1 * d_mean)
         if c + 1 < eigen_weights.shape[-2]:
-            # remove the projection of R onto the updated eigen probe
-            coef = torch.sum(R * E.conj(), dim=(-2, -1),
-                             keepdim=True) / torch.sum(E * E.conj())
-            R = R - coef * E
+            coefs[:B, c - 1] = torch.complex(s[:, 3], s[:, 4]) / torch.sum(
+                E * E.conj())
     return eigen_probe, eigen_weights
 
 
