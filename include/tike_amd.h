@@ -162,11 +162,12 @@ int tike_scatter_patches(const void* objproj, const float* scan, float* acc, int
 int tike_probe_grad(const void* chi, const float* scan, const void* psi, void* patches,
                     void* m_probe_update, int nscan, int S, int pw, int H, int W, void* stream);
 
-/* out (H,W) f32 += scatter_n( sum_s |probe_s|^2 ), the (real-valued) object
+/* out (H,W) f32 += scatter_n( probe_amp ), the (real-valued) object
  * preconditioner (solvers/_preconditioner.py:48-104 = Patch.adj of one
- * broadcast patch).  probe (S,pw,pw) shared.  Positions must satisfy
+ * broadcast patch); probe_amp (pw,pw) f32 = sum_s |probe_s|^2
+ * (_preconditioner.py:40-45).  Positions must satisfy
  * check_allowed_positions (position.py:600-628). */
-int tike_psi_preconditioner(const void* probe, const float* scan, void* out, int nscan, int S,
+int tike_psi_preconditioner(const float* probe_amp, const float* scan, void* out, int nscan,
                             int pw, int H, int W, void* stream);
 
 /* out (pw,pw) c64: real part += sum_n |patch_n(psi)|^2

@@ -147,14 +147,13 @@ extern "C" int tike_scatter_patches(const void* objproj, const float* scan, floa
 }
 
 // ------------------------------------------------------ psi preconditioner
-// out (H,W) float32 += scatter_n( sum_s |probe_s|^2 )
+// out (H,W) float32 += scatter_n( probe_amp ),  probe_amp = sum_s |probe_s|^2 (pw,pw) f32
 // (solvers/_preconditioner.py:48-104: Patch.adj of one broadcast patch).
-__global__ __launch_bounds__(256) void psi_precond_kernel(const cf* __restrict__ probe,
+__global__ __launch_bounds__(256) void psi_precond_kernel(const float* __restrict__ amp,
                                                           const float* __restrict__ scan,
                                                           float* __restrict__ out, int nscan,
-                                                          int S, int pw, int H, int W) {
+                                                          int pw, int H, int W) {
   const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
-  const long P = (long)pw * pw;
   for (long w = blockIdx.x; w < (long)nscan * nstrip; w += gridDim.x) {
     const long n = w / nstrip;
     const int strip = (int)(w % nstrip);
@@ -162,26 +161,20 @@ __global__ __launch_bounds__(256) void psi_precond_kernel(const cf* __restrict__
     const float fy = scan[2 * n] - floorf(scan[2 * n]);
     const float fx = scan[2 * n + 1] - floorf(scan[2 * n + 1]);
     scatter_footprint<true>(
-        [&](int y, int x) {
-          const long p = (long)y * pw + x;
-          float a = 0.f;
-          for (int s = 0; s < S; ++s) a += norm2(probe[s * P + p]);
-          return mk(a, 0.f);
-        },
-        c, fx, fy, out, out, pw, H, W, strip);
+        [&](int y, int x) { return mk(amp[(long)y * pw + x], 0.f); }, c, fx, fy, out, out, pw, H,
+        W, strip);
   }
 }
 
-extern "C" int tike_psi_preconditioner(const void* probe, const float* scan, void* out,
-                                       int nscan, int S, int pw, int H, int W, void* stream) {
+extern "C" int tike_psi_preconditioner(const float* probe_amp, const float* scan, void* out,
+                                       int nscan, int pw, int H, int W, void* stream) {
   TK_ENTER();
-  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && H >= 1 && W >= 1);
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
-  TK_CHECK_ARG(probe && scan && out);
+  TK_CHECK_ARG(probe_amp && scan && out);
   const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
   hipLaunchKernelGGL(psi_precond_kernel, dim3(tk_grid((long)nscan * nstrip, 16)), dim3(256), 0,
-                     (hipStream_t)stream, (const cf*)probe, scan, (float*)out, nscan, S, pw, H,
-                     W);
+                     (hipStream_t)stream, probe_amp, scan, (float*)out, nscan, pw, H, W);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

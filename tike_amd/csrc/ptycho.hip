@@ -250,7 +250,11 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
         const bool ok = col_ok && py >= 0 && py < pw && y >= 0 && y < H;
         const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
         const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
+#ifdef TK_DBG_FWD_NOLOAD
+        const cf o = mk((float)yc, (float)xc);
+#else
         const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
+#endif
         pv[l] = ok ? o : mk(0.f, 0.f);
       }
       for (int s = 0; s < S; ++s) {
@@ -267,7 +271,11 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
           const int py = r + G2::RB * l - pad;
           const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
           const long pi = (long)pyc * pw + pxc;
+#ifdef TK_DBG_FWD_NOLOAD
+          cf pr = mk(w0, (float)pi);
+#else
           cf pr = Pn[pi] * w0;
+#endif
           for (int k = 0; k < nE; ++k) {
             const cf ev = probe.eigen[((long)k * probe.Sm + s) * PP + pi];
             const float wk =
@@ -284,6 +292,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
       }
     }
     __syncthreads();
+#ifndef TK_DBG_FWD_NOPASS2
     for (int k1 = 0; k1 < 16; ++k1) {
       float I[G2::RB];
 #pragma unroll
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
           intensity[n * (long)N * N + (k1 + 16 * k2) * N + t] = I[k2];
       }
     }
+#endif
     __syncthreads();
   }
 }

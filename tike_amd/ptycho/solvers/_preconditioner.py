@@ -18,11 +18,13 @@ def _psi_preconditioner(parameters, operator):
     assert psi.shape[0] == 1, "single-slice objects only"
     out = torch.zeros(tuple(psi.shape), dtype=torch.float32, device=psi.device)
     pw = probe.shape[-1]
+    # sum_s |probe_s|^2 (probe-sized; _preconditioner.py:40-45)
+    probe_amp = torch.sum(torch.square(probe.abs()), dim=-3)[0, 0].contiguous()
     check(
-        lib.tike_psi_preconditioner(A.ptr(probe), A.ptr(scan), A.ptr(out),
-                                    scan.shape[0], probe.shape[-3], pw,
-                                    psi.shape[-2], psi.shape[-1],
-                                    A.stream_ptr()), "psi preconditioner")
+        lib.tike_psi_preconditioner(A.ptr(probe_amp), A.ptr(scan), A.ptr(out),
+                                    scan.shape[0], pw, psi.shape[-2],
+                                    psi.shape[-1], A.stream_ptr()),
+        "psi preconditioner")
     return out
 
 

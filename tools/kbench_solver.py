@@ -36,6 +36,7 @@ data = torch.rand(N, pw, pw, dtype=torch.float32, device=dev)
 obj = torch.zeros_like(psi)
 proj = torch.zeros(N, pw, pw, dtype=torch.complex64, device=dev)
 acc = torch.zeros(2, HW, HW, dtype=torch.float32, device=dev)
+amp = torch.rand(pw, pw, dtype=torch.float32, device=dev)
 mpu = torch.zeros_like(probe)
 costs = torch.zeros(N, device=dev)
 stats = torch.zeros(N, 8, device=dev)
@@ -47,7 +48,7 @@ rows = [
     ("probe_grad", lambda: check(lib.tike_probe_grad(chi.data_ptr(), scan.data_ptr(), psi.data_ptr(), None, mpu.data_ptr(), N, S, pw, HW, HW, st)), gb),
     ("farplane_gradient", lambda: check(lib.tike_farplane_gradient(chi.data_ptr(), data.data_ptr(), None, None, costs.data_ptr(), N, S, pw, 0, 1, 1.0, pw * pw, st)), 2 * gb),
     ("step_stats", lambda: check(lib.tike_lstsq_step_stats(chi.data_ptr(), scan.data_ptr(), psi.data_ptr(), obj.data_ptr(), probe.data_ptr(), None, None, 0, 0, mpu.data_ptr(), stats.data_ptr(), N, S, S, pw, HW, HW, st)), N * pw * pw * 8 / 1e9),
-    ("psi_precond", lambda: check(lib.tike_psi_preconditioner(probe.data_ptr(), scan.data_ptr(), acc.data_ptr(), N, S, pw, HW, HW, st)), 0),
+    ("psi_precond", lambda: check(lib.tike_psi_preconditioner(amp.data_ptr(), scan.data_ptr(), acc.data_ptr(), N, pw, HW, HW, st)), 0),
 ]
 for name, fn, g in rows:
     ms = timeit(fn)
