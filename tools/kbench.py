@@ -69,6 +69,20 @@ def main():
         psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0, None, None, 0, 0,
         far.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st)), a.reps)
     rows.append((f"ptycho_fwd S={S}", ms, N * S * tile_bytes + N * tile_bytes))
+    if n in (128, 256):
+        inten = torch.empty(N, n, n, dtype=torch.float32, device=dev)
+        ms = timeit(lambda: check(lib.tike_ptycho_fwd_intensity(
+            psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0, None, None, 0,
+            0, far.data_ptr(), inten.data_ptr(), N, S, n, n, HW, HW, 1.0 / n,
+            st)), a.reps)
+        rows.append((f"fwd_intensity S={S}", ms,
+                     N * S * tile_bytes + N * tile_bytes))
+        g = torch.rand(N, n, n, dtype=torch.float32, device=dev)
+        mid = torch.empty_like(far)
+        ms = timeit(lambda: check(lib.tike_ifft2_crop_scaled(
+            far.data_ptr(), g.data_ptr(), S, mid.data_ptr(), mid.data_ptr(),
+            N * S, n, n, 1.0 / n, st)), a.reps)
+        rows.append((f"ifft2_crop_scaled S={S}", ms, 2 * N * S * tile_bytes))
     for name, ms, nbytes in rows:
         print(f"{name:28s} {ms:8.3f} ms  {T / ms / 1e3:8.3f} Mtile/s  "
               f"{nbytes / ms / 1e6:8.1f} GB/s (algorithmic)")
