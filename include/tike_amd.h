@@ -84,9 +84,11 @@ int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe, int p
  * intensity[n] = sum_s |farplane[n][s]|^2 (ptycho.py:18-23) accumulated in
  * registers, so the far-plane is not re-read to form it.  det in {128, 256}
  * (TIKE_ERR_UNSUPPORTED otherwise: use tike_ptycho_fwd + tike_intensity).
- * intensity (nscan,det,det) f32 may be NULL. */
+ * intensity (nscan,det,det) f32 may be NULL.  With eigen_weights the probe of
+ * mode s at position n is unique_probe[n][s] for s < eigen_modes (from
+ * tike_varying_probe) and eigen_weights[n][0][s] * probe[s] otherwise. */
 int tike_ptycho_fwd_intensity(const void* psi, const float* scan, const void* probe,
-                              int probe_per_scan, const void* eigen_probe,
+                              int probe_per_scan, const void* unique_probe,
                               const float* eigen_weights, int num_eigen, int eigen_modes,
                               void* farplane, float* intensity, int nscan, int S, int pw, int det,
                               int H, int W, float scale, void* stream);
@@ -143,11 +145,15 @@ int tike_objective_grad(const float* data, const void* farplane, const float* in
  *   m_probe_update (S,pw,pw) += sum_n conj(patch_n(psi)) * chi_n,s
  *   objproj (nscan,pw,pw)     = sum_s conj(P_n,s) * chi_n,s
  *   patches (nscan,pw,pw)     = patch_n(psi)            (the reference's bpatches)
- * any of the three outputs may be NULL.  S <= 16. */
+ * any of the three outputs may be NULL.  S <= 16.  unique_probe (nscan,
+ * eigen_modes,pw,pw), if not NULL, is the varying probe of the first
+ * eigen_modes modes from tike_varying_probe (used instead of re-synthesising
+ * it from eigen_probe / eigen_weights). */
 int tike_lstsq_gradients(const void* chi, const float* scan, const void* psi, const void* probe,
                          const void* eigen_probe, const float* eigen_weights, int num_eigen,
-                         int eigen_modes, void* patches, void* m_probe_update, void* objproj,
-                         int nscan, int S, int pw, int H, int W, void* stream);
+                         int eigen_modes, const void* unique_probe, void* patches,
+                         void* m_probe_update, void* objproj, int nscan, int S, int pw, int H,
+                         int W, void* stream);
 
 /* acc (2,H,W) f32, PLANAR (real plane, imaginary plane) += scatter_n( objproj_n ):
  * the adjoint of the bilinear patch gather (Patch.adj, patch.py:132-188) with
@@ -188,8 +194,16 @@ int tike_probe_preconditioner(const float* scan, const void* psi, void* out, int
 int tike_lstsq_step_stats(const void* chi, const float* scan, const void* psi,
                           const void* object_update_precond, const void* probe,
                           const void* eigen_probe, const float* eigen_weights, int num_eigen,
-                          int eigen_modes, const void* m_probe_update, float* stats, int nscan,
-                          int S, int chi_modes, int pw, int H, int W, void* stream);
+                          int eigen_modes, const void* unique_probe, const void* m_probe_update,
+                          float* stats, int nscan, int S, int chi_modes, int pw, int H, int W,
+                          void* stream);
+
+/* out (nscan, eigen_modes, pw, pw) = weights[n][0][s]*probe[s] +
+ * sum_c weights[n][c+1][s]*eigen[c][s]: the varying probe of the modes that
+ * own eigen probes (ptycho/probe.py:272-303), synthesised once per chunk. */
+int tike_varying_probe(const void* probe, const void* eigen_probe, const float* eigen_weights,
+                       int num_eigen, int eigen_modes, void* out, int nscan, int S, int pw,
+                       void* stream);
 
 /* ==== eigen-probe ("OPR") update for mode 0 (ptycho/probe.py:362-476,
  * solvers/lstsq.py:297-364,740-761).  The residual

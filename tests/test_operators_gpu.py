@@ -391,8 +391,12 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
     far = torch.empty((N, 1, S, det, det), dtype=torch.complex64, device=dev)
     I = torch.empty((N, det, det), dtype=torch.float32, device=dev)
     st = A.stream_ptr()
+    uq = torch.empty((N, 1, pw, pw), dtype=torch.complex64, device=dev)
+    check(lib.tike_varying_probe(A.ptr(probe_d), A.ptr(eig_d), A.ptr(w_d), C, 1,
+                                 A.ptr(uq), N, S, pw, st))
+    assert_close(uq.cpu().numpy(), uprobe[:, 0, :1], what="varying probe")
     check(lib.tike_ptycho_fwd_intensity(
-        A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, A.ptr(eig_d),
+        A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, A.ptr(uq),
         A.ptr(w_d), C, 1, A.ptr(far), A.ptr(I), N, S, pw, det, HW, HW,
         1.0 / det, st))
     assert_close(far.cpu().numpy(), want_far, what="farplane")

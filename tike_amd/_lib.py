@@ -54,8 +54,9 @@ _PROTOTYPES = {
     "tike_intensity": [_p, _p, _l, _i, _l, _p],
     "tike_cost_each_pattern": [_p, _p, _p, _l, _l, _i, _p],
     "tike_objective_grad": [_p, _p, _p, _p, _l, _i, _l, _i, _p],
-    "tike_lstsq_gradients": [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _i,
-                             _i, _i, _i, _p],
+    "tike_lstsq_gradients": [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _i,
+                             _i, _i, _i, _i, _p],
+    "tike_varying_probe": [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p],
     "tike_scatter_patches": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_eigen_position_sums": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i,
                                  _p],
@@ -64,8 +65,8 @@ _PROTOTYPES = {
     "tike_probe_grad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "tike_probe_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_psi_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
-    "tike_lstsq_step_stats": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _i,
-                              _i, _i, _i, _i, _i, _p],
+    "tike_lstsq_step_stats": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p,
+                              _i, _i, _i, _i, _i, _i, _p],
 }
 
 

@@ -116,11 +116,14 @@ struct TkProbe {
   long pos_stride;       // 0 when shared, S*pw*pw when per position
   const cf* eigen;       // (C, Sm, pw, pw) or nullptr
   const float* weights;  // (N, C+1, S) or nullptr; row 0 scales the shared probe
+  const cf* unique;      // (N, Sm, pw, pw) or nullptr: the varying probe of the
+                         // first Sm modes already synthesised (tike_varying_probe)
   int C, Sm, S, pw;
 
   __device__ __forceinline__ cf at(long n, int s, long pix) const {
     const long pp = (long)pw * pw;
     if (weights == nullptr) return probe[n * pos_stride + s * pp + pix];
+    if (unique != nullptr && s < Sm) return unique[(n * Sm + s) * pp + pix];
     const float* w = weights + n * (long)(C + 1) * S;
     cf v = probe[s * pp + pix] * w[s];
     if (eigen != nullptr && s < Sm) {
@@ -136,8 +139,10 @@ struct TkProbe {
 };
 
 static inline TkProbe tk_make_probe(const void* probe, int probe_per_scan, const void* eigen,
-                                    const float* weights, int C, int Sm, int S, int pw) {
+                                    const float* weights, int C, int Sm, int S, int pw,
+                                    const void* unique = nullptr) {
   TkProbe p;
+  p.unique = (const cf*)unique;
   p.probe = (const cf*)probe;
   p.pos_stride = probe_per_scan ? (long)S * pw * pw : 0L;
   p.eigen = (const cf*)eigen;

@@ -18,7 +18,22 @@
 // Pass 1 is NOT in place (it reads rows r + RB*y2 and writes rows 16*r + k1).
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include "fft_engine.h"
+
+// Compile-time loop: f(std::integral_constant<int, I>{}) for I in [0, NN).
+// Used where a caller-side register array must be indexed by a constant
+// (runtime-indexed arrays are placed in scratch memory).
+template <class F, int... I>
+__device__ __forceinline__ void tk_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int NN, class F>
+__device__ __forceinline__ void tk_static_for(F&& f) {
+  tk_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, NN>{});
+}
 
 // minimum waves per SIMD requested from the register allocator for the v2
 // kernels (N threads per workgroup): tunable at build time.
@@ -122,8 +137,8 @@ struct FftStageWave {
   }
 };
 
-// Pass 1 for the 16 rows {r + RB*y2}.  `load(y, e)` returns input element e
-// of row y; results go to rows 16*r + k1 of `mid` (row-major N x N tile).
+// Pass 1 for the 16 rows {r + RB*y2}.  `load(y, e, i)` returns input element
+// e = j + i*T of row y (i = the caller's register slot, a compile-time index); results go to rows 16*r + k1 of `mid` (row-major N x N tile).
 // Contains two workgroup barriers; every thread of the NT = N workgroup calls.
 template <int N, bool INV, class Tw, class Load>
 __device__ __forceinline__ void fft2_pass1(cf* __restrict__ lds, const cf* __restrict__ twtab,
@@ -132,8 +147,10 @@ __device__ __forceinline__ void fft2_pass1(cf* __restrict__ lds, const cf* __res
   using G2 = Fft2Geom<N>;
   cf v[16];
   const int y = r + G2::RB * line;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = load(y, j + i * G2::T);
+  tk_static_for<16>([&](auto I) {
+    constexpr int i = decltype(I)::value;  // register slot, a constant expression
+    v[i] = load(y, j + i * G2::T, I);
+  });
   cf* lbase = lds + line * G2::LS;
   FftStageWave<N, INV, 0>::run(v, lbase, j, tw);
   // natural-order row spectrum -> LDS [line][e]

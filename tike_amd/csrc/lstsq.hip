@@ -299,8 +299,9 @@ extern "C" int tike_probe_grad(const void* chi, const float* scan, const void* p
 extern "C" int tike_lstsq_gradients(const void* chi, const float* scan, const void* psi,
                                     const void* probe, const void* eigen_probe,
                                     const float* eigen_weights, int num_eigen, int eigen_modes,
-                                    void* patches, void* m_probe_update, void* objproj,
-                                    int nscan, int S, int pw, int H, int W, void* stream) {
+                                    const void* unique_probe, void* patches,
+                                    void* m_probe_update, void* objproj, int nscan, int S,
+                                    int pw, int H, int W, void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && S <= TK_MAX_MODES && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
@@ -311,7 +312,7 @@ extern "C" int tike_lstsq_gradients(const void* chi, const float* scan, const vo
   launch_probe_grad<true>(grid, (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,
                           (cf*)patches, (float*)m_probe_update,
                           tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen,
-                                        eigen_modes, S, pw),
+                                        eigen_modes, S, pw, unique_probe),
                           (cf*)objproj, nscan, S, pw, H, W, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;
@@ -389,9 +390,9 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
 extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const void* psi,
                                      const void* object_update_precond, const void* probe,
                                      const void* eigen_probe, const float* eigen_weights,
-                                     int num_eigen, int eigen_modes, const void* m_probe_update,
-                                     float* stats, int nscan, int S, int chi_modes, int pw,
-                                     int H, int W, void* stream) {
+                                     int num_eigen, int eigen_modes, const void* unique_probe,
+                                     const void* m_probe_update, float* stats, int nscan, int S,
+                                     int chi_modes, int pw, int H, int W, void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && chi_modes >= 1 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
@@ -400,7 +401,7 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
                      (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,
                      (const cf*)object_update_precond,
                      tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes, S,
-                                   pw),
+                                   pw, unique_probe),
                      (const cf*)m_probe_update, stats, nscan, chi_modes, pw, H, W);
   TK_LAUNCH_CHECK();
   return TK_OK;
@@ -525,6 +526,39 @@ extern "C" int tike_eigen_pixel_update(const void* patches, const void* chi0, co
                      make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
                                    eigen_modes, c, pw),
                      pm, (float*)update, nscan, chunk);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// ------------------------------------------------------- varying probe
+// out[n][s] = weights[n][0][s] * probe[s] + sum_c weights[n][c+1][s] * eigen[c][s]
+// for the first Sm modes (probe.py:272-303 get_varying_probe); the modes
+// without eigen probes only need the scalar weights[n][0][s].
+__global__ __launch_bounds__(256) void varying_probe_kernel(const TkProbe probe,
+                                                            cf* __restrict__ out, long total,
+                                                            long PP) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total;
+       i += (long)gridDim.x * blockDim.x) {
+    const long pix = i % PP;
+    const long ns = i / PP;
+    out[i] = probe.at(ns / probe.Sm, (int)(ns % probe.Sm), pix);
+  }
+}
+
+extern "C" int tike_varying_probe(const void* probe, const void* eigen_probe,
+                                  const float* eigen_weights, int num_eigen, int eigen_modes,
+                                  void* out, int nscan, int S, int pw, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && eigen_modes >= 1 && eigen_modes <= S);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(probe && eigen_weights && out && (num_eigen == 0 || eigen_probe));
+  const long PP = (long)pw * pw;
+  const long total = (long)nscan * eigen_modes * PP;
+  hipLaunchKernelGGL(varying_probe_kernel, dim3(tk_grid((total + 255) / 256, 16)), dim3(256), 0,
+                     (hipStream_t)stream,
+                     tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
+                                   S, pw),
+                     (cf*)out, total, PP);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

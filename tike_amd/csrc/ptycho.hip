@@ -197,7 +197,7 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
       }
       __syncthreads();
       fft2_pass1<N, false>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
-                           [&](int y, int e) { return lds[line * G2::LS + tk_pad16(e)]; }, dst);
+                           [&](int y, int e, auto) { return lds[line * G2::LS + tk_pad16(e)]; }, dst);
     }
     __syncthreads();
 #ifndef TK_DBG_FWD_NOPASS2
@@ -236,59 +236,58 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
     asm volatile("" : "+v"(line), "+v"(j));
     const FftTwLds<N> tw{twl, j};
     const int t = threadIdx.x;
-    const int px = t - pad;
-    const int x = c.sx + px;
-    const bool col_ok = px >= 0 && px < pw && x >= 0 && x < W;
-    const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
-    const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
     for (int r = 0; r < G2::RB; ++r) {
+      // Patch values of row y = r + RB*line in the FFT register layout
+      // (element e = j + i*T), gathered once and shared by all S modes: the
+      // row FFT consumes them straight from registers (no LDS staging pass).
+      const int py = r + G2::RB * line - pad;
+      const int y = c.sy + py;
+      const bool row_ok = py >= 0 && py < pw && y >= 0 && y < H;
+      const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
+      const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
       cf pv[16];
-#pragma unroll 8
-      for (int l = 0; l < 16; ++l) {
-        const int py = r + G2::RB * l - pad;
-        const int y = c.sy + py;
-        const bool ok = col_ok && py >= 0 && py < pw && y >= 0 && y < H;
-        const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
-        const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int px = j + i * G2::T - pad;
+        const int x = c.sx + px;
+        const bool ok = row_ok && px >= 0 && px < pw && x >= 0 && x < W;
+        const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+        const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
 #ifdef TK_DBG_FWD_NOLOAD
         const cf o = mk((float)yc, (float)xc);
 #else
         const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
 #endif
-        pv[l] = ok ? o : mk(0.f, 0.f);
+        pv[i] = ok ? o : mk(0.f, 0.f);
+        // bound the taps in flight (4 elements = 16 loads) and with them the
+        // register footprint of this phase
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       for (int s = 0; s < S; ++s) {
-        // probe of this (position, mode): hoisted scalars + one load per pixel
+        // probe of this (position, mode): a base pointer and a scale, both
+        // uniform -- either the shared probe times its weight or the varying
+        // probe synthesised beforehand by tike_varying_probe
         const cf* __restrict__ Pn = probe.probe + n * probe.pos_stride + s * PP;
         float w0 = 1.0f;
-        int nE = 0;
         if (probe.weights != nullptr) {
-          w0 = probe.weights[n * (long)(probe.C + 1) * probe.S + s];
-          if (probe.eigen != nullptr && s < probe.Sm) nE = probe.C;
+          if (probe.unique != nullptr && s < probe.Sm)
+            Pn = probe.unique + (n * probe.Sm + s) * PP;
+          else
+            w0 = probe.weights[n * (long)(probe.C + 1) * probe.S + s];
         }
-#pragma unroll
-        for (int l = 0; l < 16; ++l) {
-          const int py = r + G2::RB * l - pad;
-          const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
-          const long pi = (long)pyc * pw + pxc;
+        fft2_pass1<N, false>(
+            lds, twtab, tw, line, j, r,
+            [&](int, int e, auto I) {
+              constexpr int i = decltype(I)::value;
+              const int px = e - pad;
+              const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
 #ifdef TK_DBG_FWD_NOLOAD
-          cf pr = mk(w0, (float)pi);
+              return pv[i] * mk(w0, (float)pxc);
 #else
-          cf pr = Pn[pi] * w0;
+              return pv[i] * (Pn[pyc * pw + pxc] * w0);
 #endif
-          for (int k = 0; k < nE; ++k) {
-            const cf ev = probe.eigen[((long)k * probe.Sm + s) * PP + pi];
-            const float wk =
-                probe.weights[n * (long)(probe.C + 1) * probe.S + (k + 1) * probe.S + s];
-            pr.x += wk * ev.x;
-            pr.y += wk * ev.y;
-          }
-          lds[l * G2::LS + tk_pad16(t)] = pv[l] * pr;
-        }
-        __syncthreads();
-        fft2_pass1<N, false>(lds, twtab, tw, line, j, r,
-                             [&](int y, int e) { return lds[line * G2::LS + tk_pad16(e)]; },
-                             dst0 + s * (long)N * N);
+            },
+            dst0 + s * (long)N * N);
       }
     }
     __syncthreads();
@@ -329,7 +328,7 @@ static int launch_fwd_pos(const cf* psi, const float* scan, const TkProbe& probe
 }
 
 extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, const void* probe,
-                                         int probe_per_scan, const void* eigen_probe,
+                                         int probe_per_scan, const void* unique_probe,
                                          const float* eigen_weights, int num_eigen,
                                          int eigen_modes, void* farplane, float* intensity,
                                          int nscan, int S, int pw, int det, int H, int W,
@@ -340,8 +339,9 @@ extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, con
   TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(psi && scan && probe && farplane);
-  const TkProbe P = tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
-                                  eigen_modes, S, pw);
+  TK_CHECK_ARG(!(eigen_weights && eigen_modes > 0 && !unique_probe));
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, nullptr, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw, unique_probe);
   switch (det) {
     case 128:
       return launch_fwd_pos<128>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
@@ -476,11 +476,11 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ifft2_crop_v2_kernel(
       const float* __restrict__ gs = gscale + (tile / S) * (long)N * N;
       for (int r = 0; r < G2::RB; ++r)
         fft2_pass1<N, true>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
-                            [&](int y, int e) { return src[y * N + e] * gs[y * N + e]; }, mid);
+                            [&](int y, int e, auto) { return src[y * N + e] * gs[y * N + e]; }, mid);
     } else {
       for (int r = 0; r < G2::RB; ++r)
         fft2_pass1<N, true>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
-                            [&](int y, int e) { return src[y * N + e]; }, mid);
+                            [&](int y, int e, auto) { return src[y * N + e]; }, mid);
     }
     __syncthreads();
     for (int k1 = 0; k1 < 16; ++k1)

@@ -61,7 +61,7 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
                                 pw, inv_scale, st), "cgrad ifft2")
         check(
             lib.tike_lstsq_gradients(A.ptr(chi), A.ptr(scan[lo:hi]), A.ptr(psi),
-                                     A.ptr(probe), None, None, 0, 0, None,
+                                     A.ptr(probe), None, None, 0, 0, None, None,
                                      A.ptr(gprobe), A.ptr(objproj), n, S, pw,
                                      H, W, st), "cgrad gradients")
         if gacc is not None:

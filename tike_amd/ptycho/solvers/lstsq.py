@@ -269,6 +269,10 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                         torch.float32, dev)
     objproj = ws.get("objproj", (min(chunk, max(B, 1)), pw, pw),
                      torch.complex64, dev)
+    unique = None
+    if w_old is not None and Sm > 0:
+        unique = ws.get("unique", (min(chunk, max(B, 1)), Sm, pw, pw),
+                        torch.complex64, dev)
     far = ws.get("far", (min(chunk, max(B, 1)), 1, S, det, det),
                  torch.complex64, dev)
     # the inverse transform is out of place (far -> mid); chi is the cropped
@@ -285,6 +289,14 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         blo = clo - lo
         w_c = None if w_old is None else w_old[blo:blo + n]
         chi = chi_ws
+        uq = None
+        if w_c is not None and Sm > 0:
+            # varying probe of the modes that own eigen probes, once per chunk
+            uq = unique[:n]
+            check(
+                lib.tike_varying_probe(A.ptr(probe), A.ptr(ep), A.ptr(w_c), C,
+                                       Sm, A.ptr(uq), n, S, pw, st),
+                "varying probe")
         model = _MODELS[exitwave_options.noise_model]
         unmeasured = float(exitwave_options.unmeasured_pixels_scaling)
         if pos_major:
@@ -293,7 +305,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             check(
                 lib.tike_ptycho_fwd_intensity(
                     A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
-                    A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(far), A.ptr(inten), n,
+                    A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far), A.ptr(inten), n,
                     S, pw, det, H, W, fwd_scale, st), "forward + intensity")
             check(
                 lib.tike_gradient_scale(A.ptr(inten), A.ptr(data[clo:chi_hi]),
@@ -321,7 +333,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         check(
             lib.tike_lstsq_gradients(
                 A.ptr(chi), A.ptr(scan[clo:chi_hi]), A.ptr(psi), A.ptr(probe),
-                A.ptr(ep), A.ptr(w_c), C, Sm,
+                A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(uq),
                 None if patches is None else A.ptr(patches[blo:blo + n]),
                 A.ptr(m_probe_update), A.ptr(objproj) if recover_psi else None,
                 n, S, pw, H, W, st), "probe gradient + object projection")
@@ -372,7 +384,8 @@ def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
         lib.tike_lstsq_step_stats(
             A.ptr(g["chi0"]), A.ptr(scan[lo:hi]), A.ptr(psi),
             A.ptr(object_update_precond), A.ptr(probe), A.ptr(ep),
-            A.ptr(w_old), C, Sm, A.ptr(g["m_probe_update"]), A.ptr(stats), B,
+            A.ptr(w_old), C, Sm, None, A.ptr(g["m_probe_update"]),
+            A.ptr(stats), B,
             S, 1, pw, psi.shape[-2], psi.shape[-1], A.stream_ptr()),
         "step-size statistics")
     return stats[:B]
