@@ -73,16 +73,18 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void fft2_v2_kernel(
     const cf* __restrict__ in, cf* __restrict__ out, long ntile, float scale,
     const cf* __restrict__ twtab) {
   using G2 = Fft2Geom<N>;
-  __shared__ cf lds[G2::LDS_ELEMS];
-  FftTw<N> tw;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
   for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const cf* __restrict__ src = in + tile * (long)N * N;
     cf* __restrict__ dst = out + tile * (long)N * N;
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
-    tw.init(twtab, j);
+    const FftTwLds<N> tw{twl, j};
     for (int r = 0; r < G2::RB; ++r)
-      fft2_pass1<N, INV>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
+      fft2_pass1<N, INV>(lds, twtab, tw, line, j, r,
                          [&](int y, int e, auto) { return src[y * N + e]; }, dst);
     __syncthreads();
     for (int k1 = 0; k1 < 16; ++k1)

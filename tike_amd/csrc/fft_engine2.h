@@ -38,7 +38,7 @@ __device__ __forceinline__ void tk_static_for(F&& f) {
 // minimum waves per SIMD requested from the register allocator for the v2
 // kernels (N threads per workgroup): tunable at build time.
 #ifndef TK_V2_WAVES
-#define TK_V2_WAVES 4
+#define TK_V2_WAVES 3
 #endif
 #define TK_V2_MINW(N) ((N) <= 256 ? TK_V2_WAVES : 2)
 

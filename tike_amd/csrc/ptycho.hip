@@ -114,8 +114,10 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
     cf* __restrict__ farplane, long ntile, int S, int pw, int H, int W, float scale,
     const cf* __restrict__ twtab) {
   using G2 = Fft2Geom<N>;
-  __shared__ cf lds[G2::LDS_ELEMS];
-  FftTw<N> tw;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
   const int pad = (N - pw) / 2;
   const long total = (long)H * W;
   for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
     cf* __restrict__ dst = farplane + tile * (long)N * N;
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
-    tw.init(twtab, j);
+    const FftTwLds<N> tw{twl, j};
     const int t = threadIdx.x;
     const int px = t - pad;
     const int x = c.sx + px;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
         }
       }
       __syncthreads();
-      fft2_pass1<N, false>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
+      fft2_pass1<N, false>(lds, twtab, tw, line, j, r,
                            [&](int y, int e, auto) { return lds[line * G2::LS + tk_pad16(e)]; }, dst);
     }
     __syncthreads();
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
 // pass 2 -- the far-plane is never re-read to form it (ptycho.py:18-23,
 // lstsq.py:444-447).
 #ifndef TK_POS_WAVES
-#define TK_POS_WAVES 4
+#define TK_POS_WAVES 2
 #endif
 template <int N>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_pos_kernel(
@@ -461,8 +463,10 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ifft2_crop_v2_kernel(
     const cf* __restrict__ farplane, cf* work, cf* chi, long ntile, int pw, float scale,
     const cf* __restrict__ twtab, const float* __restrict__ gscale, int S) {
   using G2 = Fft2Geom<N>;
-  __shared__ cf lds[G2::LDS_ELEMS];
-  FftTw<N> tw;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
   const int pad = (N - pw) / 2;
   for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const cf* __restrict__ src = farplane + tile * (long)N * N;
@@ -470,16 +474,16 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ifft2_crop_v2_kernel(
     cf* dst = chi + tile * (long)pw * pw;
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
-    tw.init(twtab, j);
+    const FftTwLds<N> tw{twl, j};
     if (gscale) {
       // far-plane gradient applied on the fly: F_s * g, g per (position, pixel)
       const float* __restrict__ gs = gscale + (tile / S) * (long)N * N;
       for (int r = 0; r < G2::RB; ++r)
-        fft2_pass1<N, true>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
+        fft2_pass1<N, true>(lds, twtab, tw, line, j, r,
                             [&](int y, int e, auto) { return src[y * N + e] * gs[y * N + e]; }, mid);
     } else {
       for (int r = 0; r < G2::RB; ++r)
-        fft2_pass1<N, true>(lds, twtab, FftTwReg<N>{tw}, line, j, r,
+        fft2_pass1<N, true>(lds, twtab, tw, line, j, r,
                             [&](int y, int e, auto) { return src[y * N + e]; }, mid);
     }
     __syncthreads();

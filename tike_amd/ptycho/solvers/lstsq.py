@@ -333,7 +333,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         check(
             lib.tike_lstsq_gradients(
                 A.ptr(chi), A.ptr(scan[clo:chi_hi]), A.ptr(psi), A.ptr(probe),
-                A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(uq),
+                A.ptr(ep), A.ptr(w_c), C, Sm, None,  # on the fly: L2-resident
                 None if patches is None else A.ptr(patches[blo:blo + n]),
                 A.ptr(m_probe_update), A.ptr(objproj) if recover_psi else None,
                 n, S, pw, H, W, st), "probe gradient + object projection")
