@@ -458,8 +458,11 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_k
 }
 
 // v2: pass 1 farplane -> work (must not alias), pass 2 in place / cropped.
+#ifndef TK_ICROP_WAVES
+#define TK_ICROP_WAVES 4
+#endif
 template <int N>
-__global__ __launch_bounds__(N, TK_V2_MINW(N)) void ifft2_crop_v2_kernel(
+__global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop_v2_kernel(
     const cf* __restrict__ farplane, cf* work, cf* chi, long ntile, int pw, float scale,
     const cf* __restrict__ twtab, const float* __restrict__ gscale, int S) {
   using G2 = Fft2Geom<N>;
