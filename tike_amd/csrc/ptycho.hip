@@ -397,6 +397,21 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
   const cf* psi_ = (const cf*)psi;
   cf* far = (cf*)farplane;
   static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
+  static const bool use_pos = getenv("TIKE_FWD_TILE_MAJOR") == nullptr;
+  if (use_v2 && use_pos && !(eigen_weights && eigen_modes > 0)) {
+    // position-major kernel (patch gathered once per position, straight-line
+    // loader); the varying-probe case needs tike_varying_probe first and is
+    // served by tike_ptycho_fwd_intensity
+    switch (det) {
+      case 128:
+        return launch_fwd_pos<128>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale,
+                                   stream);
+      case 256:
+        return launch_fwd_pos<256>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale,
+                                   stream);
+      default: break;
+    }
+  }
   if (use_v2) {
     switch (det) {
       case 128: return launch_fwd_v2<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
