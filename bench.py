@@ -177,6 +177,24 @@ def algorithmic_bytes(name, n, S, det, pw, C):
     return 0
 
 
+def measured_traffic(workload, kernel, launch_n):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_traffic_<workload>.json: FETCH_SIZE / WRITE_SIZE collected
+    in separate --pmc runs of this same command, gfx950-corrected), or None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles",
+                                           f"r*_pmc_traffic_{workload}.json"))):
+        try:
+            doc = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        k = doc.get("kernels", {}).get(kernel)
+        if k and doc.get("positions_per_launch") == launch_n:
+            best = k.get("hbm_bytes_per_launch")
+    return best
+
+
 def main():
     a = parse()
     import torch
@@ -331,7 +349,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": dominant,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(a.workload, dominant, launch_n),
+                "algorithmic_bytes": nbytes,
                 "avg_launch_ms": k["avg_ms"], "positions_per_launch": launch_n,
                 "share_of_kernel_time": k["total_ms"] /
                 sum(v["total_ms"] for v in summ.values()),
