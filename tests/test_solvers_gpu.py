@@ -202,3 +202,109 @@ def test_lstsq_converges_and_resumes(tp):
     assert len(costs) == 8 and len(params.algorithm_options.times) == 8
     assert all(np.isfinite(costs))
     assert costs[-1] < 0.5 * costs[0], costs
+
+
+def _oracle_state(g_psi, g_probe, scan, order):
+    return dict(psi=g_psi.copy(), probe=g_probe.copy(),
+                scan=scan[order].copy(), costs=[], eigen_probe=None,
+                eigen_weights=None)
+
+
+@pytest.mark.parametrize("det,pw,S,N,num_batch,masked", [
+    (128, 128, 2, 37, 3, True),    # position-major kernels, ragged batches, mask
+    (128, 96, 3, 30, 2, False),    # zero-padded probe window (pw < det)
+    (64, 64, 1, 9, 4, True),       # v1 engine path, tiny batches (2-3 positions)
+    (48, 32, 2, 12, 1, False),     # non-power-of-two detector: generic DFT path
+])
+def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked):
+    """Two lstsq_grad epochs against the CPU oracle on seeded problems that
+    exercise ragged minibatches, unmeasured pixels holding NaN (reference
+    tests/ptycho/test_ptycho.py:334,553), pw < det and every FFT path."""
+    from oracle import solvers as osol
+    rng = np.random.default_rng(det * 7 + N)
+    side = int(np.ceil(np.sqrt(N)))
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
+                              indexing="ij"), -1).reshape(-1, 2)[:N]
+    scan = (2 + 5.0 * ij + rng.random((N, 2))).astype(np.float32)
+    HW = 5 * (side - 1) + pw + 8
+    psi_true = ((0.75 + 0.25 * rng.random((1, HW, HW))) * np.exp(
+        1j * np.pi * (rng.random((1, HW, HW)) - 0.5))).astype(np.complex64)
+    w = tp.gaussian(pw, rin=0.6)
+    probe = np.stack([w * np.exp(1j * np.pi * rng.random((pw, pw))) / (m + 1)
+                      for m in range(S)])[None, None].astype(np.complex64)
+    data = tp.simulate(det, probe, scan, psi_true)
+    mask = np.ones((det, det), dtype=bool)
+    if masked:
+        mask = rng.random((det, det)) > 0.15
+        data[:, ~mask] = np.nan
+    psi0 = np.full_like(psi_true, 0.5)
+    probe0 = (probe * (1 + 0.05 * rng.standard_normal(probe.shape))).astype(
+        np.complex64)
+    batches = np.array_split(np.arange(N), num_batch)
+    order = np.arange(N)
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
+        algorithm_options=tp.LstsqOptions(num_batch=num_batch, num_iter=2,
+                                          batch_method="compact"),
+        probe_options=tp.ProbeOptions(force_orthogonality=True),
+        object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(measured_pixels=mask,
+                                            unmeasured_pixels_scaling=0.9))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # NaN in data warns, as the reference
+        with tp.Reconstruction(data, params, order=order,
+                               batches=batches) as ctx:
+            ctx.iterate(2)
+            got = ctx.get_result()
+    state = _oracle_state(psi0, probe0, scan, order)
+    odata = np.where(mask, np.nan_to_num(data), 0).astype(np.float32)
+    state = osol.rescale_probe(state, odata, det, measured_pixels=mask)
+    state = osol.iterate(state, odata, batches, 2, detector_shape=det,
+                         batch_method="compact", force_orthogonality=True,
+                         measured_pixels=mask, unmeasured_pixels_scaling=0.9)
+    np.testing.assert_allclose(
+        np.array(got.algorithm_options.costs), np.array(state["costs"]),
+        rtol=1e-3)
+    assert_close(got.psi, state["psi"], normwise=SOLVER_NORMWISE, maxabs=1e-2,
+                 what="psi")
+    assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe")
+
+
+def test_full_size_operator_properties(tp):
+    """BASELINE size (256x256, 8 modes): size-independent properties of the
+    fused kernels -- adjoint identity <F m, d> = <m, F* d> for psi and probe,
+    linearity in psi, and Parseval between chi and the far-plane gradient."""
+    import torch
+    import tike_amd.operators as ops
+    rng = np.random.default_rng(1)
+    N, S, pw, det = 96, 8, 256, 256
+    HW = 420
+    rc = lambda *s: torch.from_numpy((rng.random((*s, 2), dtype=np.float32) -
+                                      0.5).view(np.complex64)[..., 0]).cuda()
+    scan = torch.from_numpy((rng.random((N, 2)) * (HW - pw - 3) + 1).astype(
+        np.float32)).cuda()
+    psi, psi2 = rc(1, HW, HW), rc(1, HW, HW)
+    probe = rc(1, 1, S, pw, pw)
+    d = rc(N, 1, S, det, det)
+    with ops.Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+        Fm = op.fwd(probe=probe, scan=scan, psi=psi)
+        Fm2 = op.fwd(probe=probe, scan=scan, psi=psi2)
+        Fsum = op.fwd(probe=probe, scan=scan, psi=psi + 2 * psi2)
+        assert float((Fsum - Fm - 2 * Fm2).abs().max()) < 1e-3 * float(
+            Fsum.abs().max())
+        bprobe = probe.expand(N, 1, S, pw, pw).contiguous()
+        m0, m1 = op.adj(farplane=d, probe=bprobe, scan=scan, psi=psi)
+    a = (Fm * d.conj()).sum()
+    b = (psi * m0.conj()).sum()
+    c = (bprobe * m1.conj()).sum()
+    for x in (b, c):
+        np.testing.assert_allclose([float(a.real), float(a.imag)],
+                                   [float(x.real), float(x.imag)], rtol=1e-3)
+    # Parseval: ||F m||^2 = ||pad(patch * probe)||^2 (ortho norm)
+    near = (Fm.abs()**2).sum()
+    with ops.Propagation(detector_shape=det) as prop:
+        back = prop.adj(farplane=Fm)
+    np.testing.assert_allclose(float(near), float((back.abs()**2).sum()),
+                               rtol=1e-4)
