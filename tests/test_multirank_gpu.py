@@ -104,3 +104,40 @@ def test_two_ranks_match_one_rank(eigen, method):
         if eigen:
             assert_close(ew, single.eigen_weights, normwise=5e-3, maxabs=5e-2,
                          what=f"eigen weights rank {rank}")
+
+
+def _rccl_worker(port, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TIKE_FORCE_COLLECTIVES"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        r = _reconstruct(True, "wobbly_center")
+        ret[0] = (r.psi, r.probe, r.eigen_weights, r.scan,
+                  np.array(r.algorithm_options.costs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_single_rank():
+    """The production backend: every collective of the solver (packed f32
+    all-reduce, f64 scalar all-reduces, position gather) issued through RCCL
+    ("nccl") on a one-rank group must leave the result unchanged."""
+    import torch.multiprocessing as mp
+    single = _reconstruct(True, "wobbly_center")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    psi, probe, ew, scan, costs = ret[0]
+    np.testing.assert_allclose(costs, np.array(single.algorithm_options.costs),
+                               rtol=1e-5)
+    assert_close(psi, single.psi, normwise=1e-5, maxabs=1e-4, what="psi")
+    assert_close(probe, single.probe, normwise=1e-5, maxabs=1e-4, what="probe")
+    np.testing.assert_array_equal(scan, single.scan)

@@ -8,6 +8,8 @@ path needs is a sum all-reduce, executed by RCCL over xGMI through
 ``torch.distributed`` (backend "nccl"; "gloo" on CPU for the tests).
 With a single rank every call is the identity.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -20,6 +22,10 @@ class Comm:
         self.enabled = dist.is_available() and dist.is_initialized()
         self.size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        # collectives are skipped for a single rank; TIKE_FORCE_COLLECTIVES=1
+        # issues them anyway (used to exercise RCCL on a one-GPU test box)
+        self.collective = self.size > 1 or (
+            self.enabled and os.environ.get("TIKE_FORCE_COLLECTIVES") == "1")
 
     def __enter__(self):
         return self
@@ -31,7 +37,7 @@ class Comm:
         """Sum the tensors across ranks IN PLACE; complex tensors are reduced
         as interleaved float32.  Several tensors are packed into one flat
         buffer so that a minibatch costs one collective."""
-        if self.size == 1:
+        if not self.collective:
             return tensors if len(tensors) != 1 else tensors[0]
         views = [
             torch.view_as_real(t) if t.is_complex() else t for t in tensors
@@ -58,14 +64,14 @@ class Comm:
             if isinstance(v, torch.Tensor) else torch.tensor(
                 float(v), dtype=torch.float64, device=device) for v in values
         ])
-        if self.size > 1:
+        if self.collective:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def Allreduce_count(self, n: int) -> float:
         """Sum of a host integer over ranks, returned as a host float
         (used once per run for the global minibatch sizes)."""
-        if self.size == 1:
+        if not self.collective:
             return float(n)
         t = torch.tensor([float(n)], dtype=torch.float64)
         if dist.get_backend(self.group) == "nccl":
@@ -74,5 +80,5 @@ class Comm:
         return float(t.item())
 
     def barrier(self):
-        if self.size > 1:
+        if self.collective:
             dist.barrier(group=self.group)

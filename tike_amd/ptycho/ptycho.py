@@ -263,7 +263,7 @@ class Reconstruction():
         if local is None:
             return None
         local = A.to_host(local)
-        if self.comm.size == 1 or self._presharded:
+        if not self.comm.collective or self._presharded:
             full_order, parts = self.local_order, local
         else:
             import torch.distributed as dist

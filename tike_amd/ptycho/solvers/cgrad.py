@@ -72,7 +72,7 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
     tot = comm.Allreduce_scalars([costs[:N].sum()], dev)
     cost = float((tot[0] / global_count(comm, op, 0, N)).item())
     grads = [t for t in (gacc, gprobe) if t is not None]
-    if grads and comm.size > 1:
+    if grads and comm.collective:
         comm.Allreduce(*grads)
     gpsi = None
     if gacc is not None:

@@ -348,7 +348,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # complete the sums over positions across ranks
     cost_sum = costs[:B].sum() if B > 0 else torch.zeros((), device=dev)
     reduced = [t for t in (obj_acc, m_probe_update) if t is not None]
-    if comm.size > 1:
+    if comm.collective:
         comm.Allreduce(*reduced)
     object_upd_sum = (torch.complex(obj_acc[0], obj_acc[1])[None]
                       if recover_psi else None)
@@ -471,7 +471,7 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
                                         C, Sm, c - 1, A.ptr(proj_mean),
                                         A.ptr(update), B, pw, st),
             "eigen pixel update")
-        if comm.size > 1:
+        if comm.collective:
             comm.Allreduce(update)
         update = update / count
         E = ep[0, c - 1, m]

@@ -77,6 +77,14 @@ def main():
             st)), a.reps)
         rows.append((f"fwd_intensity S={S}", ms,
                      N * S * tile_bytes + N * tile_bytes))
+        uniq = torch.randn(N, 1, n, n, dtype=torch.complex64, device=dev)
+        wts = torch.rand(N, 2, S, dtype=torch.float32, device=dev)
+        ms = timeit(lambda: check(lib.tike_ptycho_fwd_intensity(
+            psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0,
+            uniq.data_ptr(), wts.data_ptr(), 1, 1, far.data_ptr(),
+            inten.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st)), a.reps)
+        rows.append((f"fwd_intensity eigen S={S}", ms,
+                     N * S * tile_bytes + 2 * N * tile_bytes))
         g = torch.rand(N, n, n, dtype=torch.float32, device=dev)
         mid = torch.empty_like(far)
         ms = timeit(lambda: check(lib.tike_ifft2_crop_scaled(
