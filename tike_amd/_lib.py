@@ -15,7 +15,9 @@ import re
 import torch  # noqa: F401  (load order matters, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtike_amd.so")
+# TIKE_AMD_LIB: alternative build of the same library (A/B tuning runs)
+LIB_PATH = os.environ.get("TIKE_AMD_LIB") or os.path.join(
+    _HERE, "csrc", "libtike_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
 ERR_ARG = 1000001

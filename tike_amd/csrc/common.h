@@ -43,6 +43,26 @@ static inline int tk_grid(long work_items, int per_cu = 8) {
   return (int)(g < 1 ? 1 : g);
 }
 
+// Streaming (read-once / write-once) accesses: the non-temporal hint keeps
+// them from displacing the lines that ARE re-read soon (the FFT intermediate,
+// the probe, the object window) in the 4 MiB L2 of the XCD.
+#ifndef TK_NO_NT
+__device__ __forceinline__ cf tk_ld_stream(const cf* p) {
+  const double d = __builtin_nontemporal_load(reinterpret_cast<const double*>(p));
+  return __builtin_bit_cast(cf, d);
+}
+__device__ __forceinline__ void tk_st_stream(cf* p, cf v) {
+  __builtin_nontemporal_store(__builtin_bit_cast(double, v), reinterpret_cast<double*>(p));
+}
+__device__ __forceinline__ void tk_st_stream(float* p, float v) {
+  __builtin_nontemporal_store(v, p);
+}
+#else
+__device__ __forceinline__ cf tk_ld_stream(const cf* p) { return *p; }
+__device__ __forceinline__ void tk_st_stream(cf* p, cf v) { *p = v; }
+__device__ __forceinline__ void tk_st_stream(float* p, float v) { *p = v; }
+#endif
+
 __device__ __forceinline__ float tk_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

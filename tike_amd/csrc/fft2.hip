@@ -85,10 +85,11 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void fft2_v2_kernel(
     const FftTwLds<N> tw{twl, j};
     for (int r = 0; r < G2::RB; ++r)
       fft2_pass1<N, INV>(lds, twtab, tw, line, j, r,
-                         [&](int y, int e, auto) { return src[y * N + e]; }, dst);
+                         [&](int y, int e, auto) { return tk_ld_stream(src + y * N + e); }, dst);
     __syncthreads();
     for (int k1 = 0; k1 < 16; ++k1)
-      fft2_pass2<N, INV>(dst, k1, [&](int ky, int t, cf v) { dst[ky * N + t] = v * scale; });
+      fft2_pass2<N, INV>(dst, k1,
+                         [&](int ky, int t, cf v) { tk_st_stream(dst + ky * N + t, v * scale); });
     __syncthreads();
   }
 }

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
     if (WITH_CHI) {
 #pragma unroll
       for (int s = 0; s < SM; ++s)
-        if (SC > 0 || s < S) xs[s] = chi[((long)b * S + s) * P + p];
+        if (SC > 0 || s < S) xs[s] = tk_ld_stream(chi + ((long)b * S + s) * P + p);
     }
     cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
     if (!ok) o = mk(0.f, 0.f);

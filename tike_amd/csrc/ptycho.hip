@@ -302,14 +302,14 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
         cf* __restrict__ dst = dst0 + s * (long)N * N;
         fft2_pass2<N, false>(dst, k1, [&](int ky, int tt, cf v) {
           const cf o = v * scale;
-          dst[ky * N + tt] = o;
+          tk_st_stream(dst + ky * N + tt, o);
           I[(ky - k1) >> 4] += norm2(o);
         });
       }
       if (intensity) {
 #pragma unroll
         for (int k2 = 0; k2 < G2::RB; ++k2)
-          intensity[n * (long)N * N + (k1 + 16 * k2) * N + t] = I[k2];
+          tk_st_stream(intensity + n * (long)N * N + (k1 + 16 * k2) * N + t, I[k2]);
       }
     }
 #endif
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_k
           lds, col, tw, [&](int line, int e) { return mid[e * N + g + line]; },
           [&](int line, int e, cf v) {
             const int py = e - pad, px = g + line - pad;
-            if (py >= 0 && py < pw && px >= 0 && px < pw) dst[py * pw + px] = v * scale;
+            if (py >= 0 && py < pw && px >= 0 && px < pw) tk_st_stream(dst + py * pw + px, v * scale);
           });
     }
     __syncthreads();
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_k
 template <int N>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop_v2_kernel(
     const cf* __restrict__ farplane, cf* work, cf* chi, long ntile, int pw, float scale,
-    const cf* __restrict__ twtab, const float* __restrict__ gscale, int S) {
+    const cf* __restrict__ twtab, const float* __restrict__ gscale, int S, int wg_scratch) {
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
   cf* twl = lds + G2::LDS_ELEMS;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
   const int pad = (N - pw) / 2;
   for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const cf* __restrict__ src = farplane + tile * (long)N * N;
-    cf* mid = work + tile * (long)N * N;
+    cf* mid = work + (wg_scratch ? (long)blockIdx.x : tile) * (long)N * N;
     cf* dst = chi + tile * (long)pw * pw;
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
@@ -498,17 +498,20 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
       const float* __restrict__ gs = gscale + (tile / S) * (long)N * N;
       for (int r = 0; r < G2::RB; ++r)
         fft2_pass1<N, true>(lds, twtab, tw, line, j, r,
-                            [&](int y, int e, auto) { return src[y * N + e] * gs[y * N + e]; }, mid);
+                            [&](int y, int e, auto) {
+                              return tk_ld_stream(src + y * N + e) * gs[y * N + e];
+                            },
+                            mid);
     } else {
       for (int r = 0; r < G2::RB; ++r)
         fft2_pass1<N, true>(lds, twtab, tw, line, j, r,
-                            [&](int y, int e, auto) { return src[y * N + e]; }, mid);
+                            [&](int y, int e, auto) { return tk_ld_stream(src + y * N + e); }, mid);
     }
     __syncthreads();
     for (int k1 = 0; k1 < 16; ++k1)
       fft2_pass2<N, true>(mid, k1, [&](int ky, int t, cf v) {
         const int py = ky - pad, px = t - pad;
-        if (py >= 0 && py < pw && px >= 0 && px < pw) dst[py * pw + px] = v * scale;
+        if (py >= 0 && py < pw && px >= 0 && px < pw) tk_st_stream(dst + py * pw + px, v * scale);
       });
     __syncthreads();
   }
@@ -519,8 +522,9 @@ static int launch_icrop_v2(const cf* far, cf* work, cf* chi, long ntile, int pw,
                            hipStream_t stream, const float* gscale = nullptr, int S = 1) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
+  static const int wg_scratch = getenv("TIKE_WG_SCRATCH") != nullptr;
   hipLaunchKernelGGL((ifft2_crop_v2_kernel<N>), dim3(tk_grid(ntile, 4)), dim3(N), 0, stream, far,
-                     work, chi, ntile, pw, scale, tw, gscale, S);
+                     work, chi, ntile, pw, scale, tw, gscale, S, wg_scratch && work != chi);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

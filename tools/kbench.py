@@ -28,12 +28,35 @@ def timeit(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def timeit_gap(fn, reps, gap_s, pre=None):
+    """Per-launch events with the GPU left idle for gap_s (or running `pre`)
+    before every launch: exposes clock-ramp / cold-cache effects."""
+    import time
+    tot = 0.0
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        time.sleep(gap_s)
+        if pre is not None:
+            pre()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(
+            enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        tot += e0.elapsed_time(e1)
+    return tot / reps
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--det", type=int, default=256)
     p.add_argument("--tiles", type=int, default=2048)
     p.add_argument("--reps", type=int, default=10)
     p.add_argument("--modes", type=int, default=1)
+    p.add_argument("--hw", type=int, default=0, help="object side (0: small)")
+    p.add_argument("--sort", action="store_true", help="row-major sort positions")
+    p.add_argument("--c3", action="store_true", help="bench.py's synthetic problem")
     a = p.parse_args()
     n, T, S = a.det, a.tiles, a.modes
     dev = torch.device("cuda", 0)
@@ -58,12 +81,20 @@ def main():
 
     N = T // S
     side = int(np.ceil(np.sqrt(N)))
-    HW = 8 * side + n + 8
+    HW = a.hw or 8 * side + n + 8
     rng = np.random.default_rng(0)
-    scan = torch.tensor(1 + rng.random((N, 2)) * (HW - n - 3),
-                        dtype=torch.float32, device=dev)
+    sc = 1 + rng.random((N, 2)) * (HW - n - 3)
+    if a.sort:
+        sc = sc[np.lexsort((sc[:, 1], sc[:, 0] // 64))]
+    scan = torch.tensor(sc, dtype=torch.float32, device=dev)
     psi = torch.randn(1, HW, HW, dtype=torch.complex64, device=dev)
     probe = torch.randn(1, 1, S, n, n, dtype=torch.complex64, device=dev)
+    if a.c3:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        pr = bench.synthetic(10000, S, n, 0, N)
+        HW = pr["HW"]
+        scan, psi, probe = (A.to_device(pr[k]) for k in ("scan", "psi", "probe"))
     far = y[:N * S]
     ms = timeit(lambda: check(lib.tike_ptycho_fwd(
         psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0, None, None, 0, 0,
@@ -85,12 +116,36 @@ def main():
             inten.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st)), a.reps)
         rows.append((f"fwd_intensity eigen S={S}", ms,
                      N * S * tile_bytes + 2 * N * tile_bytes))
+        fwd_e = lambda: check(lib.tike_ptycho_fwd_intensity(
+            psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0,
+            uniq.data_ptr(), wts.data_ptr(), 1, 1, far.data_ptr(),
+            inten.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st))
+        for gap in (0.0, 0.002, 0.02):
+            ms = timeit_gap(fwd_e, a.reps, gap)
+            rows.append((f"  .. after {gap*1e3:.0f} ms idle", ms,
+                         N * S * tile_bytes + 2 * N * tile_bytes))
+        small = torch.zeros(1 << 16, device=dev)
+        def pre():
+            for _ in range(40):
+                small.add_(1.0)
+        ms = timeit_gap(fwd_e, a.reps, 0.0, pre)
+        rows.append(("  .. after 40 tiny kernels", ms,
+                     N * S * tile_bytes + 2 * N * tile_bytes))
+        big = torch.empty(1 << 29, device=dev)
+        ms = timeit_gap(fwd_e, a.reps, 0.0, lambda: big.fill_(1.0))
+        rows.append(("  .. after 2 GiB fill", ms,
+                     N * S * tile_bytes + 2 * N * tile_bytes))
         g = torch.rand(N, n, n, dtype=torch.float32, device=dev)
         mid = torch.empty_like(far)
         ms = timeit(lambda: check(lib.tike_ifft2_crop_scaled(
             far.data_ptr(), g.data_ptr(), S, mid.data_ptr(), mid.data_ptr(),
             N * S, n, n, 1.0 / n, st)), a.reps)
         rows.append((f"ifft2_crop_scaled S={S}", ms, 2 * N * S * tile_bytes))
+        chi = torch.empty_like(far)
+        ms = timeit(lambda: check(lib.tike_ifft2_crop_scaled(
+            far.data_ptr(), g.data_ptr(), S, mid.data_ptr(), chi.data_ptr(),
+            N * S, n, n, 1.0 / n, st)), a.reps)
+        rows.append((f"ifft2_crop_scaled sep. chi", ms, 2 * N * S * tile_bytes))
     for name, ms, nbytes in rows:
         print(f"{name:28s} {ms:8.3f} ms  {T / ms / 1e3:8.3f} Mtile/s  "
               f"{nbytes / ms / 1e6:8.1f} GB/s (algorithmic)")
