@@ -32,7 +32,7 @@ METRIC = "diffraction patterns/sec/GPU (256x256, 8-mode probe)"
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--workload", default="c3")
     p.add_argument("--positions", type=int, default=0,
