@@ -203,6 +203,41 @@ def probe_preconditioner(psi, probe, scan):
 # --------------------------------------------------------------------------
 
 
+def poisson_steplength_all_modes(xi, abs2_Psi, I_e, I_m, measured_pixels,
+                                 step_length, weight_avg):
+    """exitwave.py:122-184: two fixed-point sweeps of the per-mode optimal
+    step, averaged with the previous value by `weight_avg`."""
+    I_e = I_e[:, None, None, ...]
+    I_m = I_m[:, None, None, ...]
+    xi_abs_Psi2 = xi * abs2_Psi
+    denom_final = np.sum((xi * xi_abs_Psi2)[..., measured_pixels], axis=-1)
+    w = np.float32(weight_avg)
+    for _ in range(2):
+        xi_alpha_minus_one = xi * step_length - 1
+        denom = abs2_Psi * np.square(xi_alpha_minus_one) + I_e - abs2_Psi
+        numer = np.sum((xi_abs_Psi2 * (1 + (I_m * xi_alpha_minus_one) /
+                                       denom))[..., measured_pixels], axis=-1)
+        step_length = (step_length * (1 - w) +
+                       (numer / denom_final)[..., None, None] * w)
+    return step_length.astype(np.float32)
+
+
+def poisson_steplength_dominant_mode(xi, I_e, I_m, measured_pixels,
+                                     step_length, weight_avg):
+    """exitwave.py:187-234: the same with the modes collapsed."""
+    I_e = I_e[:, None, None, ...]
+    I_m = I_m[:, None, None, ...]
+    sum_denom = np.sum((np.square(xi) * I_e)[..., measured_pixels], axis=-1)
+    w = np.float32(weight_avg)
+    for _ in range(2):
+        numer = xi * (I_e - I_m / (1 - step_length * xi))
+        numer_over_denom = np.sum(numer[..., measured_pixels],
+                                  axis=-1) / sum_denom
+        step_length = ((1 - w) * step_length +
+                       w * numer_over_denom[..., None, None])
+    return step_length.astype(np.float32)
+
+
 def precondition_object_update(object_upd_sum, psi_update_denominator,
                                alpha=0.05):
     """lstsq.py:605-616."""
@@ -217,7 +252,10 @@ def get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                             detector_shape, measured_pixels,
                             noise_model="gaussian",
                             unmeasured_pixels_scaling=1.0, norm="ortho",
-                            recover_psi=True, recover_probe=True):
+                            recover_psi=True, recover_probe=True,
+                            step_length_start=0.5,
+                            step_length_usemodes="all_modes",
+                            step_length_weight=0.5):
     """lstsq.py:367-602 for one minibatch [lo, hi) (chunking of 64 elided)."""
     pw = probe.shape[-1]
     pad = (detector_shape - pw) // 2
@@ -236,10 +274,28 @@ def get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     each = getattr(ops, f"{noise_model}_each_pattern")
     costs = each(d[:, measured_pixels][:, None, :],
                  intensity[:, measured_pixels][:, None, :])
-    if noise_model != "gaussian":
-        raise NotImplementedError("oracle restates the gaussian path only")
-    grad = ops.gaussian_grad(d, farplane, intensity)
-    farplane[..., measured_pixels] = -grad[..., measured_pixels]
+    if noise_model == "poisson":
+        # lstsq.py:454-489: gradient F * xi with a per-(position, mode) step
+        with np.errstate(invalid="ignore", divide="ignore"):
+            xi = (1 - d / (intensity + np.float32(1e-9)))[:, None, None, ...]
+            grad_cost = farplane * xi
+            step = np.full((farplane.shape[0], 1, farplane.shape[2], 1, 1),
+                           np.float32(step_length_start), dtype=np.float32)
+            if step_length_usemodes == "dominant_mode":
+                step = poisson_steplength_dominant_mode(
+                    xi, intensity, d, measured_pixels, step,
+                    step_length_weight)
+            else:
+                step = poisson_steplength_all_modes(
+                    xi, np.square(np.abs(farplane)), intensity, d,
+                    measured_pixels, step, step_length_weight)
+            farplane[..., measured_pixels] = (
+                -step * grad_cost)[..., measured_pixels]
+    elif noise_model == "gaussian":
+        grad = ops.gaussian_grad(d, farplane, intensity)
+        farplane[..., measured_pixels] = -grad[..., measured_pixels]
+    else:
+        raise ValueError(noise_model)
     unmeasured = np.logical_not(measured_pixels)
     farplane[..., unmeasured] *= np.float32(unmeasured_pixels_scaling - 1.0)
     farplane = ops.propagation_adj(farplane, norm)
@@ -380,10 +436,12 @@ def momentum_checked(g, v, m, mdecay, errors, beta=1.0, memory_length=3):
 def lstsq_grad(state, data, batches, *, epoch, detector_shape,
                batch_method="compact", measured_pixels=None,
                unmeasured_pixels_scaling=1.0, norm="ortho",
+               noise_model="gaussian", step_length_start=0.5,
+               step_length_usemodes="all_modes", step_length_weight=0.5,
                recover_psi=True, recover_probe=True, probe_update_start=0,
                object_adaptive_moment=False, object_mdecay=0.9,
                probe_adaptive_moment=False, probe_mdecay=0.9, rng=None):
-    """One epoch of lstsq.py:25-294 (positions fixed, gaussian noise model)."""
+    """One epoch of lstsq.py:25-294 (positions fixed)."""
     psi, probe, scan = state["psi"], state["probe"], state["scan"]
     eigen_probe = state.get("eigen_probe")
     eigen_weights = state.get("eigen_weights")
@@ -407,6 +465,9 @@ def lstsq_grad(state, data, batches, *, epoch, detector_shape,
             num_batch=num_batch, detector_shape=detector_shape,
             measured_pixels=measured_pixels,
             unmeasured_pixels_scaling=unmeasured_pixels_scaling, norm=norm,
+            noise_model=noise_model, step_length_start=step_length_start,
+            step_length_usemodes=step_length_usemodes,
+            step_length_weight=step_length_weight,
             recover_psi=recover_psi, recover_probe=recover_probe)
         if recover_probe:
             eigen_probe, eigen_weights = update_nearplane(

@@ -252,11 +252,19 @@ lstsq_parts("eigen", N=24, pw=16, det=24, S=3, eigen=2)
 
 # ---- full reconstructions (3 epochs, called twice like ReconstructTwice) ---
 def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
-          adaptive=False, orth=False):
+          adaptive=False, orth=False, rng=None, noise_model="gaussian",
+          usemodes="all_modes", mask_frac=0.0, scaling=1.0):
+    rng = globals()["rng"] if rng is None else rng
     p = make_problem(rng, N, pw, det, S, eigen=eigen)
     np.random.seed(7)
     tike.random.randomizer_np = np.random.default_rng(11)
     measured = np.ones((det, det), dtype=bool)
+    if mask_frac > 0:
+        # unmeasured pixels hold NaN, as in the reference's own tests
+        # (tests/ptycho/test_ptycho.py:334,553)
+        measured = rng.random((det, det)) > mask_frac
+        p["data"] = p["data"].copy()
+        p["data"][:, ~measured] = np.nan
     params = tike.ptycho.PtychoParameters(
         probe=p["probe0"].copy(), psi=p["psi0"].copy(),
         scan=p["scan"].copy(),
@@ -270,7 +278,10 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
             force_orthogonality=orth, use_adaptive_moment=adaptive),
         object_options=tike.ptycho.ObjectOptions(
             use_adaptive_moment=adaptive),
-        exitwave_options=tike.ptycho.ExitWaveOptions(measured_pixels=measured),
+        exitwave_options=tike.ptycho.ExitWaveOptions(
+            measured_pixels=measured, noise_model=noise_model,
+            step_length_usemodes=usemodes,
+            unmeasured_pixels_scaling=scaling),
     )
     # record the batches the reference's clustering chooses (host-side,
     # out of scope): one worker => order = concatenated batches
@@ -293,7 +304,9 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
          probe0=p["probe0"], scan=p["scan"], det=det, order=order,
          batch_sizes=np.array([len(b) for b in batches]),
          num_batch=num_batch, batch_method=batch_method, epochs=epochs,
-         adaptive=adaptive, orth=orth, psi_1=r1.psi, probe_1=r1.probe,
+         adaptive=adaptive, orth=orth, measured=measured,
+         noise_model=noise_model, usemodes=usemodes, scaling=scaling,
+         psi_1=r1.psi, probe_1=r1.probe,
          costs_1=np.array(r1.algorithm_options.costs[:epochs]),
          costs_2=np.array(r2.algorithm_options.costs), psi_2=r2.psi,
          probe_2=r2.probe, **extra)
@@ -339,3 +352,14 @@ with tike.operators.Ptycho(probe_shape=16, detector_shape=16, nz=HW, n=HW,
 save("cgrad.npz", data=p["data"], psi0=p["psi0"], probe=p["probe_true"],
      scan=p["scan"], det=16, costs=np.array(costs), psis=np.stack(psis))
 print("cgrad costs", costs)
+
+
+# ---- Poisson noise model with per-mode step lengths (SURVEY 8f rank 2;
+# lstsq.py:454-489, exitwave.py:122-234), NaN-masked data --------------------
+rng_p = np.random.default_rng(4321)
+recon("poisson_all", N=40, pw=24, det=32, S=3, eigen=0, num_batch=2,
+      batch_method="compact", epochs=3, orth=True, rng=rng_p,
+      noise_model="poisson", usemodes="all_modes", mask_frac=0.1, scaling=0.9)
+recon("poisson_dominant", N=40, pw=32, det=32, S=2, eigen=0, num_batch=2,
+      batch_method="compact", epochs=3, orth=True, rng=rng_p,
+      noise_model="poisson", usemodes="dominant_mode")

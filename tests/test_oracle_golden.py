@@ -206,24 +206,29 @@ def _replay(g, second=False):
                  if "eigen_weights" in g else None)
     data = g["data"][order]
     rng = np.random.default_rng(11)
+    measured = g["measured"].astype(bool)
     kw = dict(detector_shape=det, batch_method=str(g["batch_method"]),
               force_orthogonality=bool(g["orth"]),
               object_adaptive_moment=bool(g["adaptive"]),
-              probe_adaptive_moment=bool(g["adaptive"]), rng=rng)
+              probe_adaptive_moment=bool(g["adaptive"]), rng=rng,
+              measured_pixels=measured, noise_model=str(g["noise_model"]),
+              step_length_usemodes=str(g["usemodes"]),
+              unmeasured_pixels_scaling=float(g["scaling"]))
     epochs = int(g["epochs"])
-    state = sol.rescale_probe(state, data, det)
+    state = sol.rescale_probe(state, data, det, measured_pixels=measured)
     state = sol.iterate(state, data, batches, epochs, **kw)
     first = {k: (None if v is None else np.array(v, copy=True))
              for k, v in state.items() if k in ("psi", "probe", "eigen_probe",
                                                 "eigen_weights")}
     first["costs"] = list(state["costs"])
     if second:
-        state = sol.rescale_probe(state, data, det)
+        state = sol.rescale_probe(state, data, det, measured_pixels=measured)
         state = sol.iterate(state, data, batches, epochs, **kw)
     return first, state, order
 
 
-@pytest.mark.parametrize("tag", ["compact", "wobbly_eigen"])
+@pytest.mark.parametrize("tag", ["compact", "wobbly_eigen", "poisson_all",
+                                 "poisson_dominant"])
 def test_lstsq_reconstruction_vs_reference(golden, tag):
     g = golden(f"lstsq_recon_{tag}.npz")
     first, state, order = _replay(g, second=True)
