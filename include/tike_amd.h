@@ -108,6 +108,28 @@ int tike_gradient_scale(const float* intensity, const float* data, const unsigne
 int tike_ifft2_crop_scaled(const void* farplane, const float* gscale, int S, void* work,
                            void* chi, long ntile, int det, int pw, float scale, void* stream);
 
+/* ---- poisson noise model (lstsq.py:454-489): per-(position, mode) step
+ * lengths of exitwave.py:122-184 (all modes) or :187-234 (dominant_mode != 0:
+ * one step per position, written to all S entries).  steps (nscan, S) f32;
+ * farplane (nscan,S,det,det) scaled far-plane waves (unused for dominant mode);
+ * intensity, data (nscan,det,det) f32; measured (det,det) u8 or NULL. */
+int tike_poisson_steps(const void* farplane, const float* intensity, const float* data,
+                       const unsigned char* measured, float* steps, int nscan, int S, int det,
+                       float step_start, float weight, int dominant_mode, void* stream);
+
+/* tike_ifft2_crop_scaled with the factor of mode s multiplied by
+ * mode_scale[n][s] on measured pixels (lstsq.py:487-489: farplane[measured] =
+ * -step_length * grad_cost). */
+int tike_ifft2_crop_scaled_modes(const void* farplane, const float* gscale,
+                                 const float* mode_scale, const unsigned char* measured, int S,
+                                 void* work, void* chi, long ntile, int det, int pw, float scale,
+                                 void* stream);
+
+/* farplane[tile][p] *= mode_scale[tile] on measured pixels: the same factor
+ * for detector sizes the fused inverse does not cover. */
+int tike_scale_modes(void* farplane, const float* mode_scale, const unsigned char* measured,
+                     long ntile, int det, void* stream);
+
 /* ---- IFFT2 + crop to the probe window (propagation.py:59-73 followed by
  * lstsq.py:506-507 / convolution.py:108-110 crop).  work (ntile,det,det) holds
  * the intermediate and may alias farplane; chi (ntile,pw,pw) may alias work

@@ -115,7 +115,10 @@ def _reconstruct_like_reference(tp, g, second):
                                       use_adaptive_moment=adaptive),
         object_options=tp.ObjectOptions(use_adaptive_moment=adaptive),
         exitwave_options=tp.ExitWaveOptions(
-            measured_pixels=np.ones((det, det), dtype=bool)))
+            measured_pixels=g["measured"].astype(bool),
+            noise_model=str(g["noise_model"]),
+            step_length_usemodes=str(g["usemodes"]),
+            unmeasured_pixels_scaling=float(g["scaling"])))
     results = []
     for _ in range(2 if second else 1):
         with tp.Reconstruction(g["data"], params, order=g["order"],
@@ -126,7 +129,8 @@ def _reconstruct_like_reference(tp, g, second):
     return results
 
 
-@pytest.mark.parametrize("tag", ["compact", "wobbly_eigen"])
+@pytest.mark.parametrize("tag", ["compact", "wobbly_eigen", "poisson_all",
+                                 "poisson_dominant"])
 def test_lstsq_reconstruct_twice_vs_reference(tp, golden, tag):
     """The reference's ReconstructTwice template (tests/ptycho/templates.py:
     115-129), asserted against the reference's own iterates."""
@@ -210,13 +214,16 @@ def _oracle_state(g_psi, g_probe, scan, order):
                 eigen_weights=None)
 
 
-@pytest.mark.parametrize("det,pw,S,N,num_batch,masked", [
-    (128, 128, 2, 37, 3, True),    # position-major kernels, ragged batches, mask
-    (128, 96, 3, 30, 2, False),    # zero-padded probe window (pw < det)
-    (64, 64, 1, 9, 4, True),       # v1 engine path, tiny batches (2-3 positions)
-    (48, 32, 2, 12, 1, False),     # non-power-of-two detector: generic DFT path
+@pytest.mark.parametrize("det,pw,S,N,num_batch,masked,model", [
+    (128, 128, 2, 37, 3, True, "gaussian"),   # position-major kernels, ragged batches, mask
+    (128, 96, 3, 30, 2, False, "gaussian"),   # zero-padded probe window (pw < det)
+    (64, 64, 1, 9, 4, True, "gaussian"),      # v1 engine path, tiny batches (2-3 positions)
+    (48, 32, 2, 12, 1, False, "gaussian"),    # non-power-of-two detector: generic DFT path
+    (128, 128, 3, 24, 2, True, "poisson:all_modes"),      # fused inverse with per-mode steps
+    (256, 256, 2, 10, 1, False, "poisson:dominant_mode"),
+    (48, 32, 2, 12, 2, True, "poisson:all_modes"),        # generic path: tike_scale_modes
 ])
-def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked):
+def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
     """Two lstsq_grad epochs against the CPU oracle on seeded problems that
     exercise ragged minibatches, unmeasured pixels holding NaN (reference
     tests/ptycho/test_ptycho.py:334,553), pw < det and every FFT path."""
@@ -248,8 +255,10 @@ def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked):
                                           batch_method="compact"),
         probe_options=tp.ProbeOptions(force_orthogonality=True),
         object_options=tp.ObjectOptions(),
-        exitwave_options=tp.ExitWaveOptions(measured_pixels=mask,
-                                            unmeasured_pixels_scaling=0.9))
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=mask, unmeasured_pixels_scaling=0.9,
+            noise_model=model.split(":")[0],
+            step_length_usemodes=(model.split(":") + ["all_modes"])[1]))
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")  # NaN in data warns, as the reference
@@ -262,7 +271,10 @@ def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked):
     state = osol.rescale_probe(state, odata, det, measured_pixels=mask)
     state = osol.iterate(state, odata, batches, 2, detector_shape=det,
                          batch_method="compact", force_orthogonality=True,
-                         measured_pixels=mask, unmeasured_pixels_scaling=0.9)
+                         measured_pixels=mask, unmeasured_pixels_scaling=0.9,
+                         noise_model=model.split(":")[0],
+                         step_length_usemodes=(model.split(":") +
+                                               ["all_modes"])[1])
     np.testing.assert_allclose(
         np.array(got.algorithm_options.costs), np.array(state["costs"]),
         rtol=1e-3)

@@ -51,6 +51,10 @@ _PROTOTYPES = {
                                   _i, _i, _i, _i, _i, _f, _p],
     "tike_gradient_scale": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _l, _p],
     "tike_ifft2_crop_scaled": [_p, _p, _i, _p, _p, _l, _i, _i, _f, _p],
+    "tike_ifft2_crop_scaled_modes": [_p, _p, _p, _p, _i, _p, _p, _l, _i, _i, _f,
+                                     _p],
+    "tike_poisson_steps": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
+    "tike_scale_modes": [_p, _p, _p, _l, _i, _p],
     "tike_farplane_gradient": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _l,
                                _p],
     "tike_intensity": [_p, _p, _l, _i, _l, _p],

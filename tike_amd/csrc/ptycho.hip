@@ -476,10 +476,11 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_k
 #ifndef TK_ICROP_WAVES
 #define TK_ICROP_WAVES 4
 #endif
-template <int N>
+template <int N, int MODE>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop_v2_kernel(
     const cf* __restrict__ farplane, cf* work, cf* chi, long ntile, int pw, float scale,
-    const cf* __restrict__ twtab, const float* __restrict__ gscale, int S, int wg_scratch) {
+    const cf* __restrict__ twtab, const float* __restrict__ gscale, int S, int wg_scratch,
+    const float* __restrict__ mode_scale, const unsigned char* __restrict__ measured) {
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
   cf* twl = lds + G2::LDS_ELEMS;
@@ -493,20 +494,21 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
     const FftTwLds<N> tw{twl, j};
-    if (gscale) {
-      // far-plane gradient applied on the fly: F_s * g, g per (position, pixel)
-      const float* __restrict__ gs = gscale + (tile / S) * (long)N * N;
-      for (int r = 0; r < G2::RB; ++r)
-        fft2_pass1<N, true>(lds, twtab, tw, line, j, r,
-                            [&](int y, int e, auto) {
-                              return tk_ld_stream(src + y * N + e) * gs[y * N + e];
-                            },
-                            mid);
-    } else {
-      for (int r = 0; r < G2::RB; ++r)
-        fft2_pass1<N, true>(lds, twtab, tw, line, j, r,
-                            [&](int y, int e, auto) { return tk_ld_stream(src + y * N + e); }, mid);
-    }
+    // far-plane gradient applied on the fly: F_s * g, g per (position, pixel);
+    // MODE 2 (poisson): times the step of this (position, mode) on measured pixels
+    const float* __restrict__ gs = MODE ? gscale + (tile / S) * (long)N * N : nullptr;
+    const float ms = MODE == 2 ? mode_scale[tile] : 1.0f;
+    for (int r = 0; r < G2::RB; ++r)
+      fft2_pass1<N, true>(
+          lds, twtab, tw, line, j, r,
+          [&](int y, int e, auto) {
+            const cf f = tk_ld_stream(src + y * N + e);
+            if (MODE == 0) return f;
+            float g = gs[y * N + e];
+            if (MODE == 2 && (measured == nullptr || measured[y * N + e])) g *= ms;
+            return f * g;
+          },
+          mid);
     __syncthreads();
     for (int k1 = 0; k1 < 16; ++k1)
       fft2_pass2<N, true>(mid, k1, [&](int ky, int t, cf v) {
@@ -519,12 +521,23 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
 
 template <int N>
 static int launch_icrop_v2(const cf* far, cf* work, cf* chi, long ntile, int pw, float scale,
-                           hipStream_t stream, const float* gscale = nullptr, int S = 1) {
+                           hipStream_t stream, const float* gscale = nullptr, int S = 1,
+                           const float* mode_scale = nullptr,
+                           const unsigned char* measured = nullptr) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   static const int wg_scratch = getenv("TIKE_WG_SCRATCH") != nullptr;
-  hipLaunchKernelGGL((ifft2_crop_v2_kernel<N>), dim3(tk_grid(ntile, 4)), dim3(N), 0, stream, far,
-                     work, chi, ntile, pw, scale, tw, gscale, S, wg_scratch && work != chi);
+#define TK_ICROP(MODE)                                                                        \
+  hipLaunchKernelGGL((ifft2_crop_v2_kernel<N, MODE>), dim3(tk_grid(ntile, 4)), dim3(N), 0,    \
+                     stream, far, work, chi, ntile, pw, scale, tw, gscale, S,                 \
+                     wg_scratch && work != chi, mode_scale, measured)
+  if (gscale && mode_scale)
+    TK_ICROP(2);
+  else if (gscale)
+    TK_ICROP(1);
+  else
+    TK_ICROP(0);
+#undef TK_ICROP
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -769,6 +782,143 @@ extern "C" int tike_ifft2_crop_scaled(const void* farplane, const float* gscale,
     default:
       return TK_ERR_UNSUPPORTED;
   }
+}
+
+// Poisson variant (lstsq.py:454-489): the gradient factor of mode s at a
+// measured pixel is gscale[n][p] * mode_scale[n][s]; unmeasured pixels keep
+// gscale alone.  measured == NULL: every pixel is measured.
+extern "C" int tike_ifft2_crop_scaled_modes(const void* farplane, const float* gscale,
+                                            const float* mode_scale,
+                                            const unsigned char* measured, int S, void* work,
+                                            void* chi, long ntile, int det, int pw, float scale,
+                                            void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && S >= 1 && pw >= 1 && det >= pw);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(farplane && gscale && mode_scale && work && chi && work != farplane &&
+               ntile % S == 0);
+  TK_CHECK_ARG(!(chi == work && pw != det));
+  switch (det) {
+    case 128:
+      return launch_icrop_v2<128>((const cf*)farplane, (cf*)work, (cf*)chi, ntile, pw, scale,
+                                  stream, gscale, S, mode_scale, measured);
+    case 256:
+      return launch_icrop_v2<256>((const cf*)farplane, (cf*)work, (cf*)chi, ntile, pw, scale,
+                                  stream, gscale, S, mode_scale, measured);
+    case 512:
+      return launch_icrop_v2<512>((const cf*)farplane, (cf*)work, (cf*)chi, ntile, pw, scale,
+                                  stream, gscale, S, mode_scale, measured);
+    default:
+      return TK_ERR_UNSUPPORTED;
+  }
+}
+
+// ---------------------------------------------------- poisson step lengths
+// exitwave.py:122-234.  One workgroup per (position, mode) tile; three sweeps
+// over the measured pixels (denominator, then two fixed-point updates of the
+// step), each closed by a block reduction.  xi = 1 - d / (I + 1e-9).
+//   all modes:     denom = sum xi^2 a,   a = |F_s|^2
+//                  numer = sum xi a (1 + d (xi alpha - 1) / (a (xi alpha - 1)^2 + I - a))
+//   dominant mode: denom = sum xi^2 I
+//                  numer = sum xi (I - d / (1 - alpha xi))      (same for all modes)
+//   alpha <- (1 - w) alpha + w numer / denom
+template <bool DOMINANT>
+__global__ __launch_bounds__(256) void poisson_steps_kernel(
+    const cf* __restrict__ farplane, const float* __restrict__ intensity,
+    const float* __restrict__ data, const unsigned char* __restrict__ mask,
+    float* __restrict__ steps, int S, long npix, float start, float w) {
+  __shared__ float red[4];
+  const long tile = blockIdx.x;  // DOMINANT: position; else position * S + mode
+  const long n = DOMINANT ? tile : tile / S;
+  const cf* __restrict__ F = farplane + tile * npix;
+  const float* __restrict__ I = intensity + n * npix;
+  const float* __restrict__ d = data + n * npix;
+  float denom = 0.f;
+  for (long p = threadIdx.x; p < npix; p += blockDim.x) {
+    if (mask && !mask[p]) continue;
+    const float Ie = I[p];
+    const float xi = 1.0f - d[p] / (Ie + 1e-9f);
+    denom += xi * xi * (DOMINANT ? Ie : norm2(F[p]));
+  }
+  denom = tk_block_sum256(denom, red);
+  float alpha = start;
+  for (int it = 0; it < 2; ++it) {
+    float numer = 0.f;
+    for (long p = threadIdx.x; p < npix; p += blockDim.x) {
+      if (mask && !mask[p]) continue;
+      const float Ie = I[p], Im = d[p];
+      const float xi = 1.0f - Im / (Ie + 1e-9f);
+      if (DOMINANT) {
+        numer += xi * (Ie - Im / (1.0f - alpha * xi));
+      } else {
+        const float a = norm2(F[p]);
+        const float xam1 = xi * alpha - 1.0f;
+        numer += xi * a * (1.0f + Im * xam1 / (a * xam1 * xam1 + Ie - a));
+      }
+    }
+    numer = tk_block_sum256(numer, red);
+    alpha = alpha * (1.0f - w) + (numer / denom) * w;
+  }
+  if (threadIdx.x == 0) {
+    if (DOMINANT) {
+      for (int s = 0; s < S; ++s) steps[n * S + s] = alpha;
+    } else {
+      steps[tile] = alpha;
+    }
+  }
+}
+
+extern "C" int tike_poisson_steps(const void* farplane, const float* intensity,
+                                  const float* data, const unsigned char* measured,
+                                  float* steps, int nscan, int S, int det, float step_start,
+                                  float weight, int dominant_mode, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(intensity && data && steps && (dominant_mode || farplane));
+  const long npix = (long)det * det;
+  if (dominant_mode)
+    hipLaunchKernelGGL((poisson_steps_kernel<true>), dim3(nscan), dim3(256), 0, stream,
+                       (const cf*)farplane, intensity, data, measured, steps, S, npix,
+                       step_start, weight);
+  else
+    hipLaunchKernelGGL((poisson_steps_kernel<false>), dim3((unsigned)nscan * S), dim3(256), 0,
+                       stream, (const cf*)farplane, intensity, data, measured, steps, S, npix,
+                       step_start, weight);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// farplane[n][s][p] *= mode_scale[n][s] on measured pixels (the generic-size
+// poisson path applies it after tike_farplane_gradient).
+__global__ __launch_bounds__(256) void scale_modes_kernel(cf* __restrict__ farplane,
+                                                          const float* __restrict__ mode_scale,
+                                                          const unsigned char* __restrict__ mask,
+                                                          long npix) {
+  const long tile = blockIdx.y;
+  const float ms = mode_scale[tile];
+  cf* __restrict__ F = farplane + tile * npix;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
+       p += (long)gridDim.x * blockDim.x)
+    if (!mask || mask[p]) F[p] = F[p] * ms;
+}
+
+extern "C" int tike_scale_modes(void* farplane, const float* mode_scale,
+                                const unsigned char* measured, long ntile, int det,
+                                void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && det >= 1);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(farplane && mode_scale);
+  const long npix = (long)det * det;
+  const unsigned gx = (unsigned)((npix + 1023) / 1024);
+  hipLaunchKernelGGL(scale_modes_kernel, dim3(gx, (unsigned)ntile), dim3(256), 0, stream,
+                     (cf*)farplane, mode_scale, measured, npix);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
 }
 
 // ------------------------------------------------ stand-alone objective ops

@@ -112,9 +112,9 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
     if parameters.position_options is not None:
         raise NotImplementedError(
             "position correction is not accelerated yet (DESIGN.md: next)")
-    if exitwave_options.noise_model != "gaussian":
-        raise NotImplementedError(
-            "only the gaussian noise model is accelerated (DESIGN.md: next)")
+    if exitwave_options.noise_model not in _MODELS:
+        raise ValueError(
+            f"unknown noise model {exitwave_options.noise_model!r}")
     recover_probe = (probe_options is not None
                      and epoch >= probe_options.update_start)
     recover_psi = object_options is not None
@@ -261,12 +261,22 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     costs = ws.get("costs", (max(B, 1),), torch.float32, dev)
     pos_major = det in POSITION_MAJOR_SIZES
     chunk = chunk_positions(S, det, pos_major)
-    inten = gscale = None
-    if pos_major:
+    poisson = exitwave_options.noise_model == "poisson"
+    inten = gscale = steps = None
+    if pos_major or poisson:
         inten = ws.get("intensity", (min(chunk, max(B, 1)), det, det),
                        torch.float32, dev)
+    if pos_major:
         gscale = ws.get("gscale", (min(chunk, max(B, 1)), det, det),
                         torch.float32, dev)
+    if poisson:
+        # per-(position, mode) step lengths (exitwave.py:122-234)
+        steps = ws.get("steps", (min(chunk, max(B, 1)), S), torch.float32,
+                       dev)
+        dominant = int(
+            exitwave_options.step_length_usemodes == "dominant_mode")
+        step_start = float(exitwave_options.step_length_start)
+        step_weight = float(exitwave_options.step_length_weight)
     objproj = ws.get("objproj", (min(chunk, max(B, 1)), pw, pw),
                      torch.complex64, dev)
     unique = None
@@ -313,19 +323,45 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                                         A.ptr(costs[blo:blo + n]), n, det,
                                         model, unmeasured, nmeasured, st),
                 "gradient scale")
-            check(
-                lib.tike_ifft2_crop_scaled(A.ptr(far), A.ptr(gscale), S,
-                                           A.ptr(mid), A.ptr(chi), n * S, det,
-                                           pw, inv_scale, st),
-                "scaled ifft2 + crop")
+            if poisson:
+                check(
+                    lib.tike_poisson_steps(
+                        A.ptr(far), A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                        A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
+                        step_weight, dominant, st), "poisson step lengths")
+                check(
+                    lib.tike_ifft2_crop_scaled_modes(
+                        A.ptr(far), A.ptr(gscale), A.ptr(steps),
+                        A.ptr(mask_u8), S, A.ptr(mid), A.ptr(chi), n * S, det,
+                        pw, inv_scale, st), "scaled ifft2 + crop (poisson)")
+            else:
+                check(
+                    lib.tike_ifft2_crop_scaled(A.ptr(far), A.ptr(gscale), S,
+                                               A.ptr(mid), A.ptr(chi), n * S,
+                                               det, pw, inv_scale, st),
+                    "scaled ifft2 + crop")
         else:
             op.fwd_device(probe, scan[clo:chi_hi], psi, eigen_probe, w_c,
                           out=far[:n])
+            if poisson:
+                check(
+                    lib.tike_intensity(A.ptr(far), A.ptr(inten), n, S,
+                                       det * det, st), "intensity")
+                check(
+                    lib.tike_poisson_steps(
+                        A.ptr(far), A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                        A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
+                        step_weight, dominant, st), "poisson step lengths")
             check(
                 lib.tike_farplane_gradient(
                     A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), None,
                     A.ptr(costs[blo:blo + n]), n, S, det, model, 1, unmeasured,
                     nmeasured, st), "farplane gradient")
+            if poisson:
+                check(
+                    lib.tike_scale_modes(A.ptr(far), A.ptr(steps),
+                                         A.ptr(mask_u8), n * S, det, st),
+                    "poisson step scaling")
             check(
                 lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S,
                                     det, pw, inv_scale, st), "ifft2 + crop")
