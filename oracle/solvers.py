@@ -16,6 +16,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import operators as ops
+from . import position as opos
 
 # --------------------------------------------------------------------------
 # tike.linalg (src/tike/linalg.py:12-32)
@@ -255,7 +256,7 @@ def get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                             recover_psi=True, recover_probe=True,
                             step_length_start=0.5,
                             step_length_usemodes="all_modes",
-                            step_length_weight=0.5):
+                            step_length_weight=0.5, recover_positions=False):
     """lstsq.py:367-602 for one minibatch [lo, hi) (chunking of 64 elided)."""
     pw = probe.shape[-1]
     pad = (detector_shape - pw) // 2
@@ -312,15 +313,21 @@ def get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             nrepeat=S,
         )
     patches = probe_update = m_probe_update = None
-    if recover_probe:
+    if recover_probe or recover_positions:
         patches = ops.patch_fwd(psi[0], scan[lo:hi],
                                 patch_width=pw)[..., None, None, :, :]
+    if recover_probe:
         probe_update = np.conj(patches) * chi
         m_probe_update = np.sum(probe_update, axis=-5,
                                 keepdims=True) / num_batch
+    pos_num = pos_den = None
+    if recover_positions:
+        pos_num, pos_den = opos.position_update_terms(patches, unique_probe,
+                                                      chi, m=0)
     return dict(chi=chi, unique_probe=unique_probe, probe_update=probe_update,
                 object_upd_sum=object_upd_sum, m_probe_update=m_probe_update,
-                costs=costs, patches=patches, intensity=intensity)
+                costs=costs, patches=patches, intensity=intensity,
+                position_numerator=pos_num, position_denominator=pos_den)
 
 
 def precondition_nearplane_gradients(nearplane, scan, unique_probe, probe,
@@ -457,6 +464,9 @@ def lstsq_grad(state, data, batches, *, epoch, detector_shape,
     probe_combined_update = np.zeros_like(probe)
     batch_cost = np.empty(num_batch, dtype=np.float32)
     beta_object, beta_probe = [], []
+    position = state.get("position")
+    pos_num = np.zeros_like(scan) if position is not None else None
+    pos_den = np.zeros_like(scan) if position is not None else None
     for batch_index in order:
         lo = int(batches[batch_index][0])
         hi = lo + len(batches[batch_index])
@@ -468,7 +478,11 @@ def lstsq_grad(state, data, batches, *, epoch, detector_shape,
             noise_model=noise_model, step_length_start=step_length_start,
             step_length_usemodes=step_length_usemodes,
             step_length_weight=step_length_weight,
-            recover_psi=recover_psi, recover_probe=recover_probe)
+            recover_psi=recover_psi, recover_probe=recover_probe,
+            recover_positions=position is not None)
+        if position is not None:
+            pos_num[lo:hi] = g["position_numerator"]
+            pos_den[lo:hi] = g["position_denominator"]
         if recover_probe:
             eigen_probe, eigen_weights = update_nearplane(
                 g, probe, eigen_probe, eigen_weights, lo, hi,
@@ -496,6 +510,10 @@ def lstsq_grad(state, data, batches, *, epoch, detector_shape,
             probe = (probe + dprobe).astype(np.complex64)
             beta_probe.append(bbeta_probe)
         batch_cost[batch_index] = np.mean(g["costs"])
+    if position is not None:
+        # lstsq.py:209-220 (the minibatches above used the old positions)
+        state["scan"] = opos.update_position(scan, position, pos_num, pos_den,
+                                             epoch=epoch)
     state["costs"].append([float(batch_cost.mean())])
     if recover_psi and batch_method == "compact":
         precond = precondition_object_update(object_combined_update,
@@ -593,6 +611,11 @@ def iterate(state, data, batches, num_iter, *, detector_shape,
                 and len(state["costs"]) % rescale_period == 0):
             state["psi"], state["probe"] = remove_object_ambiguity(
                 state["psi"], state["probe"], state["psi_precond"])
+        if state.get("position") is not None:
+            # _apply_position_constraints (ptycho.py:521-524, 854-866)
+            state["scan"] = opos.affine_position_regularization(
+                state["scan"], state["position"],
+                kw.get("rng") or np.random.default_rng()).astype(np.float32)
     return state
 
 

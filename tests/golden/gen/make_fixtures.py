@@ -156,12 +156,13 @@ for tag, (nscan, pw, det, S, HW, shared) in {
 
 
 # ---- synthetic ptychography problem ---------------------------------------
-def make_problem(rng, N, pw, det, S, pitch=3.0, eigen=0):
+def make_problem(rng, N, pw, det, S, pitch=3.0, eigen=0, margin=0,
+                 position_error=0.0):
     side = int(np.ceil(np.sqrt(N)))
     ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
                               indexing="ij"), -1).reshape(-1, 2)[:N]
-    scan = (2 + pitch * ij + rng.random((N, 2))).astype(np.float32)
-    HW = int(np.ceil(pitch * (side - 1) + pw + 6))
+    scan = (2 + margin + pitch * ij + rng.random((N, 2))).astype(np.float32)
+    HW = int(np.ceil(pitch * (side - 1) + pw + 6 + 2 * margin))
     psi_true = ((0.75 + 0.25 * rng.random((1, HW, HW))) * np.exp(
         1j * np.pi * (rng.random((1, HW, HW)) - 0.5))).astype(np.complex64)
     w = tike.ptycho.probe.gaussian(pw, rin=0.6, rout=1.0)
@@ -169,8 +170,14 @@ def make_problem(rng, N, pw, det, S, pitch=3.0, eigen=0):
         w * np.exp(1j * np.pi * rng.random((pw, pw))) / (m + 1)
         for m in range(S)
     ])[None, None].astype(np.complex64)
-    data = tike.ptycho.simulate(detector_shape=det, probe=probe, scan=scan,
-                                psi=psi_true, **PHYS)
+    scan_true = scan
+    if position_error > 0:
+        # the data is simulated at perturbed positions; the reconstruction
+        # starts from the nominal ones
+        scan_true = (scan + position_error *
+                     (2 * rng.random((N, 2)) - 1)).astype(np.float32)
+    data = tike.ptycho.simulate(detector_shape=det, probe=probe,
+                                scan=scan_true, psi=psi_true, **PHYS)
     psi0 = np.full((1, HW, HW), 0.5 + 0j, dtype=np.complex64)
     probe0 = (probe * (1 + 0.1 * rc(rng, *probe.shape))).astype(np.complex64)
     eigen_probe = eigen_weights = None
@@ -180,7 +187,8 @@ def make_problem(rng, N, pw, det, S, pitch=3.0, eigen=0):
             int(rng.integers(1 << 30)))
         eigen_probe, eigen_weights = tike.ptycho.probe.init_varying_probe(
             scan, probe0, num_eigen_probes=eigen + 1, probes_with_modes=1)
-    return dict(scan=scan, psi_true=psi_true, probe_true=probe, data=data,
+    return dict(scan=scan, scan_true=scan_true, psi_true=psi_true,
+                probe_true=probe, data=data,
                 psi0=psi0, probe0=probe0, eigen_probe=eigen_probe,
                 eigen_weights=eigen_weights, det=det)
 
@@ -253,9 +261,16 @@ lstsq_parts("eigen", N=24, pw=16, det=24, S=3, eigen=2)
 # ---- full reconstructions (3 epochs, called twice like ReconstructTwice) ---
 def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
           adaptive=False, orth=False, rng=None, noise_model="gaussian",
-          usemodes="all_modes", mask_frac=0.0, scaling=1.0):
+          usemodes="all_modes", mask_frac=0.0, scaling=1.0, positions=None,
+          position_error=0.0, psi_true_start=False):
     rng = globals()["rng"] if rng is None else rng
-    p = make_problem(rng, N, pw, det, S, eigen=eigen)
+    p = make_problem(rng, N, pw, det, S, eigen=eigen,
+                     margin=8 if positions else 0,
+                     position_error=position_error)
+    if psi_true_start:
+        # position correction needs object structure to lock on to
+        p["psi0"] = (p["psi_true"] * (1 + 0.05 * rc(rng, *p["psi_true"].shape))
+                     ).astype(np.complex64)
     np.random.seed(7)
     tike.random.randomizer_np = np.random.default_rng(11)
     measured = np.ones((det, det), dtype=bool)
@@ -282,6 +297,8 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
             measured_pixels=measured, noise_model=noise_model,
             step_length_usemodes=usemodes,
             unmeasured_pixels_scaling=scaling),
+        position_options=None if positions is None else
+        tike.ptycho.PositionOptions(p["scan"].copy(), **positions),
     )
     # record the batches the reference's clustering chooses (host-side,
     # out of scope): one worker => order = concatenated batches
@@ -294,15 +311,32 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
         r1 = ctx.get_result()
     # second call continues from r1 (state round trip), as ReconstructTwice
     np.random.seed(7)
-    r2 = tike.ptycho.reconstruct(p["data"], r1, 1, False)
+    # == tike.ptycho.reconstruct(p["data"], r1, 1, False), with the second
+    # call's clustering recorded (it differs once positions have moved)
+    with tike.ptycho.Reconstruction(p["data"], r1, 1, False) as ctx:
+        order_2 = np.asarray(ctx.comm.order[0])
+        batches_2 = [np.asarray(b) for b in ctx.batches[0]]
+        ctx.iterate(r1.algorithm_options.num_iter)
+        r2 = ctx.get_result()
     extra = {}
     for k in ("eigen_probe", "eigen_weights"):
         if p[k] is not None:
             extra[k] = p[k]
             extra[k + "_1"] = getattr(r1, k)
+    if positions is not None:
+        extra.update(
+            scan_true=p["scan_true"], scan_1=r1.scan, scan_2=r2.scan,
+            transform_1=r1.position_options.transform.asbuffer(),
+            transform_2=r2.position_options.transform.asbuffer(),
+            momentum_1=r1.position_options._momentum
+            if positions.get("use_adaptive_moment") else np.zeros(0),
+            position_keys=np.array(sorted(positions)),
+            position_vals=np.array([float(positions[k])
+                                    for k in sorted(positions)]))
     save(f"lstsq_recon_{tag}.npz", data=p["data"], psi0=p["psi0"],
          probe0=p["probe0"], scan=p["scan"], det=det, order=order,
-         batch_sizes=np.array([len(b) for b in batches]),
+         batch_sizes=np.array([len(b) for b in batches]), order_2=order_2,
+         batch_sizes_2=np.array([len(b) for b in batches_2]),
          num_batch=num_batch, batch_method=batch_method, epochs=epochs,
          adaptive=adaptive, orth=orth, measured=measured,
          noise_model=noise_model, usemodes=usemodes, scaling=scaling,
@@ -363,3 +397,17 @@ recon("poisson_all", N=40, pw=24, det=32, S=3, eigen=0, num_batch=2,
 recon("poisson_dominant", N=40, pw=32, det=32, S=2, eigen=0, num_batch=2,
       batch_method="compact", epochs=3, orth=True, rng=rng_p,
       noise_model="poisson", usemodes="dominant_mode")
+
+
+# ---- position correction inside lstsq_grad (SURVEY 8f rank 1;
+# lstsq.py:545-579,764-806; position.py:716-810) ------------------------------
+rng_q = np.random.default_rng(8765)
+recon("positions_adam", N=36, pw=24, det=24, S=2, eigen=0, num_batch=2,
+      batch_method="compact", epochs=3, orth=True, rng=rng_q,
+      positions=dict(use_adaptive_moment=True,
+                     use_position_regularization=True,
+                     update_magnitude_limit=5), position_error=1.0,
+      psi_true_start=True)
+recon("positions_plain", N=30, pw=16, det=32, S=1, eigen=0, num_batch=3,
+      batch_method="wobbly_center", epochs=3, rng=rng_q,
+      positions=dict(), position_error=0.7, psi_true_start=True)

@@ -205,6 +205,12 @@ def _replay(g, second=False):
                  eigen_weights=g["eigen_weights"][order].copy()
                  if "eigen_weights" in g else None)
     data = g["data"][order]
+    if "position_keys" in g:
+        opts = dict(zip((str(k) for k in g["position_keys"]),
+                        (float(v) for v in g["position_vals"])))
+        state["position"] = dict(
+            initial_scan=g["scan"][order].copy(),
+            momentum=np.zeros((len(order), 4), dtype=np.float32), **opts)
     rng = np.random.default_rng(11)
     measured = g["measured"].astype(bool)
     kw = dict(detector_shape=det, batch_method=str(g["batch_method"]),
@@ -219,9 +225,27 @@ def _replay(g, second=False):
     state = sol.iterate(state, data, batches, epochs, **kw)
     first = {k: (None if v is None else np.array(v, copy=True))
              for k, v in state.items() if k in ("psi", "probe", "eigen_probe",
-                                                "eigen_weights")}
+                                                "eigen_weights", "scan")}
+    if "position" in state:
+        first["transform"] = tuple(state["position"]["transform"])
     first["costs"] = list(state["costs"])
     if second:
+        order2 = g["order_2"] if "order_2" in g else order
+        if not np.array_equal(order2, order):
+            # the second call clusters the (moved) positions again: bring the
+            # per-position state from the first arrangement into the second
+            perm = np.argsort(order)[order2]
+            for k in ("scan", "eigen_weights"):
+                if state.get(k) is not None:
+                    state[k] = state[k][perm]
+            if "position" in state:
+                for k in ("initial_scan", "momentum"):
+                    state["position"][k] = state["position"][k][perm]
+            data = g["data"][order2]
+            ends2 = np.cumsum(g["batch_sizes_2"])
+            batches = [np.arange(e - s, e)
+                       for s, e in zip(g["batch_sizes_2"], ends2)]
+            order = order2
         state = sol.rescale_probe(state, data, det, measured_pixels=measured)
         state = sol.iterate(state, data, batches, epochs, **kw)
     return first, state, order
@@ -239,13 +263,35 @@ def test_lstsq_reconstruction_vs_reference(golden, tag):
     assert_close(first["probe"], g["probe_1"], normwise=SOLVER_NORMWISE,
                  maxabs=1e-2, what="probe after call 1")
     if "eigen_weights" in g:
-        inv = np.argsort(order)
+        inv = np.argsort(g["order"])
         assert_close(first["eigen_weights"][inv], g["eigen_weights_1"],
                      normwise=5e-3, maxabs=5e-2, what="eigen_weights")
     np.testing.assert_allclose(np.array(state["costs"]), g["costs_2"],
                                rtol=5e-3)
     assert_close(state["psi"], g["psi_2"], normwise=5e-3, maxabs=5e-2,
                  what="psi after call 2")
+
+
+@pytest.mark.parametrize("tag", ["positions_adam", "positions_plain"])
+def test_position_correction_vs_reference(golden, tag):
+    """lstsq_grad with position correction (gaussian-derivative shift
+    estimate, trimmed mean, ADAM, affine regularisation with RANSAC draws from
+    the shared generator) replayed against the reference's own run."""
+    g = golden(f"lstsq_recon_{tag}.npz")
+    first, state, order = _replay(g, second=True)
+    inv = np.argsort(g["order"])
+    np.testing.assert_allclose(np.array(first["costs"]), g["costs_1"],
+                               rtol=2e-3)
+    # positions in pixels: absolute tolerance
+    np.testing.assert_allclose(first["scan"][inv], g["scan_1"], atol=2e-3)
+    inv = np.argsort(order)
+    np.testing.assert_allclose(first["transform"], g["transform_1"],
+                               rtol=1e-3, atol=1e-3)
+    assert_close(first["psi"], g["psi_1"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="psi after call 1")
+    np.testing.assert_allclose(state["scan"][inv], g["scan_2"], atol=2e-2)
+    np.testing.assert_allclose(np.array(state["costs"]), g["costs_2"],
+                               rtol=1e-2)
 
 
 def test_cgrad_vs_reference_composition(golden):
