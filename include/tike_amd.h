@@ -247,6 +247,20 @@ int tike_eigen_pixel_update(const void* patches, const void* chi0, const void* m
                             int eigen_modes, int c, const float* pm, void* update, int nscan,
                             int pw, void* stream);
 
+/* ---- position correction (lstsq.py:545-579): per position, over the central
+ * half of the probe window and for mode 0,
+ *   numerator[n]   = ( sum Re(conj(gx P) chi), sum Re(conj(gy P) chi) )
+ *   denominator[n] = ( sum |gx P|^2, sum |gy P|^2 )
+ * with gx / gy the first-order Gaussian derivatives of the object patch along
+ * rows / columns (position.py:779-810; `taps` = 2*radius+1 HOST floats t[d],
+ * g[i] = sum_d t[d] x[i+d], edge mode 'nearest') and P the probe of that
+ * position (shared, or varying as in tike_ptycho_fwd).  patches (nscan,pw,pw),
+ * chi (nscan,chi_modes,pw,pw) c64; numerator, denominator (nscan,2) f32. */
+int tike_position_sums(const void* patches, const void* chi, int chi_modes, const void* probe,
+                       const void* eigen_probe, const float* eigen_weights, int num_eigen,
+                       int eigen_modes, const float* taps, int radius, float* numerator,
+                       float* denominator, int nscan, int S, int pw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,14 +47,20 @@ def _allreduce(rank, world):
     comm.Allreduce(a, b)
     s = comm.Allreduce_scalars([rank + 1, torch.tensor(2.0 * rank)], "cpu")
     single = comm.Allreduce(torch.ones(2, dtype=torch.complex64) * (rank + 1))
+    mx = comm.Allreduce_max(torch.tensor(3.0 - rank))
+    rows = comm.Allgather_rows(
+        torch.full((2 + rank, 2), float(rank), dtype=torch.float32))
     return (a.numpy(), b.numpy(), s.numpy(), single.numpy(), comm.size,
-            comm.rank)
+            comm.rank, float(mx), rows.numpy())
 
 
 def test_comm_allreduce_gloo():
     out = _run(_allreduce)
-    for r, (a, b, s, single, size, rank) in enumerate(out):
+    for r, (a, b, s, single, size, rank, mx, rows) in enumerate(out):
         assert size == 2 and rank == r
+        assert mx == 3.0
+        # ragged gather: 2 rows of rank 0 then 3 rows of rank 1
+        np.testing.assert_array_equal(rows[:, 0], [0, 0, 1, 1, 1])
         np.testing.assert_allclose(a, np.full((3, 4), 3 * (1 + 2j)))
         np.testing.assert_allclose(b, np.arange(5) * 3.0)
         np.testing.assert_allclose(s, [3.0, 2.0])

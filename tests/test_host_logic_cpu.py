@@ -169,3 +169,69 @@ def test_unsupported_features_fail_loudly():
                               probe=params.probe, psi=params.psi,
                               scan=params.scan,
                               algorithm_options=tp.LstsqOptions()))
+
+
+# ------------------------------------------------------- position correction
+def test_gaussian_derivative_taps_match_scipy():
+    """The taps handed to tike_position_sums reproduce the reference's
+    gaussian_gradient (position.py:779-810 = scipy gaussian_filter1d)."""
+    import scipy.ndimage
+    from tike_amd.ptycho.position import gaussian_derivative_taps
+    from oracle import position as opos
+    taps, r = gaussian_derivative_taps(0.333)
+    assert r == 2 and taps.shape == (5,)
+    rng = np.random.default_rng(0)
+    x = (rng.random((2, 9, 11)) + 1j * rng.random((2, 9, 11))).astype(
+        np.complex64)
+    ref = scipy.ndimage.gaussian_filter1d(-x, sigma=0.333, order=1, axis=-1,
+                                          mode="nearest", truncate=6.0)
+    pad = np.pad(x, ((0, 0), (0, 0), (r, r)), mode="edge")
+    mine = sum(taps[d + r] * pad[..., r + d:r + d + x.shape[-1]]
+               for d in range(-r, r + 1))
+    np.testing.assert_allclose(mine, ref, atol=1e-6)
+    gx, gy = opos.gaussian_gradient(x)
+    np.testing.assert_allclose(gy, ref, atol=1e-6)
+
+
+def test_affine_transform_roundtrip_and_fit():
+    """AffineTransform decomposition / composition and the least-squares and
+    RANSAC estimators (position.py:137-327) against the oracle."""
+    import tike_amd.random as trandom
+    from tike_amd.ptycho import position as pos
+    from oracle import position as opos
+    t = pos.AffineTransform(scale0=1.02, scale1=0.97, shear1=0.03, angle=0.05,
+                            t0=1.5, t1=-2.0)
+    back = pos.AffineTransform.fromarray(t.asarray3())
+    np.testing.assert_allclose(back.astuple(), t.astuple(), atol=1e-5)
+    np.testing.assert_allclose(t.asarray(), opos.transform_matrix(t.astuple()),
+                               atol=1e-7)
+    rng = np.random.default_rng(3)
+    p0 = rng.random((50, 2)) * 100
+    p1 = t(p0) + 0.01 * rng.standard_normal((50, 2))
+    fit, err = pos.estimate_global_transformation(p0, p1)
+    np.testing.assert_allclose(fit.astuple(), t.astuple(), atol=2e-2)
+    ofit, oerr = opos.estimate_global_transformation(p0, p1)
+    np.testing.assert_allclose(fit.astuple(), ofit, atol=1e-6)
+    trandom.randomizer_np = np.random.default_rng(5)
+    rfit, _ = pos.estimate_global_transformation_ransac(p0, p1)
+    ofit, _ = opos.estimate_global_transformation_ransac(
+        p0, p1, opos.IDENTITY, np.random.default_rng(5))
+    np.testing.assert_allclose(rfit.astuple(), ofit, atol=1e-6)
+
+
+def test_position_options_split_join():
+    """PositionOptions.split / join / insert keep per-position state aligned
+    (reference tests/ptycho/test_position.py:24-60)."""
+    from tike_amd.ptycho.position import PositionOptions
+    rng = np.random.default_rng(0)
+    scan = rng.random((20, 2)).astype(np.float32) * 30
+    opts = PositionOptions(scan, use_adaptive_moment=True)
+    opts._momentum[:] = rng.random((20, 4))
+    order = rng.permutation(20)
+    parts = [order[:7], order[7:]]
+    split = [opts.split(b) for b in parts]
+    joined = PositionOptions.join(split, reorder=np.argsort(order))
+    np.testing.assert_array_equal(joined.initial_scan, opts.initial_scan)
+    np.testing.assert_array_equal(joined._momentum, opts._momentum)
+    np.testing.assert_array_equal(joined.confidence, opts.confidence)
+    assert joined.v.shape == (20, 2) and joined.m.shape == (20, 2)

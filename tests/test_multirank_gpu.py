@@ -44,7 +44,7 @@ def _problem(eigen):
     return data, scan, probe, np.full_like(psi_true, 0.5), ep, ew
 
 
-def _reconstruct(eigen, method):
+def _reconstruct(eigen, method, positions=False):
     import tike_amd.ptycho as tp
     import tike_amd.random
     data, scan, probe, psi0, ep, ew = _problem(eigen)
@@ -56,11 +56,15 @@ def _reconstruct(eigen, method):
         algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=3,
                                           batch_method=method),
         probe_options=tp.ProbeOptions(force_orthogonality=True),
-        object_options=tp.ObjectOptions())
+        object_options=tp.ObjectOptions(),
+        position_options=tp.PositionOptions(
+            scan.copy(), use_adaptive_moment=True,
+            use_position_regularization=True, update_magnitude_limit=2)
+        if positions else None)
     return tp.reconstruct(data, params)
 
 
-def _worker(rank, world, port, eigen, method, ret):
+def _worker(rank, world, port, eigen, method, ret, positions=False):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -68,24 +72,25 @@ def _worker(rank, world, port, eigen, method, ret):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        r = _reconstruct(eigen, method)
+        r = _reconstruct(eigen, method, positions)
         ret[rank] = (r.psi, r.probe, r.eigen_weights, r.scan,
                      np.array(r.algorithm_options.costs))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("eigen,method", [(False, "compact"),
-                                          (True, "wobbly_center")])
-def test_two_ranks_match_one_rank(eigen, method):
+@pytest.mark.parametrize("eigen,method,positions", [
+    (False, "compact", False), (True, "wobbly_center", False),
+    (False, "compact", True)])
+def test_two_ranks_match_one_rank(eigen, method, positions):
     import torch.multiprocessing as mp
-    single = _reconstruct(eigen, method)
+    single = _reconstruct(eigen, method, positions)
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = _free_port()
     procs = [ctx.Process(target=_worker,
-                         args=(r, 2, port, eigen, method, ret))
+                         args=(r, 2, port, eigen, method, ret, positions))
              for r in range(2)]
     for p in procs:
         p.start()
@@ -100,7 +105,12 @@ def test_two_ranks_match_one_rank(eigen, method):
                      what=f"psi rank {rank}")
         assert_close(probe, single.probe, normwise=1e-3, maxabs=1e-2,
                      what=f"probe rank {rank}")
-        np.testing.assert_array_equal(scan, single.scan)
+        if positions:
+            # corrected positions (pixels); moved by up to ~1 px per epoch
+            assert np.abs(single.scan - _problem(eigen)[1]).max() > 0.05
+            np.testing.assert_allclose(scan, single.scan, atol=5e-3)
+        else:
+            np.testing.assert_allclose(scan, single.scan, atol=1e-5)
         if eigen:
             assert_close(ew, single.eigen_weights, normwise=5e-3, maxabs=5e-2,
                          what=f"eigen weights rank {rank}")
@@ -116,7 +126,7 @@ def _rccl_worker(port, ret):
     dist.init_process_group("nccl", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
-        r = _reconstruct(True, "wobbly_center")
+        r = _reconstruct(True, "wobbly_center", positions=True)
         ret[0] = (r.psi, r.probe, r.eigen_weights, r.scan,
                   np.array(r.algorithm_options.costs))
     finally:
@@ -125,10 +135,11 @@ def _rccl_worker(port, ret):
 
 def test_rccl_collectives_single_rank():
     """The production backend: every collective of the solver (packed f32
-    all-reduce, f64 scalar all-reduces, position gather) issued through RCCL
-    ("nccl") on a one-rank group must leave the result unchanged."""
+    all-reduce, f64 scalar all-reduces, max all-reduce, row all-gather,
+    position gather) issued through RCCL ("nccl") on a one-rank group must
+    leave the result unchanged."""
     import torch.multiprocessing as mp
-    single = _reconstruct(True, "wobbly_center")
+    single = _reconstruct(True, "wobbly_center", positions=True)
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret))
@@ -140,4 +151,4 @@ def test_rccl_collectives_single_rank():
                                rtol=1e-5)
     assert_close(psi, single.psi, normwise=1e-5, maxabs=1e-4, what="psi")
     assert_close(probe, single.probe, normwise=1e-5, maxabs=1e-4, what="probe")
-    np.testing.assert_array_equal(scan, single.scan)
+    np.testing.assert_allclose(scan, single.scan, atol=1e-5)

@@ -55,6 +55,8 @@ _PROTOTYPES = {
                                      _p],
     "tike_poisson_steps": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
     "tike_scale_modes": [_p, _p, _p, _l, _i, _p],
+    "tike_position_sums": [_p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p, _i,
+                           _i, _i, _p],
     "tike_farplane_gradient": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _l,
                                _p],
     "tike_intensity": [_p, _p, _l, _i, _l, _p],

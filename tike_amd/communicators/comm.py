@@ -79,6 +79,29 @@ class Comm:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return float(t.item())
 
+    def Allreduce_max(self, t):
+        """Maximum of a 0-d device tensor over ranks (stays on the device)."""
+        if self.collective:
+            t = t.clone()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def Allgather_rows(self, t):
+        """Concatenation along axis 0 of a per-rank tensor whose leading
+        length may differ between ranks (once per epoch: small arrays)."""
+        if not self.collective:
+            return t
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        sizes = [torch.zeros_like(n) for _ in range(self.size)]
+        dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        pad = torch.zeros((max(sizes), *t.shape[1:]), dtype=t.dtype,
+                          device=t.device)
+        pad[:t.shape[0]] = t
+        parts = [torch.empty_like(pad) for _ in range(self.size)]
+        dist.all_gather(parts, pad, group=self.group)
+        return torch.cat([p[:k] for p, k in zip(parts, sizes)], dim=0)
+
     def barrier(self):
         if self.collective:
             dist.barrier(group=self.group)

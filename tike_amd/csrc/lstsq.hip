@@ -562,3 +562,81 @@ extern "C" int tike_varying_probe(const void* probe, const void* eigen_probe,
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
+
+// ------------------------------------------------------- position correction
+// lstsq.py:545-579.  Per position n (mode m = 0, central window [crop, pw-crop)):
+//   gx = gaussian derivative of the object patch along rows, gy along columns
+//        (position.py:779-810: scipy gaussian_filter1d(-x, order=1, mode
+//        'nearest'); the taps come precomputed from the host),
+//   num[n] = ( sum Re(conj(gx P) chi), sum Re(conj(gy P) chi) ),
+//   den[n] = ( sum |gx P|^2,           sum |gy P|^2 ),    P = probe_n mode 0.
+// One workgroup per position.
+struct TkTaps {
+  float t[9];
+  int r;
+};
+
+__global__ __launch_bounds__(256) void position_sums_kernel(
+    const cf* __restrict__ patches, const cf* __restrict__ chi, int chi_modes,
+    const TkProbe probe, const TkTaps taps, float* __restrict__ num, float* __restrict__ den,
+    int pw) {
+  __shared__ float red[4];
+  const long n = blockIdx.x;
+  const long P = (long)pw * pw;
+  const cf* __restrict__ O = patches + n * P;
+  const cf* __restrict__ X = chi + n * chi_modes * P;
+  const int crop = pw / 4;
+  const int w = pw - 2 * crop;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < w * w; i += blockDim.x) {
+    const int y = crop + i / w, x = crop + i % w;
+    cf gx = mk(0.f, 0.f), gy = mk(0.f, 0.f);
+    for (int d = -taps.r; d <= taps.r; ++d) {
+      const float t = taps.t[d + taps.r];
+      int yy = y + d, xx = x + d;
+      yy = yy < 0 ? 0 : (yy >= pw ? pw - 1 : yy);
+      xx = xx < 0 ? 0 : (xx >= pw ? pw - 1 : xx);
+      const cf oy = O[yy * pw + x], ox = O[y * pw + xx];
+      gx.x += t * oy.x;
+      gx.y += t * oy.y;
+      gy.x += t * ox.x;
+      gy.y += t * ox.y;
+    }
+    const long pix = (long)y * pw + x;
+    const cf Pm = probe.at(n, 0, pix);
+    const cf c = X[pix];
+    const cf px = gx * Pm, py = gy * Pm;
+    a[0] += px.x * c.x + px.y * c.y;
+    a[1] += py.x * c.x + py.y * c.y;
+    a[2] += norm2(px);
+    a[3] += norm2(py);
+  }
+  for (int k = 0; k < 4; ++k) a[k] = tk_block_sum256(a[k], red);
+  if (threadIdx.x == 0) {
+    num[2 * n] = a[0];
+    num[2 * n + 1] = a[1];
+    den[2 * n] = a[2];
+    den[2 * n + 1] = a[3];
+  }
+}
+
+extern "C" int tike_position_sums(const void* patches, const void* chi, int chi_modes,
+                                  const void* probe, const void* eigen_probe,
+                                  const float* eigen_weights, int num_eigen, int eigen_modes,
+                                  const float* taps_host, int radius, float* numerator,
+                                  float* denominator, int nscan, int S, int pw, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 4 && chi_modes >= 1 && radius >= 0 && radius <= 4);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(patches && chi && probe && taps_host && numerator && denominator);
+  TkTaps taps;
+  taps.r = radius;
+  for (int k = 0; k < 9; ++k) taps.t[k] = k <= 2 * radius ? taps_host[k] : 0.f;
+  const TkProbe pr =
+      tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes, S, pw);
+  hipLaunchKernelGGL(position_sums_kernel, dim3(nscan), dim3(256), 0, (hipStream_t)stream,
+                     (const cf*)patches, (const cf*)chi, chi_modes, pr, taps, numerator,
+                     denominator, pw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}

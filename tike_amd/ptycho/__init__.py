@@ -2,7 +2,8 @@
 from .exitwave import ExitWaveOptions
 from .object import (ObjectOptions, get_padded_object, positivity_constraint,
                      remove_object_ambiguity, smoothness_constraint)
-from .position import PositionOptions, check_allowed_positions
+from .position import (AffineTransform, PositionOptions,
+                       affine_position_regularization, check_allowed_positions)
 from .probe import (ProbeOptions, add_modes_random_phase, adjust_probe_power,
                     constrain_variable_probe, gaussian, get_varying_probe,
                     init_varying_probe, orthogonalize_eig)
@@ -13,7 +14,8 @@ from . import probe, object, position, exitwave, solvers  # noqa: F401,A004
 
 __all__ = [
     "CgradOptions", "ExitWaveOptions", "LstsqOptions", "ObjectOptions",
-    "PositionOptions", "ProbeOptions", "PtychoParameters", "Reconstruction",
+    "AffineTransform", "PositionOptions", "affine_position_regularization",
+    "ProbeOptions", "PtychoParameters", "Reconstruction",
     "RpieOptions", "cgrad", "check_allowed_positions", "lstsq_grad",
     "reconstruct", "simulate", "update_preconditioners",
 ]

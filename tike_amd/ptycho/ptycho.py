@@ -30,7 +30,8 @@ from ..operators import Ptycho
 from . import solvers
 from .object import (positivity_constraint, remove_object_ambiguity,
                      smoothness_constraint)
-from .position import check_allowed_positions
+from .position import (affine_position_regularization,
+                       check_allowed_positions)
 from .probe import (constrain_variable_probe, finite_probe_support,
                     get_varying_probe, orthogonalize_eig, power as probe_power,
                     rescale_probe_using_fixed_intensity_photons)
@@ -251,11 +252,29 @@ class Reconstruction():
                 self.parameters, self.data, self.batches, self.comm,
                 op=self.operator, epoch=total_epochs)
             self.parameters = _apply_object_constraints(self.parameters)
+            self._apply_position_constraints()
             o.times.append(time.perf_counter() - start)
             start = time.perf_counter()
             logger.info("%10s cost is %+1.3e",
                         self.parameters.exitwave_options.noise_model,
                         np.mean(o.costs[-1]))
+
+    def _apply_position_constraints(self):
+        """Affine regularisation of the updated positions (ptycho.py:521-524,
+        854-866).  The fit sees ALL positions of the job (every rank runs the
+        same host fit with its synchronised generator), so the result does
+        not depend on the number of ranks."""
+        p = self.parameters
+        if p.position_options is None:
+            return
+        pos0 = pos1 = None
+        if self.comm.collective and not self._presharded:
+            pos0 = self._gather_positions(
+                p.position_options.initial_scan)[self.order]
+            pos1 = self._gather_positions(p.scan)[self.order]
+        p.scan, p.position_options = affine_position_regularization(
+            updated=p.scan, position_options=p.position_options,
+            positions0=pos0, positions1=pos1)
 
     # ------------------------------------------------------------- results
     def _gather_positions(self, local):
@@ -283,6 +302,11 @@ class Reconstruction():
         p = self.parameters.copy_to_host()
         p.scan = self._gather_positions(self.parameters.scan)
         p.eigen_weights = self._gather_positions(self.parameters.eigen_weights)
+        po = self.parameters.position_options
+        if po is not None:
+            g = self._gather_positions
+            p.position_options = po._like(g(po.initial_scan),
+                                          g(po.confidence), g(po._momentum))
         return p
 
     def get_convergence(self):

@@ -28,6 +28,7 @@ from ... import opt
 from ... import random as trandom
 from ..._lib import check, lib
 from ...operators.propagation import fft_scales
+from ..position import gaussian_derivative_taps
 
 logger = logging.getLogger(__name__)
 
@@ -109,9 +110,7 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
     exitwave_options = parameters.exitwave_options
     object_options = parameters.object_options
     probe_options = parameters.probe_options
-    if parameters.position_options is not None:
-        raise NotImplementedError(
-            "position correction is not accelerated yet (DESIGN.md: next)")
+    position_options = parameters.position_options
     if exitwave_options.noise_model not in _MODELS:
         raise ValueError(
             f"unknown noise model {exitwave_options.noise_model!r}")
@@ -127,6 +126,10 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
     probe_combined_update = torch.zeros_like(probe)
     batch_cost = torch.zeros(num_batch, dtype=torch.float32, device=psi.device)
     beta_object, beta_probe = [], []
+    position_terms = None
+    if position_options is not None:
+        # numerator / denominator of the shift estimate, all local positions
+        position_terms = (torch.zeros_like(scan), torch.zeros_like(scan))
 
     for batch_index in order:
         lo = int(batches[batch_index][0]) if len(batches[batch_index]) else 0
@@ -134,7 +137,8 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
         g = _get_nearplane_gradients(
             data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi, comm,
             num_batch=num_batch, exitwave_options=exitwave_options, op=op,
-            recover_psi=recover_psi, recover_probe=recover_probe)
+            recover_psi=recover_psi, recover_probe=recover_probe,
+            position_terms=position_terms)
 
         object_update_precond = None
         if recover_psi:
@@ -172,6 +176,11 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
             beta_probe.append(bbeta_probe)
 
         batch_cost[batch_index] = g["cost"]
+
+    if position_options is not None:
+        # the minibatches above all used the old positions (lstsq.py:209-220)
+        scan = _update_position(scan, position_options, *position_terms, comm,
+                                epoch=epoch)
 
     # one device->host scalar per epoch, as in the reference (lstsq.py:222)
     algorithm_options.costs.append([float(batch_cost.mean().item())])
@@ -231,7 +240,8 @@ def _eigen_args(eigen_probe, weights):
 
 def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                              eigen_weights, lo, hi, comm, *, num_batch,
-                             exitwave_options, op, recover_psi, recover_probe):
+                             exitwave_options, op, recover_psi, recover_probe,
+                             position_terms=None):
     """Object / probe gradients of one minibatch (lstsq.py:367-602)."""
     dev = psi.device
     B = hi - lo
@@ -256,8 +266,10 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     m_probe_update = torch.zeros_like(probe) if recover_probe else None
     chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
     patches = None
-    if recover_probe and eigen_weights is not None:
+    if (recover_probe and eigen_weights is not None) or position_terms:
         patches = ws.get("patches", (max(B, 1), pw, pw), torch.complex64, dev)
+    if position_terms:
+        taps, taps_r = gaussian_derivative_taps(sigma=0.333)
     costs = ws.get("costs", (max(B, 1),), torch.float32, dev)
     pos_major = det in POSITION_MAJOR_SIZES
     chunk = chunk_positions(S, det, pos_major)
@@ -373,6 +385,14 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                 None if patches is None else A.ptr(patches[blo:blo + n]),
                 A.ptr(m_probe_update), A.ptr(objproj) if recover_psi else None,
                 n, S, pw, H, W, st), "probe gradient + object projection")
+        if position_terms:
+            check(
+                lib.tike_position_sums(
+                    A.ptr(patches[blo:blo + n]), A.ptr(chi), S, A.ptr(probe),
+                    A.ptr(ep), A.ptr(w_c), C, Sm, taps.ctypes.data, taps_r,
+                    A.ptr(position_terms[0][clo:chi_hi]),
+                    A.ptr(position_terms[1][clo:chi_hi]), n, S, pw, st),
+                "position shift sums")
         if recover_psi:
             check(
                 lib.tike_scatter_patches(A.ptr(objproj),
@@ -526,6 +546,32 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
             coefs[:B, c - 1] = torch.complex(s[:, 3], s[:, 4]) / torch.sum(
                 E * E.conj())
     return eigen_probe, eigen_weights
+
+
+def _update_position(scan, position_options, numerator, denominator, comm,
+                     *, alpha=0.05, epoch=0):
+    """Shift every position against its least-squares estimate
+    (lstsq.py:764-806).  The damping maximum and the trimmed mean run over
+    the positions of ALL ranks."""
+    if epoch < position_options.update_start:
+        return scan
+    dmax = comm.Allreduce_max(denominator.max())
+    step = numerator / ((1 - alpha) * denominator +
+                        alpha * torch.clamp(dmax, min=1e-6))
+    limit = position_options.update_magnitude_limit
+    if limit > 0:
+        step = torch.clamp(step, -limit, limit)
+    # remove outliers and subtract the mean (scipy.stats.trim_mean, 5 %)
+    every = comm.Allgather_rows(step)
+    n = every.shape[0]
+    cut = int(0.05 * n)
+    trimmed = torch.sort(every, dim=0).values[cut:n - cut].mean(dim=0)
+    step = step - trimmed
+    if position_options.use_adaptive_moment:
+        step, position_options.v, position_options.m = opt.adam(
+            step, position_options.v, position_options.m,
+            vdecay=position_options.vdecay, mdecay=position_options.mdecay)
+    return scan - step
 
 
 def _momentum_checked(g, v, m, mdecay, errors, beta=1.0, memory_length=3):

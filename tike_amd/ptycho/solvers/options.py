@@ -115,7 +115,7 @@ class PtychoParameters():
             exitwave_options=fo(self.exitwave_options),
             probe_options=fo(self.probe_options),
             object_options=fo(self.object_options),
-            position_options=self.position_options,
+            position_options=fo(self.position_options),
         )
 
     def copy_to_device(self) -> "PtychoParameters":
@@ -144,5 +144,6 @@ class PtychoParameters():
             exitwave_options=x.exitwave_options,
             probe_options=x.probe_options,
             object_options=x.object_options,
-            position_options=x.position_options,
+            position_options=x.position_options.split(indices)
+            if x.position_options is not None else None,
         )
