@@ -232,20 +232,22 @@ int tike_varying_probe(const void* probe, const void* eigen_probe, const float* 
  *   R_n = conj(patches[n]) * chi0[n] - mpu0 - sum_{c'<c} coefs[n][c'] * eigen[c'][0]
  * is recomputed on the fly by both kernels.  patches, chi0 (nscan,pw,pw) c64;
  * mpu0 (pw,pw) c64 = m_probe_update mode 0; eigen_probe (C,Sm,pw,pw) c64;
- * coefs (nscan,C) c64 (unused entries >= c ignored; may be NULL when c == 0). */
+ * coefs (nscan,C) c64 (unused entries >= c ignored; may be NULL when c == 0).
+ * chi0 of position n starts at chi0 + n*chi_modes*pw*pw (chi_modes = 1 for a
+ * packed mode-0 array, S to read mode 0 out of the full chi). */
 
 /* sums (nscan,5) f32 = { sum Re(conj(R) E_c), sum Re(chi0 conj(O E_c)),
  * sum |O E_c|^2, Re sum R conj(E_c), Im sum R conj(E_c) } with E_c = eigen[c][0]. */
 int tike_eigen_position_sums(const void* patches, const void* chi0, const void* mpu0,
                              const void* eigen_probe, const void* coefs, int num_eigen,
                              int eigen_modes, int c, float* sums, int nscan, int pw,
-                             void* stream);
+                             int chi_modes, void* stream);
 
 /* update (pw,pw) c64 += sum_n R_n * pm[n]   (pm (nscan) f32). */
 int tike_eigen_pixel_update(const void* patches, const void* chi0, const void* mpu0,
                             const void* eigen_probe, const void* coefs, int num_eigen,
                             int eigen_modes, int c, const float* pm, void* update, int nscan,
-                            int pw, void* stream);
+                            int pw, int chi_modes, void* stream);
 
 /* ---- position correction (lstsq.py:545-579): per position, over the central
  * half of the probe window and for mode 0,

@@ -67,9 +67,9 @@ _PROTOTYPES = {
     "tike_varying_probe": [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p],
     "tike_scatter_patches": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_eigen_position_sums": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _i, _i,
-                                 _p],
+                                 _i, _p],
     "tike_eigen_pixel_update": [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _i, _i,
-                                _p],
+                                _i, _p],
     "tike_probe_grad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "tike_probe_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_psi_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],

@@ -205,6 +205,16 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
   cf acc[SM];
 #pragma unroll
   for (int s = 0; s < SM; ++s) acc[s] = mk(0.f, 0.f);
+  // The shared probe value of this pixel is the same for every position of
+  // the chunk: keep it in registers instead of re-reading it per position
+  // (only the modes that own eigen probes vary beyond a scalar weight).
+  const bool hoist = WITH_CHI && objproj != nullptr && probe.pos_stride == 0;
+  cf pr[SM];
+  if (hoist) {
+#pragma unroll
+    for (int s = 0; s < SM; ++s)
+      if (SC > 0 || s < S) pr[s] = probe.probe[s * P + p];
+  }
   for (int b = b0; b < b1; ++b) {
     const TkCorner c = tk_corner(scan, b);
     const int y = c.sy + py, x = c.sx + px;
@@ -227,7 +237,17 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
       for (int s = 0; s < SM; ++s)
         if (SC > 0 || s < S) {
           if (out) acc[s] = acc[s] + oc * xs[s];
-          if (objproj) proj = proj + conjf(probe.at(b, s, p)) * xs[s];
+          if (objproj) {
+            cf ps;
+            if (hoist && !(probe.weights != nullptr && probe.eigen != nullptr && s < probe.Sm)) {
+              const float w0 =
+                  probe.weights ? probe.weights[b * (long)(probe.C + 1) * probe.S + s] : 1.0f;
+              ps = pr[s] * w0;
+            } else {
+              ps = probe.at(b, s, p);
+            }
+            proj = proj + conjf(ps) * xs[s];
+          }
         }
       if (objproj) objproj[b * P + p] = proj;
     } else {
@@ -422,8 +442,9 @@ struct TkResidual {
   const cf* coefs;
   int C, Sm, c;
   long P;
+  long XS;  // elements between chi0 of consecutive positions (chi_modes * P)
   __device__ __forceinline__ cf at(long n, long p) const {
-    cf r = conjf(patches[n * P + p]) * chi0[n * P + p] - mpu0[p];
+    cf r = conjf(patches[n * P + p]) * chi0[n * XS + p] - mpu0[p];
     for (int k = 0; k < c; ++k) r = r - coefs[n * C + k] * eigen[((long)k * Sm) * P + p];
     return r;
   }
@@ -442,7 +463,7 @@ __global__ __launch_bounds__(256) void eigen_position_sums_kernel(const TkResidu
       const cf e = E[p];
       const cf r = R.at(n, p);
       const cf phi = R.patches[n * R.P + p] * e;
-      const cf x = R.chi0[n * R.P + p];
+      const cf x = R.chi0[n * R.XS + p];
       a[0] += r.x * e.x + r.y * e.y;
       a[1] += x.x * phi.x + x.y * phi.y;
       a[2] += norm2(phi);
@@ -480,7 +501,7 @@ __global__ __launch_bounds__(256) void eigen_pixel_update_kernel(const TkResidua
 
 static TkResidual make_residual(const void* patches, const void* chi0, const void* mpu0,
                                 const void* eigen, const void* coefs, int C, int Sm, int c,
-                                int pw) {
+                                int pw, int chi_modes) {
   TkResidual R;
   R.patches = (const cf*)patches;
   R.chi0 = (const cf*)chi0;
@@ -491,21 +512,23 @@ static TkResidual make_residual(const void* patches, const void* chi0, const voi
   R.Sm = Sm;
   R.c = c;
   R.P = (long)pw * pw;
+  R.XS = R.P * chi_modes;
   return R;
 }
 
 extern "C" int tike_eigen_position_sums(const void* patches, const void* chi0, const void* mpu0,
                                         const void* eigen_probe, const void* coefs,
                                         int num_eigen, int eigen_modes, int c, float* sums,
-                                        int nscan, int pw, void* stream) {
+                                        int nscan, int pw, int chi_modes, void* stream) {
   TK_ENTER();
-  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && num_eigen >= 1 && c >= 0 && c < num_eigen);
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && num_eigen >= 1 && c >= 0 && c < num_eigen &&
+               chi_modes >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen_probe && sums && (c == 0 || coefs));
   hipLaunchKernelGGL(eigen_position_sums_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
                      (hipStream_t)stream,
                      make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
-                                   eigen_modes, c, pw),
+                                   eigen_modes, c, pw, chi_modes),
                      sums, nscan);
   TK_LAUNCH_CHECK();
   return TK_OK;
@@ -514,9 +537,11 @@ extern "C" int tike_eigen_position_sums(const void* patches, const void* chi0, c
 extern "C" int tike_eigen_pixel_update(const void* patches, const void* chi0, const void* mpu0,
                                        const void* eigen_probe, const void* coefs,
                                        int num_eigen, int eigen_modes, int c, const float* pm,
-                                       void* update, int nscan, int pw, void* stream) {
+                                       void* update, int nscan, int pw, int chi_modes,
+                                       void* stream) {
   TK_ENTER();
-  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && num_eigen >= 1 && c >= 0 && c < num_eigen);
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && num_eigen >= 1 && c >= 0 && c < num_eigen &&
+               chi_modes >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen_probe && pm && update && (c == 0 || coefs));
   const long P = (long)pw * pw;
@@ -524,7 +549,7 @@ extern "C" int tike_eigen_pixel_update(const void* patches, const void* chi0, co
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
   hipLaunchKernelGGL(eigen_pixel_update_kernel, grid, dim3(256), 0, (hipStream_t)stream,
                      make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
-                                   eigen_modes, c, pw),
+                                   eigen_modes, c, pw, chi_modes),
                      pm, (float*)update, nscan, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;

@@ -18,6 +18,7 @@ Differences from the reference that do not change the mathematics:
     iterates up to summation order.
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -67,6 +68,9 @@ def chunk_positions(S, det, position_major=False):
     """Positions per kernel launch: enough workgroups to fill the chip several
     times over while bounding the far-plane workspace.  The position-major
     kernels run one workgroup per position (not per tile)."""
+    forced = os.environ.get("TIKE_CHUNK_POSITIONS")  # tests: force chunking
+    if forced:
+        return max(1, int(forced))
     tiles = max(2048, (1 << 28) // (det * det * 8))  # >= 2048 tiles or 256 MiB
     if position_major:
         return max(1024, tiles // max(S, 1))
@@ -264,7 +268,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     obj_acc = (torch.zeros((2, H, W), dtype=torch.float32, device=dev)
                if recover_psi else None)
     m_probe_update = torch.zeros_like(probe) if recover_probe else None
-    chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
+    chi0 = None  # allocated below unless chi itself can be handed on
     patches = None
     if (recover_probe and eigen_weights is not None) or position_terms:
         patches = ws.get("patches", (max(B, 1), pw, pw), torch.complex64, dev)
@@ -305,6 +309,12 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         chi_ws = ws.get("chi", (min(chunk, max(B, 1)), 1, S, pw, pw),
                         torch.complex64, dev)
 
+    # mode 0 of chi is read again after the whole minibatch (step sizes,
+    # eigen probes).  When the minibatch is one chunk, chi is still intact
+    # then and is handed on with a mode stride; otherwise mode 0 is packed.
+    single_chunk = B <= chunk
+    if not single_chunk:
+        chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
     for clo in range(lo, hi, chunk):
         chi_hi = min(hi, clo + chunk)
         n = chi_hi - clo
@@ -399,7 +409,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                                          A.ptr(scan[clo:chi_hi]),
                                          A.ptr(obj_acc), n, pw, H, W, st),
                 "object scatter")
-        chi0[blo:blo + n] = chi[:n, 0, 0]
+        if not single_chunk:
+            chi0[blo:blo + n] = chi[:n, 0, 0]
 
     # complete the sums over positions across ranks
     cost_sum = costs[:B].sum() if B > 0 else torch.zeros((), device=dev)
@@ -412,7 +423,9 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     tot = comm.Allreduce_scalars([cost_sum], dev)
     if recover_probe:
         m_probe_update = m_probe_update / num_batch
-    return dict(chi0=chi0[:B], w_old=w_old, patches=None if patches is None
+    return dict(chi0=chi_ws if single_chunk else chi0[:B],
+                chi_modes=S if single_chunk else 1, w_old=w_old,
+                patches=None if patches is None
                 else patches[:B], object_upd_sum=object_upd_sum,
                 m_probe_update=m_probe_update,
                 cost=(tot[0] / count).to(torch.float32), count=count,
@@ -442,7 +455,8 @@ def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
             A.ptr(object_update_precond), A.ptr(probe), A.ptr(ep),
             A.ptr(w_old), C, Sm, None, A.ptr(g["m_probe_update"]),
             A.ptr(stats), B,
-            S, 1, pw, psi.shape[-2], psi.shape[-1], A.stream_ptr()),
+            S, g["chi_modes"], pw, psi.shape[-2], psi.shape[-1],
+            A.stream_ptr()),
         "step-size statistics")
     return stats[:B]
 
@@ -507,7 +521,8 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
         check(
             lib.tike_eigen_position_sums(A.ptr(patches), A.ptr(chi0),
                                          A.ptr(mpu0), A.ptr(ep), A.ptr(coefs),
-                                         C, Sm, c, A.ptr(sums), B, pw, st),
+                                         C, Sm, c, A.ptr(sums), B, pw,
+                                         g["chi_modes"], st),
             "eigen position sums")
         return sums[:B]
 
@@ -525,7 +540,8 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
             lib.tike_eigen_pixel_update(A.ptr(patches), A.ptr(chi0),
                                         A.ptr(mpu0), A.ptr(ep), A.ptr(coefs),
                                         C, Sm, c - 1, A.ptr(proj_mean),
-                                        A.ptr(update), B, pw, st),
+                                        A.ptr(update), B, pw, g["chi_modes"],
+                                        st),
             "eigen pixel update")
         if comm.collective:
             comm.Allreduce(update)
