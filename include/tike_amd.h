@@ -212,13 +212,15 @@ int tike_probe_preconditioner(const float* scan, const void* psi, void* out, int
  * O_n = patch_n(psi), P_0 = shared probe mode 0.  object_update_precond and
  * m_probe_update may be NULL (that direction is then zero).  chi is laid out
  * (nscan, chi_modes, pw, pw) and only its mode 0 is read (chi_modes = 1 when
- * the caller kept just that mode). */
+ * the caller kept just that mode). 
+ * patches (nscan,pw,pw), if not NULL, holds patch_n(psi) as stored by
+ * tike_lstsq_gradients and replaces the bilinear gather of psi. */
 int tike_lstsq_step_stats(const void* chi, const float* scan, const void* psi,
                           const void* object_update_precond, const void* probe,
                           const void* eigen_probe, const float* eigen_weights, int num_eigen,
                           int eigen_modes, const void* unique_probe, const void* m_probe_update,
-                          float* stats, int nscan, int S, int chi_modes, int pw, int H, int W,
-                          void* stream);
+                          const void* patches, float* stats, int nscan, int S, int chi_modes,
+                          int pw, int H, int W, void* stream);
 
 /* out (nscan, eigen_modes, pw, pw) = weights[n][0][s]*probe[s] +
  * sum_c weights[n][c+1][s]*eigen[c][s]: the varying probe of the modes that

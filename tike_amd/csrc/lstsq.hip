@@ -366,24 +366,34 @@ extern "C" int tike_probe_preconditioner(const float* scan, const void* psi, voi
 //                sum Re(conj(O_n P_0) chi_n,0), sum |O_n P_0|^2 }
 // (the last two feed _get_coefs_intensity, lstsq.py:721-738, which uses the
 // SHARED probe P_0).  eps terms (:641,661,667) are added by the solver.
+template <bool HAVE_PATCHES, bool HAVE_GOBJ>
 __global__ __launch_bounds__(256) void step_stats_kernel(
     const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
     const cf* __restrict__ gobj, const TkProbe probe, const cf* __restrict__ mpu,
-    float* __restrict__ stats, int nscan, int chi_modes, int pw, int H, int W) {
+    const cf* __restrict__ patches, float* __restrict__ stats, int nscan, int chi_modes, int pw,
+    int H, int W) {
   __shared__ float red[4];
   const long P = (long)pw * pw;
   const long total = (long)H * W;
   for (int n = blockIdx.x; n < nscan; n += gridDim.x) {
     const TkCorner c = tk_corner(scan, n);
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // branch-free body (clamped addresses, results zeroed by select) so that
+    // the loads of two pixels are in flight together
+#pragma unroll 2
     for (long p = threadIdx.x; p < P; p += blockDim.x) {
       const int py = (int)(p / pw), px = (int)(p % pw);
       const int y = c.sy + py, x = c.sx + px;
-      cf o = mk(0.f, 0.f), g = mk(0.f, 0.f);
-      if (y >= 0 && y < H && x >= 0 && x < W) {
-        const long ii = (long)y * W + x;
-        o = tk_gather(psi, ii, W, total, c);
-        if (gobj) g = tk_gather(gobj, ii, W, total, c);
+      const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+      const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+      const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+      const long ii = (long)yc * W + xc;
+      // O_n: the patch stored by tike_lstsq_gradients when available
+      cf o = HAVE_PATCHES ? patches[n * P + p] : tk_gather(psi, ii, W, total, c);
+      cf g = HAVE_GOBJ ? tk_gather(gobj, ii, W, total, c) : mk(0.f, 0.f);
+      if (!ok) {
+        if (!HAVE_PATCHES) o = mk(0.f, 0.f);
+        g = mk(0.f, 0.f);
       }
       const cf x0 = chi[((long)n * chi_modes) * P + p];
       const cf dOP = g * probe.at(n, 0, p);
@@ -411,18 +421,25 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
                                      const void* object_update_precond, const void* probe,
                                      const void* eigen_probe, const float* eigen_weights,
                                      int num_eigen, int eigen_modes, const void* unique_probe,
-                                     const void* m_probe_update, float* stats, int nscan, int S,
-                                     int chi_modes, int pw, int H, int W, void* stream) {
+                                     const void* m_probe_update, const void* patches,
+                                     float* stats, int nscan, int S, int chi_modes, int pw, int H,
+                                     int W, void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && chi_modes >= 1 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(chi && scan && psi && probe && stats);
-  hipLaunchKernelGGL(step_stats_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
-                     (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,
-                     (const cf*)object_update_precond,
-                     tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes, S,
-                                   pw, unique_probe),
-                     (const cf*)m_probe_update, stats, nscan, chi_modes, pw, H, W);
+  const TkProbe pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
+                                   S, pw, unique_probe);
+#define TK_SS(HP, HG)                                                                         \
+  hipLaunchKernelGGL((step_stats_kernel<HP, HG>), dim3(tk_grid(nscan, 16)), dim3(256), 0,     \
+                     (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,               \
+                     (const cf*)object_update_precond, pr, (const cf*)m_probe_update,         \
+                     (const cf*)patches, stats, nscan, chi_modes, pw, H, W)
+  if (patches && object_update_precond) TK_SS(true, true);
+  else if (patches) TK_SS(true, false);
+  else if (object_update_precond) TK_SS(false, true);
+  else TK_SS(false, false);
+#undef TK_SS
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -454,7 +454,7 @@ def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
             A.ptr(g["chi0"]), A.ptr(scan[lo:hi]), A.ptr(psi),
             A.ptr(object_update_precond), A.ptr(probe), A.ptr(ep),
             A.ptr(w_old), C, Sm, None, A.ptr(g["m_probe_update"]),
-            A.ptr(stats), B,
+            A.ptr(g["patches"]), A.ptr(stats), B,
             S, g["chi_modes"], pw, psi.shape[-2], psi.shape[-1],
             A.stream_ptr()),
         "step-size statistics")
