@@ -241,10 +241,12 @@ def main():
             cpu = cpu_baseline_fwd(p, S, det)
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, solver=None)
-    elif a.workload in ("c2", "c3"):
-        det = 256
-        S = 8 if a.workload == "c3" else 1
-        N = a.positions or 10000
+    elif a.workload in ("c2", "c3", "c5"):
+        # c2: 1 mode; c3 (default, = one GPU's share of c4): 8 modes + eigen
+        # probes; c5: 512x512, 4 modes, position correction on
+        det = 512 if a.workload == "c5" else 256
+        S = {"c2": 1, "c3": 8, "c5": 4}[a.workload]
+        N = a.positions or (4000 if a.workload == "c5" else 10000)
         num_batch = 10
         # global problem: N*world positions; this rank's share of every
         # global minibatch, concatenated (see Reconstruction(presharded=True))
@@ -275,7 +277,10 @@ def main():
             algorithm_options=tp.LstsqOptions(num_batch=num_batch,
                                               batch_method="compact"),
             probe_options=tp.ProbeOptions(force_orthogonality=True),
-            object_options=tp.ObjectOptions())
+            object_options=tp.ObjectOptions(),
+            position_options=tp.PositionOptions(
+                p["scan"].copy(), use_adaptive_moment=True,
+                update_magnitude_limit=1.0) if a.workload == "c5" else None)
         ctx = tp.Reconstruction(data_dev, params, presharded=True,
                                 order=np.arange(N),
                                 batches=np.array_split(np.arange(N),
@@ -286,14 +291,14 @@ def main():
             ctx.iterate(1)
 
         units = N
-        launch_n = min(chunk_positions(S, det, det in (128, 256)),
-                       N // num_batch)
+        launch_n = min(chunk_positions(S, det, True), N // num_batch)
         dominant = None
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_epoch(p, data, S, det)
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, eigen_probes=C, solver="lstsq_grad",
-                        num_batch=num_batch, chunk_positions=launch_n)
+                        num_batch=num_batch, chunk_positions=launch_n,
+                        position_correction=a.workload == "c5")
     else:
         raise SystemExit(f"unknown workload {a.workload}")
 
@@ -333,7 +338,8 @@ def main():
             print(f"  kernels {tot:.1f} ms of wall {wall * 1e3:.1f} ms",
                   file=sys.stderr)
         line = {
-            "metric": METRIC,
+            "metric": METRIC if (det, S) == (256, 8) else
+            f"diffraction patterns/sec/GPU ({det}x{det}, {S}-mode probe)",
             "value": units * world * a.steps / wall,
             "unit": "patterns/s",
             "n_gpus": world,

@@ -82,7 +82,7 @@ int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe, int p
 /* ---- Ptycho.fwd + intensity, position-major (one workgroup per position
  * walks all S modes): same far-plane as tike_ptycho_fwd plus
  * intensity[n] = sum_s |farplane[n][s]|^2 (ptycho.py:18-23) accumulated in
- * registers, so the far-plane is not re-read to form it.  det in {128, 256}
+ * registers, so the far-plane is not re-read to form it.  det in {128, 256, 512}
  * (TIKE_ERR_UNSUPPORTED otherwise: use tike_ptycho_fwd + tike_intensity).
  * intensity (nscan,det,det) f32 may be NULL.  With eigen_weights the probe of
  * mode s at position n is unique_probe[n][s] for s < eigen_modes (from

@@ -354,7 +354,8 @@ def test_full_size_roundtrip_property(ops):
 
 
 @pytest.mark.parametrize("det,pw,S", [(128, 128, 3), (256, 256, 2),
-                                      (128, 96, 2)])
+                                      (128, 96, 2), (512, 512, 2),
+                                      (512, 384, 1)])
 def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
     """tike_ptycho_fwd_intensity -> tike_gradient_scale ->
     tike_ifft2_crop_scaled == oracle fwd, intensity, per-pattern cost and

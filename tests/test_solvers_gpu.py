@@ -315,6 +315,7 @@ def _oracle_state(g_psi, g_probe, scan, order):
     (128, 128, 3, 24, 2, True, "poisson:all_modes"),      # fused inverse with per-mode steps
     (256, 256, 2, 10, 1, False, "poisson:dominant_mode"),
     (48, 32, 2, 12, 2, True, "poisson:all_modes"),        # generic path: tike_scale_modes
+    (512, 512, 2, 6, 2, True, "gaussian"),                # config-5 size: 512^2 position-major
 ])
 def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
     """Two lstsq_grad epochs against the CPU oracle on seeded problems that

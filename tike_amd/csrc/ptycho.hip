@@ -351,6 +351,9 @@ extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, con
     case 256:
       return launch_fwd_pos<256>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
                                  H, W, scale, stream);
+    case 512:
+      return launch_fwd_pos<512>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
+                                 H, W, scale, stream);
     default:
       return TK_ERR_UNSUPPORTED;
   }
@@ -408,6 +411,9 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
                                    stream);
       case 256:
         return launch_fwd_pos<256>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale,
+                                   stream);
+      case 512:
+        return launch_fwd_pos<512>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale,
                                    stream);
       default: break;
     }

@@ -59,7 +59,7 @@ def _workspace(op):
     return ws
 
 
-POSITION_MAJOR_SIZES = (128, 256)
+POSITION_MAJOR_SIZES = (128, 256, 512)
 """Detector sizes served by the position-major forward kernel
 (tike_ptycho_fwd_intensity) and the gradient-scaled inverse."""
 
