@@ -158,9 +158,11 @@ def algorithmic_bytes(name, n, S, det, pw, C):
     T = 8 * S * det * det  # one position's far-plane, bytes
     if name == "tike_ptycho_fwd":
         return n * (T + 8 * pw * pw + 8) + 8 * (S + C) * pw * pw
-    if name == "tike_ptycho_fwd_intensity":
+    if name in ("tike_ptycho_fwd_intensity", "tike_ptycho_fwd_intensity_only"):
+        # the intensity-only form hands a far-plane-sized array (the input of
+        # its column pass) to tike_grad_ifft2_crop instead of the far plane
         return n * (T + 8 * pw * pw + 4 * det * det + 8) + 8 * (S + C) * pw * pw
-    if name == "tike_ifft2_crop_scaled":
+    if name in ("tike_ifft2_crop_scaled", "tike_grad_ifft2_crop"):
         return n * (T + 8 * S * pw * pw + 4 * det * det)
     if name == "tike_gradient_scale":
         return n * 3 * 4 * det * det
@@ -215,7 +217,8 @@ def main():
     timers = KernelTimers(lib, [
         "tike_ptycho_fwd", "tike_farplane_gradient", "tike_ifft2_crop",
         "tike_ptycho_fwd_intensity", "tike_gradient_scale",
-        "tike_ifft2_crop_scaled",
+        "tike_ifft2_crop_scaled", "tike_ptycho_fwd_intensity_only",
+        "tike_grad_ifft2_crop",
         "tike_lstsq_gradients", "tike_scatter_patches",
         "tike_lstsq_step_stats", "tike_psi_preconditioner",
         "tike_probe_preconditioner", "tike_intensity"

@@ -93,6 +93,27 @@ int tike_ptycho_fwd_intensity(const void* psi, const float* scan, const void* pr
                               void* farplane, float* intensity, int nscan, int S, int pw, int det,
                               int H, int W, float scale, void* stream);
 
+/* ---- the same forward model for the intensity ONLY (det = 256;
+ * TIKE_ERR_UNSUPPORTED otherwise): the far-plane waves are formed in registers
+ * and never stored; `scratch` (nscan,S,det,det) c64 receives instead the input
+ * of the column pass of every tile, the operand of tike_grad_ifft2_crop. */
+int tike_ptycho_fwd_intensity_only(const void* psi, const float* scan, const void* probe,
+                                   int probe_per_scan, const void* unique_probe,
+                                   const float* eigen_weights, int num_eigen, int eigen_modes,
+                                   void* scratch, float* intensity, int nscan, int S, int pw,
+                                   int det, int H, int W, float scale, void* stream);
+
+/* ---- far-plane gradient + IFFT2 + crop from that scratch (lstsq.py:491-507):
+ * chi = crop(IFFT2(F * gscale [* mode_scale on measured pixels])) * inv_scale
+ * with F = fwd_scale * (column pass of `colin`) re-formed in registers, so the
+ * far plane is neither written nor read.  mode_scale / measured as in
+ * tike_ifft2_crop_scaled_modes (both may be NULL).  work (ntile,det,det) must
+ * not alias colin; chi may alias work only when pw == det.  det = 256. */
+int tike_grad_ifft2_crop(const void* colin, const float* gscale, const float* mode_scale,
+                         const unsigned char* measured, int S, void* work, void* chi,
+                         long ntile, int det, int pw, float fwd_scale, float inv_scale,
+                         void* stream);
+
 /* ---- far-plane gradient factor from the intensity (objective.py:31-44,97-109;
  * lstsq.py:491-502): gscale[n][p] = -(1 - sqrt(d)/(sqrt(I)+1e-9)) (gaussian) or
  * -(1 - d/(I+1e-9)) (poisson) on measured pixels, (unmeasured_scaling - 1)

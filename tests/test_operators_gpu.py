@@ -355,7 +355,7 @@ def test_full_size_roundtrip_property(ops):
 
 @pytest.mark.parametrize("det,pw,S", [(128, 128, 3), (256, 256, 2),
                                       (128, 96, 2), (512, 512, 2),
-                                      (512, 384, 1)])
+                                      (512, 384, 1), (256, 192, 3)])
 def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
     """tike_ptycho_fwd_intensity -> tike_gradient_scale ->
     tike_ifft2_crop_scaled == oracle fwd, intensity, per-pattern cost and
@@ -417,3 +417,31 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
                                      st))
     assert_close(chi.cpu().numpy(), want_chi, normwise=1e-4, maxabs=1e-3,
                  what="chi")
+    if det == 256:
+        # the far-plane-free pipeline: forward for the intensity only, then the
+        # gradient and the inverse transform from the column-pass scratch
+        scratch = torch.empty_like(far)
+        I2 = torch.empty_like(I)
+        check(lib.tike_ptycho_fwd_intensity_only(
+            A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, A.ptr(uq),
+            A.ptr(w_d), C, 1, A.ptr(scratch), A.ptr(I2), N, S, pw, det, HW, HW,
+            1.0 / det, st))
+        assert_close(I2.cpu().numpy(), want_I, what="intensity (only)")
+        mid2 = torch.empty_like(far)
+        chi2 = mid2 if pw == det else torch.empty_like(chi)
+        check(lib.tike_grad_ifft2_crop(
+            A.ptr(scratch), A.ptr(g), None, None, S, A.ptr(mid2), A.ptr(chi2),
+            N * S, det, pw, 1.0 / det, 1.0 / det, st))
+        assert_close(chi2.cpu().numpy(), want_chi, normwise=1e-4, maxabs=1e-3,
+                     what="chi (no far plane)")
+        # per-mode factor on measured pixels (poisson form)
+        steps = torch.rand((N, S), dtype=torch.float32, device=dev) + 0.5
+        check(lib.tike_grad_ifft2_crop(
+            A.ptr(scratch), A.ptr(g), A.ptr(steps), A.ptr(m_d), S, A.ptr(mid2),
+            A.ptr(chi2), N * S, det, pw, 1.0 / det, 1.0 / det, st))
+        chi3 = mid if pw == det else torch.empty_like(chi)
+        check(lib.tike_ifft2_crop_scaled_modes(
+            A.ptr(far), A.ptr(g), A.ptr(steps), A.ptr(m_d), S, A.ptr(mid),
+            A.ptr(chi3), N * S, det, pw, 1.0 / det, st))
+        assert_close(chi2.cpu().numpy(), chi3.cpu().numpy(), normwise=1e-5,
+                     maxabs=1e-4, what="chi with mode steps")

@@ -194,3 +194,29 @@ __device__ __forceinline__ void fft2_pass2(const cf* __restrict__ mid, int k1, S
 #pragma unroll
   for (int k2 = 0; k2 < G2::RB; ++k2) store(k1 + 16 * k2, t, u[k2]);
 }
+
+// Column-first counterpart of fft2_pass1 (N = 256: RB = 16 rows of T = 16
+// threads): every thread t holds a[ya], ya < 16 -- column t of 16 rows whose
+// COLUMN stage is already done -- and the rows still need their length-N
+// transform.  The values are transposed through LDS into the row layout
+// (16 threads per row, element e = j + i*T), transformed with the in-wave
+// Stockham stages and stored as the 16 consecutive rows starting at `rows`.
+// Contains two workgroup barriers; every thread of the workgroup calls.
+template <int N, bool INV, class Tw>
+__device__ __forceinline__ void fft2_rows_from_columns(cf* __restrict__ lds, const Tw& tw, int line,
+                                                       int j, cf (&a)[16], cf* __restrict__ rows) {
+  using G2 = Fft2Geom<N>;
+  static_assert(G2::RB == 16, "one pass: 16 rows x 16 threads");
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int ya = 0; ya < 16; ++ya) lds[ya * G2::LS + tk_pad16(t)] = a[ya];
+  __syncthreads();
+  cf v[16];
+  cf* lbase = lds + line * G2::LS;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = lbase[tk_pad16(j + i * G2::T)];
+  FftStageWave<N, INV, 0>::run(v, lbase, j, tw);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) rows[line * N + j + i * G2::T] = v[i];
+  __syncthreads();
+}

@@ -218,7 +218,10 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
 #ifndef TK_POS_WAVES
 #define TK_POS_WAVES 2
 #endif
-template <int N>
+// STORE = false: the far-plane waves are formed in registers for the intensity
+// only; `farplane` then keeps the INPUT of the column pass (rows 16r + k1 of
+// fft2_pass1), which tike_grad_ifft2_crop consumes.
+template <int N, bool STORE = true>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_pos_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ farplane, float* __restrict__ intensity, int nscan, int S, int pw, int H,
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
         cf* __restrict__ dst = dst0 + s * (long)N * N;
         fft2_pass2<N, false>(dst, k1, [&](int ky, int tt, cf v) {
           const cf o = v * scale;
-          tk_st_stream(dst + ky * N + tt, o);
+          if (STORE) tk_st_stream(dst + ky * N + tt, o);
           I[(ky - k1) >> 4] += norm2(o);
         });
       }
@@ -317,14 +320,14 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
   }
 }
 
-template <int N>
+template <int N, bool STORE = true>
 static int launch_fwd_pos(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                           float* intensity, int nscan, int S, int pw, int H, int W, float scale,
                           hipStream_t stream) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
-  hipLaunchKernelGGL((ptycho_fwd_pos_kernel<N>), dim3(tk_grid(nscan, 4)), dim3(N), 0, stream,
-                     psi, scan, probe, farplane, intensity, nscan, S, pw, H, W, scale, tw);
+  hipLaunchKernelGGL((ptycho_fwd_pos_kernel<N, STORE>), dim3(tk_grid(nscan, 4)), dim3(N), 0,
+                     stream, psi, scan, probe, farplane, intensity, nscan, S, pw, H, W, scale, tw);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -357,6 +360,29 @@ extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, con
     default:
       return TK_ERR_UNSUPPORTED;
   }
+}
+
+// Forward model for the intensity only (det = 256): `scratch` (nscan,S,det,det)
+// receives the column-pass input of every tile instead of the far-plane waves.
+extern "C" int tike_ptycho_fwd_intensity_only(const void* psi, const float* scan,
+                                              const void* probe, int probe_per_scan,
+                                              const void* unique_probe,
+                                              const float* eigen_weights, int num_eigen,
+                                              int eigen_modes, void* scratch, float* intensity,
+                                              int nscan, int S, int pw, int det, int H, int W,
+                                              float scale, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(psi && scan && probe && scratch && intensity);
+  TK_CHECK_ARG(!(eigen_weights && eigen_modes > 0 && !unique_probe));
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, nullptr, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw, unique_probe);
+  return launch_fwd_pos<256, false>((const cf*)psi, scan, P, (cf*)scratch, intensity, nscan, S,
+                                    pw, H, W, scale, stream);
 }
 
 template <int N>
@@ -788,6 +814,98 @@ extern "C" int tike_ifft2_crop_scaled(const void* farplane, const float* gscale,
     default:
       return TK_ERR_UNSUPPORTED;
   }
+}
+
+// ------------------------------------------- gradient + inverse, no far plane
+// Consumes the column-pass input left by tike_ptycho_fwd_intensity_only.  Per
+// tile and per k1 (a thread owns one column):
+//   F[k1 + 16 k2] = radix-16 over r of rows 16r + k1      (forward column pass)
+//   G = F * fwd_scale * gscale                            (lstsq.py:491-502)
+// and the inverse transform starts on the same registers: with ky = k1 + 16 k2
+// and y = ya + 16 yb,
+//   w^-(ky y) = w_16^-(k2 ya) * w_N^-(k1 ya) * w_16^-(k1 yb),
+//   A[ya] = w_N^-(k1 ya) * radix-16 over k2 of G          (registers)
+//   rows (k1, ya): inverse row transforms                 (LDS, in-wave stages)
+//   stored as rows 16 k1 + ya of `work`; after a barrier fft2_pass2 (radix-16
+//   over k1, in place, rows {ya + 16 yb}) finishes, crops and scales.
+// The far-plane waves are therefore never written to or read from memory.
+#ifndef TK_GINV_WAVES
+#define TK_GINV_WAVES 3
+#endif
+template <int N, int MODE>
+__global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
+    const cf* __restrict__ colin, cf* work, cf* chi, long ntile, int pw, float fwd_scale,
+    float inv_scale, const cf* __restrict__ twtab, const float* __restrict__ gscale, int S,
+    const float* __restrict__ mode_scale, const unsigned char* __restrict__ measured) {
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int pad = (N - pw) / 2;
+  const int t = threadIdx.x;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const cf* __restrict__ src = colin + tile * (long)N * N;
+    cf* mid = work + tile * (long)N * N;
+    cf* dst = chi + tile * (long)pw * pw;
+    const float* __restrict__ gs = gscale + (tile / S) * (long)N * N;
+    const float ms = MODE == 2 ? mode_scale[tile] : 1.0f;
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    for (int k1 = 0; k1 < 16; ++k1) {
+      cf u[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(src + (16 * r + k1) * N + t);
+      Dft<16, false>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const int p = (k1 + 16 * k2) * N + t;
+        float g = gs[p] * fwd_scale;
+        if (MODE == 2 && (measured == nullptr || measured[p])) g *= ms;
+        u[k2] = u[k2] * g;
+      }
+      Dft<16, true>::run(u);
+#pragma unroll
+      for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
+      fft2_rows_from_columns<N, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
+    }
+    __syncthreads();
+    for (int ya = 0; ya < 16; ++ya)
+      fft2_pass2<N, true>(mid, ya, [&](int y, int x, cf v) {
+        const int py = y - pad, px = x - pad;
+        if (py >= 0 && py < pw && px >= 0 && px < pw)
+          tk_st_stream(dst + py * pw + px, v * inv_scale);
+      });
+    __syncthreads();
+  }
+}
+
+extern "C" int tike_grad_ifft2_crop(const void* colin, const float* gscale,
+                                    const float* mode_scale, const unsigned char* measured,
+                                    int S, void* work, void* chi, long ntile, int det, int pw,
+                                    float fwd_scale, float inv_scale, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && S >= 1 && pw >= 1 && det >= pw);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(colin && gscale && work && chi && work != colin && ntile % S == 0);
+  TK_CHECK_ARG(!(chi == work && pw != det));
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  constexpr int N = 256;
+#define TK_GINV(MODE)                                                                          \
+  hipLaunchKernelGGL((grad_ifft2_crop_kernel<N, MODE>), dim3(tk_grid(ntile, 4)), dim3(N), 0,   \
+                     stream, (const cf*)colin, (cf*)work, (cf*)chi, ntile, pw, fwd_scale,      \
+                     inv_scale, tw, gscale, S, mode_scale, measured)
+  if (mode_scale)
+    TK_GINV(2);
+  else
+    TK_GINV(1);
+#undef TK_GINV
+  TK_LAUNCH_CHECK();
+  return TK_OK;
 }
 
 // Poisson variant (lstsq.py:454-489): the gradient factor of mode s at a

@@ -60,6 +60,7 @@ def _workspace(op):
 
 
 POSITION_MAJOR_SIZES = (128, 256, 512)
+NO_FARPLANE_SIZES = (256,)
 """Detector sizes served by the position-major forward kernel
 (tike_ptycho_fwd_intensity) and the gradient-scaled inverse."""
 
@@ -285,6 +286,12 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     if pos_major:
         gscale = ws.get("gscale", (min(chunk, max(B, 1)), det, det),
                         torch.float32, dev)
+    # detector sizes with the far-plane-free pipeline (the per-mode poisson
+    # steps of 'all_modes' need |F_s|^2 and keep the stored far plane)
+    no_farplane = (pos_major and det in NO_FARPLANE_SIZES
+                   and os.environ.get("TIKE_KEEP_FARPLANE") is None
+                   and not (poisson and exitwave_options.step_length_usemodes
+                            != "dominant_mode"))
     if poisson:
         # per-(position, mode) step lengths (exitwave.py:122-234)
         steps = ws.get("steps", (min(chunk, max(B, 1)), S), torch.float32,
@@ -331,7 +338,36 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                 "varying probe")
         model = _MODELS[exitwave_options.noise_model]
         unmeasured = float(exitwave_options.unmeasured_pixels_scaling)
-        if pos_major:
+        if pos_major and no_farplane:
+            # the far-plane waves never reach memory: the forward kernel forms
+            # them in registers for the intensity and leaves the input of its
+            # column pass in `far`; the inverse kernel re-forms them from
+            # there, applies the gradient factor and transforms back
+            check(
+                lib.tike_ptycho_fwd_intensity_only(
+                    A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
+                    A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far), A.ptr(inten), n,
+                    S, pw, det, H, W, fwd_scale, st), "forward (intensity)")
+            check(
+                lib.tike_gradient_scale(A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                                        A.ptr(mask_u8), A.ptr(gscale),
+                                        A.ptr(costs[blo:blo + n]), n, det,
+                                        model, unmeasured, nmeasured, st),
+                "gradient scale")
+            if poisson:  # dominant mode: the steps need no far-plane waves
+                check(
+                    lib.tike_poisson_steps(
+                        None, A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                        A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
+                        step_weight, 1, st), "poisson step lengths")
+            check(
+                lib.tike_grad_ifft2_crop(
+                    A.ptr(far), A.ptr(gscale),
+                    A.ptr(steps) if poisson else None,
+                    A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
+                    A.ptr(chi), n * S, det, pw, fwd_scale, inv_scale, st),
+                "gradient + ifft2 + crop")
+        elif pos_major:
             # forward + intensity in one kernel; the gradient factor is a
             # per-pixel table applied while the inverse transform loads rows
             check(

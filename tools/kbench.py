@@ -141,6 +141,19 @@ def main():
             far.data_ptr(), g.data_ptr(), S, mid.data_ptr(), mid.data_ptr(),
             N * S, n, n, 1.0 / n, st)), a.reps)
         rows.append((f"ifft2_crop_scaled S={S}", ms, 2 * N * S * tile_bytes))
+        if n == 256:
+            scratch = torch.empty_like(far)
+            ms = timeit(lambda: check(lib.tike_ptycho_fwd_intensity_only(
+                psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0,
+                uniq.data_ptr(), wts.data_ptr(), 1, 1, scratch.data_ptr(),
+                inten.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st)), a.reps)
+            rows.append((f"fwd intensity-only S={S}", ms,
+                         N * S * tile_bytes + 2 * N * tile_bytes))
+            ms = timeit(lambda: check(lib.tike_grad_ifft2_crop(
+                scratch.data_ptr(), g.data_ptr(), None, None, S,
+                mid.data_ptr(), mid.data_ptr(), N * S, n, n, 1.0 / n, 1.0 / n,
+                st)), a.reps)
+            rows.append((f"grad_ifft2_crop S={S}", ms, 2 * N * S * tile_bytes))
         chi = torch.empty_like(far)
         ms = timeit(lambda: check(lib.tike_ifft2_crop_scaled(
             far.data_ptr(), g.data_ptr(), S, mid.data_ptr(), chi.data_ptr(),
