@@ -297,6 +297,35 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
     }
     __syncthreads();
 #ifndef TK_DBG_FWD_NOPASS2
+    if constexpr (!STORE) {
+      // intensity only: nothing is stored per tile, so the column pass is a
+      // pure read stream -- keep the rows of the NEXT (k1, mode) in flight
+      // while the current ones go through the butterfly
+      cf nxt[G2::RB];
+#pragma unroll
+      for (int r = 0; r < G2::RB; ++r) nxt[r] = dst0[(16 * r) * N + t];
+      for (int k1 = 0; k1 < 16; ++k1) {
+        float I[G2::RB];
+#pragma unroll
+        for (int k2 = 0; k2 < G2::RB; ++k2) I[k2] = 0.f;
+        for (int s = 0; s < S; ++s) {
+          cf u[G2::RB];
+#pragma unroll
+          for (int r = 0; r < G2::RB; ++r) u[r] = nxt[r];
+          const int s2 = s + 1 < S ? s + 1 : 0;
+          const int k2n = s + 1 < S ? k1 : (k1 + 1 < 16 ? k1 + 1 : k1);
+          const cf* __restrict__ nsrc = dst0 + s2 * (long)N * N;
+#pragma unroll
+          for (int r = 0; r < G2::RB; ++r) nxt[r] = nsrc[(16 * r + k2n) * N + t];
+          Dft<G2::RB, false>::run(u);
+#pragma unroll
+          for (int k2 = 0; k2 < G2::RB; ++k2) I[k2] += norm2(u[k2] * scale);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < G2::RB; ++k2)
+          tk_st_stream(intensity + n * (long)N * N + (k1 + 16 * k2) * N + t, I[k2]);
+      }
+    } else
     for (int k1 = 0; k1 < 16; ++k1) {
       float I[G2::RB];
 #pragma unroll
@@ -830,7 +859,7 @@ extern "C" int tike_ifft2_crop_scaled(const void* farplane, const float* gscale,
 //   over k1, in place, rows {ya + 16 yb}) finishes, crops and scales.
 // The far-plane waves are therefore never written to or read from memory.
 #ifndef TK_GINV_WAVES
-#define TK_GINV_WAVES 3
+#define TK_GINV_WAVES 4
 #endif
 template <int N, int MODE>
 __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
