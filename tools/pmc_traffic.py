@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into
+profiles/rNN_pmc_traffic_<workload>.json.
+
+python tools/pmc_traffic.py <fetch_dir> <write_dir> <workload> <positions_per_launch> <out.json>
+
+Per kernel, only the launches with the largest grid are kept (the timed
+epoch's full chunks; set-up launches are smaller) and averaged.  HBM bytes =
+(2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B
+request; WRITE_SIZE is exact) as MI355X_MICROARCH.md prescribes.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+# kernel-name prefix -> C-ABI entry whose launch it is
+KERNELS = {
+    "void ptycho_fwd_pos_kernel<256, false>": "tike_ptycho_fwd_intensity_only",
+    "void ptycho_fwd_pos_kernel<256, true>": "tike_ptycho_fwd_intensity",
+    "void ptycho_fwd_pos_kernel<512": "tike_ptycho_fwd_intensity",
+    "void grad_ifft2_crop_kernel": "tike_grad_ifft2_crop",
+    "void ifft2_crop_v2_kernel": "tike_ifft2_crop_scaled",
+    "void probe_grad_kernel<true": "tike_lstsq_gradients",
+    "void step_stats_kernel": "tike_lstsq_step_stats",
+    "scatter_patches_kernel": "tike_scatter_patches",
+    "void gradient_scale_kernel": "tike_gradient_scale",
+    "psi_precond_kernel": "tike_psi_preconditioner",
+    "eigen_position_sums_kernel": "tike_eigen_position_sums",
+    "eigen_pixel_update_kernel": "tike_eigen_pixel_update",
+    "varying_probe_kernel": "tike_varying_probe",
+    "position_sums_kernel": "tike_position_sums",
+}
+
+
+def collect(d, counter):
+    rows = collections.defaultdict(list)  # entry -> [(grid, value)]
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            for prefix, entry in KERNELS.items():
+                if r["Kernel_Name"].startswith(prefix):
+                    rows[entry].append((int(r["Grid_Size"]),
+                                        float(r["Counter_Value"])))
+    out = {}
+    for entry, v in rows.items():
+        g = max(x[0] for x in v)
+        vals = [x[1] for x in v if x[0] == g]
+        out[entry] = (sum(vals) / len(vals), len(vals))
+    return out
+
+
+def main():
+    fetch_dir, write_dir, workload, n, out = sys.argv[1:6]
+    fetch = collect(fetch_dir, "FETCH_SIZE")
+    write = collect(write_dir, "WRITE_SIZE")
+    doc = {
+        "workload": workload,
+        "positions_per_launch": int(n),
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
+                "`python3 bench.py --no-cpu-baseline --steps 1 --warmup 0`, "
+                "averaged over the launches with the largest grid (the timed "
+                "epoch); hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: "
+                "FETCH_SIZE counts 64 B per 128-B request)",
+        "kernels": {},
+    }
+    for entry in sorted(set(fetch) & set(write)):
+        f, nf = fetch[entry]
+        w, _ = write[entry]
+        doc["kernels"][entry] = {
+            "fetch_kib_per_launch": f,
+            "write_kib_per_launch": w,
+            "launches": nf,
+            "hbm_bytes_per_launch": (2 * f + w) * 1024,
+        }
+    json.dump(doc, open(out, "w"), indent=1)
+    for k, v in doc["kernels"].items():
+        print(f"{k:34s} read {2*v['fetch_kib_per_launch']/1048576:7.2f} GiB  "
+              f"write {v['write_kib_per_launch']/1048576:7.2f} GiB")
+
+
+if __name__ == "__main__":
+    main()
