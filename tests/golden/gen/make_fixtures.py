@@ -262,7 +262,7 @@ lstsq_parts("eigen", N=24, pw=16, det=24, S=3, eigen=2)
 def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
           adaptive=False, orth=False, rng=None, noise_model="gaussian",
           usemodes="all_modes", mask_frac=0.0, scaling=1.0, positions=None,
-          position_error=0.0, psi_true_start=False):
+          position_error=0.0, psi_true_start=False, algo="lstsq"):
     rng = globals()["rng"] if rng is None else rng
     p = make_problem(rng, N, pw, det, S, eigen=eigen,
                      margin=8 if positions else 0,
@@ -287,7 +287,8 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
         p["eigen_probe"].copy(),
         eigen_weights=None if p["eigen_weights"] is None else
         p["eigen_weights"].copy(),
-        algorithm_options=tike.ptycho.LstsqOptions(
+        algorithm_options=(tike.ptycho.RpieOptions if algo == "rpie" else
+                           tike.ptycho.LstsqOptions)(
             num_batch=num_batch, batch_method=batch_method, num_iter=epochs),
         probe_options=tike.ptycho.ProbeOptions(
             force_orthogonality=orth, use_adaptive_moment=adaptive),
@@ -333,7 +334,7 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
             position_keys=np.array(sorted(positions)),
             position_vals=np.array([float(positions[k])
                                     for k in sorted(positions)]))
-    save(f"lstsq_recon_{tag}.npz", data=p["data"], psi0=p["psi0"],
+    save(f"{algo}_recon_{tag}.npz", data=p["data"], psi0=p["psi0"],
          probe0=p["probe0"], scan=p["scan"], det=det, order=order,
          batch_sizes=np.array([len(b) for b in batches]), order_2=order_2,
          batch_sizes_2=np.array([len(b) for b in batches_2]),
@@ -411,3 +412,9 @@ recon("positions_adam", N=36, pw=24, det=24, S=2, eigen=0, num_batch=2,
 recon("positions_plain", N=30, pw=16, det=32, S=1, eigen=0, num_batch=3,
       batch_method="wobbly_center", epochs=3, rng=rng_q,
       positions=dict(), position_error=0.7, psi_true_start=True)
+
+
+# rpie is NOT pinned: at this snapshot the reference's own
+# rpie diverges on these problems (costs 0.024 -> 0.69 -> 41 -> ...; NaN with
+# eigen probes), so its iterates are no usable golden vectors.
+# recon(..., algo="rpie") reproduces that observation.
