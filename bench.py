@@ -205,7 +205,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
-    if world > 1:
+    # TIKE_FORCE_COLLECTIVES=1 (under torchrun --nproc-per-node 1) issues the
+    # RCCL collectives of the multi-GPU path on a single rank: a dry run of
+    # that path on a one-GPU box
+    forced = (os.environ.get("TIKE_FORCE_COLLECTIVES") == "1"
+              and "MASTER_ADDR" in os.environ)
+    if world > 1 or forced:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import tike_amd._arrays as A
@@ -369,7 +374,7 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

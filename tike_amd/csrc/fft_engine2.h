@@ -167,11 +167,7 @@ __device__ __forceinline__ void fft2_pass1(cf* __restrict__ lds, const cf* __res
   for (int k1 = 0; k1 < 16; ++k1) {
     cf o = v[k1];
     if (k1 > 0) o = mul_tw<INV>(o, twtab[N + r * k1]);  // uniform address -> scalar load
-#ifdef TK_NT_MIDST
-    tk_st_stream(mid + (16 * r + k1) * N + t, o);
-#else
     mid[(16 * r + k1) * N + t] = o;
-#endif
   }
 }
 
@@ -183,13 +179,7 @@ __device__ __forceinline__ void fft2_pass2(const cf* __restrict__ mid, int k1, S
   const int t = threadIdx.x;
   cf u[G2::RB];
 #pragma unroll
-  for (int r = 0; r < G2::RB; ++r) {
-#ifdef TK_NT_MID
-    u[r] = tk_ld_stream(mid + (16 * r + k1) * N + t);
-#else
-    u[r] = mid[(16 * r + k1) * N + t];
-#endif
-  }
+  for (int r = 0; r < G2::RB; ++r) u[r] = mid[(16 * r + k1) * N + t];
   Dft<G2::RB, INV>::run(u);
 #pragma unroll
   for (int k2 = 0; k2 < G2::RB; ++k2) store(k1 + 16 * k2, t, u[k2]);

@@ -540,7 +540,7 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_k
 template <int N, int MODE>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop_v2_kernel(
     const cf* __restrict__ farplane, cf* work, cf* chi, long ntile, int pw, float scale,
-    const cf* __restrict__ twtab, const float* __restrict__ gscale, int S, int wg_scratch,
+    const cf* __restrict__ twtab, const float* __restrict__ gscale, int S,
     const float* __restrict__ mode_scale, const unsigned char* __restrict__ measured) {
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
   const int pad = (N - pw) / 2;
   for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const cf* __restrict__ src = farplane + tile * (long)N * N;
-    cf* mid = work + (wg_scratch ? (long)blockIdx.x : tile) * (long)N * N;
+    cf* mid = work + tile * (long)N * N;
     cf* dst = chi + tile * (long)pw * pw;
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
@@ -587,11 +587,10 @@ static int launch_icrop_v2(const cf* far, cf* work, cf* chi, long ntile, int pw,
                            const unsigned char* measured = nullptr) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
-  static const int wg_scratch = getenv("TIKE_WG_SCRATCH") != nullptr;
 #define TK_ICROP(MODE)                                                                        \
   hipLaunchKernelGGL((ifft2_crop_v2_kernel<N, MODE>), dim3(tk_grid(ntile, 4)), dim3(N), 0,    \
-                     stream, far, work, chi, ntile, pw, scale, tw, gscale, S,                 \
-                     wg_scratch && work != chi, mode_scale, measured)
+                     stream, far, work, chi, ntile, pw, scale, tw, gscale, S, mode_scale,    \
+                     measured)
   if (gscale && mode_scale)
     TK_ICROP(2);
   else if (gscale)
