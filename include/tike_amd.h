@@ -201,7 +201,9 @@ int tike_lstsq_gradients(const void* chi, const float* scan, const void* psi, co
 /* acc (2,H,W) f32, PLANAR (real plane, imaginary plane) += scatter_n( objproj_n ):
  * the adjoint of the bilinear patch gather (Patch.adj, patch.py:132-188) with
  * one atomic per object pixel and position.  Positions must satisfy
- * check_allowed_positions (position.py:600-628). */
+ * check_allowed_positions (position.py:600-628). 
+ * Consecutive positions that are spatial neighbours (spread <= 112 px) are
+ * summed on chip first, 8 at a time; any order gives the same sums. */
 int tike_scatter_patches(const void* objproj, const float* scan, float* acc, int nscan, int pw,
                          int H, int W, void* stream);
 

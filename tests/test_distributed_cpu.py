@@ -82,6 +82,7 @@ def _shard(rank, world):
     rec._parameters_in = params
     rec._presharded = False
     rec._order_in = rec._batches_in = None
+    rec._spatial_sort = True
     rec.comm = Comm()
     order, local, batches = rec._shard(N)
     return order, local, [b.tolist() for b in batches]

@@ -445,3 +445,50 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
             A.ptr(chi3), N * S, det, pw, 1.0 / det, st))
         assert_close(chi2.cpu().numpy(), chi3.cpu().numpy(), normwise=1e-5,
                      maxabs=1e-4, what="chi with mode steps")
+
+
+@pytest.mark.parametrize("layout", ["neighbours", "far_apart", "tall_group",
+                                    "border", "ragged"])
+def test_grouped_footprint_scatter(oracle, layout):
+    """tike_scatter_patches / tike_psi_preconditioner == Patch.adj (oracle) for
+    position lists that take the on-chip grouped path (neighbours), the
+    per-position fallback (far apart / tall boxes), image-border positions and
+    a count that is not a multiple of the group size."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import lib, check
+    rng = np.random.default_rng(7)
+    pw, H, W = 48, 400, 380
+    if layout == "neighbours":
+        scan = 60 + rng.random((24, 2)) * 40
+    elif layout == "far_apart":
+        scan = 1 + rng.random((24, 2)) * np.array([H - pw - 3, W - pw - 3])
+    elif layout == "tall_group":  # narrow in x, spread in y beyond the box
+        scan = np.stack([1 + rng.random(16) * (H - pw - 3),
+                         100 + rng.random(16) * 10], -1)
+    elif layout == "border":
+        scan = np.array([[1.0, 1.0], [1.5, 2.25], [H - pw - 1.5, W - pw - 1.25],
+                         [H - pw - 2.0, W - pw - 2.0], [1.25, W - pw - 1.5]])
+    else:
+        scan = 30 + rng.random((13, 2)) * 60
+    scan = scan.astype(np.float32)
+    N = len(scan)
+    proj = rc(rng, N, pw, pw)
+    want = oracle.patch_adj(patches=proj, images=np.zeros((H, W), np.complex64),
+                            positions=scan, nrepeat=1)
+    acc = torch.zeros((2, H, W), dtype=torch.float32, device="cuda")
+    proj_d, scan_d = A.to_device(proj), A.to_device(scan)  # keep alive
+    check(lib.tike_scatter_patches(A.ptr(proj_d), A.ptr(scan_d), A.ptr(acc), N,
+                                   pw, H, W, A.stream_ptr()))
+    got = (acc[0] + 1j * acc[1]).cpu().numpy()
+    assert_close(got, want, normwise=2e-6, maxabs=1e-5, what="object scatter")
+    amp = rng.random((pw, pw)).astype(np.float32)
+    wantp = oracle.patch_adj(
+        patches=np.broadcast_to(amp.astype(np.complex64), (N, pw, pw)).copy(),
+        images=np.zeros((H, W), np.complex64), positions=scan, nrepeat=1)
+    out = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+    amp_d = A.to_device(amp)
+    check(lib.tike_psi_preconditioner(A.ptr(amp_d), A.ptr(scan_d), A.ptr(out),
+                                      N, pw, H, W, A.stream_ptr()))
+    assert_close(out.cpu().numpy(), wantp.real, normwise=2e-6, maxabs=1e-5,
+                 what="psi preconditioner")

@@ -131,3 +131,32 @@ def batches_contiguous(scan, batch_method, num_batch):
     order = np.concatenate(groups)
     breaks = np.cumsum([len(g) for g in groups])[:-1]
     return order, np.array_split(np.arange(len(order)), breaks)
+
+
+def spatial_order(scan, leaf=8):
+    """Permutation that lists positions leaf by leaf of a k-d tree (median
+    splits along the longer side, every leaf exactly `leaf` positions except
+    the last), so that each run of `leaf` consecutive positions is a compact
+    spatial cluster.  The grouped footprint scatter (tike_scatter_patches,
+    tike_psi_preconditioner) sums `leaf` consecutive positions on chip before
+    it touches the object; the order changes no result beyond summation
+    order."""
+    scan = np.asarray(scan, dtype=np.float64)
+    out = []
+
+    def split(idx):
+        n = len(idx)
+        if n <= leaf:
+            out.append(idx)
+            return
+        pts = scan[idx]
+        axis = int(np.argmax(np.ptp(pts, axis=0)))
+        m = ((n + leaf - 1) // leaf // 2) * leaf  # whole leaves on the left
+        part = np.argpartition(pts[:, axis], m - 1)
+        split(idx[part[:m]])
+        split(idx[part[m:]])
+
+    if len(scan):
+        split(np.arange(len(scan)))
+        return np.concatenate(out)
+    return np.zeros(0, dtype=np.int64)

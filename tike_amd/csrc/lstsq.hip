@@ -34,13 +34,11 @@ constexpr int TK_STRIP = 32;
 // The accumulation image is PLANAR (all real parts, then all imaginary parts):
 // one atomic wave-instruction then covers 256 contiguous bytes, the shape that
 // runs at the full atomic rate (interleaved complex halves it).
-template <bool REAL_ONLY, class ValueFn>
-__device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorner& c,
-                                                  float fx, float fy, float* __restrict__ re,
-                                                  float* __restrict__ im, int pw, int H, int W,
-                                                  int strip) {
-  const int r0 = strip * TK_STRIP;
-  const int r1 = min(pw + 1, r0 + TK_STRIP);  // rows y' in [r0, r1)
+// `sink(yp, xp, re, im)` receives the footprint value of row y' = yp, column
+// x' = xp (0 <= yp, xp <= pw); rows y' in [r0, r1) are produced.
+template <bool REAL_ONLY, class ValueFn, class Sink>
+__device__ __forceinline__ void scatter_footprint_rows(ValueFn&& value, float fx, float fy,
+                                                       int pw, int r0, int r1, Sink&& sink) {
   for (int x0 = 0; x0 < pw; x0 += blockDim.x) {
     const int xp = x0 + threadIdx.x;  // column x' (also the patch column)
     const bool active = xp < pw;
@@ -82,21 +80,11 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
         // the thread owning the last patch column also produces column x' = pw
         const cf ulast = mk(fx * v.x, fx * v.y);
         if (yp >= r0 && active) {
-          const int Y = c.sy + yp;
-          if (Y >= 0 && Y < H) {
-            const int X = c.sx + xp;
-            if (X >= 0 && X < W) {
-              const long ii = (long)Y * W + X;
-              TK_ATOMIC_ADD(&re[ii], (1.0f - fy) * u.x + fy * uprev.x);
-              if (!REAL_ONLY) TK_ATOMIC_ADD(&im[ii], (1.0f - fy) * u.y + fy * uprev.y);
-            }
-            if (xp == pw - 1 && X + 1 >= 0 && X + 1 < W) {
-              const long ii = (long)Y * W + X + 1;
-              TK_ATOMIC_ADD(&re[ii], (1.0f - fy) * ulast.x + fy * uprev_last.x);
-              if (!REAL_ONLY)
-                TK_ATOMIC_ADD(&im[ii], (1.0f - fy) * ulast.y + fy * uprev_last.y);
-            }
-          }
+          sink(yp, xp, (1.0f - fy) * u.x + fy * uprev.x,
+               REAL_ONLY ? 0.f : (1.0f - fy) * u.y + fy * uprev.y);
+          if (xp == pw - 1)
+            sink(yp, pw, (1.0f - fy) * ulast.x + fy * uprev_last.x,
+                 REAL_ONLY ? 0.f : (1.0f - fy) * ulast.y + fy * uprev_last.y);
         }
         uprev = u;
         uprev_last = ulast;
@@ -110,6 +98,126 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
   }
 }
 
+// One position, one strip of TK_STRIP rows, straight to the image by atomics.
+template <bool REAL_ONLY, class ValueFn>
+__device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorner& c,
+                                                  float fx, float fy, float* __restrict__ re,
+                                                  float* __restrict__ im, int pw, int H, int W,
+                                                  int strip) {
+  const int r0 = strip * TK_STRIP;
+  const int r1 = min(pw + 1, r0 + TK_STRIP);  // rows y' in [r0, r1)
+  scatter_footprint_rows<REAL_ONLY>(value, fx, fy, pw, r0, r1,
+                                    [&](int yp, int xp, float vr, float vi) {
+                                      const int Y = c.sy + yp, X = c.sx + xp;
+                                      if (Y >= 0 && Y < H && X >= 0 && X < W) {
+                                        const long ii = (long)Y * W + X;
+                                        TK_ATOMIC_ADD(&re[ii], vr);
+                                        if (!REAL_ONLY) TK_ATOMIC_ADD(&im[ii], vi);
+                                      }
+                                    });
+}
+
+// ------------------------------------------- grouped footprint scatter-add
+// Footprints of neighbouring scan positions overlap almost entirely (pw =
+// 256 against a pitch of tens of pixels), so TK_GROUP CONSECUTIVE positions
+// are summed in LDS first -- over the bounding box of their footprints, one
+// strip of TK_GROWS image rows per workgroup -- and the image then takes ONE
+// atomic per box pixel instead of one per position and pixel.  The caller
+// orders positions so that consecutive ones are neighbours (the solver sorts
+// every minibatch spatially); a group whose box is wider than the LDS strip
+// falls back to the per-position atomics, so any order gives the same sums.
+constexpr int TK_GROUP = 8;
+constexpr int TK_GROWS = 16;    // image rows per workgroup
+constexpr int TK_GSPREAD = 112;  // extra box width and height beyond one footprint
+
+struct TkGroupBox {
+  int ymin, ymax, xmin, xmax;  // inclusive image bounds of the union footprint
+};
+
+__device__ __forceinline__ TkGroupBox tk_group_box(const float* __restrict__ scan, long n0,
+                                                   long n1, int pw) {
+  TkGroupBox b = {1 << 30, -(1 << 30), 1 << 30, -(1 << 30)};
+  for (long n = n0; n < n1; ++n) {
+    const int sy = (int)floorf(scan[2 * n]), sx = (int)floorf(scan[2 * n + 1]);
+    b.ymin = min(b.ymin, sy);
+    b.ymax = max(b.ymax, sy + pw);
+    b.xmin = min(b.xmin, sx);
+    b.xmax = max(b.xmax, sx + pw);
+  }
+  return b;
+}
+
+// value(n, y, x): patch value of position n.  lds: TK_GROWS * wmax floats per plane.
+template <bool REAL_ONLY, class ValueFn>
+__device__ __forceinline__ void scatter_group(ValueFn&& value, const float* __restrict__ scan,
+                                              long n0, long n1, int strip, float* lds, int wmax,
+                                              float* __restrict__ re, float* __restrict__ im,
+                                              int pw, int H, int W) {
+  const TkGroupBox b = tk_group_box(scan, n0, n1, pw);
+  const int wb = b.xmax - b.xmin + 1;
+  const int hb = b.ymax - b.ymin + 1;
+  const int nstrip_direct = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
+  if (wb > wmax || hb > pw + 1 + TK_GSPREAD) {
+    // positions too far apart for one LDS strip: per-position atomics; the
+    // first workgroups of the group share the (position, strip) items
+    const int nwg = (pw + 1 + TK_GSPREAD + TK_GROWS - 1) / TK_GROWS;
+    for (long w = strip; w < (n1 - n0) * nstrip_direct; w += nwg) {
+      const long n = n0 + w / nstrip_direct;
+      const TkCorner c = tk_corner(scan, n);
+      const float fy = scan[2 * n] - floorf(scan[2 * n]);
+      const float fx = scan[2 * n + 1] - floorf(scan[2 * n + 1]);
+      scatter_footprint<REAL_ONLY>([&](int y, int x) { return value(n, y, x); }, c, fx, fy, re,
+                                   im, pw, H, W, (int)(w % nstrip_direct));
+    }
+    return;
+  }
+  const int Y0 = b.ymin + strip * TK_GROWS;
+  if (Y0 > b.ymax) return;
+  const int Y1 = min(b.ymax + 1, Y0 + TK_GROWS);
+  float* lre = lds;
+  float* lim = lds + TK_GROWS * wmax;
+  const int cells = TK_GROWS * wmax;
+  for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+    lre[i] = 0.f;
+    if (!REAL_ONLY) lim[i] = 0.f;
+  }
+  __syncthreads();
+  for (long n = n0; n < n1; ++n) {
+    const float py = scan[2 * n], px = scan[2 * n + 1];
+    const int sy = (int)floorf(py), sx = (int)floorf(px);
+    const float fy = py - floorf(py), fx = px - floorf(px);
+    const int r0 = max(0, Y0 - sy), r1 = min(pw + 1, Y1 - sy);  // rows y' of this strip
+    if (r0 < r1) {
+      const int xoff = sx - b.xmin;
+      scatter_footprint_rows<REAL_ONLY>(
+          [&](int y, int x) { return value(n, y, x); }, fx, fy, pw, r0, r1,
+          [&](int yp, int xp, float vr, float vi) {
+            const int cell = (sy + yp - Y0) * wmax + xoff + xp;
+            lre[cell] += vr;
+            if (!REAL_ONLY) lim[cell] += vi;
+          });
+    }
+    __syncthreads();  // the next position maps columns to other threads
+  }
+  for (int i = threadIdx.x; i < (Y1 - Y0) * wb; i += blockDim.x) {
+    const int ry = i / wb, rx = i % wb;
+    const int Y = Y0 + ry, X = b.xmin + rx;
+    if (Y < 0 || Y >= H || X < 0 || X >= W) continue;
+    const float vr = lre[ry * wmax + rx];
+    const long ii = (long)Y * W + X;
+    if (REAL_ONLY) {
+      if (vr != 0.f) TK_ATOMIC_ADD(&re[ii], vr);
+    } else {
+      const float vi = lim[ry * wmax + rx];
+      if (vr != 0.f || vi != 0.f) {
+        TK_ATOMIC_ADD(&re[ii], vr);
+        TK_ATOMIC_ADD(&im[ii], vi);
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ----------------------------------------------------------- object gradient
 // acc (2,H,W) planar f32 += scatter_n( objproj_n ),  objproj (nscan,pw,pw) c64 =
 // sum_s conj(P_n,s) chi_n,s  computed by tike_lstsq_gradients
@@ -117,20 +225,21 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
 __global__ __launch_bounds__(256) void scatter_patches_kernel(const cf* __restrict__ proj,
                                                               const float* __restrict__ scan,
                                                               float* __restrict__ acc, int nscan,
-                                                              int pw, int H, int W) {
-  const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
+                                                              int pw, int H, int W, int wmax) {
+  extern __shared__ float tk_scatter_lds[];
   const long P = (long)pw * pw;
   float* __restrict__ re = acc;
   float* __restrict__ im = acc + (long)H * W;
-  for (long w = blockIdx.x; w < (long)nscan * nstrip; w += gridDim.x) {
-    const long n = w / nstrip;
-    const int strip = (int)(w % nstrip);
-    const TkCorner c = tk_corner(scan, n);
-    const float fy = scan[2 * n] - floorf(scan[2 * n]);
-    const float fx = scan[2 * n + 1] - floorf(scan[2 * n + 1]);
-    scatter_footprint<false>([&](int y, int x) { return proj[n * P + (long)y * pw + x]; }, c, fx,
-                             fy, re, im, pw, H, W, strip);
-  }
+  const long g = blockIdx.y;
+  const long n0 = g * TK_GROUP, n1 = min((long)nscan, n0 + TK_GROUP);
+  scatter_group<false>([&](long n, int y, int x) { return proj[n * P + (long)y * pw + x]; },
+                       scan, n0, n1, blockIdx.x, tk_scatter_lds, wmax, re, im, pw, H, W);
+}
+
+// (strips per group, LDS width) of the grouped scatter for a probe width
+static inline void tk_group_geometry(int pw, int* nstrip, int* wmax) {
+  *wmax = pw + 1 + TK_GSPREAD;
+  *nstrip = (pw + 1 + TK_GSPREAD + TK_GROWS - 1) / TK_GROWS;
 }
 
 extern "C" int tike_scatter_patches(const void* objproj, const float* scan, float* acc,
@@ -139,9 +248,18 @@ extern "C" int tike_scatter_patches(const void* objproj, const float* scan, floa
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(objproj && scan && acc);
-  const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
-  hipLaunchKernelGGL(scatter_patches_kernel, dim3(tk_grid((long)nscan * nstrip, 16)), dim3(256),
-                     0, (hipStream_t)stream, (const cf*)objproj, scan, acc, nscan, pw, H, W);
+  int nstrip, wmax;
+  tk_group_geometry(pw, &nstrip, &wmax);
+  const size_t lds = sizeof(float) * 2 * TK_GROWS * wmax;
+  TK_CHECK_ARG(lds <= 160 * 1024);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)scatter_patches_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const dim3 grid(nstrip, (nscan + TK_GROUP - 1) / TK_GROUP);
+  hipLaunchKernelGGL(scatter_patches_kernel, grid, dim3(256), lds, (hipStream_t)stream,
+                     (const cf*)objproj, scan, acc, nscan, pw, H, W, wmax);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -152,18 +270,12 @@ extern "C" int tike_scatter_patches(const void* objproj, const float* scan, floa
 __global__ __launch_bounds__(256) void psi_precond_kernel(const float* __restrict__ amp,
                                                           const float* __restrict__ scan,
                                                           float* __restrict__ out, int nscan,
-                                                          int pw, int H, int W) {
-  const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
-  for (long w = blockIdx.x; w < (long)nscan * nstrip; w += gridDim.x) {
-    const long n = w / nstrip;
-    const int strip = (int)(w % nstrip);
-    const TkCorner c = tk_corner(scan, n);
-    const float fy = scan[2 * n] - floorf(scan[2 * n]);
-    const float fx = scan[2 * n + 1] - floorf(scan[2 * n + 1]);
-    scatter_footprint<true>(
-        [&](int y, int x) { return mk(amp[(long)y * pw + x], 0.f); }, c, fx, fy, out, out, pw, H,
-        W, strip);
-  }
+                                                          int pw, int H, int W, int wmax) {
+  extern __shared__ float tk_scatter_lds[];
+  const long g = blockIdx.y;
+  const long n0 = g * TK_GROUP, n1 = min((long)nscan, n0 + TK_GROUP);
+  scatter_group<true>([&](long, int y, int x) { return mk(amp[(long)y * pw + x], 0.f); }, scan,
+                      n0, n1, blockIdx.x, tk_scatter_lds, wmax, out, out, pw, H, W);
 }
 
 extern "C" int tike_psi_preconditioner(const float* probe_amp, const float* scan, void* out,
@@ -172,9 +284,18 @@ extern "C" int tike_psi_preconditioner(const float* probe_amp, const float* scan
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(probe_amp && scan && out);
-  const int nstrip = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
-  hipLaunchKernelGGL(psi_precond_kernel, dim3(tk_grid((long)nscan * nstrip, 16)), dim3(256), 0,
-                     (hipStream_t)stream, probe_amp, scan, (float*)out, nscan, pw, H, W);
+  int nstrip, wmax;
+  tk_group_geometry(pw, &nstrip, &wmax);
+  const size_t lds = sizeof(float) * TK_GROWS * wmax;
+  TK_CHECK_ARG(lds <= 160 * 1024);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)psi_precond_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const dim3 grid(nstrip, (nscan + TK_GROUP - 1) / TK_GROUP);
+  hipLaunchKernelGGL(psi_precond_kernel, grid, dim3(256), lds, (hipStream_t)stream, probe_amp,
+                     scan, (float*)out, nscan, pw, H, W, wmax);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -117,10 +117,14 @@ class Reconstruction():
         contiguous splits of the local arrays.
       order, batches: inject a precomputed position order and batch split
         (parity tests replay the reference's clustering this way).
+      spatial_sort: list the positions of every minibatch along a Z-order
+        curve (default) so that the grouped scatter kernels find neighbours
+        next to each other; results change only by summation order.
     """
 
     def __init__(self, data, parameters, num_gpu=1, use_mpi=False, *,
-                 presharded=False, order=None, batches=None):
+                 presharded=False, order=None, batches=None,
+                 spatial_sort=True):
         if (np.any(np.asarray(data.shape) < 1) or data.ndim != 3
                 or data.shape[-2] != data.shape[-1]):
             raise ValueError(
@@ -155,6 +159,7 @@ class Reconstruction():
         self._presharded = presharded
         self._order_in = order
         self._batches_in = batches
+        self._spatial_sort = spatial_sort
         self.operator = Ptycho(
             probe_shape=parameters.probe.shape[-1],
             detector_shape=data.shape[-1],
@@ -184,6 +189,15 @@ class Reconstruction():
         else:
             order, batches = cluster.batches_contiguous(
                 scan_host, o.batch_method, o.num_batch)
+        if self._spatial_sort:
+            # neighbours in space become neighbours in memory inside every
+            # minibatch (see cluster.spatial_order); batch membership and
+            # therefore every sum over a batch is unchanged
+            order = np.array(order, copy=True)
+            for b in batches:
+                if len(b) > 1:
+                    idx = order[b]
+                    order[b] = idx[cluster.spatial_order(scan_host[idx])]
         if self._presharded or self.comm.size == 1:
             return order, order, batches
         # split every global batch evenly (contiguously) over the ranks
