@@ -237,13 +237,17 @@ int tike_probe_preconditioner(const float* scan, const void* psi, void* out, int
  * (nscan, chi_modes, pw, pw) and only its mode 0 is read (chi_modes = 1 when
  * the caller kept just that mode). 
  * patches (nscan,pw,pw), if not NULL, holds patch_n(psi) as stored by
- * tike_lstsq_gradients and replaces the bilinear gather of psi. */
+ * tike_lstsq_gradients and replaces the bilinear gather of psi.
+ * eigen_proj (nscan) f32, if not NULL, receives sum Re(conj(R_n) E) with
+ * R_n = conj(O_n) chi_n,0 - m_probe_update[0] and E = eigen0 (pw,pw) c64: the
+ * first sum of tike_eigen_position_sums for the first eigen probe, for free. */
 int tike_lstsq_step_stats(const void* chi, const float* scan, const void* psi,
                           const void* object_update_precond, const void* probe,
                           const void* eigen_probe, const float* eigen_weights, int num_eigen,
                           int eigen_modes, const void* unique_probe, const void* m_probe_update,
                           const void* patches, float* stats, int nscan, int S, int chi_modes,
-                          int pw, int H, int W, void* stream);
+                          int pw, int H, int W, const void* eigen0, float* eigen_proj,
+                          void* stream);
 
 /* out (nscan, eigen_modes, pw, pw) = weights[n][0][s]*probe[s] +
  * sum_c weights[n][c+1][s]*eigen[c][s]: the varying probe of the modes that

@@ -78,7 +78,7 @@ _PROTOTYPES = {
     "tike_probe_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_psi_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_lstsq_step_stats": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p,
-                              _p, _i, _i, _i, _i, _i, _i, _p],
+                              _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
 }
 
 

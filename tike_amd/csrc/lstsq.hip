@@ -492,13 +492,14 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
     const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
     const cf* __restrict__ gobj, const TkProbe probe, const cf* __restrict__ mpu,
     const cf* __restrict__ patches, float* __restrict__ stats, int nscan, int chi_modes, int pw,
-    int H, int W) {
+    int H, int W, const cf* __restrict__ eigen0, float* __restrict__ eigen_proj) {
   __shared__ float red[4];
   const long P = (long)pw * pw;
   const long total = (long)H * W;
   for (int n = blockIdx.x; n < nscan; n += gridDim.x) {
     const TkCorner c = tk_corner(scan, n);
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ep = 0.f;  // sum Re(conj(R_n) E_0), R_n = conj(O_n) chi_n,0 - mpu_0
     // branch-free body (clamped addresses, results zeroed by select) so that
     // the loads of two pixels are in flight together
 #pragma unroll 2
@@ -529,11 +530,20 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
       a[5] += dPO.x * x0.x + dPO.y * x0.y;
       a[6] += OP.x * x0.x + OP.y * x0.y;
       a[7] += norm2(OP);
+      if (eigen_proj) {
+        const cf r = conjf(o) * x0 - mpu[p];
+        const cf e = eigen0[p];
+        ep += r.x * e.x + r.y * e.y;
+      }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float v = tk_block_sum256(a[k], red);
       if (threadIdx.x == 0) stats[(long)n * 8 + k] = v;
+    }
+    if (eigen_proj) {
+      const float v = tk_block_sum256(ep, red);
+      if (threadIdx.x == 0) eigen_proj[n] = v;
     }
   }
 }
@@ -544,18 +554,20 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
                                      int num_eigen, int eigen_modes, const void* unique_probe,
                                      const void* m_probe_update, const void* patches,
                                      float* stats, int nscan, int S, int chi_modes, int pw, int H,
-                                     int W, void* stream) {
+                                     int W, const void* eigen0, float* eigen_proj, void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && chi_modes >= 1 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(chi && scan && psi && probe && stats);
+  TK_CHECK_ARG(!eigen_proj || (eigen0 && m_probe_update));
   const TkProbe pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
                                    S, pw, unique_probe);
 #define TK_SS(HP, HG)                                                                         \
   hipLaunchKernelGGL((step_stats_kernel<HP, HG>), dim3(tk_grid(nscan, 16)), dim3(256), 0,     \
                      (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,               \
                      (const cf*)object_update_precond, pr, (const cf*)m_probe_update,         \
-                     (const cf*)patches, stats, nscan, chi_modes, pw, H, W)
+                     (const cf*)patches, stats, nscan, chi_modes, pw, H, W, (const cf*)eigen0, \
+                     eigen_proj)
   if (patches && object_update_precond) TK_SS(true, true);
   else if (patches) TK_SS(true, false);
   else if (object_update_precond) TK_SS(false, true);

@@ -485,6 +485,15 @@ def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
     S, pw = probe.shape[-3], probe.shape[-1]
     stats = _workspace(op).get("stats", (max(B, 1), 8), torch.float32, dev)
     ep, w_old, C, Sm = _eigen_args(eigen_probe, g["w_old"])
+    # the eigen-probe update starts with the projection of every position's
+    # residual onto the first eigen probe: same operands as this pass
+    eigen0 = eproj = None
+    if (ep is not None and C >= 1 and Sm >= 1 and g["patches"] is not None
+            and g["m_probe_update"] is not None):
+        eigen0 = ep[0, 0, 0]
+        eproj = _workspace(op).get("eigen_proj", (max(B, 1),), torch.float32,
+                                   dev)
+    g["eigen_proj"] = None if eproj is None else eproj[:B]
     check(
         lib.tike_lstsq_step_stats(
             A.ptr(g["chi0"]), A.ptr(scan[lo:hi]), A.ptr(psi),
@@ -492,7 +501,7 @@ def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
             A.ptr(w_old), C, Sm, None, A.ptr(g["m_probe_update"]),
             A.ptr(g["patches"]), A.ptr(stats), B,
             S, g["chi_modes"], pw, psi.shape[-2], psi.shape[-1],
-            A.stream_ptr()),
+            A.ptr(eigen0), A.ptr(eproj), A.stream_ptr()),
         "step-size statistics")
     return stats[:B]
 
@@ -569,8 +578,11 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
         # a batch whose weights are all zero would divide by zero; the
         # reference raises ValueError after a host sync (probe.py:426) --
         # here the symptom is deferred to the epoch cost (NaN).
-        s = position_sums(c - 1)
-        proj_mean = ((s[:, 0] / P + w) / norm_weights).contiguous()
+        if c == 1 and g.get("eigen_proj") is not None:
+            first = g["eigen_proj"]  # formed by the step-statistics pass
+        else:
+            first = position_sums(c - 1)[:, 0]
+        proj_mean = ((first / P + w) / norm_weights).contiguous()
         update = torch.zeros((pw, pw), dtype=torch.complex64, device=dev)
         check(
             lib.tike_eigen_pixel_update(A.ptr(patches), A.ptr(chi0),

@@ -47,7 +47,7 @@ rows = [
     ("scatter_patches", lambda: check(lib.tike_scatter_patches(proj.data_ptr(), scan.data_ptr(), acc.data_ptr(), N, pw, HW, HW, st)), N * pw * pw * 8 / 1e9),
     ("probe_grad", lambda: check(lib.tike_probe_grad(chi.data_ptr(), scan.data_ptr(), psi.data_ptr(), None, mpu.data_ptr(), N, S, pw, HW, HW, st)), gb),
     ("farplane_gradient", lambda: check(lib.tike_farplane_gradient(chi.data_ptr(), data.data_ptr(), None, None, costs.data_ptr(), N, S, pw, 0, 1, 1.0, pw * pw, st)), 2 * gb),
-    ("step_stats", lambda: check(lib.tike_lstsq_step_stats(chi.data_ptr(), scan.data_ptr(), psi.data_ptr(), obj.data_ptr(), probe.data_ptr(), None, None, 0, 0, None, mpu.data_ptr(), None, stats.data_ptr(), N, S, S, pw, HW, HW, st)), N * pw * pw * 8 / 1e9),
+    ("step_stats", lambda: check(lib.tike_lstsq_step_stats(chi.data_ptr(), scan.data_ptr(), psi.data_ptr(), obj.data_ptr(), probe.data_ptr(), None, None, 0, 0, None, mpu.data_ptr(), None, stats.data_ptr(), N, S, S, pw, HW, HW, None, None, st)), N * pw * pw * 8 / 1e9),
     ("psi_precond", lambda: check(lib.tike_psi_preconditioner(amp.data_ptr(), scan.data_ptr(), acc.data_ptr(), N, pw, HW, HW, st)), 0),
 ]
 for name, fn, g in rows:
