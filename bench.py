@@ -158,6 +158,10 @@ def algorithmic_bytes(name, n, S, det, pw, C):
     T = 8 * S * det * det  # one position's far-plane, bytes
     if name == "tike_ptycho_fwd":
         return n * (T + 8 * pw * pw + 8) + 8 * (S + C) * pw * pw
+    if name == "tike_ptycho_fwd_gradient_scale":
+        # as below, plus the data read and the gradient-factor write in
+        # place of the intensity write
+        return n * (T + 8 * pw * pw + 2 * 4 * det * det + 8) + 8 * (S + C) * pw * pw
     if name in ("tike_ptycho_fwd_intensity", "tike_ptycho_fwd_intensity_only"):
         # the intensity-only form hands a far-plane-sized array (the input of
         # its column pass) to tike_grad_ifft2_crop instead of the far plane
@@ -223,6 +227,7 @@ def main():
         "tike_ptycho_fwd", "tike_farplane_gradient", "tike_ifft2_crop",
         "tike_ptycho_fwd_intensity", "tike_gradient_scale",
         "tike_ifft2_crop_scaled", "tike_ptycho_fwd_intensity_only",
+        "tike_ptycho_fwd_gradient_scale",
         "tike_grad_ifft2_crop",
         "tike_lstsq_gradients", "tike_scatter_patches",
         "tike_lstsq_step_stats", "tike_psi_preconditioner",

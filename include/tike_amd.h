@@ -103,6 +103,19 @@ int tike_ptycho_fwd_intensity_only(const void* psi, const float* scan, const voi
                                    void* scratch, float* intensity, int nscan, int S, int pw,
                                    int det, int H, int W, float scale, void* stream);
 
+/* tike_ptycho_fwd_intensity_only followed by tike_gradient_scale, in one
+ * launch: gscale and costs are formed from the intensity while it is still in
+ * registers (objective.py:31-44,47-70,90-125; lstsq.py:444-502).  intensity may
+ * be NULL (not stored); costs may be NULL.  det = 256. */
+int tike_ptycho_fwd_gradient_scale(const void* psi, const float* scan, const void* probe,
+                                   int probe_per_scan, const void* unique_probe,
+                                   const float* eigen_weights, int num_eigen, int eigen_modes,
+                                   void* scratch, float* intensity, const float* data,
+                                   const unsigned char* measured, float* gscale, float* costs,
+                                   int nscan, int S, int pw, int det, int H, int W, float scale,
+                                   int model, float unmeasured_scaling, long num_measured,
+                                   void* stream);
+
 /* ---- far-plane gradient + IFFT2 + crop from that scratch (lstsq.py:491-507):
  * chi = crop(IFFT2(F * gscale [* mode_scale on measured pixels])) * inv_scale
  * with F = fwd_scale * (column pass of `colin`) re-formed in registers, so the

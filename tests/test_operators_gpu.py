@@ -427,6 +427,21 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
             A.ptr(w_d), C, 1, A.ptr(scratch), A.ptr(I2), N, S, pw, det, HW, HW,
             1.0 / det, st))
         assert_close(I2.cpu().numpy(), want_I, what="intensity (only)")
+        # ... and with the gradient factor + costs formed in the same launch
+        g2 = torch.empty_like(g)
+        costs2 = torch.empty_like(costs)
+        scratch2 = torch.empty_like(far)
+        check(lib.tike_ptycho_fwd_gradient_scale(
+            A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, A.ptr(uq),
+            A.ptr(w_d), C, 1, A.ptr(scratch2), None, A.ptr(d_d), A.ptr(m_d),
+            A.ptr(g2), A.ptr(costs2), N, S, pw, det, HW, HW, 1.0 / det, 0, 0.5,
+            int(mask.sum()), st))
+        np.testing.assert_allclose(costs2.cpu().numpy(), want_cost,
+                                   rtol=COST_RTOL)
+        np.testing.assert_allclose(g2.cpu().numpy(), g.cpu().numpy(),
+                                   rtol=1e-4, atol=1e-5)
+        assert_close(scratch2.cpu().numpy(), scratch.cpu().numpy(),
+                     normwise=1e-6, maxabs=1e-5, what="column-pass scratch")
         mid2 = torch.empty_like(far)
         chi2 = mid2 if pw == det else torch.empty_like(chi)
         check(lib.tike_grad_ifft2_crop(

@@ -57,6 +57,9 @@ _PROTOTYPES = {
     "tike_scale_modes": [_p, _p, _p, _l, _i, _p],
     "tike_ptycho_fwd_intensity_only": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p,
                                        _i, _i, _i, _i, _i, _i, _f, _p],
+    "tike_ptycho_fwd_gradient_scale": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p,
+                                       _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
+                                       _f, _i, _f, _l, _p],
     "tike_grad_ifft2_crop": [_p, _p, _p, _p, _i, _p, _p, _l, _i, _i, _f, _f,
                              _p],
     "tike_position_sums": [_p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p, _i,

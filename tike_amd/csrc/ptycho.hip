@@ -218,6 +218,19 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
 #ifndef TK_POS_WAVES
 #define TK_POS_WAVES 2
 #endif
+// Optional epilogue of the intensity-only forward kernel: the far-plane
+// gradient factor and the per-pattern cost (objective.py:11-124,
+// lstsq.py:444-502) straight from the intensity in registers.
+struct TkGradScale {
+  const float* data;           // (nscan, det, det) or nullptr: epilogue off
+  const unsigned char* mask;   // (det, det) or nullptr (all measured)
+  float* gscale;               // (nscan, det, det)
+  float* costs;                // (nscan) or nullptr
+  int model;                   // 0 gaussian, 1 poisson
+  float unmeasured_scaling;
+  float inv_nmeasured;
+};
+
 // STORE = false: the far-plane waves are formed in registers for the intensity
 // only; `farplane` then keeps the INPUT of the column pass (rows 16r + k1 of
 // fft2_pass1), which tike_grad_ifft2_crop consumes.
@@ -225,7 +238,7 @@ template <int N, bool STORE = true>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_pos_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ farplane, float* __restrict__ intensity, int nscan, int S, int pw, int H,
-    int W, float scale, const cf* __restrict__ twtab) {
+    int W, float scale, const cf* __restrict__ twtab, const TkGradScale gsc) {
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
   cf* twl = lds + G2::LDS_ELEMS;
@@ -302,6 +315,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
       // pure read stream -- keep the rows of the NEXT (k1, mode) in flight
       // while the current ones go through the butterfly
       cf nxt[G2::RB];
+      float cost = 0.f;
 #pragma unroll
       for (int r = 0; r < G2::RB; ++r) nxt[r] = dst0[(16 * r) * N + t];
       for (int k1 = 0; k1 < 16; ++k1) {
@@ -321,9 +335,45 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
 #pragma unroll
           for (int k2 = 0; k2 < G2::RB; ++k2) I[k2] += norm2(u[k2] * scale);
         }
+        if (intensity) {
 #pragma unroll
-        for (int k2 = 0; k2 < G2::RB; ++k2)
-          tk_st_stream(intensity + n * (long)N * N + (k1 + 16 * k2) * N + t, I[k2]);
+          for (int k2 = 0; k2 < G2::RB; ++k2)
+            tk_st_stream(intensity + n * (long)N * N + (k1 + 16 * k2) * N + t, I[k2]);
+        }
+        if (gsc.data) {
+          // gradient factor and cost from the intensity in registers
+#pragma unroll
+          for (int k2 = 0; k2 < G2::RB; ++k2) {
+            const long p = (long)(k1 + 16 * k2) * N + t;
+            float g = gsc.unmeasured_scaling - 1.0f;
+            if (gsc.mask == nullptr || gsc.mask[p]) {
+              const float dv = gsc.data[n * (long)N * N + p];
+              if (gsc.model == 0) {
+                const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
+                const float diff = sI - sd;
+                cost += diff * diff;
+                g = -(1.0f - sd / (sI + 1e-9f));
+              } else {
+                cost += I[k2] - dv * logf(I[k2] + 1e-9f);
+                g = -(1.0f - dv / (I[k2] + 1e-9f));
+              }
+            }
+            gsc.gscale[n * (long)N * N + p] = g;
+          }
+        }
+      }
+      if (gsc.data && gsc.costs) {
+        // block sum through the (now idle) FFT exchange area
+        float* red = reinterpret_cast<float*>(lds);
+        __syncthreads();
+        cost = tk_wave_sum(cost);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cost;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float tot = 0.f;
+          for (int w = 0; w < N / 64; ++w) tot += red[w];
+          gsc.costs[n] = tot * gsc.inv_nmeasured;
+        }
       }
     } else
     for (int k1 = 0; k1 < 16; ++k1) {
@@ -352,11 +402,14 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
 template <int N, bool STORE = true>
 static int launch_fwd_pos(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                           float* intensity, int nscan, int S, int pw, int H, int W, float scale,
-                          hipStream_t stream) {
+                          hipStream_t stream, const TkGradScale* gsc = nullptr) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
+  TkGradScale g = {};
+  if (gsc) g = *gsc;
   hipLaunchKernelGGL((ptycho_fwd_pos_kernel<N, STORE>), dim3(tk_grid(nscan, 4)), dim3(N), 0,
-                     stream, psi, scan, probe, farplane, intensity, nscan, S, pw, H, W, scale, tw);
+                     stream, psi, scan, probe, farplane, intensity, nscan, S, pw, H, W, scale, tw,
+                     g);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -412,6 +465,38 @@ extern "C" int tike_ptycho_fwd_intensity_only(const void* psi, const float* scan
                                   eigen_modes, S, pw, unique_probe);
   return launch_fwd_pos<256, false>((const cf*)psi, scan, P, (cf*)scratch, intensity, nscan, S,
                                     pw, H, W, scale, stream);
+}
+
+// tike_ptycho_fwd_intensity_only + tike_gradient_scale in one launch: the
+// gradient factor and the per-pattern cost are formed from the intensity while
+// it is still in registers (intensity itself is stored only if asked for).
+extern "C" int tike_ptycho_fwd_gradient_scale(
+    const void* psi, const float* scan, const void* probe, int probe_per_scan,
+    const void* unique_probe, const float* eigen_weights, int num_eigen, int eigen_modes,
+    void* scratch, float* intensity, const float* data, const unsigned char* measured,
+    float* gscale, float* costs, int nscan, int S, int pw, int det, int H, int W, float scale,
+    int model, float unmeasured_scaling, long num_measured, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan) && (model == 0 || model == 1) &&
+               num_measured > 0);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(psi && scan && probe && scratch && data && gscale);
+  TK_CHECK_ARG(!(eigen_weights && eigen_modes > 0 && !unique_probe));
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, nullptr, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw, unique_probe);
+  TkGradScale g;
+  g.data = data;
+  g.mask = measured;
+  g.gscale = gscale;
+  g.costs = costs;
+  g.model = model;
+  g.unmeasured_scaling = unmeasured_scaling;
+  g.inv_nmeasured = 1.0f / (float)num_measured;
+  return launch_fwd_pos<256, false>((const cf*)psi, scan, P, (cf*)scratch, intensity, nscan, S,
+                                    pw, H, W, scale, stream, &g);
 }
 
 template <int N>

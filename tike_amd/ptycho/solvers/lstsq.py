@@ -343,17 +343,17 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             # them in registers for the intensity and leaves the input of its
             # column pass in `far`; the inverse kernel re-forms them from
             # there, applies the gradient factor and transforms back
+            # (the gradient factor and the costs come out of the same launch;
+            # the intensity itself is stored only for the poisson steps)
             check(
-                lib.tike_ptycho_fwd_intensity_only(
+                lib.tike_ptycho_fwd_gradient_scale(
                     A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
-                    A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far), A.ptr(inten), n,
-                    S, pw, det, H, W, fwd_scale, st), "forward (intensity)")
-            check(
-                lib.tike_gradient_scale(A.ptr(inten), A.ptr(data[clo:chi_hi]),
-                                        A.ptr(mask_u8), A.ptr(gscale),
-                                        A.ptr(costs[blo:blo + n]), n, det,
-                                        model, unmeasured, nmeasured, st),
-                "gradient scale")
+                    A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far),
+                    A.ptr(inten) if poisson else None,
+                    A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), A.ptr(gscale),
+                    A.ptr(costs[blo:blo + n]), n, S, pw, det, H, W, fwd_scale,
+                    model, unmeasured, nmeasured, st),
+                "forward + gradient scale")
             if poisson:  # dominant mode: the steps need no far-plane waves
                 check(
                     lib.tike_poisson_steps(

@@ -17,7 +17,7 @@ import sys
 
 # kernel-name prefix -> C-ABI entry whose launch it is
 KERNELS = {
-    "void ptycho_fwd_pos_kernel<256, false>": "tike_ptycho_fwd_intensity_only",
+    "void ptycho_fwd_pos_kernel<256, false>": "tike_ptycho_fwd_gradient_scale",
     "void ptycho_fwd_pos_kernel<256, true>": "tike_ptycho_fwd_intensity",
     "void ptycho_fwd_pos_kernel<512": "tike_ptycho_fwd_intensity",
     "void grad_ifft2_crop_kernel": "tike_grad_ifft2_crop",
