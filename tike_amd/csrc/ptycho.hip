@@ -929,6 +929,18 @@ extern "C" int tike_ifft2_crop_scaled(const void* farplane, const float* gscale,
   }
 }
 
+// XCD-aware tile order for kernels whose S mode tiles of one position share a
+// per-position table (gscale): workgroups are dealt round-robin over the 8
+// XCDs, so virtual block v runs on XCD v % 8; giving the S modes of a position
+// to consecutive blocks OF ONE XCD lets that XCD's L2 fetch the table once
+// instead of every XCD fetching it.  v ranges over ceil(nscan/8)*8*S; returns
+// -1 for the padding.  Placement only affects speed, never results.
+__device__ __forceinline__ long tk_xcd_tile(long v, int S, long nscan) {
+  const long xcd = v & 7, slot = v >> 3;
+  const long p = (slot / S) * 8 + xcd;
+  return p < nscan ? p * S + slot % S : -1;
+}
+
 // ------------------------------------------- gradient + inverse, no far plane
 // Consumes the column-pass input left by tike_ptycho_fwd_intensity_only.  Per
 // tile and per k1 (a thread owns one column):
@@ -957,7 +969,11 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
   __syncthreads();
   const int pad = (N - pw) / 2;
   const int t = threadIdx.x;
-  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+  const long nscan = ntile / S;
+  const long nvirt = ((nscan + 7) / 8) * 8 * S;
+  for (long v = blockIdx.x; v < nvirt; v += gridDim.x) {
+    const long tile = tk_xcd_tile(v, S, nscan);
+    if (tile < 0) continue;  // uniform
     const cf* __restrict__ src = colin + tile * (long)N * N;
     cf* mid = work + tile * (long)N * N;
     cf* dst = chi + tile * (long)pw * pw;
@@ -1008,8 +1024,11 @@ extern "C" int tike_grad_ifft2_crop(const void* colin, const float* gscale,
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   constexpr int N = 256;
+  // a multiple of 8 workgroups keeps "virtual block % 8" equal to the XCD of
+  // the workgroup across the grid-stride loop
+  const int grid8 = (tk_grid(((ntile / S + 7) / 8) * 8 * S, 4) + 7) / 8 * 8;
 #define TK_GINV(MODE)                                                                          \
-  hipLaunchKernelGGL((grad_ifft2_crop_kernel<N, MODE>), dim3(tk_grid(ntile, 4)), dim3(N), 0,   \
+  hipLaunchKernelGGL((grad_ifft2_crop_kernel<N, MODE>), dim3(grid8), dim3(N), 0,                \
                      stream, (const cf*)colin, (cf*)work, (cf*)chi, ntile, pw, fwd_scale,      \
                      inv_scale, tw, gscale, S, mode_scale, measured)
   if (mode_scale)
