@@ -287,8 +287,11 @@ def main():
             probe=p["probe"].copy(),
             psi=np.full_like(p["psi"], 0.5 + 0j), scan=p["scan"],
             eigen_probe=eigen_probe, eigen_weights=eigen_weights,
-            algorithm_options=tp.LstsqOptions(num_batch=num_batch,
-                                              batch_method="compact"),
+            # BASELINE configs[1] names the conjugate-gradient solver
+            algorithm_options=(tp.CgradOptions(num_batch=num_batch, cg_iter=4)
+                               if a.workload == "c2" else
+                               tp.LstsqOptions(num_batch=num_batch,
+                                               batch_method="compact")),
             probe_options=tp.ProbeOptions(force_orthogonality=True),
             object_options=tp.ObjectOptions(),
             position_options=tp.PositionOptions(
@@ -309,7 +312,9 @@ def main():
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_epoch(p, data, S, det)
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
-                        detector=det, eigen_probes=C, solver="lstsq_grad",
+                        detector=det, eigen_probes=C,
+                        solver="cgrad (cg_iter=4)" if a.workload == "c2"
+                        else "lstsq_grad",
                         num_batch=num_batch, chunk_positions=launch_n,
                         position_correction=a.workload == "c5")
     else:

@@ -268,6 +268,49 @@ def test_cgrad_vs_reference_composition(tp, golden):
         assert relerr(params.psi, g["psis"][i]) < 2e-3
 
 
+@pytest.mark.parametrize("det,pw,S,N", [(256, 256, 1, 6), (256, 192, 2, 5),
+                                        (128, 128, 1, 8)])
+def test_cgrad_vs_oracle(tp, det, pw, S, N):
+    """cgrad (object then probe, 2 CG iterations each) against the oracle's
+    composition at the sizes with fused kernels: 256 takes the far-plane-free
+    forward / gradient+inverse pair, 128 the stored-far-plane path."""
+    from oracle import solvers as osol
+    rng = np.random.default_rng(det + N)
+    side = int(np.ceil(np.sqrt(N)))
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
+                              indexing="ij"), -1).reshape(-1, 2)[:N]
+    scan = (2 + 7.0 * ij + rng.random((N, 2))).astype(np.float32)
+    HW = 7 * (side - 1) + pw + 8
+    psi_true = ((0.75 + 0.25 * rng.random((1, HW, HW))) * np.exp(
+        1j * np.pi * (rng.random((1, HW, HW)) - 0.5))).astype(np.complex64)
+    w = tp.gaussian(pw, rin=0.6)
+    probe = np.stack([w * np.exp(1j * np.pi * rng.random((pw, pw))) / (m + 1)
+                      for m in range(S)])[None, None].astype(np.complex64)
+    data = tp.simulate(det, probe, scan, psi_true)
+    psi0 = np.full_like(psi_true, 0.5)
+    params = tp.PtychoParameters(
+        probe=probe.copy(), psi=psi0.copy(), scan=scan.copy(),
+        algorithm_options=tp.CgradOptions(num_batch=1, cg_iter=2, num_iter=1,
+                                          batch_method="contiguous"),
+        probe_options=tp.ProbeOptions(init_rescale_from_measurements=False),
+        object_options=tp.ObjectOptions())
+    batches = [np.arange(N)]
+    with tp.Reconstruction(data, params, order=np.arange(N),
+                           batches=batches) as ctx:
+        ctx.iterate(2)
+        got = ctx.get_result()
+    state = dict(psi=psi0.copy(), probe=probe.copy(), scan=scan.copy(),
+                 costs=[])
+    for _ in range(2):
+        state = osol.cgrad(state, data, batches, detector_shape=det, cg_iter=2,
+                           recover_probe=True)
+    np.testing.assert_allclose(np.array(got.algorithm_options.costs),
+                               np.array(state["costs"]), rtol=2e-3)
+    assert_close(got.psi, state["psi"], normwise=2e-3, maxabs=2e-2, what="psi")
+    assert_close(got.probe, state["probe"], normwise=2e-3, maxabs=2e-2,
+                 what="probe")
+
+
 def test_lstsq_converges_and_resumes(tp):
     """Cost decreases monotonically on a clean synthetic problem and state
     round-trips through PtychoParameters (larger, pow-2 sizes)."""

@@ -15,7 +15,8 @@ from ... import _arrays as A
 from ... import opt
 from ..._lib import check, lib
 from ...operators.propagation import fft_scales
-from .lstsq import _workspace, chunk_positions, global_count, mask_info
+from .lstsq import (NO_FARPLANE_SIZES, _workspace, chunk_positions,
+                    global_count, mask_info)
 
 
 def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
@@ -29,8 +30,13 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
     H, W = psi.shape[-2:]
     ws = _workspace(op)
     st = A.stream_ptr()
-    inv_scale = fft_scales(det, op.norm)[1]
-    chunk = chunk_positions(S, det)
+    fwd_scale, inv_scale = fft_scales(det, op.norm)
+    # 256^2: the far-plane-free kernels of lstsq_grad serve here too -- a
+    # line-search probe (cost only) then never writes the far plane at all
+    lean = det in NO_FARPLANE_SIZES
+    chunk = chunk_positions(S, det, lean)
+    gscale = (ws.get("gscale", (min(chunk, max(N, 1)), det, det),
+                     torch.float32, dev) if lean else None)
     far = ws.get("far", (min(chunk, max(N, 1)), 1, S, det, det),
                  torch.complex64, dev)
     mid = ws.get("mid", tuple(far.shape), torch.complex64, dev)
@@ -45,20 +51,36 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
     for lo in range(0, N, chunk):
         hi = min(N, lo + chunk)
         n = hi - lo
-        op.fwd_device(probe, scan[lo:hi], psi, out=far[:n])
-        # gaussian cost per pattern; with the gradient requested the farplane
-        # becomes -grad (sign flipped back below)
-        check(
-            lib.tike_farplane_gradient(A.ptr(far), A.ptr(data[lo:hi]), None,
-                                       None, A.ptr(costs[lo:hi]), n, S, det, 0,
-                                       int(want_grad), 1.0, det * det, st),
-            "cgrad cost")
-        if not want_grad:
-            continue
         chi = chi_ws
-        check(
-            lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S, det,
-                                pw, inv_scale, st), "cgrad ifft2")
+        if lean:
+            # cost (and the -gradient factor) from the intensity in registers
+            check(
+                lib.tike_ptycho_fwd_gradient_scale(
+                    A.ptr(psi), A.ptr(scan[lo:hi]), A.ptr(probe), 0, None,
+                    None, 0, 0, A.ptr(far), None, A.ptr(data[lo:hi]), None,
+                    A.ptr(gscale), A.ptr(costs[lo:hi]), n, S, pw, det, H, W,
+                    fwd_scale, 0, 1.0, det * det, st), "cgrad cost")
+            if not want_grad:
+                continue
+            check(
+                lib.tike_grad_ifft2_crop(A.ptr(far), A.ptr(gscale), None, None,
+                                         S, A.ptr(mid), A.ptr(chi), n * S, det,
+                                         pw, fwd_scale, inv_scale, st),
+                "cgrad gradient + ifft2")
+        else:
+            op.fwd_device(probe, scan[lo:hi], psi, out=far[:n])
+            # gaussian cost per pattern; with the gradient requested the
+            # farplane becomes -grad (sign flipped back below)
+            check(
+                lib.tike_farplane_gradient(A.ptr(far), A.ptr(data[lo:hi]),
+                                           None, None, A.ptr(costs[lo:hi]), n,
+                                           S, det, 0, int(want_grad), 1.0,
+                                           det * det, st), "cgrad cost")
+            if not want_grad:
+                continue
+            check(
+                lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S,
+                                    det, pw, inv_scale, st), "cgrad ifft2")
         check(
             lib.tike_lstsq_gradients(A.ptr(chi), A.ptr(scan[lo:hi]), A.ptr(psi),
                                      A.ptr(probe), None, None, 0, 0, None, None,
