@@ -541,10 +541,12 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
   cf* far = (cf*)farplane;
   static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
   static const bool use_pos = getenv("TIKE_FWD_TILE_MAJOR") == nullptr;
-  if (use_v2 && use_pos && !(eigen_weights && eigen_modes > 0)) {
-    // position-major kernel (patch gathered once per position, straight-line
-    // loader); the varying-probe case needs tike_varying_probe first and is
-    // served by tike_ptycho_fwd_intensity
+  if (use_v2 && use_pos && S > 1 && !(eigen_weights && eigen_modes > 0)) {
+    // position-major kernel (patch gathered once per position and shared by
+    // the modes, straight-line loader; with a single mode there is nothing to
+    // share and the tile-major kernel below, with its higher occupancy, is
+    // 7 % faster); the varying-probe case needs tike_varying_probe first and
+    // is served by tike_ptycho_fwd_intensity
     switch (det) {
       case 128:
         return launch_fwd_pos<128>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale,
