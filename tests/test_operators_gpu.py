@@ -507,3 +507,47 @@ def test_grouped_footprint_scatter(oracle, layout):
                                       N, pw, H, W, A.stream_ptr()))
     assert_close(out.cpu().numpy(), wantp.real, normwise=2e-6, maxabs=1e-5,
                  what="psi preconditioner")
+
+
+def test_abi_edge_cases():
+    """C-ABI contract on degenerate input: zero positions are a no-op (rc 0,
+    no pointer dereferenced), unsupported detector sizes of the specialised
+    entries report TIKE_ERR_UNSUPPORTED, bad arguments TIKE_ERR_ARG."""
+    import torch
+    import tike_amd._arrays as A
+    import tike_amd._lib as L
+    lib = L.lib
+    st = A.stream_ptr()
+    z = None
+    assert lib.tike_ptycho_fwd_intensity(z, z, z, 0, z, z, 0, 0, z, z, 0, 2,
+                                         64, 64, 100, 100, 1.0, st) == 0
+    assert lib.tike_ptycho_fwd_gradient_scale(
+        z, z, z, 0, z, z, 0, 0, z, z, z, z, z, z, 0, 2, 256, 256, 400, 400,
+        1.0, 0, 1.0, 65536, st) == 0
+    assert lib.tike_grad_ifft2_crop(z, z, z, z, 2, z, z, 0, 256, 256, 1.0, 1.0,
+                                    st) == 0
+    assert lib.tike_scatter_patches(z, z, z, 0, 64, 100, 100, st) == 0
+    assert lib.tike_psi_preconditioner(z, z, z, 0, 64, 100, 100, st) == 0
+    assert lib.tike_position_sums(z, z, 1, z, z, z, 0, 0, z, 2, z, z, 0, 1, 64,
+                                  st) == 0
+    assert lib.tike_poisson_steps(z, z, z, z, z, 0, 2, 64, 0.5, 0.5, 0,
+                                  st) == 0
+    assert lib.tike_lstsq_step_stats(z, z, z, z, z, z, z, 0, 0, z, z, z, z, 0,
+                                     1, 1, 64, 100, 100, z, z, st) == 0
+    # specialised entries refuse sizes they do not implement
+    x = torch.zeros(4 * 128 * 128, dtype=torch.complex64, device="cuda")
+    f = torch.zeros(128 * 128, dtype=torch.float32, device="cuda")
+    s = torch.full((1, 2), 5.0, dtype=torch.float32, device="cuda")
+    p = lambda t: t.data_ptr()
+    assert lib.tike_ptycho_fwd_gradient_scale(
+        p(x), p(s), p(x), 0, z, z, 0, 0, p(x), z, p(f), z, p(f), z, 1, 1, 128,
+        128, 200, 200, 1.0, 0, 1.0, 128 * 128, st) == L.ERR_UNSUPPORTED
+    assert lib.tike_grad_ifft2_crop(p(x), p(f), z, z, 1, p(x) + 8, p(x) + 16,
+                                    1, 128, 128, 1.0, 1.0,
+                                    st) == L.ERR_UNSUPPORTED
+    # argument errors: probe wider than the detector, work aliasing the input
+    assert lib.tike_ptycho_fwd_intensity(p(x), p(s), p(x), 0, z, z, 0, 0, p(x),
+                                         z, 1, 1, 256, 128, 300, 300, 1.0,
+                                         st) == L.ERR_ARG
+    assert lib.tike_ifft2_crop_scaled(p(x), p(f), 1, p(x), p(x), 1, 128, 128,
+                                      1.0, st) == L.ERR_ARG
