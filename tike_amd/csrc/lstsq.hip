@@ -502,9 +502,12 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
     float ep = 0.f;  // sum Re(conj(R_n) E_0), R_n = conj(O_n) chi_n,0 - mpu_0
     // branch-free body (clamped addresses, results zeroed by select) so that
     // the loads of two pixels are in flight together
+    // (row, column) of the pixel advance with the stride instead of a
+    // division per pixel
+    const int qstep = (int)blockDim.x / pw, rstep = (int)blockDim.x % pw;
+    int py = (int)threadIdx.x / pw, px = (int)threadIdx.x % pw;
 #pragma unroll 2
-    for (long p = threadIdx.x; p < P; p += blockDim.x) {
-      const int py = (int)(p / pw), px = (int)(p % pw);
+    for (int p = threadIdx.x; p < (int)P; p += blockDim.x) {
       const int y = c.sy + py, x = c.sx + px;
       const bool ok = y >= 0 && y < H && x >= 0 && x < W;
       const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
@@ -534,6 +537,12 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
         const cf r = conjf(o) * x0 - mpu[p];
         const cf e = eigen0[p];
         ep += r.x * e.x + r.y * e.y;
+      }
+      py += qstep;
+      px += rstep;
+      if (px >= pw) {
+        px -= pw;
+        ++py;
       }
     }
 #pragma unroll
