@@ -38,3 +38,17 @@ def test_no_product_module_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src,
                                      flags=re.M), os.path.join(dirpath, f)
+
+
+def test_every_entry_point_is_documented():
+    """INTEGRATION.md names every extern "C" entry of include/tike_amd.h (the
+    table that maps each one to the reference lines it replaces)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "tike_amd.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\bint (tike_[a-z0-9_]+)\(", header)))
+    assert names, "no entry points found"
+    missing = [n for n in names if n not in doc]
+    assert not missing, missing
