@@ -418,3 +418,35 @@ recon("positions_plain", N=30, pw=16, det=32, S=1, eigen=0, num_batch=3,
 # rpie diverges on these problems (costs 0.024 -> 0.69 -> 41 -> ...; NaN with
 # eigen probes), so its iterates are no usable golden vectors.
 # recon(..., algo="rpie") reproduces that observation.
+
+
+# ---- reconstruct_multigrid (ptycho.py:975-1047,
+# options.py:332-409): coarse-to-fine reconstruction, 2 levels ------------------
+def multigrid(tag, interp):
+    rng_m = np.random.default_rng(1357)
+    p = make_problem(rng_m, N=30, pw=32, det=32, S=2, pitch=4.0, margin=6)
+    np.random.seed(7)
+    tike.random.randomizer_np = np.random.default_rng(11)
+    params = tike.ptycho.PtychoParameters(
+        probe=p["probe0"].copy(), psi=p["psi0"].copy(), scan=p["scan"].copy(),
+        algorithm_options=tike.ptycho.LstsqOptions(
+            num_batch=2, batch_method="compact", num_iter=2),
+        probe_options=tike.ptycho.ProbeOptions(force_orthogonality=True),
+        object_options=tike.ptycho.ObjectOptions(),
+        exitwave_options=tike.ptycho.ExitWaveOptions(
+            measured_pixels=np.ones((32, 32), dtype=bool)),
+    )
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        coarse = params.resample(0.5, interp)
+        r = tike.ptycho.reconstruct_multigrid(p["data"], params, 1, False,
+                                              num_levels=2, interp=interp)
+    save(f"multigrid_{tag}.npz", data=p["data"], psi0=p["psi0"],
+         probe0=p["probe0"], scan=p["scan"], coarse_probe=coarse.probe,
+         coarse_psi=coarse.psi, coarse_scan=coarse.scan, psi=r.psi,
+         probe=r.probe, costs=np.array(r.algorithm_options.costs))
+    print("multigrid", tag, np.array(r.algorithm_options.costs).ravel())
+
+
+multigrid("fft", None)

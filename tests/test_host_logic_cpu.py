@@ -235,3 +235,32 @@ def test_position_options_split_join():
     np.testing.assert_array_equal(joined._momentum, opts._momentum)
     np.testing.assert_array_equal(joined.confidence, opts.confidence)
     assert joined.v.shape == (20, 2) and joined.m.shape == (20, 2)
+
+
+def test_resample_matches_reference(golden):
+    """PtychoParameters.resample (Fourier-interpolated probe, spline-zoomed
+    object, scaled positions, Fourier-cropped mask; options.py:170-196,332-409)
+    against the reference's own coarse level, and crop/pad round trip."""
+    from tike_amd.ptycho.solvers import (_resize_fft, crop_fourier_space,
+                                         pad_fourier_space)
+    g = golden("multigrid_fft.npz")
+    params = tp.PtychoParameters(
+        probe=g["probe0"].copy(), psi=g["psi0"].copy(), scan=g["scan"].copy(),
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2),
+        probe_options=tp.ProbeOptions(use_adaptive_moment=True),
+        object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((32, 32), dtype=bool)))
+    params.probe_options.m = np.ones(3)  # momentum must restart on a new grid
+    coarse = params.resample(0.5)
+    np.testing.assert_allclose(coarse.probe, g["coarse_probe"], atol=1e-7)
+    np.testing.assert_allclose(coarse.psi, g["coarse_psi"], atol=1e-7)
+    np.testing.assert_allclose(coarse.scan, g["coarse_scan"], atol=0)
+    assert coarse.exitwave_options.measured_pixels.shape == (16, 16)
+    assert coarse.probe_options.m is None
+    rng = np.random.default_rng(0)
+    x = rng.random((2, 8, 8)) + 1j * rng.random((2, 8, 8))
+    np.testing.assert_allclose(crop_fourier_space(pad_fourier_space(x, 12), 8),
+                               x)
+    np.testing.assert_allclose(_resize_fft(x, 1), x)
+    assert _resize_fft(x, 2.0).shape == (2, 16, 16)

@@ -7,7 +7,8 @@ from .position import (AffineTransform, PositionOptions,
 from .probe import (ProbeOptions, add_modes_random_phase, adjust_probe_power,
                     constrain_variable_probe, gaussian, get_varying_probe,
                     init_varying_probe, orthogonalize_eig)
-from .ptycho import Reconstruction, reconstruct, simulate
+from .ptycho import (Reconstruction, reconstruct, reconstruct_multigrid,
+                     simulate)
 from .solvers import (CgradOptions, LstsqOptions, PtychoParameters,
                       RpieOptions, cgrad, lstsq_grad, update_preconditioners)
 from . import probe, object, position, exitwave, solvers  # noqa: F401,A004
@@ -17,5 +18,6 @@ __all__ = [
     "AffineTransform", "PositionOptions", "affine_position_regularization",
     "ProbeOptions", "PtychoParameters", "Reconstruction",
     "RpieOptions", "cgrad", "check_allowed_positions", "lstsq_grad",
-    "reconstruct", "simulate", "update_preconditioners",
+    "reconstruct", "reconstruct_multigrid", "simulate",
+    "update_preconditioners",
 ]

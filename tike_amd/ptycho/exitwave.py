@@ -40,6 +40,13 @@ class ExitWaveOptions:
             unmeasured_pixels_scaling=self.unmeasured_pixels_scaling,
         )
 
+    def resample(self, factor: float) -> "ExitWaveOptions":
+        """The mask cropped in Fourier space to the rescaled detector
+        (exitwave.py:106-119)."""
+        mask = np.asarray(A.to_host(self.measured_pixels))
+        return self._copy(crop_fourier_space(mask,
+                                             int(mask.shape[-1] * factor)))
+
     def copy_to_device(self) -> "ExitWaveOptions":
         return self._copy(A.to_device(np.asarray(A.to_host(
             self.measured_pixels), dtype=bool)))
@@ -47,3 +54,26 @@ class ExitWaveOptions:
     def copy_to_host(self) -> "ExitWaveOptions":
         return self._copy(np.asarray(A.to_host(self.measured_pixels),
                                      dtype=bool))
+
+
+def crop_fourier_space(x, w: int):
+    """Crop the last two axes of x to w x w keeping the low frequencies of a
+    corner-centred spectrum (exitwave.py:237-249, options.py:366-377)."""
+    assert x.shape[-2] == x.shape[-1], "Only works on square arrays right now."
+    half1 = w // 2
+    half0 = w - half1
+    keep = np.r_[0:half0, (x.shape[-1] - half1):x.shape[-1]]
+    return x[..., keep][..., keep, :]
+
+
+def pad_fourier_space(x, w: int):
+    """Inverse of crop_fourier_space: zero-pad the high frequencies
+    (options.py:380-388)."""
+    assert x.shape[-2] == x.shape[-1], "Only works on square arrays right now."
+    half1 = x.shape[-1] // 2
+    half0 = x.shape[-1] - half1
+    new_x = np.zeros((*x.shape[:-2], w, w), dtype=x.dtype)
+    cols = np.r_[0:half0, (w - half1):w]
+    new_x[..., 0:half0, cols] = x[..., 0:half0, :]
+    new_x[..., w - half1:w, cols] = x[..., x.shape[-2] - half1:, :]
+    return new_x

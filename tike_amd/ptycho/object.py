@@ -58,6 +58,11 @@ class ObjectOptions:
         o.preconditioner = f(self.preconditioner)
         return o
 
+    def resample(self, factor: float, interp=None) -> "ObjectOptions":
+        """Settings for a grid rescaled by `factor`; the momentum and the
+        preconditioner restart (object.py:138-152)."""
+        return self._copy(lambda x: None)
+
     def copy_to_device(self) -> "ObjectOptions":
         return self._copy(_to_dev)
 

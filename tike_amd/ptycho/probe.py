@@ -79,6 +79,11 @@ class ProbeOptions:
         o.preconditioner = f(self.preconditioner)
         return o
 
+    def resample(self, factor: float, interp=None) -> "ProbeOptions":
+        """Settings for a grid rescaled by `factor`; the momentum and the
+        preconditioner restart (probe.py:246-270)."""
+        return self._copy(lambda x: None)
+
     def copy_to_device(self) -> "ProbeOptions":
         return self._copy(_to_dev)
 

@@ -102,6 +102,33 @@ def reconstruct(data, parameters, num_gpu=1, use_mpi=False):
     return result
 
 
+def reconstruct_multigrid(data, parameters, num_gpu=1, use_mpi=False,
+                          num_levels=3, interp=None):
+    """Coarse-to-fine reconstruction (ptycho.py:975-1047): the real-space
+    parameters are downsampled by 2^(num_levels-1) and the diffraction
+    patterns cropped in Fourier space, every level runs
+    `algorithm_options.num_iter` epochs and hands its upsampled result to the
+    next."""
+    data = A.to_host(data)
+    if (data.shape[-1] * 0.5**(num_levels - 1)) < 64:
+        warnings.warn("Cropping diffraction patterns to less than 64 pixels "
+                      "wide is not recommended because the full doughnut"
+                      " may be visible.")
+    resampled = parameters.resample(0.5**(num_levels - 1), interp)
+    for level in range(num_levels - 1, -1, -1):
+        with Reconstruction(
+                data=data if level == 0 else solvers.crop_fourier_space(
+                    data, data.shape[-1] // (2**level)),
+                parameters=resampled, num_gpu=num_gpu,
+                use_mpi=use_mpi) as context:
+            context.iterate(resampled.algorithm_options.num_iter)
+            result = context.get_result()
+        if level == 0:
+            return result
+        resampled = result.resample(2.0, interp)
+    raise RuntimeError("This should not happen.")
+
+
 def _clip_magnitude(x, a_max):
     magnitude = x.abs()
     return torch.where(magnitude > a_max, a_max * x / magnitude, x)

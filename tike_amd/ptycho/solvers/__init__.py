@@ -3,6 +3,8 @@ from ._preconditioner import update_preconditioners
 from .cgrad import cgrad
 from .lstsq import lstsq_grad
 from .options import (CgradOptions, IterativeOptions, LstsqOptions,
+                      crop_fourier_space, pad_fourier_space, _resize_fft,
+                      _resize_spline,
                       PtychoParameters, RpieOptions)
 
 __all__ = [

@@ -11,7 +11,8 @@ import numpy as np
 
 from ... import _arrays as A
 from ... import precision
-from ..exitwave import ExitWaveOptions
+from ..exitwave import (ExitWaveOptions, crop_fourier_space,
+                        pad_fourier_space)
 from ..object import ObjectOptions
 from ..position import PositionOptions, check_allowed_positions
 from ..probe import ProbeOptions
@@ -118,6 +119,31 @@ class PtychoParameters():
             position_options=fo(self.position_options),
         )
 
+    def resample(self, factor: float, interp=None) -> "PtychoParameters":
+        """Host copy of the parameters on a grid rescaled by `factor`
+        (options.py:170-196): probes by `interp` (Fourier interpolation by
+        default), the object by a cubic spline, positions scaled."""
+        interp = _resize_fft if interp is None else interp
+        h = A.to_host
+        return PtychoParameters(
+            probe=interp(h(self.probe), factor),
+            psi=_resize_spline(h(self.psi), factor),
+            scan=h(self.scan) * factor,
+            eigen_probe=interp(h(self.eigen_probe), factor)
+            if self.eigen_probe is not None else None,
+            eigen_weights=None if self.eigen_weights is None else h(
+                self.eigen_weights),
+            algorithm_options=self.algorithm_options,
+            probe_options=self.probe_options.resample(factor, interp)
+            if self.probe_options is not None else None,
+            object_options=self.object_options.resample(factor, interp)
+            if self.object_options is not None else None,
+            position_options=self.position_options.copy_to_host().resample(
+                factor) if self.position_options is not None else None,
+            exitwave_options=self.exitwave_options.resample(factor)
+            if self.exitwave_options is not None else None,
+        )
+
     def copy_to_device(self) -> "PtychoParameters":
         return self._map(
             lambda x, dt: A.to_device(x, dt),
@@ -147,3 +173,20 @@ class PtychoParameters():
             position_options=x.position_options.split(indices)
             if x.position_options is not None else None,
         )
+
+
+def _resize_spline(x, f: float):
+    """Cubic-spline zoom of the last two axes (options.py:332-338)."""
+    import scipy.ndimage
+    return scipy.ndimage.zoom(x, zoom=[1] * (x.ndim - 2) + [f, f],
+                              grid_mode=True, prefilter=False)
+
+
+def _resize_fft(x, f: float):
+    """Fourier interpolation of the last two axes (options.py:391-409)."""
+    if f == 1:
+        return x
+    crop_or_pad = crop_fourier_space if f < 1 else pad_fourier_space
+    return np.fft.ifft2(
+        crop_or_pad(np.fft.fft2(x, norm="ortho", axes=(-2, -1)),
+                    w=int(x.shape[-1] * f)), norm="ortho", axes=(-2, -1))
