@@ -103,6 +103,55 @@ def test_position_sharding_covers_every_position_once():
         assert abs(len(x) - len(y)) <= 1
 
 
+def _shard_unsynchronised_generators(rank, world):
+    """Ranks start from DIFFERENT generator states (what separately launched
+    processes have); Reconstruction.__enter__ calls Comm.sync_random() before
+    sharding, reproduced here."""
+    import tike_amd.ptycho as tp
+    import tike_amd.random as trandom
+    from tike_amd.communicators import Comm
+    np.random.seed(100 + rank)
+    trandom.randomizer_np = np.random.default_rng(200 + rank)
+    rng = np.random.default_rng(0)
+    N, pw = 60, 8
+    scan = (rng.random((N, 2)) * 20 + 2).astype(np.float32)
+    params = tp.PtychoParameters(
+        probe=np.ones((1, 1, 1, pw, pw), np.complex64),
+        psi=np.ones((1, 40, 40), np.complex64), scan=scan,
+        algorithm_options=tp.LstsqOptions(num_batch=4,
+                                          batch_method="compact"))
+    rec = tp.Reconstruction.__new__(tp.Reconstruction)
+    rec._parameters_in = params
+    rec._presharded = False
+    rec._order_in = rec._batches_in = None
+    rec._spatial_sort = True
+    rec.comm = Comm()
+    rec.comm.sync_random()
+    order, local, batches = rec._shard(N)
+    draws = (trandom.randomizer_np.permutation(7).tolist(),
+             np.random.rand(3).tolist())
+    return order, local, [b.tolist() for b in batches], draws
+
+
+def test_ranks_with_different_seeds_share_one_clustering():
+    (o0, l0, b0, d0), (o1, l1, b1, d1) = _run(_shard_unsynchronised_generators)
+    np.testing.assert_array_equal(o0, o1)
+    assert sorted(np.concatenate([l0, l1]).tolist()) == list(range(60))
+    assert d0 == d1  # later draws (minibatch permutation, RANSAC) agree too
+
+
+def test_injected_batches_are_validated():
+    from tike_amd.ptycho.ptycho import _check_batches
+    order = np.random.default_rng(0).permutation(10)
+    _check_batches(order, np.array_split(np.arange(10), 3), 10)
+    with pytest.raises(ValueError):  # reference-style index batches
+        _check_batches(order, [order[:5], order[5:]], 10)
+    with pytest.raises(ValueError):  # not a tiling
+        _check_batches(order, [np.arange(0, 4), np.arange(5, 10)], 10)
+    with pytest.raises(ValueError):
+        _check_batches(np.arange(9), [np.arange(10)], 10)
+
+
 def test_single_rank_comm_is_identity():
     from tike_amd.communicators import Comm
     comm = Comm()

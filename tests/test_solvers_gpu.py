@@ -179,7 +179,8 @@ def test_chunked_minibatches_vs_reference(tp, golden, tag, monkeypatch):
     """Minibatches split into several kernel chunks (7 positions each) give the
     reference's iterates too: exercises the packed mode-0 copy of chi and the
     per-chunk offsets of every per-position array."""
-    monkeypatch.setenv("TIKE_CHUNK_POSITIONS", "7")
+    from tike_amd.ptycho.solvers import lstsq as L
+    monkeypatch.setattr(L, "CHUNK_POSITIONS_OVERRIDE", 7)
     g = golden(f"lstsq_recon_{tag}.npz")
     (r1,) = _reconstruct_like_reference(tp, g, second=False)
     epochs = int(g["epochs"])

@@ -33,12 +33,7 @@ static inline bool tk_is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 // Number of persistent workgroups for grid-stride kernels: enough to fill
 // 256 CUs several times over, capped by the amount of work.
 static inline int tk_grid(long work_items, int per_cu = 8) {
-  // TIKE_GRID_CAP: tuning/experiment override of the workgroup cap
-  static const long env_cap = [] {
-    const char* e = getenv("TIKE_GRID_CAP");
-    return e ? atol(e) : 0L;
-  }();
-  long cap = env_cap > 0 ? env_cap : 256L * per_cu;
+  const long cap = 256L * per_cu;
   long g = work_items < cap ? work_items : cap;
   return (int)(g < 1 ? 1 : g);
 }
@@ -46,7 +41,6 @@ static inline int tk_grid(long work_items, int per_cu = 8) {
 // Streaming (read-once / write-once) accesses: the non-temporal hint keeps
 // them from displacing the lines that ARE re-read soon (the FFT intermediate,
 // the probe, the object window) in the 4 MiB L2 of the XCD.
-#ifndef TK_NO_NT
 __device__ __forceinline__ cf tk_ld_stream(const cf* p) {
   const double d = __builtin_nontemporal_load(reinterpret_cast<const double*>(p));
   return __builtin_bit_cast(cf, d);
@@ -57,11 +51,6 @@ __device__ __forceinline__ void tk_st_stream(cf* p, cf v) {
 __device__ __forceinline__ void tk_st_stream(float* p, float v) {
   __builtin_nontemporal_store(v, p);
 }
-#else
-__device__ __forceinline__ cf tk_ld_stream(const cf* p) { return *p; }
-__device__ __forceinline__ void tk_st_stream(cf* p, cf v) { *p = v; }
-__device__ __forceinline__ void tk_st_stream(float* p, float v) { *p = v; }
-#endif
 
 __device__ __forceinline__ float tk_wave_sum(float v) {
 #pragma unroll

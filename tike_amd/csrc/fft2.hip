@@ -186,8 +186,7 @@ int tk_fft2(const cf* in, cf* out, long ntile, int n, int inverse, float scale,
             hipStream_t stream) {
   TK_CHECK_ARG(in && out && n >= 1 && ntile >= 0);
   if (ntile == 0) return TK_OK;
-  static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
-  if (use_v2 && in != out) {
+  if (in != out) {
     switch (n) {
       case 128: return launch_v2<128>(in, out, ntile, inverse, scale, stream);
       case 256: return launch_v2<256>(in, out, ntile, inverse, scale, stream);

@@ -25,11 +25,7 @@
 // inside the image (check_allowed_positions, position.py:600-628); pixels
 // falling outside are dropped.
 constexpr int TK_STRIP = 32;
-#ifdef TK_DBG_NO_ATOMIC
-#define TK_ATOMIC_ADD(p, v) asm volatile("" ::"v"(p), "v"(v))
-#else
 #define TK_ATOMIC_ADD(p, v) unsafeAtomicAdd(p, v)
-#endif
 
 // The accumulation image is PLANAR (all real parts, then all imaginary parts):
 // one atomic wave-instruction then covers 256 contiguous bytes, the shape that

@@ -158,15 +158,9 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
           const bool row_ok = py >= 0 && py < pw;        // uniform
           const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
           const cf* __restrict__ q = psi + (long)(c.sy + pyc) * W + c.sx + pxc;
-#ifdef TK_DBG_FWD_NOLOAD
-          const cf a = mk(1.f, 0.f), b = a, d = a, e = a;
-          const long pi = (long)pyc * pw + pxc;
-          cf pr = mk(w0, (float)pi);
-#else
           const cf a = q[0], b = q[1], d = q[W], e = q[W + 1];
           const long pi = (long)pyc * pw + pxc;
           cf pr = Pn[pi] * w0;
-#endif
           for (int k = 0; k < nE; ++k) {
             const cf ev = probe.eigen[((long)k * probe.Sm + s) * PP + pi];
             const float wk =
@@ -202,11 +196,9 @@ __global__ __launch_bounds__(N, TK_V2_MINW(N)) void ptycho_fwd_v2_kernel(
                            [&](int y, int e, auto) { return lds[line * G2::LS + tk_pad16(e)]; }, dst);
     }
     __syncthreads();
-#ifndef TK_DBG_FWD_NOPASS2
     for (int k1 = 0; k1 < 16; ++k1)
       fft2_pass2<N, false>(dst, k1, [&](int ky, int tt, cf v) { dst[ky * N + tt] = v * scale; });
     __syncthreads();
-#endif
   }
 }
 
@@ -271,11 +263,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
         const bool ok = row_ok && px >= 0 && px < pw && x >= 0 && x < W;
         const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
         const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
-#ifdef TK_DBG_FWD_NOLOAD
-        const cf o = mk((float)yc, (float)xc);
-#else
         const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
-#endif
         pv[i] = ok ? o : mk(0.f, 0.f);
         // bound the taps in flight (4 elements = 16 loads) and with them the
         // register footprint of this phase
@@ -299,17 +287,12 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
               constexpr int i = decltype(I)::value;
               const int px = e - pad;
               const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
-#ifdef TK_DBG_FWD_NOLOAD
-              return pv[i] * mk(w0, (float)pxc);
-#else
               return pv[i] * (Pn[pyc * pw + pxc] * w0);
-#endif
             },
             dst0 + s * (long)N * N);
       }
     }
     __syncthreads();
-#ifndef TK_DBG_FWD_NOPASS2
     if constexpr (!STORE) {
       // intensity only: nothing is stored per tile, so the column pass is a
       // pure read stream -- keep the rows of the NEXT (k1, mode) in flight
@@ -394,7 +377,6 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
           tk_st_stream(intensity + n * (long)N * N + (k1 + 16 * k2) * N + t, I[k2]);
       }
     }
-#endif
     __syncthreads();
   }
 }
@@ -539,9 +521,7 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
   const long ntile = (long)nscan * S;
   const cf* psi_ = (const cf*)psi;
   cf* far = (cf*)farplane;
-  static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
-  static const bool use_pos = getenv("TIKE_FWD_TILE_MAJOR") == nullptr;
-  if (use_v2 && use_pos && S > 1 && !(eigen_weights && eigen_modes > 0)) {
+  if (S > 1 && !(eigen_weights && eigen_modes > 0)) {
     // position-major kernel (patch gathered once per position and shared by
     // the modes, straight-line loader; with a single mode there is nothing to
     // share and the tile-major kernel below, with its higher occupancy, is
@@ -560,7 +540,7 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
       default: break;
     }
   }
-  if (use_v2) {
+  {
     switch (det) {
       case 128: return launch_fwd_v2<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
       case 256: return launch_fwd_v2<256>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
@@ -725,8 +705,7 @@ extern "C" int tike_ifft2_crop(const void* farplane, void* work, void* chi, long
   const cf* far = (const cf*)farplane;
   cf* wk = (cf*)work;
   cf* out = (cf*)chi;
-  static const bool use_v2 = getenv("TIKE_FFT_V1") == nullptr;
-  if (use_v2 && (const cf*)wk != far) {
+  if ((const cf*)wk != far) {
     switch (det) {
       case 128: return launch_icrop_v2<128>(far, wk, out, ntile, pw, scale, stream);
       case 256: return launch_icrop_v2<256>(far, wk, out, ntile, pw, scale, stream);

@@ -129,6 +129,25 @@ def reconstruct_multigrid(data, parameters, num_gpu=1, use_mpi=False,
     raise RuntimeError("This should not happen.")
 
 
+def _check_batches(order, batches, n_total):
+    """Injected batches must be contiguous ascending index ranges that tile
+    [0, n) -- the solvers address a batch as [b[0], b[0] + len(b))."""
+    if (order.ndim != 1 or len(order) != n_total or not np.array_equal(
+            np.sort(order), np.arange(n_total))):
+        raise ValueError("`order` must be a permutation of the positions")
+    start = 0
+    for b in batches:
+        if len(b) and not np.array_equal(b, np.arange(start, start + len(b))):
+            raise ValueError(
+                "`batches` must be contiguous ascending index ranges into "
+                "`order` that tile [0, N) (e.g. np.array_split(np.arange(N), "
+                "num_batch)); reference-style index batches are expressed "
+                "through `order`")
+        start += len(b)
+    if start != n_total:
+        raise ValueError("`batches` must cover every position exactly once")
+
+
 def _clip_magnitude(x, a_max):
     magnitude = x.abs()
     return torch.where(magnitude > a_max, a_max * x / magnitude, x)
@@ -171,6 +190,13 @@ class Reconstruction():
                              f"and data shape {data.shape} are incompatible. "
                              "The probe width/height must be "
                              f"<= the data width/height .")
+        mp = parameters.exitwave_options.measured_pixels
+        if (parameters.algorithm_options.name != "cgrad"  # cgrad: no mask
+                and tuple(mp.shape) != tuple(data.shape[-2:])):
+            raise ValueError(
+                f"exitwave_options.measured_pixels shape {tuple(mp.shape)} "
+                f"does not match the diffraction patterns "
+                f"{tuple(data.shape[-2:])}")
         name = parameters.algorithm_options.name
         if not hasattr(solvers, name):
             raise NotImplementedError(
@@ -210,12 +236,19 @@ class Reconstruction():
         p = self._parameters_in
         o = p.algorithm_options
         scan_host = A.to_host(p.scan)
+        if (self._order_in is None) != (self._batches_in is None):
+            raise ValueError("`order` and `batches` must be given together")
         if self._order_in is not None:
             order = np.asarray(self._order_in)
             batches = [np.asarray(b) for b in self._batches_in]
+            _check_batches(order, batches, n_total)
         else:
             order, batches = cluster.batches_contiguous(
                 scan_host, o.batch_method, o.num_batch)
+            if not self._presharded:
+                # one clustering for the whole job: rank 0's (the generators
+                # are synchronised too, see Comm.sync_random)
+                order, batches = self.comm.broadcast_object((order, batches))
         if self._spatial_sort:
             # neighbours in space become neighbours in memory inside every
             # minibatch (see cluster.spatial_order); batch membership and
@@ -246,6 +279,8 @@ class Reconstruction():
             warnings.warn(
                 "Diffraction patterns contain invalid data. "
                 "All data should be non-negative and finite.", UserWarning)
+        if not self._presharded:
+            self.comm.sync_random()
         self.order, self.local_order, self.batches = self._shard(
             data.shape[0])
         # HBM-resident data in batch-contiguous order (float32)
@@ -331,7 +366,11 @@ class Reconstruction():
             dist.all_gather_object(gathered, (self.local_order, local))
             full_order = np.concatenate([g[0] for g in gathered])
             parts = np.concatenate([g[1] for g in gathered], axis=0)
-        out = np.empty_like(parts)
+        if not np.array_equal(np.sort(full_order), np.arange(len(parts))):
+            raise RuntimeError(
+                "the ranks' position shards do not partition the scan "
+                "(duplicated or dropped positions)")
+        out = np.zeros_like(parts)
         out[full_order] = parts
         return out
 
@@ -445,7 +484,8 @@ def _apply_object_constraints(parameters):
 def _rescale_probe(operator, comm, data, parameters):
     """probe *= sqrt(sum(data) / sum(intensity)) over measured pixels and all
     ranks (ptycho.py:873-972)."""
-    nmeasured, mask_u8 = mask_info(parameters.exitwave_options)
+    nmeasured, mask_u8 = mask_info(parameters.exitwave_options,
+                                   operator.detector_shape)
     sums = torch.zeros(2, dtype=torch.float64, device=parameters.psi.device)
     for lo, hi, inten in _intensity_chunks(operator, parameters.psi,
                                            parameters.scan, parameters.probe):

@@ -16,7 +16,7 @@ from ... import opt
 from ..._lib import check, lib
 from ...operators.propagation import fft_scales
 from .lstsq import (NO_FARPLANE_SIZES, _workspace, chunk_positions,
-                    global_count, mask_info)
+                    global_count)
 
 
 def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,

@@ -18,7 +18,6 @@ Differences from the reference that do not change the mathematics:
     iterates up to summation order.
 """
 import logging
-import os
 
 import numpy as np
 import torch
@@ -65,13 +64,16 @@ NO_FARPLANE_SIZES = (256,)
 (tike_ptycho_fwd_intensity) and the gradient-scaled inverse."""
 
 
+CHUNK_POSITIONS_OVERRIDE = None
+"""Tests set this to force small kernel chunks (several per minibatch)."""
+
+
 def chunk_positions(S, det, position_major=False):
     """Positions per kernel launch: enough workgroups to fill the chip several
     times over while bounding the far-plane workspace.  The position-major
     kernels run one workgroup per position (not per tile)."""
-    forced = os.environ.get("TIKE_CHUNK_POSITIONS")  # tests: force chunking
-    if forced:
-        return max(1, int(forced))
+    if CHUNK_POSITIONS_OVERRIDE:
+        return max(1, int(CHUNK_POSITIONS_OVERRIDE))
     tiles = max(2048, (1 << 28) // (det * det * 8))  # >= 2048 tiles or 256 MiB
     if position_major:
         return max(1024, tiles // max(S, 1))
@@ -89,19 +91,27 @@ def global_count(comm, op, lo, hi):
     return cache[key]
 
 
-def mask_info(exitwave_options):
+def mask_info(exitwave_options, det=None):
     """(number of measured pixels, uint8 device mask or None when every pixel
-    is measured); computed once and cached on the options object."""
-    info = exitwave_options.__dict__.get("_mask_info")
-    if info is None:
-        mask = exitwave_options.measured_pixels
-        mask = mask if A.is_device(mask) else A.to_device(
+    is measured).  Cached on the options object, keyed on the identity and
+    shape of `measured_pixels` so that a caller who swaps the mask on a
+    reused options object is seen.  `det`: the detector width the kernels
+    will read the mask with (they read det*det bytes)."""
+    mask = exitwave_options.measured_pixels
+    if det is not None and tuple(mask.shape) != (det, det):
+        raise ValueError(
+            f"measured_pixels shape {tuple(mask.shape)} does not match the "
+            f"detector ({det}, {det})")
+    key = (id(mask), tuple(mask.shape))
+    cached = exitwave_options.__dict__.get("_mask_info")
+    if cached is None or cached[0] != key:
+        m = mask if A.is_device(mask) else A.to_device(
             np.asarray(mask, dtype=bool))
-        n = int(mask.sum().item())
-        info = (n, None if n == mask.numel() else mask.to(
-            torch.uint8).contiguous())
-        exitwave_options.__dict__["_mask_info"] = info
-    return info
+        n = int(m.sum().item())
+        info = (n, None if n == m.numel() else m.to(torch.uint8).contiguous())
+        cached = (key, info)
+        exitwave_options.__dict__["_mask_info"] = cached
+    return cached[1]
 
 
 def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
@@ -189,6 +199,21 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
 
     # one device->host scalar per epoch, as in the reference (lstsq.py:222)
     algorithm_options.costs.append([float(batch_cost.mean().item())])
+    if (eigen_weights is not None and eigen_weights.shape[1] > 1
+            and not np.isfinite(algorithm_options.costs[-1][0])):
+        # probe.py:426-427 raises when a minibatch's eigen weights are all
+        # zero; the check costs a host sync per minibatch there and is made
+        # here once per epoch, on the symptom (a non-finite cost)
+        nonzero = torch.stack([
+            (eigen_weights[int(idx[0]):int(idx[0]) + len(idx), 1:, 0]
+             != 0).sum(dim=0).to(torch.float32) if len(idx) else torch.zeros(
+                 eigen_weights.shape[1] - 1, device=psi.device)
+            for idx in batches
+        ])
+        if comm.collective:
+            comm.Allreduce(nonzero)  # the reference tests the whole batch
+        if bool((nonzero == 0).any().item()):
+            raise ValueError("eigen_probe weights cannot all be zero?")
 
     if recover_psi and compact:
         object_update_precond = _precondition_object_update(
@@ -256,7 +281,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     ws = _workspace(op)
     st = A.stream_ptr()
     fwd_scale, inv_scale = fft_scales(det, op.norm)
-    nmeasured, mask_u8 = mask_info(exitwave_options)
+    nmeasured, mask_u8 = mask_info(exitwave_options, det)
 
     # old weights: the step-size pass must see the probe this gradient used
     w_old = None
@@ -289,7 +314,6 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # detector sizes with the far-plane-free pipeline (the per-mode poisson
     # steps of 'all_modes' need |F_s|^2 and keep the stored far plane)
     no_farplane = (pos_major and det in NO_FARPLANE_SIZES
-                   and os.environ.get("TIKE_KEEP_FARPLANE") is None
                    and not (poisson and exitwave_options.step_length_usemodes
                             != "dominant_mode"))
     if poisson:
@@ -575,9 +599,9 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
         w = eigen_weights[lo:hi, c, m]
         norm_weights = comm.Allreduce_scalars([torch.sum(w * w)], dev)[0].to(
             torch.float32)
-        # a batch whose weights are all zero would divide by zero; the
+        # a batch whose weights are all zero divides by zero here; the
         # reference raises ValueError after a host sync (probe.py:426) --
-        # here the symptom is deferred to the epoch cost (NaN).
+        # lstsq_grad raises the same error at the end of the epoch
         if c == 1 and g.get("eigen_proj") is not None:
             first = g["eigen_proj"]  # formed by the step-statistics pass
         else:
