@@ -194,8 +194,11 @@ def make_problem(rng, N, pw, det, S, pitch=3.0, eigen=0, margin=0,
 
 
 # ---- lstsq pieces: one minibatch through the reference internals ----------
-def lstsq_parts(tag, N, pw, det, S, eigen):
-    p = make_problem(rng, N, pw, det, S, eigen=eigen)
+def lstsq_parts(tag, N, pw, det, S, eigen, slim=False, rng=None):
+    """slim: large tiles (128^2 / 256^2) -- keep only what the parity test
+    compares (mode 0 of chi, no per-position probe arrays)."""
+    rng = rng or globals()["rng"]
+    p = make_problem(rng, N, pw, det, S, eigen=eigen, pitch=5.0 if slim else 3.0)
     HW = p["psi0"].shape[-1]
     psi = (p["psi0"] * (1 + 0.2 * rc(rng, 1, HW, HW))).astype(np.complex64)
     measured = np.ones((det, det), dtype=bool)
@@ -243,6 +246,11 @@ def lstsq_parts(tag, N, pw, det, S, eigen):
             probe_options=params.probe_options)
         out.update(object_update_precond=precond, beta_object=beta_o,
                    beta_probe=beta_p)
+    if slim:
+        out["chi"] = np.asarray(out["chi"])[:, :, :1]
+        for k in ("unique_probe", "probe_update", "patches",
+                  "object_update_precond"):
+            del out[k]
     extra = {}
     if p["eigen_probe"] is not None:
         extra["eigen_probe"] = p["eigen_probe"]
@@ -253,6 +261,17 @@ def lstsq_parts(tag, N, pw, det, S, eigen):
          batch_hi=batches[bi][-1] + 1, psi_precond=psi_pre,
          probe_precond=probe_pre, **extra, **out)
 
+
+ONLY = os.environ.get("TIKE_FIXTURES_ONLY")  # e.g. "big": new fixtures only
+if ONLY == "big":
+    # the tile sizes of the fused FFT kernels (v2 engine, position-major
+    # forward, far-plane-free inverse): one minibatch each, own generators so
+    # that adding them leaves every other fixture bit-identical
+    lstsq_parts("eigen128", N=6, pw=128, det=128, S=8, eigen=1, slim=True,
+                rng=np.random.default_rng(128))
+    lstsq_parts("eigen256", N=4, pw=256, det=256, S=3, eigen=1, slim=True,
+                rng=np.random.default_rng(256))
+    sys.exit(0)
 
 lstsq_parts("plain", N=24, pw=16, det=16, S=2, eigen=0)
 lstsq_parts("eigen", N=24, pw=16, det=24, S=3, eigen=2)

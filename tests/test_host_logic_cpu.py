@@ -264,3 +264,24 @@ def test_resample_matches_reference(golden):
                                x)
     np.testing.assert_allclose(_resize_fft(x, 1), x)
     assert _resize_fft(x, 2.0).shape == (2, 16, 16)
+
+
+def test_bench_gpus_flag_is_never_silently_ignored():
+    """bench.py --gpus N: with WORLD_SIZE unset it must start N ranks or fail
+    (here: no GPU -> non-zero exit, nothing printed on stdout); with a
+    WORLD_SIZE that disagrees it must refuse."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "64"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert "refusing" in r.stderr
+    r = subprocess.run([sys.executable, bench, "--gpus", "4"],
+                       env=dict(env, WORLD_SIZE="2"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -152,7 +152,7 @@ def test_adjoint_identity_reference_shapes():
     np.testing.assert_allclose([a.real, a.imag], [c.real, c.imag], rtol=1e-3)
 
 
-@pytest.mark.parametrize("tag", ["plain", "eigen"])
+@pytest.mark.parametrize("tag", ["plain", "eigen", "eigen128", "eigen256"])
 def test_lstsq_parts_vs_reference(golden, tag):
     g = golden(f"lstsq_parts_{tag}.npz")
     det = int(g["det"])
@@ -170,7 +170,11 @@ def test_lstsq_parts_vs_reference(golden, tag):
         measured_pixels=np.ones((det, det), dtype=bool))
     for k in ("chi", "unique_probe", "probe_update", "object_upd_sum",
               "m_probe_update", "patches"):
-        assert_close(out[k], g[k], normwise=2e-5, what=k)
+        if k not in g:  # the 128^2 / 256^2 fixtures keep mode 0 of chi only
+            continue
+        want = g[k]
+        got = out[k][:, :, :want.shape[2]] if k == "chi" else out[k]
+        assert_close(got, want, normwise=2e-5, what=k)
     np.testing.assert_allclose(out["costs"], g["costs"], rtol=COST_RTOL)
     if ew is not None:
         ep2, ew2 = sol.update_nearplane(out, probe,
@@ -183,8 +187,9 @@ def test_lstsq_parts_vs_reference(golden, tag):
     precond, bo, bp = sol.precondition_nearplane_gradients(
         out["chi"], scan, out["unique_probe"], probe, out["object_upd_sum"],
         out["m_probe_update"], g["psi_precond"], out["patches"], lo, hi)
-    assert_close(precond, g["object_update_precond"], normwise=2e-5,
-                 what="object_update_precond")
+    if "object_update_precond" in g:
+        assert_close(precond, g["object_update_precond"], normwise=2e-5,
+                     what="object_update_precond")
     assert bo.shape == g["beta_object"].shape
     assert bp.shape == g["beta_probe"].shape
     np.testing.assert_allclose(bo, g["beta_object"], rtol=1e-3)
