@@ -86,12 +86,14 @@ int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe, int p
  * (TIKE_ERR_UNSUPPORTED otherwise: use tike_ptycho_fwd + tike_intensity).
  * intensity (nscan,det,det) f32 may be NULL.  With eigen_weights the probe of
  * mode s at position n is unique_probe[n][s] for s < eigen_modes (from
- * tike_varying_probe) and eigen_weights[n][0][s] * probe[s] otherwise. */
+ * tike_varying_probe) and eigen_weights[n][0][s] * probe[s] otherwise.
+ * patches (nscan,pw,pw) c64, may be NULL: the object patches O_n = Patch.fwd(psi)
+ * (lstsq.py:524-531), stored while they are in registers. */
 int tike_ptycho_fwd_intensity(const void* psi, const float* scan, const void* probe,
                               int probe_per_scan, const void* unique_probe,
                               const float* eigen_weights, int num_eigen, int eigen_modes,
-                              void* farplane, float* intensity, int nscan, int S, int pw, int det,
-                              int H, int W, float scale, void* stream);
+                              void* farplane, float* intensity, void* patches, int nscan, int S,
+                              int pw, int det, int H, int W, float scale, void* stream);
 
 /* ---- the same forward model for the intensity ONLY (det = 256;
  * TIKE_ERR_UNSUPPORTED otherwise): the far-plane waves are formed in registers
@@ -110,11 +112,11 @@ int tike_ptycho_fwd_intensity_only(const void* psi, const float* scan, const voi
 int tike_ptycho_fwd_gradient_scale(const void* psi, const float* scan, const void* probe,
                                    int probe_per_scan, const void* unique_probe,
                                    const float* eigen_weights, int num_eigen, int eigen_modes,
-                                   void* scratch, float* intensity, const float* data,
-                                   const unsigned char* measured, float* gscale, float* costs,
-                                   int nscan, int S, int pw, int det, int H, int W, float scale,
-                                   int model, float unmeasured_scaling, long num_measured,
-                                   void* stream);
+                                   void* scratch, float* intensity, void* patches,
+                                   const float* data, const unsigned char* measured,
+                                   float* gscale, float* costs, int nscan, int S, int pw, int det,
+                                   int H, int W, float scale, int model, float unmeasured_scaling,
+                                   long num_measured, void* stream);
 
 /* ---- far-plane gradient + IFFT2 + crop from that scratch (lstsq.py:491-507):
  * chi = crop(IFFT2(F * gscale [* mode_scale on measured pixels])) * inv_scale
@@ -126,6 +128,40 @@ int tike_grad_ifft2_crop(const void* colin, const float* gscale, const float* mo
                          const unsigned char* measured, int S, void* work, void* chi,
                          long ntile, int det, int pw, float fwd_scale, float inv_scale,
                          void* stream);
+
+/* ---- the inverse transform split for the gradient pass (lstsq.py:504-539).
+ * Pass 1 only: `work` (ntile,det,det) receives the INPUT of the inverse column
+ * pass of every tile (rows 16 k + ya of fft_engine2.h) -- from the forward
+ * kernel's scratch (tike_grad_ifft2_pass1, det = 256; operands as
+ * tike_grad_ifft2_crop) or from a stored far plane times gscale
+ * [* mode_scale on measured pixels] (tike_ifft2_pass1_scaled, det in
+ * {128,256,512}; operands as tike_ifft2_crop_scaled_modes, mode_scale /
+ * measured may be NULL).  work must not alias the input. */
+int tike_grad_ifft2_pass1(const void* colin, const float* gscale, const float* mode_scale,
+                          const unsigned char* measured, int S, void* work, long ntile, int det,
+                          float fwd_scale, void* stream);
+int tike_ifft2_pass1_scaled(const void* farplane, const float* gscale, const float* mode_scale,
+                            const unsigned char* measured, int S, void* work, long ntile, int det,
+                            void* stream);
+
+/* Pass 2 fused with both gradients, chi never stored (lstsq.py:504-539):
+ *   chi_n,s  = inv_scale * (column pass of work[n][s])         (registers only)
+ *   objproj[n]        = sum_s conj(P_n,s) chi_n,s     (lstsq.py:510-513)
+ *   m_probe_update[s] += sum_n conj(patches[n]) chi_n,s        (:531-539)
+ *   chi0[n]           = chi_n,0                       (:507; step sizes etc.)
+ * P_n,s = the shared probe scaled by eigen_weights[n][0][s] plus, for the first
+ * eigen_modes modes, the eigen probes (probe.py:272-303, applied on the fly from
+ * LDS-resident slices: num_eigen * eigen_modes * det * 32 bytes <= 32 KiB, else
+ * TIKE_ERR_UNSUPPORTED).  patches (nscan,det,det)
+ * = O_n as stored by the forward kernels.  objproj / chi0 / m_probe_update may
+ * each be NULL.  Probe window = detector (pw == det); det in {128,256,512};
+ * S <= 8 (<= 4 at 512): TIKE_ERR_UNSUPPORTED otherwise -- use tike_ifft2_crop*
+ * followed by tike_lstsq_gradients. */
+int tike_ifft2_pass2_gradients(const void* work, const void* patches, const void* probe,
+                               const void* eigen_probe, const float* eigen_weights,
+                               int num_eigen, int eigen_modes, void* objproj, void* chi0,
+                               void* m_probe_update, int nscan, int S, int det, float inv_scale,
+                               void* stream);
 
 /* ---- far-plane gradient factor from the intensity (objective.py:31-44,97-109;
  * lstsq.py:491-502): gscale[n][p] = -(1 - sqrt(d)/(sqrt(I)+1e-9)) (gaussian) or

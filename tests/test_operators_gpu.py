@@ -355,7 +355,10 @@ def test_full_size_roundtrip_property(ops):
 
 @pytest.mark.parametrize("det,pw,S", [(128, 128, 3), (256, 256, 2),
                                       (128, 96, 2), (512, 512, 2),
-                                      (512, 384, 1), (256, 192, 3)])
+                                      (512, 384, 1), (256, 192, 3),
+                                      (256, 256, 8), (256, 256, 1),
+                                      (256, 256, 5), (128, 128, 8),
+                                      (128, 128, 1), (512, 512, 4)])
 def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
     """tike_ptycho_fwd_intensity -> tike_gradient_scale ->
     tike_ifft2_crop_scaled == oracle fwd, intensity, per-pattern cost and
@@ -393,13 +396,16 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
     I = torch.empty((N, det, det), dtype=torch.float32, device=dev)
     st = A.stream_ptr()
     uq = torch.empty((N, 1, pw, pw), dtype=torch.complex64, device=dev)
+    pat = torch.empty((N, pw, pw), dtype=torch.complex64, device=dev)
     check(lib.tike_varying_probe(A.ptr(probe_d), A.ptr(eig_d), A.ptr(w_d), C, 1,
                                  A.ptr(uq), N, S, pw, st))
     assert_close(uq.cpu().numpy(), uprobe[:, 0, :1], what="varying probe")
     check(lib.tike_ptycho_fwd_intensity(
         A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, A.ptr(uq),
-        A.ptr(w_d), C, 1, A.ptr(far), A.ptr(I), N, S, pw, det, HW, HW,
-        1.0 / det, st))
+        A.ptr(w_d), C, 1, A.ptr(far), A.ptr(I), A.ptr(pat), N, S, pw, det, HW,
+        HW, 1.0 / det, st))
+    assert_close(pat.cpu().numpy(), oracle.patch_fwd(psi[0], scan, patch_width=pw),
+                 what="patches stored by the forward kernel")
     assert_close(far.cpu().numpy(), want_far, what="farplane")
     assert_close(I.cpu().numpy(), want_I, what="intensity")
     d_d, m_d = t(data_nan, np.float32), t(mask.astype(np.uint8))
@@ -417,6 +423,39 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
                                      st))
     assert_close(chi.cpu().numpy(), want_chi, normwise=1e-4, maxabs=1e-3,
                  what="chi")
+
+    def fused_gradients(work, what):
+        """tike_ifft2_pass2_gradients on a pass-1 intermediate == the oracle's
+        objproj / m_probe_update / chi mode 0 (lstsq.py:504-539)."""
+        proj = torch.full((N, pw, pw), 7.0, dtype=torch.complex64, device=dev)
+        chi0 = torch.full_like(proj, 7.0)
+        mpu = torch.zeros((S, pw, pw), dtype=torch.complex64, device=dev)
+        check(lib.tike_ifft2_pass2_gradients(
+            A.ptr(work), A.ptr(pat), A.ptr(probe_d), A.ptr(eig_d), A.ptr(w_d),
+            C, 1, A.ptr(proj), A.ptr(chi0), A.ptr(mpu), N, S, det, 1.0 / det,
+            st))
+        want_proj = (np.conj(uprobe[:, 0]) * want_chi[:, 0]).sum(axis=1)
+        patches = oracle.patch_fwd(psi[0], scan, patch_width=pw)
+        want_mpu = (np.conj(patches)[:, None] * want_chi[:, 0]).sum(axis=0)
+        assert_close(proj.cpu().numpy(), want_proj, normwise=1e-4, maxabs=1e-3,
+                     what=f"objproj ({what})")
+        assert_close(chi0.cpu().numpy(), want_chi[:, 0, 0], normwise=1e-4,
+                     maxabs=1e-3, what=f"chi0 ({what})")
+        assert_close(mpu.cpu().numpy(), want_mpu, normwise=1e-4, maxabs=1e-3,
+                     what=f"m_probe_update ({what})")
+        # probe gradient only (no object projection): the other instantiation
+        mpu2 = torch.zeros_like(mpu)
+        check(lib.tike_ifft2_pass2_gradients(
+            A.ptr(work), A.ptr(pat), None, None, None, 0, 0, None, None,
+            A.ptr(mpu2), N, S, det, 1.0 / det, st))
+        assert_close(mpu2.cpu().numpy(), want_mpu, normwise=1e-4, maxabs=1e-3,
+                     what=f"m_probe_update alone ({what})")
+
+    if pw == det and S <= (4 if det == 512 else 8):
+        work = torch.empty_like(far)
+        check(lib.tike_ifft2_pass1_scaled(A.ptr(far), A.ptr(g), None, None, S,
+                                          A.ptr(work), N * S, det, st))
+        fused_gradients(work, "stored far plane")
     if det == 256:
         # the far-plane-free pipeline: forward for the intensity only, then the
         # gradient and the inverse transform from the column-pass scratch
@@ -431,11 +470,13 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
         g2 = torch.empty_like(g)
         costs2 = torch.empty_like(costs)
         scratch2 = torch.empty_like(far)
+        pat2 = torch.empty_like(pat)
         check(lib.tike_ptycho_fwd_gradient_scale(
             A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, A.ptr(uq),
-            A.ptr(w_d), C, 1, A.ptr(scratch2), None, A.ptr(d_d), A.ptr(m_d),
-            A.ptr(g2), A.ptr(costs2), N, S, pw, det, HW, HW, 1.0 / det, 0, 0.5,
-            int(mask.sum()), st))
+            A.ptr(w_d), C, 1, A.ptr(scratch2), None, A.ptr(pat2), A.ptr(d_d),
+            A.ptr(m_d), A.ptr(g2), A.ptr(costs2), N, S, pw, det, HW, HW,
+            1.0 / det, 0, 0.5, int(mask.sum()), st))
+        assert torch.equal(pat2, pat)
         np.testing.assert_allclose(costs2.cpu().numpy(), want_cost,
                                    rtol=COST_RTOL)
         np.testing.assert_allclose(g2.cpu().numpy(), g.cpu().numpy(),
@@ -449,6 +490,12 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
             N * S, det, pw, 1.0 / det, 1.0 / det, st))
         assert_close(chi2.cpu().numpy(), want_chi, normwise=1e-4, maxabs=1e-3,
                      what="chi (no far plane)")
+        if pw == det:
+            work = torch.empty_like(far)
+            check(lib.tike_grad_ifft2_pass1(A.ptr(scratch), A.ptr(g), None,
+                                            None, S, A.ptr(work), N * S, det,
+                                            1.0 / det, st))
+            fused_gradients(work, "no far plane")
         # per-mode factor on measured pixels (poisson form)
         steps = torch.rand((N, S), dtype=torch.float32, device=dev) + 0.5
         check(lib.tike_grad_ifft2_crop(
@@ -519,11 +566,15 @@ def test_abi_edge_cases():
     lib = L.lib
     st = A.stream_ptr()
     z = None
-    assert lib.tike_ptycho_fwd_intensity(z, z, z, 0, z, z, 0, 0, z, z, 0, 2,
+    assert lib.tike_ptycho_fwd_intensity(z, z, z, 0, z, z, 0, 0, z, z, z, 0, 2,
                                          64, 64, 100, 100, 1.0, st) == 0
     assert lib.tike_ptycho_fwd_gradient_scale(
-        z, z, z, 0, z, z, 0, 0, z, z, z, z, z, z, 0, 2, 256, 256, 400, 400,
+        z, z, z, 0, z, z, 0, 0, z, z, z, z, z, z, z, 0, 2, 256, 256, 400, 400,
         1.0, 0, 1.0, 65536, st) == 0
+    assert lib.tike_grad_ifft2_pass1(z, z, z, z, 2, z, 0, 256, 1.0, st) == 0
+    assert lib.tike_ifft2_pass1_scaled(z, z, z, z, 2, z, 0, 128, st) == 0
+    assert lib.tike_ifft2_pass2_gradients(z, z, z, z, z, 0, 0, z, z, z, 0, 2,
+                                          256, 1.0, st) == 0
     assert lib.tike_grad_ifft2_crop(z, z, z, z, 2, z, z, 0, 256, 256, 1.0, 1.0,
                                     st) == 0
     assert lib.tike_scatter_patches(z, z, z, 0, 64, 100, 100, st) == 0
@@ -540,14 +591,22 @@ def test_abi_edge_cases():
     s = torch.full((1, 2), 5.0, dtype=torch.float32, device="cuda")
     p = lambda t: t.data_ptr()
     assert lib.tike_ptycho_fwd_gradient_scale(
-        p(x), p(s), p(x), 0, z, z, 0, 0, p(x), z, p(f), z, p(f), z, 1, 1, 128,
-        128, 200, 200, 1.0, 0, 1.0, 128 * 128, st) == L.ERR_UNSUPPORTED
+        p(x), p(s), p(x), 0, z, z, 0, 0, p(x), z, z, p(f), z, p(f), z, 1, 1,
+        128, 128, 200, 200, 1.0, 0, 1.0, 128 * 128, st) == L.ERR_UNSUPPORTED
+    assert lib.tike_grad_ifft2_pass1(p(x), p(f), z, z, 1, p(x) + 8, 1, 128,
+                                     1.0, st) == L.ERR_UNSUPPORTED
+    assert lib.tike_ifft2_pass2_gradients(p(x), p(x), p(x), z, z, 0, 0, p(x),
+                                          z, z, 1, 9, 128, 1.0,
+                                          st) == L.ERR_UNSUPPORTED  # S > 8
+    assert lib.tike_ifft2_pass2_gradients(p(x), p(x), p(x), z, z, 0, 0, p(x),
+                                          z, z, 1, 1, 64, 1.0,
+                                          st) == L.ERR_UNSUPPORTED
     assert lib.tike_grad_ifft2_crop(p(x), p(f), z, z, 1, p(x) + 8, p(x) + 16,
                                     1, 128, 128, 1.0, 1.0,
                                     st) == L.ERR_UNSUPPORTED
     # argument errors: probe wider than the detector, work aliasing the input
     assert lib.tike_ptycho_fwd_intensity(p(x), p(s), p(x), 0, z, z, 0, 0, p(x),
-                                         z, 1, 1, 256, 128, 300, 300, 1.0,
+                                         z, z, 1, 1, 256, 128, 300, 300, 1.0,
                                          st) == L.ERR_ARG
     assert lib.tike_ifft2_crop_scaled(p(x), p(f), 1, p(x), p(x), 1, 128, 128,
                                       1.0, st) == L.ERR_ARG

@@ -47,8 +47,8 @@ _PROTOTYPES = {
     "tike_ptycho_fwd": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i,
                         _i, _i, _f, _p],
     "tike_ifft2_crop": [_p, _p, _p, _l, _i, _i, _f, _p],
-    "tike_ptycho_fwd_intensity": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _i,
-                                  _i, _i, _i, _i, _i, _f, _p],
+    "tike_ptycho_fwd_intensity": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p,
+                                  _i, _i, _i, _i, _i, _i, _f, _p],
     "tike_gradient_scale": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _l, _p],
     "tike_ifft2_crop_scaled": [_p, _p, _i, _p, _p, _l, _i, _i, _f, _p],
     "tike_ifft2_crop_scaled_modes": [_p, _p, _p, _p, _i, _p, _p, _l, _i, _i, _f,
@@ -58,8 +58,12 @@ _PROTOTYPES = {
     "tike_ptycho_fwd_intensity_only": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p,
                                        _i, _i, _i, _i, _i, _i, _f, _p],
     "tike_ptycho_fwd_gradient_scale": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p,
-                                       _p, _p, _p, _p, _i, _i, _i, _i, _i, _i,
-                                       _f, _i, _f, _l, _p],
+                                       _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,
+                                       _i, _f, _i, _f, _l, _p],
+    "tike_grad_ifft2_pass1": [_p, _p, _p, _p, _i, _p, _l, _i, _f, _p],
+    "tike_ifft2_pass1_scaled": [_p, _p, _p, _p, _i, _p, _l, _i, _p],
+    "tike_ifft2_pass2_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i,
+                                   _i, _i, _f, _p],
     "tike_grad_ifft2_crop": [_p, _p, _p, _p, _i, _p, _p, _l, _i, _i, _f, _f,
                              _p],
     "tike_position_sums": [_p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p, _i,

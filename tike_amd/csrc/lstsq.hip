@@ -9,6 +9,7 @@
 // where chi is the exit-wave update (IFFT2 of the far-plane gradient cropped
 // to the probe window), P_n,s the probe at position n (shared probe plus
 // eigen probes synthesised on the fly) and O_n the bilinear object patch.
+#include "fft_engine2.h"
 #include "internal.h"
 #include "tike_amd.h"
 
@@ -451,6 +452,318 @@ extern "C" int tike_lstsq_gradients(const void* chi, const float* scan, const vo
                           tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen,
                                         eigen_modes, S, pw, unique_probe),
                           (cf*)objproj, nscan, S, pw, H, W, chunk);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// ------------------------------------------- inverse pass 2 + both gradients
+// The second pass of the inverse 2-D FFT (fft_engine2.h: in-place radix-RB over
+// rows {ya + 16 k}) run PIXEL-major and fused with everything that consumes
+// the exit-wave update chi (lstsq.py:504-539), so chi is never stored:
+//   objproj_n      = sum_s conj(P_n,s) chi_n,s      (one write per position)
+//   m_probe_update += sum_n conj(O_n) chi_n,s       (register accumulators over
+//                                                    a chunk of positions, one
+//                                                    atomic per pixel/mode/chunk)
+//   chi0_n         = chi_n,0                        (step sizes, eigen probes,
+//                                                    position correction)
+// Probe window = detector (pw == N).  A workgroup owns one slice of the tile:
+// the RB rows {ya + 16 yb} -- exactly what one radix-RB butterfly per thread
+// consumes and produces -- by 64 * (4 / MW) columns, and walks a chunk of
+// positions.  Its four waves are MW mode-waves x (4 / MW) column-waves: wave
+// (mw, cw) handles modes {mw, mw + MW, ...} (MPW of them) of column block cw,
+// lane = column, so every global access is a 512-byte row segment at one of
+// the RB offsets off0 + yb * 16 N (the same offsets for the intermediate,
+// the patches, the probe and every output).  The per-position sum over modes
+// crosses the mode-waves through LDS: every wave leaves its partial sum in a
+// slot of its own, one barrier, then mode-wave mw adds the slots of rows
+// yb = mw (mod MW) and writes them (slots double buffered where they fit).
+struct TkModeProbe {  // probe of one (position, mode): uniform values
+  const cf* base;     // shared probe of the mode, or its synthesised varying probe
+  float w0;           // scale of `base`
+  int nE;             // eigen probes to add on the fly (0 when `base` is final)
+};
+
+// Element `byte_off` bytes past a UNIFORM base pointer: written so that the
+// compiler selects the scalar-base addressing mode (SGPR pair + one 32-bit
+// VGPR offset shared by all rows of the slice) instead of a 64-bit address
+// pair per row.
+template <class T>
+__device__ __forceinline__ const T* tk_at(const T* base, unsigned byte_off) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ T* tk_at(T* base, unsigned byte_off) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+
+template <int N, int MW, int MPW, bool HAVE_PROJ>
+__global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
+    const cf* __restrict__ mid, const cf* __restrict__ patches, const TkProbe probe,
+    cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, int nscan, int S,
+    float inv_scale, int chunk) {
+  constexpr int RB = N / 16;
+  constexpr int CW = 4 / MW;            // column-waves per workgroup
+  constexpr int NCB = N / (64 * CW);    // column blocks
+  constexpr int NSLICE = 16 * NCB;      // (ya, column block) slices
+  constexpr bool REDUCE = HAVE_PROJ && MW > 1;
+  // RB = 32 (N = 512): the accumulators and one butterfly already fill the
+  // register file, so probe and patch values are re-read (L2) per use
+  constexpr bool HOIST = RB <= 16;
+  static_assert(NCB >= 1 && NSLICE % 8 == 0, "slice layout");
+  constexpr int NBUF = RB <= 16 ? 2 : 1;  // slot sets (2: one barrier per position)
+  __shared__ cf part[REDUCE ? NBUF * 4 * RB * 64 : 1];  // [buf][wave][yb][lane]
+  extern __shared__ cf eigl[];  // conj(E_c,s) on this slice: [C][Sm][RB][64 CW]
+  constexpr long P = (long)N * N;
+  // XCD-aware slice order: workgroup v runs on XCD v % 8 (round-robin
+  // dispatch); every XCD keeps NSLICE/8 slices, so its L2 holds 1/8 of the
+  // probe and of the patches.  Placement affects speed only.
+  const int v = blockIdx.x;
+  constexpr int per = NSLICE / 8;
+  const int slice = (v & 7) * per + (v >> 3) % per;
+  const int b0 = ((v >> 3) / per) * chunk;
+  const int b1 = min(nscan, b0 + chunk);
+  const int ya = slice / NCB, cb = slice % NCB;
+  // the wave index is uniform: say so, so that everything derived from it
+  // (mode, column block, base pointers, weights) lives in scalar registers
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int mw = w % MW, cw = w / MW;
+  constexpr long ROW = 16 * N;  // elements between the rows of this slice
+  // uniform element offset of the slice's first row and column block, and the
+  // per-lane byte offset inside a row segment
+  const long slice0 = (long)ya * N + (cb * CW + cw) * 64;
+  const unsigned lb = (unsigned)lane * (unsigned)sizeof(cf);
+  if (HAVE_PROJ && probe.weights != nullptr && probe.eigen != nullptr) {
+    const int total = probe.C * probe.Sm * RB * 64 * CW;
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const int x = i % (64 * CW), yb = (i / (64 * CW)) % RB, cs = i / (64 * CW * RB);
+      eigl[i] = conjf(probe.eigen[(long)cs * P + ya * N + yb * ROW + cb * CW * 64 + x]);
+    }
+  }
+  __syncthreads();
+  static_assert(MW > 1 || MPW == 1, "a lone mode-wave writes objproj straight from one mode");
+  cf acc[MPW][RB];
+  // conj(shared probe) at this thread's pixels
+  cf Pc[HAVE_PROJ && HOIST ? MPW : 1][HAVE_PROJ && HOIST ? RB : 1];
+#pragma unroll
+  for (int m = 0; m < MPW; ++m) {
+    const int s = mw + MW * m;
+    const int sc = s < S ? s : S - 1;  // idle (wave, m): any valid mode, result unused
+#pragma unroll
+    for (int yb = 0; yb < RB; ++yb) {
+      acc[m][yb] = mk(0.f, 0.f);
+      if (HAVE_PROJ && HOIST)
+        Pc[m][yb] = conjf(*tk_at(probe.probe + (long)sc * P + slice0 + yb * ROW, lb));
+    }
+  }
+  // eigen probes vary the probe of the first Sm modes per position
+  // (probe.py:272-303); only the waves that own those modes meet them
+  const bool vary = HAVE_PROJ && probe.weights != nullptr;
+  const int nE = (vary && probe.eigen != nullptr) ? probe.C : 0;
+  for (int n = b0; n < b1; ++n) {
+    // keep the per-lane offset out of the loop's induction variables: bases
+    // stay in scalar registers, one 32-bit VGPR offset serves every access
+    unsigned lo = lb;
+    asm volatile("" : "+v"(lo));
+    const cf* __restrict__ On = patches + (long)n * P + slice0;
+    // with two modes per wave the patch values are re-read for the second
+    // one (an L1/L2 hit) rather than held across both: 32 registers
+    constexpr bool O_ONCE = HOIST && MPW == 1;
+    cf O[HOIST ? RB : 1];
+    if (O_ONCE) {
+#pragma unroll
+      for (int yb = 0; yb < RB; ++yb) O[yb] = *tk_at(On + yb * ROW, lo);
+    }
+    // this wave's slot, and slot 0 of its column block, for this position
+    cf* slot = part + ((((n - b0) & (NBUF - 1)) * 4 + w) * RB) * 64 + lane;
+    const cf* slots = part + ((((n - b0) & (NBUF - 1)) * 4 + cw * MW) * RB) * 64 + lane;
+    const float* __restrict__ wn =
+        vary ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+      const int s = mw + MW * m;
+      if (s < S) {  // wave-uniform
+        const cf* __restrict__ src = mid + ((long)n * S + s) * P + slice0;
+        cf u[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) u[k] = tk_ld_stream(tk_at(src + k * ROW, lo));
+        if (HOIST && !O_ONCE) {
+#pragma unroll
+          for (int yb = 0; yb < RB; ++yb) O[yb] = *tk_at(On + yb * ROW, lo);
+        }
+        const float w0 = vary ? wn[s] : 1.0f;
+        Dft<RB, true>::run(u);
+        if (HOIST) {
+#pragma unroll
+          for (int yb = 0; yb < RB; ++yb) {
+            u[yb] = u[yb] * inv_scale;  // chi of row ya + 16 yb
+            acc[m][yb] = acc[m][yb] + conjf(O[yb]) * u[yb];
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < RB; g += 8) {
+            cf o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = *tk_at(On + (g + i) * ROW, lo);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              u[g + i] = u[g + i] * inv_scale;
+              acc[m][g + i] = acc[m][g + i] + conjf(o[i]) * u[g + i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (s == 0 && chi0 != nullptr) {
+#pragma unroll
+          for (int yb = 0; yb < RB; ++yb)
+            tk_st_stream(tk_at(chi0 + (long)n * P + slice0 + yb * ROW, lo), u[yb]);
+        }
+        if (HAVE_PROJ) {
+          const cf* __restrict__ Ps = probe.probe + (long)s * P + slice0;
+          const bool eig = nE > 0 && s < probe.Sm;  // wave-uniform, rare
+#pragma unroll
+          for (int g = 0; g < RB; g += 8) {
+            cf pc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              pc[i] = HOIST ? Pc[m][g + i] : conjf(*tk_at(Ps + (g + i) * ROW, lo));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              cf t = (pc[i] * u[g + i]) * w0;
+              if (REDUCE) {
+                // first mode of the wave fills its slot, later ones add to it
+                // (a wave's LDS operations execute in order)
+                slot[(g + i) * 64] = m == 0 ? t : slot[(g + i) * 64] + t;
+              } else {
+                // a lone mode-wave: the whole projection is this one product
+                if (eig) {
+#pragma unroll 1
+                  for (int c = 0; c < nE; ++c)
+                    t = t + (eigl[((c * probe.Sm + s) * RB + g + i) * (64 * CW) + cw * 64 + lane] *
+                             u[g + i]) * wn[(c + 1) * probe.S + s];
+                }
+                tk_st_stream(tk_at(objproj + (long)n * P + slice0 + (g + i) * ROW, lo), t);
+              }
+            }
+            if (!HOIST) __builtin_amdgcn_sched_barrier(0);
+          }
+          if (REDUCE && eig) {
+            // + sum_c w_c conj(E_c,s) chi from the LDS-resident eigen slices
+            // (only the waves owning the first Sm modes)
+#pragma unroll 1
+            for (int c = 0; c < nE; ++c) {
+              const float wc = wn[(c + 1) * probe.S + s];
+              const cf* __restrict__ el =
+                  eigl + ((c * probe.Sm + s) * RB) * (64 * CW) + cw * 64 + lane;
+#pragma unroll
+              for (int yb = 0; yb < RB; ++yb)
+                slot[yb * 64] = slot[yb * 64] + (el[yb * (64 * CW)] * u[yb]) * wc;
+            }
+          }
+        }
+      } else if (REDUCE && m == 0) {
+        // idle mode-wave (fewer modes than waves): an empty partial sum
+#pragma unroll
+        for (int yb = 0; yb < RB; ++yb) slot[yb * 64] = mk(0.f, 0.f);
+      }
+    }
+    if (REDUCE) {
+      __syncthreads();
+      // mode-wave mw finishes rows yb = mw, mw + MW, ... of its column block
+#pragma unroll
+      for (int q = 0; q < RB / MW; ++q) {
+        const int yb = mw + MW * q;
+        cf sum = slots[yb * 64];
+#pragma unroll
+        for (int k = 1; k < MW; ++k) sum = sum + slots[(k * RB + yb) * 64];
+        tk_st_stream(tk_at(objproj + (long)n * P + slice0 + yb * ROW, lo), sum);
+      }
+      if (NBUF == 1) __syncthreads();  // the single slot set is rewritten next
+    }
+  }
+  if (mpu != nullptr) {
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+      const int s = mw + MW * m;
+      if (s < S) {
+#pragma unroll
+        for (int yb = 0; yb < RB; ++yb) {
+          float* o = tk_at(mpu + 2 * ((long)s * P + slice0 + yb * ROW), lb);
+          unsafeAtomicAdd(o, acc[m][yb].x);
+          unsafeAtomicAdd(o + 1, acc[m][yb].y);
+        }
+      }
+    }
+  }
+}
+
+// work (nscan,S,det,det): output of tike_grad_ifft2_pass1 / tike_ifft2_pass1_scaled;
+// patches (nscan,det,det): O_n from the forward kernel.  Outputs (each may be
+// NULL): objproj (nscan,det,det), chi0 (nscan,det,det), m_probe_update
+// (S,det,det, accumulated).  Probe window = detector; det in {128, 256, 512};
+// S <= 8 (TIKE_ERR_UNSUPPORTED otherwise: use tike_ifft2_crop* +
+// tike_lstsq_gradients).
+extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
+                                          const void* probe, const void* eigen_probe,
+                                          const float* eigen_weights, int num_eigen,
+                                          int eigen_modes, void* objproj, void* chi0,
+                                          void* m_probe_update,
+                                          int nscan, int S, int det, float inv_scale,
+                                          void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(work && patches && (probe || !objproj));
+  if (S > 8 || (det != 128 && det != 256 && det != 512)) return TK_ERR_UNSUPPORTED;
+  const TkProbe pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
+                                   S, det);
+  // mode-waves x column-waves of a workgroup and modes per wave
+  int MW = S >= 3 ? 4 : S;
+  if (det == 128 && MW == 1) MW = 2;  // a 128-wide tile has only two 64-column waves
+  const int MPW = S > 4 ? 2 : 1;
+  const int nslice = 16 * (det / (64 * (4 / MW)));
+  // enough (slice, chunk) workgroups to fill the chip about three times
+  int nchunk = (2304 + nslice - 1) / nslice;
+  int chunk = (nscan + nchunk - 1) / nchunk;
+  if (chunk < 8) chunk = 8;
+  nchunk = (nscan + chunk - 1) / chunk;
+  const dim3 grid((unsigned)(nslice * nchunk)), block(256);
+  // LDS for the eigen-probe slices (only when they are applied on the fly)
+  size_t eig_lds = 0;
+  if (objproj && eigen_weights && eigen_probe)
+    eig_lds = sizeof(cf) * (size_t)num_eigen * eigen_modes * (det / 16) * 64 * (4 / MW);
+  if (eig_lds > 32 * 1024) return TK_ERR_UNSUPPORTED;
+#define TK_P2G(N, MW_, MPW_)                                                                 \
+  do {                                                                                       \
+    if (objproj)                                                                             \
+      hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true>), grid, block,    \
+                         eig_lds,                                                            \
+                         stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
+                         (cf*)chi0, (float*)m_probe_update, nscan, S, inv_scale, chunk);     \
+    else                                                                                     \
+      hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, false>), grid, block,   \
+                         0, stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,   \
+                         (cf*)chi0, (float*)m_probe_update, nscan, S, inv_scale, chunk);     \
+  } while (0)
+#define TK_P2G_N(N)                     \
+  do {                                  \
+    if (MW == 1)                        \
+      TK_P2G(N < 256 ? 256 : N, 1, 1);  \
+    else if (MW == 2)                   \
+      TK_P2G(N, 2, 1);                  \
+    else if (MPW == 1)                  \
+      TK_P2G(N, 4, 1);                  \
+    else                                \
+      TK_P2G(N, 4, 2);                  \
+  } while (0)
+  switch (det) {
+    case 128: TK_P2G_N(128); break;
+    case 256: TK_P2G_N(256); break;
+    default: TK_P2G_N(512); break;
+  }
+#undef TK_P2G_N
+#undef TK_P2G
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

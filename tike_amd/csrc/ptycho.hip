@@ -230,7 +230,8 @@ template <int N, bool STORE = true>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_pos_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ farplane, float* __restrict__ intensity, int nscan, int S, int pw, int H,
-    int W, float scale, const cf* __restrict__ twtab, const TkGradScale gsc) {
+    int W, float scale, const cf* __restrict__ twtab, const TkGradScale gsc,
+    cf* __restrict__ patches) {
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
   cf* twl = lds + G2::LDS_ELEMS;
@@ -268,6 +269,15 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
         // bound the taps in flight (4 elements = 16 loads) and with them the
         // register footprint of this phase
         if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (patches != nullptr && py >= 0 && py < pw) {
+        // the object patch O_n (Patch.fwd, lstsq.py:524-531) for the gradient
+        // and step-size passes, while it is in registers
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int px = j + i * G2::T - pad;
+          if (px >= 0 && px < pw) patches[n * PP + (long)py * pw + px] = pv[i];
+        }
       }
       for (int s = 0; s < S; ++s) {
         // probe of this (position, mode): a base pointer and a scale, both
@@ -384,14 +394,15 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_POS_WAVES : 2)) void ptycho_fwd_p
 template <int N, bool STORE = true>
 static int launch_fwd_pos(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                           float* intensity, int nscan, int S, int pw, int H, int W, float scale,
-                          hipStream_t stream, const TkGradScale* gsc = nullptr) {
+                          hipStream_t stream, const TkGradScale* gsc = nullptr,
+                          cf* patches = nullptr) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   TkGradScale g = {};
   if (gsc) g = *gsc;
   hipLaunchKernelGGL((ptycho_fwd_pos_kernel<N, STORE>), dim3(tk_grid(nscan, 4)), dim3(N), 0,
                      stream, psi, scan, probe, farplane, intensity, nscan, S, pw, H, W, scale, tw,
-                     g);
+                     g, patches);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -400,8 +411,8 @@ extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, con
                                          int probe_per_scan, const void* unique_probe,
                                          const float* eigen_weights, int num_eigen,
                                          int eigen_modes, void* farplane, float* intensity,
-                                         int nscan, int S, int pw, int det, int H, int W,
-                                         float scale, void* stream_) {
+                                         void* patches, int nscan, int S, int pw, int det, int H,
+                                         int W, float scale, void* stream_) {
   TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
@@ -414,13 +425,13 @@ extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, con
   switch (det) {
     case 128:
       return launch_fwd_pos<128>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
-                                 H, W, scale, stream);
+                                 H, W, scale, stream, nullptr, (cf*)patches);
     case 256:
       return launch_fwd_pos<256>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
-                                 H, W, scale, stream);
+                                 H, W, scale, stream, nullptr, (cf*)patches);
     case 512:
       return launch_fwd_pos<512>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
-                                 H, W, scale, stream);
+                                 H, W, scale, stream, nullptr, (cf*)patches);
     default:
       return TK_ERR_UNSUPPORTED;
   }
@@ -455,9 +466,10 @@ extern "C" int tike_ptycho_fwd_intensity_only(const void* psi, const float* scan
 extern "C" int tike_ptycho_fwd_gradient_scale(
     const void* psi, const float* scan, const void* probe, int probe_per_scan,
     const void* unique_probe, const float* eigen_weights, int num_eigen, int eigen_modes,
-    void* scratch, float* intensity, const float* data, const unsigned char* measured,
-    float* gscale, float* costs, int nscan, int S, int pw, int det, int H, int W, float scale,
-    int model, float unmeasured_scaling, long num_measured, void* stream_) {
+    void* scratch, float* intensity, void* patches, const float* data,
+    const unsigned char* measured, float* gscale, float* costs, int nscan, int S, int pw, int det,
+    int H, int W, float scale, int model, float unmeasured_scaling, long num_measured,
+    void* stream_) {
   TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
@@ -478,7 +490,7 @@ extern "C" int tike_ptycho_fwd_gradient_scale(
   g.unmeasured_scaling = unmeasured_scaling;
   g.inv_nmeasured = 1.0f / (float)num_measured;
   return launch_fwd_pos<256, false>((const cf*)psi, scan, P, (cf*)scratch, intensity, nscan, S,
-                                    pw, H, W, scale, stream, &g);
+                                    pw, H, W, scale, stream, &g, (cf*)patches);
 }
 
 template <int N>
@@ -604,7 +616,9 @@ __global__ __launch_bounds__(FftPlan<N>::NT, FftPlan<N>::MINW) void ifft2_crop_k
 #ifndef TK_ICROP_WAVES
 #define TK_ICROP_WAVES 4
 #endif
-template <int N, int MODE>
+// PASS2 = false: stop after pass 1 (`work` then holds the input of the column
+// pass, which tike_ifft2_pass2_gradients consumes).
+template <int N, int MODE, bool PASS2 = true>
 __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop_v2_kernel(
     const cf* __restrict__ farplane, cf* work, cf* chi, long ntile, int pw, float scale,
     const cf* __restrict__ twtab, const float* __restrict__ gscale, int S,
@@ -637,17 +651,20 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
             return f * g;
           },
           mid);
-    __syncthreads();
-    for (int k1 = 0; k1 < 16; ++k1)
-      fft2_pass2<N, true>(mid, k1, [&](int ky, int t, cf v) {
-        const int py = ky - pad, px = t - pad;
-        if (py >= 0 && py < pw && px >= 0 && px < pw) tk_st_stream(dst + py * pw + px, v * scale);
-      });
-    __syncthreads();
+    if constexpr (PASS2) {
+      __syncthreads();
+      for (int k1 = 0; k1 < 16; ++k1)
+        fft2_pass2<N, true>(mid, k1, [&](int ky, int t, cf v) {
+          const int py = ky - pad, px = t - pad;
+          if (py >= 0 && py < pw && px >= 0 && px < pw)
+            tk_st_stream(dst + py * pw + px, v * scale);
+        });
+      __syncthreads();
+    }
   }
 }
 
-template <int N>
+template <int N, bool PASS2 = true>
 static int launch_icrop_v2(const cf* far, cf* work, cf* chi, long ntile, int pw, float scale,
                            hipStream_t stream, const float* gscale = nullptr, int S = 1,
                            const float* mode_scale = nullptr,
@@ -655,8 +672,8 @@ static int launch_icrop_v2(const cf* far, cf* work, cf* chi, long ntile, int pw,
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
 #define TK_ICROP(MODE)                                                                        \
-  hipLaunchKernelGGL((ifft2_crop_v2_kernel<N, MODE>), dim3(tk_grid(ntile, 4)), dim3(N), 0,    \
-                     stream, far, work, chi, ntile, pw, scale, tw, gscale, S, mode_scale,    \
+  hipLaunchKernelGGL((ifft2_crop_v2_kernel<N, MODE, PASS2>), dim3(tk_grid(ntile, 4)), dim3(N), \
+                     0, stream, far, work, chi, ntile, pw, scale, tw, gscale, S, mode_scale, \
                      measured)
   if (gscale && mode_scale)
     TK_ICROP(2);
@@ -938,7 +955,7 @@ __device__ __forceinline__ long tk_xcd_tile(long v, int S, long nscan) {
 #ifndef TK_GINV_WAVES
 #define TK_GINV_WAVES 4
 #endif
-template <int N, int MODE>
+template <int N, int MODE, bool PASS2 = true>
 __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
     const cf* __restrict__ colin, cf* work, cf* chi, long ntile, int pw, float fwd_scale,
     float inv_scale, const cf* __restrict__ twtab, const float* __restrict__ gscale, int S,
@@ -980,15 +997,44 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
       for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
       fft2_rows_from_columns<N, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
     }
-    __syncthreads();
-    for (int ya = 0; ya < 16; ++ya)
-      fft2_pass2<N, true>(mid, ya, [&](int y, int x, cf v) {
-        const int py = y - pad, px = x - pad;
-        if (py >= 0 && py < pw && px >= 0 && px < pw)
-          tk_st_stream(dst + py * pw + px, v * inv_scale);
-      });
-    __syncthreads();
+    if constexpr (PASS2) {
+      __syncthreads();
+      for (int ya = 0; ya < 16; ++ya)
+        fft2_pass2<N, true>(mid, ya, [&](int y, int x, cf v) {
+          const int py = y - pad, px = x - pad;
+          if (py >= 0 && py < pw && px >= 0 && px < pw)
+            tk_st_stream(dst + py * pw + px, v * inv_scale);
+        });
+      __syncthreads();
+    }
   }
+}
+
+static int launch_grad_ifft2(const void* colin, const float* gscale, const float* mode_scale,
+                             const unsigned char* measured, int S, void* work, void* chi,
+                             long ntile, int pw, float fwd_scale, float inv_scale,
+                             hipStream_t stream, bool pass2) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  constexpr int N = 256;
+  // a multiple of 8 workgroups keeps "virtual block % 8" equal to the XCD of
+  // the workgroup across the grid-stride loop
+  const int grid8 = (tk_grid(((ntile / S + 7) / 8) * 8 * S, 4) + 7) / 8 * 8;
+#define TK_GINV(MODE, P2)                                                                      \
+  hipLaunchKernelGGL((grad_ifft2_crop_kernel<N, MODE, P2>), dim3(grid8), dim3(N), 0,            \
+                     stream, (const cf*)colin, (cf*)work, (cf*)chi, ntile, pw, fwd_scale,      \
+                     inv_scale, tw, gscale, S, mode_scale, measured)
+  if (mode_scale && pass2)
+    TK_GINV(2, true);
+  else if (mode_scale)
+    TK_GINV(2, false);
+  else if (pass2)
+    TK_GINV(1, true);
+  else
+    TK_GINV(1, false);
+#undef TK_GINV
+  TK_LAUNCH_CHECK();
+  return TK_OK;
 }
 
 extern "C" int tike_grad_ifft2_crop(const void* colin, const float* gscale,
@@ -1002,23 +1048,50 @@ extern "C" int tike_grad_ifft2_crop(const void* colin, const float* gscale,
   TK_CHECK_ARG(colin && gscale && work && chi && work != colin && ntile % S == 0);
   TK_CHECK_ARG(!(chi == work && pw != det));
   if (det != 256) return TK_ERR_UNSUPPORTED;
-  const cf* tw = tk_twiddles();
-  if (!tw) return (int)hipErrorNotInitialized;
-  constexpr int N = 256;
-  // a multiple of 8 workgroups keeps "virtual block % 8" equal to the XCD of
-  // the workgroup across the grid-stride loop
-  const int grid8 = (tk_grid(((ntile / S + 7) / 8) * 8 * S, 4) + 7) / 8 * 8;
-#define TK_GINV(MODE)                                                                          \
-  hipLaunchKernelGGL((grad_ifft2_crop_kernel<N, MODE>), dim3(grid8), dim3(N), 0,                \
-                     stream, (const cf*)colin, (cf*)work, (cf*)chi, ntile, pw, fwd_scale,      \
-                     inv_scale, tw, gscale, S, mode_scale, measured)
-  if (mode_scale)
-    TK_GINV(2);
-  else
-    TK_GINV(1);
-#undef TK_GINV
-  TK_LAUNCH_CHECK();
-  return TK_OK;
+  return launch_grad_ifft2(colin, gscale, mode_scale, measured, S, work, chi, ntile, pw,
+                           fwd_scale, inv_scale, stream, true);
+}
+
+// Pass 1 only of tike_grad_ifft2_crop: `work` receives the input of the inverse
+// column pass (rows 16 k1 + ya), consumed by tike_ifft2_pass2_gradients.
+extern "C" int tike_grad_ifft2_pass1(const void* colin, const float* gscale,
+                                     const float* mode_scale, const unsigned char* measured,
+                                     int S, void* work, long ntile, int det, float fwd_scale,
+                                     void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && S >= 1 && det >= 1);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(colin && gscale && work && work != colin && ntile % S == 0);
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  return launch_grad_ifft2(colin, gscale, mode_scale, measured, S, work, work, ntile, det,
+                           fwd_scale, 1.0f, stream, false);
+}
+
+// Pass 1 only of tike_ifft2_crop_scaled / _scaled_modes (stored far plane).
+extern "C" int tike_ifft2_pass1_scaled(const void* farplane, const float* gscale,
+                                       const float* mode_scale, const unsigned char* measured,
+                                       int S, void* work, long ntile, int det, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && S >= 1 && det >= 1);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(farplane && gscale && work && work != farplane && ntile % S == 0);
+  const cf* far = (const cf*)farplane;
+  cf* wk = (cf*)work;
+  switch (det) {
+    case 128:
+      return launch_icrop_v2<128, false>(far, wk, wk, ntile, det, 1.0f, stream, gscale, S,
+                                         mode_scale, measured);
+    case 256:
+      return launch_icrop_v2<256, false>(far, wk, wk, ntile, det, 1.0f, stream, gscale, S,
+                                         mode_scale, measured);
+    case 512:
+      return launch_icrop_v2<512, false>(far, wk, wk, ntile, det, 1.0f, stream, gscale, S,
+                                         mode_scale, measured);
+    default:
+      return TK_ERR_UNSUPPORTED;
+  }
 }
 
 // Poisson variant (lstsq.py:454-489): the gradient factor of mode s at a

@@ -57,7 +57,7 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
             check(
                 lib.tike_ptycho_fwd_gradient_scale(
                     A.ptr(psi), A.ptr(scan[lo:hi]), A.ptr(probe), 0, None,
-                    None, 0, 0, A.ptr(far), None, A.ptr(data[lo:hi]), None,
+                    None, 0, 0, A.ptr(far), None, None, A.ptr(data[lo:hi]), None,
                     A.ptr(gscale), A.ptr(costs[lo:hi]), n, S, pw, det, H, W,
                     fwd_scale, 0, 1.0, det * det, st), "cgrad cost")
             if not want_grad:

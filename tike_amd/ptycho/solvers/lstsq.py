@@ -68,6 +68,13 @@ CHUNK_POSITIONS_OVERRIDE = None
 """Tests set this to force small kernel chunks (several per minibatch)."""
 
 
+def fused_gradients(S, pw, det):
+    """True where tike_ifft2_pass2_gradients serves (probe window = detector,
+    a v2-engine size, at most 8 modes -- 4 at 512^2)."""
+    return (pw == det and det in POSITION_MAJOR_SIZES
+            and S <= (4 if det == 512 else 8))
+
+
 def chunk_positions(S, det, position_major=False):
     """Positions per kernel launch: enough workgroups to fill the chip several
     times over while bounding the far-plane workspace.  The position-major
@@ -296,12 +303,15 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     m_probe_update = torch.zeros_like(probe) if recover_probe else None
     chi0 = None  # allocated below unless chi itself can be handed on
     patches = None
-    if (recover_probe and eigen_weights is not None) or position_terms:
+    pos_major = det in POSITION_MAJOR_SIZES
+    # inverse pass 2 fused with both gradients (chi never stored): probe
+    # window = detector, at most 8 modes (4 at 512^2)
+    fused = fused_gradients(S, pw, det)
+    if (recover_probe and eigen_weights is not None) or position_terms or fused:
         patches = ws.get("patches", (max(B, 1), pw, pw), torch.complex64, dev)
     if position_terms:
         taps, taps_r = gaussian_derivative_taps(sigma=0.333)
     costs = ws.get("costs", (max(B, 1),), torch.float32, dev)
-    pos_major = det in POSITION_MAJOR_SIZES
     chunk = chunk_positions(S, det, pos_major)
     poisson = exitwave_options.noise_model == "poisson"
     inten = gscale = steps = None
@@ -343,7 +353,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # mode 0 of chi is read again after the whole minibatch (step sizes,
     # eigen probes).  When the minibatch is one chunk, chi is still intact
     # then and is handed on with a mode stride; otherwise mode 0 is packed.
-    single_chunk = B <= chunk
+    single_chunk = B <= chunk and not fused
     if not single_chunk:
         chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
     for clo in range(lo, hi, chunk):
@@ -374,6 +384,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
                     A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far),
                     A.ptr(inten) if poisson else None,
+                    A.ptr(patches[blo:blo + n]) if fused else None,
                     A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), A.ptr(gscale),
                     A.ptr(costs[blo:blo + n]), n, S, pw, det, H, W, fwd_scale,
                     model, unmeasured, nmeasured, st),
@@ -384,21 +395,31 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                         None, A.ptr(inten), A.ptr(data[clo:chi_hi]),
                         A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
                         step_weight, 1, st), "poisson step lengths")
-            check(
-                lib.tike_grad_ifft2_crop(
-                    A.ptr(far), A.ptr(gscale),
-                    A.ptr(steps) if poisson else None,
-                    A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
-                    A.ptr(chi), n * S, det, pw, fwd_scale, inv_scale, st),
-                "gradient + ifft2 + crop")
+            if fused:
+                check(
+                    lib.tike_grad_ifft2_pass1(
+                        A.ptr(far), A.ptr(gscale),
+                        A.ptr(steps) if poisson else None,
+                        A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
+                        n * S, det, fwd_scale, st),
+                    "gradient + inverse pass 1")
+            else:
+                check(
+                    lib.tike_grad_ifft2_crop(
+                        A.ptr(far), A.ptr(gscale),
+                        A.ptr(steps) if poisson else None,
+                        A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
+                        A.ptr(chi), n * S, det, pw, fwd_scale, inv_scale, st),
+                    "gradient + ifft2 + crop")
         elif pos_major:
             # forward + intensity in one kernel; the gradient factor is a
             # per-pixel table applied while the inverse transform loads rows
             check(
                 lib.tike_ptycho_fwd_intensity(
                     A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
-                    A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far), A.ptr(inten), n,
-                    S, pw, det, H, W, fwd_scale, st), "forward + intensity")
+                    A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far), A.ptr(inten),
+                    A.ptr(patches[blo:blo + n]) if fused else None, n, S, pw,
+                    det, H, W, fwd_scale, st), "forward + intensity")
             check(
                 lib.tike_gradient_scale(A.ptr(inten), A.ptr(data[clo:chi_hi]),
                                         A.ptr(mask_u8), A.ptr(gscale),
@@ -411,6 +432,14 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                         A.ptr(far), A.ptr(inten), A.ptr(data[clo:chi_hi]),
                         A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
                         step_weight, dominant, st), "poisson step lengths")
+            if fused:
+                check(
+                    lib.tike_ifft2_pass1_scaled(
+                        A.ptr(far), A.ptr(gscale),
+                        A.ptr(steps) if poisson else None,
+                        A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
+                        n * S, det, st), "scaled inverse pass 1")
+            elif poisson:
                 check(
                     lib.tike_ifft2_crop_scaled_modes(
                         A.ptr(far), A.ptr(gscale), A.ptr(steps),
@@ -447,18 +476,33 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             check(
                 lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S,
                                     det, pw, inv_scale, st), "ifft2 + crop")
-        # one pass over chi: probe gradient, object projection, patches
-        check(
-            lib.tike_lstsq_gradients(
-                A.ptr(chi), A.ptr(scan[clo:chi_hi]), A.ptr(psi), A.ptr(probe),
-                A.ptr(ep), A.ptr(w_c), C, Sm, None,  # on the fly: L2-resident
-                None if patches is None else A.ptr(patches[blo:blo + n]),
-                A.ptr(m_probe_update), A.ptr(objproj) if recover_psi else None,
-                n, S, pw, H, W, st), "probe gradient + object projection")
+        if fused:
+            # inverse column pass + both gradients + mode 0 of chi, one
+            # pixel-major kernel (chi itself never exists in memory)
+            check(
+                lib.tike_ifft2_pass2_gradients(
+                    A.ptr(mid), A.ptr(patches[blo:blo + n]), A.ptr(probe),
+                    A.ptr(ep), A.ptr(w_c), C, Sm,
+                    A.ptr(objproj) if recover_psi else None,
+                    A.ptr(chi0[blo:blo + n]), A.ptr(m_probe_update), n, S,
+                    det, inv_scale, st), "inverse pass 2 + gradients")
+        else:
+            # one pass over chi: probe gradient, object projection, patches
+            check(
+                lib.tike_lstsq_gradients(
+                    A.ptr(chi), A.ptr(scan[clo:chi_hi]), A.ptr(psi),
+                    A.ptr(probe), A.ptr(ep), A.ptr(w_c), C, Sm,
+                    None,  # on the fly: L2-resident
+                    None if patches is None else A.ptr(patches[blo:blo + n]),
+                    A.ptr(m_probe_update),
+                    A.ptr(objproj) if recover_psi else None, n, S, pw, H, W,
+                    st), "probe gradient + object projection")
         if position_terms:
+            chi_m, chi_modes = (chi0[blo:blo + n], 1) if fused else (chi, S)
             check(
                 lib.tike_position_sums(
-                    A.ptr(patches[blo:blo + n]), A.ptr(chi), S, A.ptr(probe),
+                    A.ptr(patches[blo:blo + n]), A.ptr(chi_m), chi_modes,
+                    A.ptr(probe),
                     A.ptr(ep), A.ptr(w_c), C, Sm, taps.ctypes.data, taps_r,
                     A.ptr(position_terms[0][clo:chi_hi]),
                     A.ptr(position_terms[1][clo:chi_hi]), n, S, pw, st),
@@ -469,7 +513,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                                          A.ptr(scan[clo:chi_hi]),
                                          A.ptr(obj_acc), n, pw, H, W, st),
                 "object scatter")
-        if not single_chunk:
+        if not single_chunk and not fused:
             chi0[blo:blo + n] = chi[:n, 0, 0]
 
     # complete the sums over positions across ranks

@@ -104,8 +104,8 @@ def main():
         inten = torch.empty(N, n, n, dtype=torch.float32, device=dev)
         ms = timeit(lambda: check(lib.tike_ptycho_fwd_intensity(
             psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0, None, None, 0,
-            0, far.data_ptr(), inten.data_ptr(), N, S, n, n, HW, HW, 1.0 / n,
-            st)), a.reps)
+            0, far.data_ptr(), inten.data_ptr(), None, N, S, n, n, HW, HW,
+            1.0 / n, st)), a.reps)
         rows.append((f"fwd_intensity S={S}", ms,
                      N * S * tile_bytes + N * tile_bytes))
         uniq = torch.randn(N, 1, n, n, dtype=torch.complex64, device=dev)
@@ -113,13 +113,13 @@ def main():
         ms = timeit(lambda: check(lib.tike_ptycho_fwd_intensity(
             psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0,
             uniq.data_ptr(), wts.data_ptr(), 1, 1, far.data_ptr(),
-            inten.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st)), a.reps)
+            inten.data_ptr(), None, N, S, n, n, HW, HW, 1.0 / n, st)), a.reps)
         rows.append((f"fwd_intensity eigen S={S}", ms,
                      N * S * tile_bytes + 2 * N * tile_bytes))
         fwd_e = lambda: check(lib.tike_ptycho_fwd_intensity(
             psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0,
             uniq.data_ptr(), wts.data_ptr(), 1, 1, far.data_ptr(),
-            inten.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st))
+            inten.data_ptr(), None, N, S, n, n, HW, HW, 1.0 / n, st))
         for gap in (0.0, 0.002, 0.02):
             ms = timeit_gap(fwd_e, a.reps, gap)
             rows.append((f"  .. after {gap*1e3:.0f} ms idle", ms,
