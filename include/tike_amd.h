@@ -118,6 +118,25 @@ int tike_ptycho_fwd_gradient_scale(const void* psi, const float* scan, const voi
                                    int H, int W, float scale, int model, float unmeasured_scaling,
                                    long num_measured, void* stream);
 
+/* ---- the same, split in two launches (det = 256).  tike_fwd_pass1: bilinear
+ * gather * probe -> row transforms -> radix-16 column stage; scratch
+ * (nscan,S,det,det) receives the UNSCALED input of the column pass of every
+ * tile, patches (nscan,pw,pw, may be NULL) the object patches O_n.  The varying
+ * probe of the first eigen_modes modes is read from unique_probe when given,
+ * otherwise formed on the fly from eigen_probe (probe.py:272-303).
+ * tike_fwd_gradient_scale: streams that scratch once, forms F = scale *
+ * (column pass) in registers, I = sum_s |F_s|^2, and emits gscale, the costs
+ * (may be NULL) and optionally the intensity (may be NULL) -- operands as
+ * tike_ptycho_fwd_gradient_scale. */
+int tike_fwd_pass1(const void* psi, const float* scan, const void* probe, int probe_per_scan,
+                   const void* unique_probe, const void* eigen_probe,
+                   const float* eigen_weights, int num_eigen, int eigen_modes, void* scratch,
+                   void* patches, int nscan, int S, int pw, int det, int H, int W, void* stream);
+int tike_fwd_gradient_scale(const void* scratch, const float* data,
+                            const unsigned char* measured, float* gscale, float* intensity,
+                            float* costs, int nscan, int S, int det, float scale, int model,
+                            float unmeasured_scaling, long num_measured, void* stream);
+
 /* ---- far-plane gradient + IFFT2 + crop from that scratch (lstsq.py:491-507):
  * chi = crop(IFFT2(F * gscale [* mode_scale on measured pixels])) * inv_scale
  * with F = fwd_scale * (column pass of `colin`) re-formed in registers, so the

@@ -483,6 +483,33 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
                                    rtol=1e-4, atol=1e-5)
         assert_close(scratch2.cpu().numpy(), scratch.cpu().numpy(),
                      normwise=1e-6, maxabs=1e-5, what="column-pass scratch")
+        # ... and as two launches (pass 1, then the streamed column pass)
+        scratch3 = torch.empty_like(far)
+        pat3, g3, costs3, I3 = (torch.empty_like(pat), torch.empty_like(g),
+                                torch.empty_like(costs), torch.empty_like(I))
+        check(lib.tike_fwd_pass1(
+            A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, A.ptr(uq), None,
+            A.ptr(w_d), C, 1, A.ptr(scratch3), A.ptr(pat3), N, S, pw, det, HW,
+            HW, st))
+        # the varying probe formed on the fly from the eigen probes instead
+        scratch4 = torch.empty_like(far)
+        check(lib.tike_fwd_pass1(
+            A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, None, A.ptr(eig_d),
+            A.ptr(w_d), C, 1, A.ptr(scratch4), None, N, S, pw, det, HW, HW,
+            st))
+        assert_close(scratch4.cpu().numpy(), scratch.cpu().numpy(),
+                     normwise=1e-6, maxabs=1e-5, what="scratch (eigen on the fly)")
+        check(lib.tike_fwd_gradient_scale(
+            A.ptr(scratch3), A.ptr(d_d), A.ptr(m_d), A.ptr(g3), A.ptr(I3),
+            A.ptr(costs3), N, S, det, 1.0 / det, 0, 0.5, int(mask.sum()), st))
+        assert torch.equal(pat3, pat)
+        assert_close(scratch3.cpu().numpy(), scratch.cpu().numpy(),
+                     normwise=1e-6, maxabs=1e-5, what="scratch (split forward)")
+        assert_close(I3.cpu().numpy(), want_I, what="intensity (split)")
+        np.testing.assert_allclose(costs3.cpu().numpy(), want_cost,
+                                   rtol=COST_RTOL)
+        np.testing.assert_allclose(g3.cpu().numpy(), g.cpu().numpy(),
+                                   rtol=1e-4, atol=1e-5)
         mid2 = torch.empty_like(far)
         chi2 = mid2 if pw == det else torch.empty_like(chi)
         check(lib.tike_grad_ifft2_crop(
@@ -572,6 +599,10 @@ def test_abi_edge_cases():
         z, z, z, 0, z, z, 0, 0, z, z, z, z, z, z, z, 0, 2, 256, 256, 400, 400,
         1.0, 0, 1.0, 65536, st) == 0
     assert lib.tike_grad_ifft2_pass1(z, z, z, z, 2, z, 0, 256, 1.0, st) == 0
+    assert lib.tike_fwd_pass1(z, z, z, 0, z, z, z, 0, 0, z, z, 0, 2, 256, 256,
+                              400, 400, st) == 0
+    assert lib.tike_fwd_gradient_scale(z, z, z, z, z, z, 0, 2, 256, 1.0, 0,
+                                       1.0, 65536, st) == 0
     assert lib.tike_ifft2_pass1_scaled(z, z, z, z, 2, z, 0, 128, st) == 0
     assert lib.tike_ifft2_pass2_gradients(z, z, z, z, z, 0, 0, z, z, z, 0, 2,
                                           256, 1.0, st) == 0

@@ -140,7 +140,10 @@ struct FftStageWave {
 // Pass 1 for the 16 rows {r + RB*y2}.  `load(y, e, i)` returns input element
 // e = j + i*T of row y (i = the caller's register slot, a compile-time index); results go to rows 16*r + k1 of `mid` (row-major N x N tile).
 // Contains two workgroup barriers; every thread of the NT = N workgroup calls.
-template <int N, bool INV, class Tw, class Load>
+// STREAM: the intermediate is consumed by a LATER kernel (not by pass 2 of this
+// one), so it is stored with the non-temporal hint and does not displace the
+// probe / object lines the next tiles re-read from L2.
+template <int N, bool INV, bool STREAM = false, class Tw, class Load>
 __device__ __forceinline__ void fft2_pass1(cf* __restrict__ lds, const cf* __restrict__ twtab,
                                            const Tw& tw, int line, int j, int r, Load&& load,
                                            cf* __restrict__ mid) {
@@ -167,7 +170,10 @@ __device__ __forceinline__ void fft2_pass1(cf* __restrict__ lds, const cf* __res
   for (int k1 = 0; k1 < 16; ++k1) {
     cf o = v[k1];
     if (k1 > 0) o = mul_tw<INV>(o, twtab[N + r * k1]);  // uniform address -> scalar load
-    mid[(16 * r + k1) * N + t] = o;
+    if (STREAM)
+      tk_st_stream(mid + (16 * r + k1) * N + t, o);
+    else
+      mid[(16 * r + k1) * N + t] = o;
   }
 }
 
@@ -192,7 +198,7 @@ __device__ __forceinline__ void fft2_pass2(const cf* __restrict__ mid, int k1, S
 // (16 threads per row, element e = j + i*T), transformed with the in-wave
 // Stockham stages and stored as the 16 consecutive rows starting at `rows`.
 // Contains two workgroup barriers; every thread of the workgroup calls.
-template <int N, bool INV, class Tw>
+template <int N, bool INV, bool STREAM = false, class Tw>
 __device__ __forceinline__ void fft2_rows_from_columns(cf* __restrict__ lds, const Tw& tw, int line,
                                                        int j, cf (&a)[16], cf* __restrict__ rows) {
   using G2 = Fft2Geom<N>;
@@ -207,6 +213,11 @@ __device__ __forceinline__ void fft2_rows_from_columns(cf* __restrict__ lds, con
   for (int i = 0; i < 16; ++i) v[i] = lbase[tk_pad16(j + i * G2::T)];
   FftStageWave<N, INV, 0>::run(v, lbase, j, tw);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) rows[line * N + j + i * G2::T] = v[i];
+  for (int i = 0; i < 16; ++i) {
+    if (STREAM)
+      tk_st_stream(rows + line * N + j + i * G2::T, v[i]);
+    else
+      rows[line * N + j + i * G2::T] = v[i];
+  }
   __syncthreads();
 }

@@ -493,6 +493,283 @@ extern "C" int tike_ptycho_fwd_gradient_scale(
                                     pw, H, W, scale, stream, &g, (cf*)patches);
 }
 
+// ---- the 256^2 forward split in two launches (both far-plane free) ----------
+// Pass 1 alone: bilinear gather * probe -> row transforms -> radix-16 column
+// stage; `scratch` receives the column-pass input of every tile and `patches`
+// the object patches.  One workgroup owns all S modes of a position (the patch
+// is gathered once per 16-row group and shared by the modes).  The probe values
+// of mode s+1 are requested BEFORE the rows of mode s are stored: the memory
+// counter retires in issue order, so a load issued behind the stores would
+// wait for them and every mode would pay a full store round trip.
+// FULL: probe window = detector (pw == N, no padding): every probe / patch
+// access of a thread is `uniform base + one 32-bit lane offset + 128 i`.
+template <int N, bool FULL>
+__global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    cf* __restrict__ scratch, cf* __restrict__ patches, int nscan, int S, int pw, int H, int W,
+    const cf* __restrict__ twtab) {
+  using G2 = Fft2Geom<N>;
+  static_assert(G2::RB == 16, "16 row groups of 16 rows");
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int pad = FULL ? 0 : (N - pw) / 2;
+  const long total = (long)H * W;
+  const long PP = (long)pw * pw;
+  const int t = threadIdx.x;
+  auto at = [](const cf* base, unsigned byte_off) -> const cf* {
+    return reinterpret_cast<const cf*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  for (long n = blockIdx.x; n < nscan; n += gridDim.x) {
+    const TkCorner c = tk_corner(scan, n);
+    cf* __restrict__ dst0 = scratch + n * S * (long)N * N;
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    const float* __restrict__ wn =
+        probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
+    // every tap of every patch pixel inside the image (any position that
+    // passes check_allowed_positions) and 32-bit byte offsets suffice
+    const bool interior = FULL && c.sy >= 0 && c.sx >= 0 && c.sy + pw < H && c.sx + pw < W &&
+                          total < (1L << 28);
+    for (int r = 0; r < G2::RB; ++r) {
+      // patch values of row y = r + RB*line in the FFT register layout
+      // (element e = j + i*T), gathered once and shared by all S modes
+      const int py = r + G2::RB * line - pad;
+      const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
+      // byte offset of this thread's first pixel inside a probe mode / patch
+      const unsigned pbo = (unsigned)(pyc * pw + j) * (unsigned)sizeof(cf);
+      cf pv[16];
+      if (interior) {
+        const unsigned g0 = (unsigned)((c.sy + py) * W + c.sx + j) * (unsigned)sizeof(cf);
+        const unsigned g1 = g0 + (unsigned)W * (unsigned)sizeof(cf);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const cf a = *at(psi, g0 + 128 * i), b = *at(psi, g0 + 128 * i + 8);
+          const cf d = *at(psi, g1 + 128 * i), e = *at(psi, g1 + 128 * i + 8);
+          cf o = mk(a.x * c.w00, a.y * c.w00);
+          o.x += b.x * c.w01;
+          o.y += b.y * c.w01;
+          o.x += d.x * c.w10;
+          o.y += d.y * c.w10;
+          o.x += e.x * c.w11;
+          o.y += e.y * c.w11;
+          pv[i] = o;
+          if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        const int y = c.sy + py;
+        const bool row_ok = py >= 0 && py < pw && y >= 0 && y < H;
+        const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int px = j + i * G2::T - pad;
+          const int x = c.sx + px;
+          const bool ok = row_ok && px >= 0 && px < pw && x >= 0 && x < W;
+          const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+          const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
+          const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
+          pv[i] = ok ? o : mk(0.f, 0.f);
+          __builtin_amdgcn_sched_barrier(0);  // rare path: one element in flight
+        }
+      }
+      if (patches != nullptr && py >= 0 && py < pw) {
+        cf* __restrict__ On = patches + n * PP;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int px = j + i * G2::T - pad;
+          if (FULL)
+            tk_st_stream(const_cast<cf*>(at(On, pbo + 128 * i)), pv[i]);
+          else if (px >= 0 && px < pw)
+            tk_st_stream(On + (long)py * pw + px, pv[i]);
+        }
+      }
+      // probe of (position, mode): shared probe times its weight, plus the
+      // eigen probes of the first Sm modes (probe.py:272-303) -- from the
+      // synthesised array when given, else on the fly
+      auto load_probe = [&](int s, cf (&pn)[16]) {
+        const cf* __restrict__ Pn = probe.probe + n * probe.pos_stride + s * PP;
+        float w0 = 1.0f;
+        int nE = 0;
+        if (wn != nullptr) {
+          if (probe.unique != nullptr && s < probe.Sm) {
+            Pn = probe.unique + (n * probe.Sm + s) * PP;
+          } else {
+            w0 = wn[s];
+            if (probe.eigen != nullptr && s < probe.Sm) nE = probe.C;
+          }
+        }
+        auto pix = [&](const cf* base, int i) {
+          if (FULL) return *at(base, pbo + 128 * i);
+          const int px = j + i * G2::T - pad;
+          const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+          return base[pyc * pw + pxc];
+        };
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pn[i] = pix(Pn, i) * w0;
+        for (int k = 0; k < nE; ++k) {  // uniform, rare (modes owning eigen probes)
+          const cf* __restrict__ E = probe.eigen + ((long)k * probe.Sm + s) * PP;
+          const float wk = wn[(k + 1) * probe.S + s];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const cf e = pix(E, i);
+            pn[i].x += wk * e.x;
+            pn[i].y += wk * e.y;
+          }
+        }
+      };
+      cf pn[16];
+      load_probe(0, pn);
+      for (int s = 0; s < S; ++s) {
+        cf v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = pv[i] * pn[i];
+        cf* lbase = lds + line * G2::LS;
+        FftStageWave<N, false, 0>::run(v, lbase, j, tw);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lbase[tk_pad16(j + i * G2::T)] = v[i];
+        // next mode's probe values: in flight across the transpose, the column
+        // butterflies and -- the point -- ahead of this mode's stores
+        if (s + 1 < S) load_probe(s + 1, pn);
+        __syncthreads();
+#pragma unroll
+        for (int y2 = 0; y2 < 16; ++y2) v[y2] = lds[y2 * G2::LS + tk_pad16(t)];
+        __syncthreads();
+        Dft<16, false>::run(v);
+        cf* __restrict__ mid = dst0 + s * (long)N * N + (long)(16 * r) * N + t;
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+          cf o = v[k1];
+          if (k1 > 0) o = mul_tw<false>(o, twtab[N + r * k1]);  // uniform -> scalar load
+          tk_st_stream(mid + k1 * N, o);
+        }
+      }
+    }
+  }
+}
+
+// unique_probe: the varying probe of the first eigen_modes modes from
+// tike_varying_probe, or NULL with eigen_probe given: formed on the fly.
+extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* probe,
+                              int probe_per_scan, const void* unique_probe,
+                              const void* eigen_probe, const float* eigen_weights,
+                              int num_eigen, int eigen_modes, void* scratch, void* patches,
+                              int nscan, int S, int pw, int det, int H, int W, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(psi && scan && probe && scratch);
+  TK_CHECK_ARG(!(eigen_weights && eigen_modes > 0 && !unique_probe && !eigen_probe));
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, unique_probe ? nullptr : eigen_probe,
+                                  eigen_weights, num_eigen, eigen_modes, S, pw, unique_probe);
+  if (pw == det)
+    hipLaunchKernelGGL((fwd_pass1_kernel<256, true>), dim3(tk_grid(nscan, 2)), dim3(256), 0,
+                       stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches, nscan, S, pw,
+                       H, W, tw);
+  else
+    hipLaunchKernelGGL((fwd_pass1_kernel<256, false>), dim3(tk_grid(nscan, 2)), dim3(256), 0,
+                       stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches, nscan, S, pw,
+                       H, W, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// The column pass as a pure read stream: one workgroup per (position, k1)
+// forms F[k1 + 16 k2] of every mode in registers (radix-16 over the rows
+// 16 r + k1 of the hand-off), accumulates I = sum_s |F_s|^2 and emits the
+// gradient factor and the cost share of those 16 rows (objective.py:11-124,
+// lstsq.py:444-502).  costs must be zero on entry (accumulated by atomics).
+template <int MODEL>
+__global__ __launch_bounds__(256, 4) void fwd_gradient_scale_kernel(
+    const cf* __restrict__ colin, const float* __restrict__ data,
+    const unsigned char* __restrict__ mask, float* __restrict__ gscale,
+    float* __restrict__ intensity, float* __restrict__ costs, long nitem, int S, float scale,
+    float unmeasured_scaling, float inv_nmeasured) {
+  constexpr int N = 256;
+  __shared__ float red[4];
+  const int t = threadIdx.x;
+  const float s2 = scale * scale;
+  for (long v = blockIdx.x; v < nitem; v += gridDim.x) {
+    const long n = v >> 4;
+    const int k1 = (int)(v & 15);
+    float I[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) I[k2] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
+      cf u[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(src + (long)(16 * r) * N);
+      Dft<16, false>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) I[k2] += norm2(u[k2]) * s2;
+    }
+    float cost = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      const long p = (long)(k1 + 16 * k2) * N + t;
+      if (intensity) tk_st_stream(intensity + n * (long)N * N + p, I[k2]);
+      float g = unmeasured_scaling - 1.0f;
+      if (mask == nullptr || mask[p]) {
+        const float dv = data[n * (long)N * N + p];
+        if (MODEL == 0) {
+          const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
+          const float diff = sI - sd;
+          cost += diff * diff;
+          g = -(1.0f - sd / (sI + 1e-9f));
+        } else {
+          cost += I[k2] - dv * logf(I[k2] + 1e-9f);
+          g = -(1.0f - dv / (I[k2] + 1e-9f));
+        }
+      }
+      gscale[n * (long)N * N + p] = g;
+    }
+    if (costs) {
+      cost = tk_block_sum256(cost, red);
+      if (t == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+    }
+  }
+}
+
+// scratch: from tike_fwd_pass1 (UNSCALED column-pass input; `scale` is the
+// forward FFT normalisation applied here).  intensity / costs may be NULL.
+extern "C" int tike_fwd_gradient_scale(const void* scratch, const float* data,
+                                       const unsigned char* measured, float* gscale,
+                                       float* intensity, float* costs, int nscan, int S, int det,
+                                       float scale, int model, float unmeasured_scaling,
+                                       long num_measured, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1 && (model == 0 || model == 1) &&
+               num_measured > 0);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(scratch && data && gscale);
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  if (costs) {
+    hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  const long nitem = (long)nscan * 16;
+  const float inv = 1.0f / (float)num_measured;
+  const dim3 grid(tk_grid(nitem, 16)), block(256);
+  if (model == 0)
+    hipLaunchKernelGGL((fwd_gradient_scale_kernel<0>), grid, block, 0, stream, (const cf*)scratch,
+                       data, measured, gscale, intensity, costs, nitem, S, scale,
+                       unmeasured_scaling, inv);
+  else
+    hipLaunchKernelGGL((fwd_gradient_scale_kernel<1>), grid, block, 0, stream, (const cf*)scratch,
+                       data, measured, gscale, intensity, costs, nitem, S, scale,
+                       unmeasured_scaling, inv);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 template <int N>
 static int launch_fwd_v2(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                          long ntile, int S, int pw, int H, int W, float scale,
@@ -641,7 +918,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
     const float* __restrict__ gs = MODE ? gscale + (tile / S) * (long)N * N : nullptr;
     const float ms = MODE == 2 ? mode_scale[tile] : 1.0f;
     for (int r = 0; r < G2::RB; ++r)
-      fft2_pass1<N, true>(
+      fft2_pass1<N, true, !PASS2>(
           lds, twtab, tw, line, j, r,
           [&](int y, int e, auto) {
             const cf f = tk_ld_stream(src + y * N + e);
@@ -995,7 +1272,7 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
       Dft<16, true>::run(u);
 #pragma unroll
       for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
-      fft2_rows_from_columns<N, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
+      fft2_rows_from_columns<N, true, !PASS2>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
     }
     if constexpr (PASS2) {
       __syncthreads();

@@ -363,8 +363,9 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         w_c = None if w_old is None else w_old[blo:blo + n]
         chi = chi_ws
         uq = None
-        if w_c is not None and Sm > 0:
+        if w_c is not None and Sm > 0 and not no_farplane:
             # varying probe of the modes that own eigen probes, once per chunk
+            # (the 256^2 kernels form it on the fly instead)
             uq = unique[:n]
             check(
                 lib.tike_varying_probe(A.ptr(probe), A.ptr(ep), A.ptr(w_c), C,
@@ -380,15 +381,18 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             # (the gradient factor and the costs come out of the same launch;
             # the intensity itself is stored only for the poisson steps)
             check(
-                lib.tike_ptycho_fwd_gradient_scale(
+                lib.tike_fwd_pass1(
                     A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
-                    A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far),
-                    A.ptr(inten) if poisson else None,
-                    A.ptr(patches[blo:blo + n]) if fused else None,
-                    A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), A.ptr(gscale),
-                    A.ptr(costs[blo:blo + n]), n, S, pw, det, H, W, fwd_scale,
-                    model, unmeasured, nmeasured, st),
-                "forward + gradient scale")
+                    None, A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(far),
+                    A.ptr(patches[blo:blo + n]) if fused else None, n, S, pw,
+                    det, H, W, st), "forward pass 1")
+            check(
+                lib.tike_fwd_gradient_scale(
+                    A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8),
+                    A.ptr(gscale), A.ptr(inten) if poisson else None,
+                    A.ptr(costs[blo:blo + n]), n, S, det, fwd_scale, model,
+                    unmeasured, nmeasured, st),
+                "forward pass 2 + gradient scale")
             if poisson:  # dominant mode: the steps need no far-plane waves
                 check(
                     lib.tike_poisson_steps(

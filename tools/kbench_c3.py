@@ -80,6 +80,15 @@ def main():
             p(psi), p(scan), p(probe), 0, p(uq), p(w), C, Sm, p(far), None,
             p(patches), p(data), None, p(gscale), p(costs), N, S, pw, det, HW,
             HW, 1.0 / det, 0, 1.0, det * det, st)), N * (T + 2 * P + 2 * D))
+        run("fwd_pass1 (unique)", lambda: check(lib.tike_fwd_pass1(
+            p(psi), p(scan), p(probe), 0, p(uq), None, p(w), C, Sm, p(far),
+            p(patches), N, S, pw, det, HW, HW, st)), N * (T + 2 * P))
+        run("fwd_pass1 (eigen on the fly)", lambda: check(lib.tike_fwd_pass1(
+            p(psi), p(scan), p(probe), 0, None, p(eig), p(w), C, Sm, p(far),
+            p(patches), N, S, pw, det, HW, HW, st)), N * (T + 2 * P))
+        run("fwd_gradient_scale (split)", lambda: check(lib.tike_fwd_gradient_scale(
+            p(far), p(data), None, p(gscale), None, p(costs), N, S, det,
+            1.0 / det, 0, 1.0, det * det, st)), N * (T + 2 * D))
         run("grad_ifft2_pass1", lambda: check(lib.tike_grad_ifft2_pass1(
             p(far), p(gscale), None, None, S, p(mid), N * S, det, 1.0 / det,
             st)), N * (2 * T + D))
