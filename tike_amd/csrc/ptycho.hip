@@ -544,19 +544,39 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
       if (interior) {
         const unsigned g0 = (unsigned)((c.sy + py) * W + c.sx + j) * (unsigned)sizeof(cf);
         const unsigned g1 = g0 + (unsigned)W * (unsigned)sizeof(cf);
+        // The two taps of a row are adjacent complex values: one 16-byte load.
+        // 8 elements = 16 loads are requested together; the empty asm reads
+        // all of them, so none can be sunk next to its use (which would
+        // cost one L2 round trip per element).
+        typedef float tk_v4f __attribute__((ext_vector_type(4)));
+        auto ld4 = [](const cf* base, unsigned byte_off) {
+          tk_v4f v;
+          __builtin_memcpy(&v, reinterpret_cast<const char*>(base) + byte_off, sizeof(v));
+          return v;
+        };
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const cf a = *at(psi, g0 + 128 * i), b = *at(psi, g0 + 128 * i + 8);
-          const cf d = *at(psi, g1 + 128 * i), e = *at(psi, g1 + 128 * i + 8);
-          cf o = mk(a.x * c.w00, a.y * c.w00);
-          o.x += b.x * c.w01;
-          o.y += b.y * c.w01;
-          o.x += d.x * c.w10;
-          o.y += d.y * c.w10;
-          o.x += e.x * c.w11;
-          o.y += e.y * c.w11;
-          pv[i] = o;
-          if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        for (int h = 0; h < 16; h += 8) {
+          tk_v4f u[8], l[8];  // upper row (a, b), lower row (d, e)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            u[i] = ld4(psi, g0 + 128 * (h + i));
+            l[i] = ld4(psi, g1 + 128 * (h + i));
+          }
+          asm volatile(""
+                       : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]),
+                         "+v"(u[6]), "+v"(u[7]), "+v"(l[0]), "+v"(l[1]), "+v"(l[2]), "+v"(l[3]),
+                         "+v"(l[4]), "+v"(l[5]), "+v"(l[6]), "+v"(l[7]));
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            cf o = mk(u[i].x * c.w00, u[i].y * c.w00);
+            o.x += u[i].z * c.w01;
+            o.y += u[i].w * c.w01;
+            o.x += l[i].x * c.w10;
+            o.y += l[i].y * c.w10;
+            o.x += l[i].z * c.w11;
+            o.y += l[i].w * c.w11;
+            pv[h + i] = o;
+          }
         }
       } else {
         const int y = c.sy + py;
@@ -611,11 +631,14 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
         for (int k = 0; k < nE; ++k) {  // uniform, rare (modes owning eigen probes)
           const cf* __restrict__ E = probe.eigen + ((long)k * probe.Sm + s) * PP;
           const float wk = wn[(k + 1) * probe.S + s];
+          cf e[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) e[i] = pix(E, i);
+          __builtin_amdgcn_sched_barrier(0);  // all 16 in flight before the first use
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const cf e = pix(E, i);
-            pn[i].x += wk * e.x;
-            pn[i].y += wk * e.y;
+            pn[i].x += wk * e[i].x;
+            pn[i].y += wk * e[i].y;
           }
         }
       };
