@@ -166,7 +166,8 @@ int tike_ifft2_pass1_scaled(const void* farplane, const float* gscale, const flo
 /* Pass 2 fused with both gradients, chi never stored (lstsq.py:504-539):
  *   chi_n,s  = inv_scale * (column pass of work[n][s])         (registers only)
  *   objproj[n]        = sum_s conj(P_n,s) chi_n,s     (lstsq.py:510-513)
- *   m_probe_update[s] += sum_n conj(patches[n]) chi_n,s        (:531-539)
+ *   m_probe_update[s] += mpu_scale * sum_n conj(patches[n]) chi_n,s   (:531-539,
+ *                        mpu_scale = 1 / num_batch is the division of :596)
  *   chi0[n]           = chi_n,0                       (:507; step sizes etc.)
  * P_n,s = the shared probe scaled by eigen_weights[n][0][s] plus, for the first
  * eigen_modes modes, the eigen probes (probe.py:272-303, applied on the fly from
@@ -179,8 +180,8 @@ int tike_ifft2_pass1_scaled(const void* farplane, const float* gscale, const flo
 int tike_ifft2_pass2_gradients(const void* work, const void* patches, const void* probe,
                                const void* eigen_probe, const float* eigen_weights,
                                int num_eigen, int eigen_modes, void* objproj, void* chi0,
-                               void* m_probe_update, int nscan, int S, int det, float inv_scale,
-                               void* stream);
+                               void* m_probe_update, float mpu_scale, int nscan, int S, int det,
+                               float inv_scale, void* stream);
 
 /* ---- far-plane gradient factor from the intensity (objective.py:31-44,97-109;
  * lstsq.py:491-502): gscale[n][p] = -(1 - sqrt(d)/(sqrt(I)+1e-9)) (gaussian) or
@@ -359,6 +360,59 @@ int tike_position_sums(const void* patches, const void* chi, int chi_modes, cons
                        const void* eigen_probe, const float* eigen_weights, int num_eigen,
                        int eigen_modes, const float* taps, int radius, float* numerator,
                        float* denominator, int nscan, int S, int pw, void* stream);
+
+/* ---- small fused kernels of the lstsq_grad host loop (psi-, probe- or
+ * (positions,)-sized work between the heavy kernels; sums that span all ranks
+ * stay in small device buffers the caller all-reduces between two phases) ---- */
+
+/* _precondition_object_update (lstsq.py:605-616) straight from the scatter
+ * accumulator: g = acc (2,npix planar re/im f32);
+ * upd_precond = g / sqrt(((1-alpha) Re precond)^2 + (alpha pmax[0])^2);
+ * upd_sum = g as complex64 (may be NULL); combined (2,npix planar, may be NULL)
+ * += g (the 'compact' epoch sum, lstsq.py:174).  upd_precond may be NULL. */
+int tike_object_update_precond(const float* acc, const void* precond, const float* pmax,
+                               float alpha, void* upd_sum, void* upd_precond, float* combined,
+                               long npix, void* stream);
+
+/* 2x2 step-length systems of a minibatch (lstsq.py:641-718) from the (B,8)
+ * table of tike_lstsq_step_stats.  tike_lstsq_step_sums: sums[0..2] = { sum(A1 +
+ * eps), sum(A4 + eps), sum(costs) } over the B local positions (costs may be
+ * NULL).  tike_lstsq_step_solve, given the sums and count over ALL ranks:
+ * out[0..1] = { sum 0.9 max(0, Re x1), sum 0.9 max(0, Re x2) } over the local
+ * positions and out[2..4] = { out0/count, out1/count, sums2/count } (beta_object,
+ * beta_probe, mean cost when one rank holds the whole minibatch). */
+int tike_lstsq_step_sums(const float* stats, const float* costs, int B, float eps, float* sums,
+                         void* stream);
+int tike_lstsq_step_solve(const float* stats, int B, float eps, const float* sums, double count,
+                          int recover_psi, int recover_probe, float* out, void* stream);
+
+/* probe += beta[0] * mpu; combined += beta[0] * mpu * inv_num_batch (combined may
+ * be NULL) over n complex elements (lstsq.py:177-181); beta is a device scalar. */
+int tike_probe_update(void* probe, void* combined, const void* mpu, const float* beta,
+                      float inv_num_batch, long n, void* stream);
+
+/* Eigen-probe ("OPR") bookkeeping of a minibatch, mode m (lstsq.py:297-364,721-761;
+ * probe.py:362-476).  weights: the minibatch's rows of eigen_weights (B, C+1, S).
+ * tike_eigen_weights0: weights[n][0][m] += 0.1 stats[n][6] / stats[n][7];
+ *   norms[c-1] = sum_n weights[n][c][m]^2 for c = 1..C (local; all-reduce).
+ * tike_eigen_proj_mean: pm[n] = (first[n*first_stride] / P + weights_c[n*row]) / norm[0].
+ * tike_eigen_normalise: E <- E + beta u / mnorm(u), u = update / count, then
+ *   E <- E / mnorm(E); esum[0] = sum |E|^2 (may be NULL).
+ * tike_eigen_dsum: dsum[0] = sum_n sums[n][2] / P (local; all-reduce).
+ * tike_eigen_weights: weights_c[n*row] += (sums[n][1]/P) / (sums[n][2]/P + 0.1
+ *   dsum[0] / count); coefs_c[n*coef_stride] = (sums[n][3] + i sums[n][4]) / esum[0]
+ *   (coefs_c may be NULL).  sums: (B,5) from tike_eigen_position_sums. */
+int tike_eigen_weights0(float* weights, const float* stats, int B, int C, int S, int m,
+                        float* norms, void* stream);
+int tike_eigen_proj_mean(const float* first, int first_stride, const float* weights_c,
+                         long weights_row, const float* norm, long P, int B, float* pm,
+                         void* stream);
+int tike_eigen_normalise(void* eigen, const void* update, double count, float beta, int npix,
+                         float* esum, void* stream);
+int tike_eigen_dsum(const float* sums, int B, long P, float* dsum, void* stream);
+int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, double count,
+                       float* weights_c, long weights_row, void* coefs_c, int coef_stride,
+                       const float* esum, void* stream);
 
 #ifdef __cplusplus
 }

@@ -432,8 +432,8 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
         mpu = torch.zeros((S, pw, pw), dtype=torch.complex64, device=dev)
         check(lib.tike_ifft2_pass2_gradients(
             A.ptr(work), A.ptr(pat), A.ptr(probe_d), A.ptr(eig_d), A.ptr(w_d),
-            C, 1, A.ptr(proj), A.ptr(chi0), A.ptr(mpu), N, S, det, 1.0 / det,
-            st))
+            C, 1, A.ptr(proj), A.ptr(chi0), A.ptr(mpu), 1.0, N, S, det,
+            1.0 / det, st))
         want_proj = (np.conj(uprobe[:, 0]) * want_chi[:, 0]).sum(axis=1)
         patches = oracle.patch_fwd(psi[0], scan, patch_width=pw)
         want_mpu = (np.conj(patches)[:, None] * want_chi[:, 0]).sum(axis=0)
@@ -447,8 +447,8 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
         mpu2 = torch.zeros_like(mpu)
         check(lib.tike_ifft2_pass2_gradients(
             A.ptr(work), A.ptr(pat), None, None, None, 0, 0, None, None,
-            A.ptr(mpu2), N, S, det, 1.0 / det, st))
-        assert_close(mpu2.cpu().numpy(), want_mpu, normwise=1e-4, maxabs=1e-3,
+            A.ptr(mpu2), 0.5, N, S, det, 1.0 / det, st))
+        assert_close(2 * mpu2.cpu().numpy(), want_mpu, normwise=1e-4, maxabs=1e-3,
                      what=f"m_probe_update alone ({what})")
 
     if pw == det and S <= (4 if det == 512 else 8):
@@ -606,8 +606,8 @@ def test_abi_edge_cases():
     assert lib.tike_fwd_gradient_scale(z, z, z, z, z, z, 0, 2, 256, 1.0, 0,
                                        1.0, 65536, st) == 0
     assert lib.tike_ifft2_pass1_scaled(z, z, z, z, 2, z, 0, 128, st) == 0
-    assert lib.tike_ifft2_pass2_gradients(z, z, z, z, z, 0, 0, z, z, z, 0, 2,
-                                          256, 1.0, st) == 0
+    assert lib.tike_ifft2_pass2_gradients(z, z, z, z, z, 0, 0, z, z, z, 1.0, 0,
+                                          2, 256, 1.0, st) == 0
     assert lib.tike_grad_ifft2_crop(z, z, z, z, 2, z, z, 0, 256, 256, 1.0, 1.0,
                                     st) == 0
     assert lib.tike_scatter_patches(z, z, z, 0, 64, 100, 100, st) == 0
@@ -629,10 +629,10 @@ def test_abi_edge_cases():
     assert lib.tike_grad_ifft2_pass1(p(x), p(f), z, z, 1, p(x) + 8, 1, 128,
                                      1.0, st) == L.ERR_UNSUPPORTED
     assert lib.tike_ifft2_pass2_gradients(p(x), p(x), p(x), z, z, 0, 0, p(x),
-                                          z, z, 1, 9, 128, 1.0,
+                                          z, z, 1.0, 1, 9, 128, 1.0,
                                           st) == L.ERR_UNSUPPORTED  # S > 8
     assert lib.tike_ifft2_pass2_gradients(p(x), p(x), p(x), z, z, 0, 0, p(x),
-                                          z, z, 1, 1, 64, 1.0,
+                                          z, z, 1.0, 1, 1, 64, 1.0,
                                           st) == L.ERR_UNSUPPORTED
     assert lib.tike_grad_ifft2_crop(p(x), p(f), z, z, 1, p(x) + 8, p(x) + 16,
                                     1, 128, 128, 1.0, 1.0,

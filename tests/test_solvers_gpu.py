@@ -63,7 +63,7 @@ def test_lstsq_minibatch_kernels_vs_reference(tp, golden, tag):
             data, psi, scan, probe, ep, ew, lo, hi, comm, num_batch=2,
             exitwave_options=params.exitwave_options, op=op, recover_psi=True,
             recover_probe=True)
-        assert_close(out["object_upd_sum"].cpu().numpy(), g["object_upd_sum"],
+        assert_close(L.object_upd_sum(out).cpu().numpy(), g["object_upd_sum"],
                      normwise=2e-5, what="object_upd_sum")
         assert_close(out["m_probe_update"].cpu().numpy(), g["m_probe_update"],
                      normwise=2e-5, what="m_probe_update")
@@ -72,13 +72,13 @@ def test_lstsq_minibatch_kernels_vs_reference(tp, golden, tag):
             chi0 = chi0[:hi - lo, 0, 0]
         assert_close(chi0.cpu().numpy(), g["chi"][:, 0, 0],
                      normwise=2e-5, what="chi mode 0")
-        np.testing.assert_allclose(float(out["cost"]), g["costs"].mean(),
-                                   rtol=COST_RTOL)
+        np.testing.assert_allclose(out["costs"].cpu().numpy(),
+                                   np.ravel(g["costs"]), rtol=COST_RTOL)
         if out["patches"] is not None and "patches" in g:
             assert_close(out["patches"].cpu().numpy(), g["patches"][:, 0, 0],
                          what="patches")
         precond = L._precondition_object_update(
-            out["object_upd_sum"], A.to_device(g["psi_precond"]))
+            out["object_acc"], A.to_device(g["psi_precond"]))
         if "object_update_precond" in g:
             assert_close(precond.cpu().numpy(), g["object_update_precond"],
                          normwise=2e-5, what="object_update_precond")
@@ -92,9 +92,11 @@ def test_lstsq_minibatch_kernels_vs_reference(tp, golden, tag):
                          normwise=1e-4, maxabs=1e-3, what="eigen_probe")
             assert_close(ew2.cpu().numpy(), g["eigen_weights_out"],
                          normwise=1e-4, maxabs=1e-3, what="eigen_weights")
-        bo, bp = L._solve_steps(stats, out["count"], comm,
-                                pw=probe.shape[-1], recover_psi=True,
-                                recover_probe=True)
+        bo, bp, cost = L._solve_steps(stats, out["costs"], out["count"], comm,
+                                      pw=probe.shape[-1], recover_psi=True,
+                                      recover_probe=True)
+        np.testing.assert_allclose(float(cost), g["costs"].mean(),
+                                   rtol=COST_RTOL)
         np.testing.assert_allclose(float(bo), g["beta_object"].ravel()[0],
                                    rtol=1e-3)
         np.testing.assert_allclose(float(bp), g["beta_probe"].ravel()[0],
@@ -625,7 +627,7 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
             comm, num_batch=2, exitwave_options=params.exitwave_options,
             op=op, recover_psi=True, recover_probe=True,
             position_terms=pos_terms)
-        assert_close(out["object_upd_sum"].cpu().numpy(), o["object_upd_sum"],
+        assert_close(L.object_upd_sum(out).cpu().numpy(), o["object_upd_sum"],
                      normwise=2e-5, what="object_upd_sum")
         assert_close(out["m_probe_update"].cpu().numpy(), o["m_probe_update"],
                      normwise=2e-5, what="m_probe_update")
@@ -634,8 +636,8 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
             chi0 = chi0[:N, 0, 0]
         assert_close(chi0.cpu().numpy(), o["chi"][:, 0, 0], normwise=2e-5,
                      what="chi mode 0")
-        np.testing.assert_allclose(float(out["cost"]), o["costs"].mean(),
-                                   rtol=COST_RTOL)
+        np.testing.assert_allclose(out["costs"].cpu().numpy(),
+                                   np.ravel(o["costs"]), rtol=COST_RTOL)
         assert_close(out["patches"].cpu().numpy(), o["patches"][:, 0, 0],
                      what="patches")
         np.testing.assert_allclose(pos_terms[0].cpu().numpy(),
@@ -648,12 +650,17 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
         precond_o, bo_o, bp_o = osol.precondition_nearplane_gradients(
             o["chi"], scan, o["unique_probe"], probe0, o["object_upd_sum"],
             o["m_probe_update"], pre, o["patches"], 0, N)
-        precond = L._precondition_object_update(out["object_upd_sum"],
+        precond = L._precondition_object_update(out["object_acc"],
                                                 A.to_device(pre))
+        assert_close(precond.cpu().numpy(), precond_o, normwise=2e-5,
+                     what="object_update_precond")
         stats = L._step_stats(out, d["psi"], d["scan"], d["probe"], d["ep"],
                               precond, 0, N, op=op)
-        bo, bp = L._solve_steps(stats, out["count"], comm, pw=det,
-                                recover_psi=True, recover_probe=True)
+        bo, bp, cost = L._solve_steps(stats, out["costs"], out["count"], comm,
+                                      pw=det, recover_psi=True,
+                                      recover_probe=True)
+        np.testing.assert_allclose(float(cost), o["costs"].mean(),
+                                   rtol=COST_RTOL)
         np.testing.assert_allclose(float(bo), np.ravel(bo_o)[0], rtol=1e-3)
         np.testing.assert_allclose(float(bp), np.ravel(bp_o)[0], rtol=1e-3)
         if eigen:

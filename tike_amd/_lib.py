@@ -35,6 +35,7 @@ _p = ctypes.c_void_p
 _i = ctypes.c_int
 _l = ctypes.c_long
 _f = ctypes.c_float
+_d = ctypes.c_double
 
 _PROTOTYPES = {
     "tike_init": [],
@@ -66,8 +67,17 @@ _PROTOTYPES = {
                                 _l, _p],
     "tike_grad_ifft2_pass1": [_p, _p, _p, _p, _i, _p, _l, _i, _f, _p],
     "tike_ifft2_pass1_scaled": [_p, _p, _p, _p, _i, _p, _l, _i, _p],
-    "tike_ifft2_pass2_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i,
-                                   _i, _i, _f, _p],
+    "tike_ifft2_pass2_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _f,
+                                   _i, _i, _i, _f, _p],
+    "tike_object_update_precond": [_p, _p, _p, _f, _p, _p, _p, _l, _p],
+    "tike_lstsq_step_sums": [_p, _p, _i, _f, _p, _p],
+    "tike_lstsq_step_solve": [_p, _i, _f, _p, _d, _i, _i, _p, _p],
+    "tike_probe_update": [_p, _p, _p, _p, _f, _l, _p],
+    "tike_eigen_weights0": [_p, _p, _i, _i, _i, _i, _p, _p],
+    "tike_eigen_proj_mean": [_p, _i, _p, _l, _p, _l, _i, _p, _p],
+    "tike_eigen_normalise": [_p, _p, _d, _f, _i, _p, _p],
+    "tike_eigen_dsum": [_p, _i, _l, _p, _p],
+    "tike_eigen_weights": [_p, _i, _l, _p, _d, _p, _l, _p, _i, _p, _p],
     "tike_grad_ifft2_crop": [_p, _p, _p, _p, _i, _p, _p, _l, _i, _i, _f, _f,
                              _p],
     "tike_position_sums": [_p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _p, _i,

@@ -499,8 +499,8 @@ __device__ __forceinline__ T* tk_at(T* base, unsigned byte_off) {
 template <int N, int MW, int MPW, bool HAVE_PROJ>
 __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
     const cf* __restrict__ mid, const cf* __restrict__ patches, const TkProbe probe,
-    cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, int nscan, int S,
-    float inv_scale, int chunk) {
+    cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, float mpu_scale,
+    int nscan, int S, float inv_scale, int chunk) {
   constexpr int RB = N / 16;
   constexpr int CW = 4 / MW;            // column-waves per workgroup
   constexpr int NCB = N / (64 * CW);    // column blocks
@@ -689,8 +689,8 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
 #pragma unroll
         for (int yb = 0; yb < RB; ++yb) {
           float* o = tk_at(mpu + 2 * ((long)s * P + slice0 + yb * ROW), lb);
-          unsafeAtomicAdd(o, acc[m][yb].x);
-          unsafeAtomicAdd(o + 1, acc[m][yb].y);
+          unsafeAtomicAdd(o, acc[m][yb].x * mpu_scale);
+          unsafeAtomicAdd(o + 1, acc[m][yb].y * mpu_scale);
         }
       }
     }
@@ -707,9 +707,8 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
                                           const void* probe, const void* eigen_probe,
                                           const float* eigen_weights, int num_eigen,
                                           int eigen_modes, void* objproj, void* chi0,
-                                          void* m_probe_update,
-                                          int nscan, int S, int det, float inv_scale,
-                                          void* stream_) {
+                                          void* m_probe_update, float mpu_scale, int nscan,
+                                          int S, int det, float inv_scale, void* stream_) {
   TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1);
@@ -740,11 +739,13 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true>), grid, block,    \
                          eig_lds,                                                            \
                          stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
-                         (cf*)chi0, (float*)m_probe_update, nscan, S, inv_scale, chunk);     \
+                         (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
+                         chunk);                                                             \
     else                                                                                     \
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, false>), grid, block,   \
                          0, stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,   \
-                         (cf*)chi0, (float*)m_probe_update, nscan, S, inv_scale, chunk);     \
+                         (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
+                         chunk);                                                             \
   } while (0)
 #define TK_P2G_N(N)                     \
   do {                                  \

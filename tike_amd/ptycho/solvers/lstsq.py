@@ -144,9 +144,20 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
     order = (range(num_batch) if compact else
              trandom.randomizer_np.permutation(num_batch))
 
-    object_combined_update = torch.zeros_like(psi)
+    dev = psi.device
+    H, W = psi.shape[-2:]
+    # 'compact': the epoch's object gradient, kept in the scatter kernels'
+    # planar (re plane, im plane) float layout
+    object_combined = (torch.zeros((2, H, W), dtype=torch.float32, device=dev)
+                       if recover_psi and compact else None)
     probe_combined_update = torch.zeros_like(probe)
-    batch_cost = torch.zeros(num_batch, dtype=torch.float32, device=psi.device)
+    # per minibatch: {sum step_o, sum step_p, beta_object, beta_probe, cost}
+    steps = torch.zeros((num_batch, 5), dtype=torch.float32, device=dev)
+    pmax = None
+    if recover_psi:
+        # max of the object preconditioner: constant during the epoch
+        pmax = torch.amax(object_options.preconditioner.real).reshape(
+            1).contiguous()
     beta_object, beta_probe = [], []
     position_terms = None
     if position_options is not None:
@@ -165,7 +176,8 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
         object_update_precond = None
         if recover_psi:
             object_update_precond = _precondition_object_update(
-                g["object_upd_sum"], object_options.preconditioner)
+                g["object_acc"], object_options.preconditioner, pmax=pmax,
+                combined=object_combined)
         stats = _step_stats(g, psi, scan, probe, eigen_probe,
                             object_update_precond, lo, hi, op=op)
 
@@ -174,9 +186,10 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
                 g, stats, probe, eigen_probe, eigen_weights, lo, hi, comm,
                 num_batch=num_batch)
 
-        bbeta_object, bbeta_probe = _solve_steps(
-            stats, g["count"], comm, pw=probe.shape[-1],
-            recover_psi=recover_psi, recover_probe=recover_probe)
+        bbeta_object, bbeta_probe, _ = _solve_steps(
+            stats, g["costs"], g["count"], comm, pw=probe.shape[-1],
+            recover_psi=recover_psi, recover_probe=recover_probe,
+            out=steps[batch_index])
 
         if recover_psi:
             if not compact:
@@ -187,18 +200,19 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
                         vdecay=object_options.vdecay,
                         mdecay=object_options.mdecay)
                 psi = psi + dpsi
-            else:
-                object_combined_update += g["object_upd_sum"]
             beta_object.append(bbeta_object)
 
         if recover_probe:
-            dprobe = bbeta_probe * g["m_probe_update"]
-            probe_combined_update += dprobe / num_batch
-            probe += dprobe
+            # probe += beta * mpu; combined += beta * mpu / num_batch
+            check(
+                lib.tike_probe_update(A.ptr(probe), A.ptr(probe_combined_update),
+                                      A.ptr(g["m_probe_update"]),
+                                      A.ptr(bbeta_probe), 1.0 / num_batch,
+                                      probe.numel(), A.stream_ptr()),
+                "probe update")
             beta_probe.append(bbeta_probe)
 
-        batch_cost[batch_index] = g["cost"]
-
+    batch_cost = steps[:, 4]
     if position_options is not None:
         # the minibatches above all used the old positions (lstsq.py:209-220)
         scan = _update_position(scan, position_options, *position_terms, comm,
@@ -224,7 +238,7 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
 
     if recover_psi and compact:
         object_update_precond = _precondition_object_update(
-            object_combined_update, object_options.preconditioner)
+            object_combined, object_options.preconditioner, pmax=pmax)
         bo = torch.mean(torch.stack(beta_object))
         dpsi = bo * object_update_precond
         psi = psi + dpsi
@@ -290,10 +304,11 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     fwd_scale, inv_scale = fft_scales(det, op.norm)
     nmeasured, mask_u8 = mask_info(exitwave_options, det)
 
-    # old weights: the step-size pass must see the probe this gradient used
+    # the weights this gradient uses; every consumer (forward, gradients, step
+    # statistics) runs before _update_nearplane changes them in place
     w_old = None
     if eigen_weights is not None:
-        w_old = eigen_weights[lo:hi].clone()
+        w_old = eigen_weights[lo:hi]
     ep, _, C, Sm = _eigen_args(eigen_probe, w_old)
 
     # planar (real plane, imaginary plane) float32 accumulator of the object
@@ -488,8 +503,9 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     A.ptr(mid), A.ptr(patches[blo:blo + n]), A.ptr(probe),
                     A.ptr(ep), A.ptr(w_c), C, Sm,
                     A.ptr(objproj) if recover_psi else None,
-                    A.ptr(chi0[blo:blo + n]), A.ptr(m_probe_update), n, S,
-                    det, inv_scale, st), "inverse pass 2 + gradients")
+                    A.ptr(chi0[blo:blo + n]), A.ptr(m_probe_update),
+                    1.0 / num_batch, n, S, det, inv_scale, st),
+                "inverse pass 2 + gradients")
         else:
             # one pass over chi: probe gradient, object projection, patches
             check(
@@ -521,32 +537,43 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             chi0[blo:blo + n] = chi[:n, 0, 0]
 
     # complete the sums over positions across ranks
-    cost_sum = costs[:B].sum() if B > 0 else torch.zeros((), device=dev)
     reduced = [t for t in (obj_acc, m_probe_update) if t is not None]
     if comm.collective:
         comm.Allreduce(*reduced)
-    object_upd_sum = (torch.complex(obj_acc[0], obj_acc[1])[None]
-                      if recover_psi else None)
     count = global_count(comm, op, lo, hi)
-    tot = comm.Allreduce_scalars([cost_sum], dev)
-    if recover_probe:
-        m_probe_update = m_probe_update / num_batch
+    if recover_probe and not fused:
+        m_probe_update = m_probe_update / num_batch  # (fused: in the kernel)
     return dict(chi0=chi_ws if single_chunk else chi0[:B],
                 chi_modes=S if single_chunk else 1, w_old=w_old,
                 patches=None if patches is None
-                else patches[:B], object_upd_sum=object_upd_sum,
-                m_probe_update=m_probe_update,
-                cost=(tot[0] / count).to(torch.float32), count=count,
+                else patches[:B], object_acc=obj_acc,
+                m_probe_update=m_probe_update, costs=costs[:B], count=count,
                 local_count=B)
 
 
-def _precondition_object_update(object_upd_sum, psi_update_denominator,
-                                alpha=0.05):
-    """g / sqrt(((1-a) P)^2 + (a max P)^2) (lstsq.py:605-616)."""
-    pmax = torch.amax(psi_update_denominator.real, dim=(-2, -1), keepdim=True)
-    return object_upd_sum / torch.sqrt(
-        torch.square((1 - alpha) * psi_update_denominator) +
-        torch.square(alpha * pmax))
+def object_upd_sum(g):
+    """The object gradient of a minibatch as a (1, H, W) complex array
+    (`object_upd_sum` of lstsq.py:514-520) from the planar accumulator."""
+    acc = g["object_acc"]
+    return None if acc is None else torch.complex(acc[0], acc[1])[None]
+
+
+def _precondition_object_update(object_acc, psi_update_denominator,
+                                alpha=0.05, *, pmax=None, combined=None):
+    """g / sqrt(((1-a) P)^2 + (a max P)^2) (lstsq.py:605-616) straight from
+    the planar (2, H, W) scatter accumulator; `combined` (planar) += g."""
+    H, W = object_acc.shape[-2:]
+    if pmax is None:
+        pmax = torch.amax(psi_update_denominator.real).reshape(1).contiguous()
+    out = torch.empty((1, H, W), dtype=torch.complex64,
+                      device=object_acc.device)
+    check(
+        lib.tike_object_update_precond(A.ptr(object_acc),
+                                       A.ptr(psi_update_denominator),
+                                       A.ptr(pmax), alpha, None, A.ptr(out),
+                                       A.ptr(combined), H * W, A.stream_ptr()),
+        "preconditioned object update")
+    return out
 
 
 def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
@@ -578,35 +605,34 @@ def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
     return stats[:B]
 
 
-def _solve_steps(stats, count, comm, *, pw, recover_psi, recover_probe):
+def _solve_steps(stats, costs, count, comm, *, pw, recover_psi, recover_probe,
+                 out=None):
     """2x2 least-squares step sizes, averaged over the minibatch
-    (lstsq.py:641-718).  Means over positions are global (all ranks)."""
+    (lstsq.py:641-718), and the minibatch cost.  Means over positions are
+    global (all ranks).  Returns 0-d device tensors (beta_object, beta_probe,
+    cost); `out`: a (5,) float32 row to keep them in."""
     dev = stats.device
-    eps_total = np.float32(np.float32(1e-9) / (pw * pw)) * (pw * pw)
-    A1 = stats[:, 0] + eps_total
-    A4 = stats[:, 1] + eps_total
-    sums = comm.Allreduce_scalars([A1.sum(), A4.sum()], dev)
-    A1 = A1 + (0.5 * sums[0] / count).to(torch.float32)
-    A4 = A4 + (0.5 * sums[1] / count).to(torch.float32)
-    b1, b2 = stats[:, 4], stats[:, 5]
-    x1 = x2 = None
-    if recover_psi and recover_probe:
-        A2 = torch.complex(stats[:, 2], stats[:, 3])
-        A3 = A2.conj()
-        determinant = A1 * A4 - A2 * A3
-        x1 = -torch.conj(A2 * b2 - A4 * b1) / determinant
-        x2 = torch.conj(A1 * b2 - A3 * b1) / determinant
-    elif recover_psi:
-        x1 = b1 / A1
-    elif recover_probe:
-        x2 = b2 / A4
-    zero = torch.zeros((), dtype=torch.float32, device=dev)
-    so = (0.9 * torch.clamp(x1.real, min=0)).sum() if recover_psi else zero
-    sp = (0.9 * torch.clamp(x2.real, min=0)).sum() if recover_probe else zero
-    tot = comm.Allreduce_scalars([so, sp], dev)
-    beta_object = (tot[0] / count).to(torch.float32) if recover_psi else None
-    beta_probe = (tot[1] / count).to(torch.float32) if recover_probe else None
-    return beta_object, beta_probe
+    B = stats.shape[0]
+    st = A.stream_ptr()
+    eps_total = float(np.float32(np.float32(1e-9) / (pw * pw)) * (pw * pw))
+    if out is None:
+        out = torch.zeros(5, dtype=torch.float32, device=dev)
+    sums = torch.empty(3, dtype=torch.float32, device=dev)
+    check(
+        lib.tike_lstsq_step_sums(A.ptr(stats), A.ptr(costs), B, eps_total,
+                                 A.ptr(sums), st), "step-size sums")
+    if comm.collective:
+        comm.Allreduce(sums)
+    check(
+        lib.tike_lstsq_step_solve(A.ptr(stats), B, eps_total, A.ptr(sums),
+                                  float(count), int(recover_psi),
+                                  int(recover_probe), A.ptr(out), st),
+        "step-size solve")
+    if comm.collective:
+        comm.Allreduce(out[:2])
+        out[2:4] = out[:2] / count
+    return (out[2] if recover_psi else None,
+            out[3] if recover_probe else None, out[4])
 
 
 def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
@@ -615,23 +641,33 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
     probe.py:362-476).  Means over positions are global."""
     m = 0
     dev = probe.device
-    count = g["count"]
-    # (lstsq.py:721-738) weights of the shared probe
-    eigen_weights[lo:hi, 0, m] += 0.1 * stats[:, 6] / stats[:, 7]
-    if eigen_weights.shape[-2] <= 1 or eigen_probe is None:
+    count = float(g["count"])
+    B = hi - lo
+    st = A.stream_ptr()
+    Cw, S = eigen_weights.shape[-2] - 1, eigen_weights.shape[-1]
+    row = (Cw + 1) * S
+    w_rows = eigen_weights[lo:hi]  # (B, C+1, S) rows of this minibatch
+    norms = torch.empty(max(Cw, 1), dtype=torch.float32, device=dev)
+    # (lstsq.py:721-738) weights of the shared probe, and sum w_c^2
+    check(
+        lib.tike_eigen_weights0(A.ptr(w_rows), A.ptr(stats), B, Cw, S, m,
+                                A.ptr(norms), st), "eigen weights (shared)")
+    if Cw < 1 or eigen_probe is None:
         return eigen_probe, eigen_weights
     if m >= eigen_probe.shape[-3]:
         return eigen_probe, eigen_weights
     assert eigen_weights.shape[-2] == eigen_probe.shape[-4] + 1
+    if comm.collective:
+        comm.Allreduce(norms)
     chi0, patches = g["chi0"], g["patches"]
-    mpu0 = g["m_probe_update"][0, 0, m].contiguous()
-    B = hi - lo
+    mpu0 = g["m_probe_update"][0, 0, m]
     C, Sm, pw = eigen_probe.shape[-4], eigen_probe.shape[-3], probe.shape[-1]
     P = pw * pw
     beta = min(0.1, 1.0 / num_batch)
-    st = A.stream_ptr()
     sums = torch.empty((max(B, 1), 5), dtype=torch.float32, device=dev)
     coefs = torch.zeros((max(B, 1), C), dtype=torch.complex64, device=dev)
+    pm = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
+    small = torch.empty(2, dtype=torch.float32, device=dev)  # dsum, esum
     ep = eigen_probe  # (1, C, Sm, pw, pw), updated in place, read by kernels
 
     def position_sums(c):
@@ -641,46 +677,50 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
                                          C, Sm, c, A.ptr(sums), B, pw,
                                          g["chi_modes"], st),
             "eigen position sums")
-        return sums[:B]
 
     for c in range(1, C + 1):
-        w = eigen_weights[lo:hi, c, m]
-        norm_weights = comm.Allreduce_scalars([torch.sum(w * w)], dev)[0].to(
-            torch.float32)
+        w_c = w_rows[:, c, m]  # strided view: element n at n * row
         # a batch whose weights are all zero divides by zero here; the
         # reference raises ValueError after a host sync (probe.py:426) --
         # lstsq_grad raises the same error at the end of the epoch
         if c == 1 and g.get("eigen_proj") is not None:
-            first = g["eigen_proj"]  # formed by the step-statistics pass
+            first, stride = g["eigen_proj"], 1  # from the step-statistics pass
         else:
-            first = position_sums(c - 1)[:, 0]
-        proj_mean = ((first / P + w) / norm_weights).contiguous()
+            position_sums(c - 1)
+            first, stride = sums, 5
+        check(
+            lib.tike_eigen_proj_mean(A.ptr(first), stride, w_c.data_ptr(), row,
+                                     norms[c - 1:].data_ptr(), P, B,
+                                     A.ptr(pm), st), "eigen projection mean")
         update = torch.zeros((pw, pw), dtype=torch.complex64, device=dev)
         check(
             lib.tike_eigen_pixel_update(A.ptr(patches), A.ptr(chi0),
                                         A.ptr(mpu0), A.ptr(ep), A.ptr(coefs),
-                                        C, Sm, c - 1, A.ptr(proj_mean),
+                                        C, Sm, c - 1, A.ptr(pm),
                                         A.ptr(update), B, pw, g["chi_modes"],
                                         st),
             "eigen pixel update")
         if comm.collective:
             comm.Allreduce(update)
-        update = update / count
-        E = ep[0, c - 1, m]
-        E = E + beta * update / linalg.mnorm(update)
-        E = E / linalg.mnorm(E)
-        ep[0, c - 1, m] = E
+        E = ep[0, c - 1, m]  # (pw, pw) view, contiguous
+        check(
+            lib.tike_eigen_normalise(A.ptr(E), A.ptr(update), count, beta, P,
+                                     small[1:].data_ptr(), st),
+            "eigen probe normalisation")
         # new weights for the updated eigen probe (and the projection of the
         # residual onto it, removed before the next eigen probe)
-        s = position_sums(c - 1)
-        n = s[:, 1] / P
-        d = s[:, 2] / P
-        d_mean = (comm.Allreduce_scalars([d.sum()], dev)[0] / count).to(
-            torch.float32)
-        eigen_weights[lo:hi, c, m] += n / (d + 0.1 * d_mean)
-        if c + 1 < eigen_weights.shape[-2]:
-            coefs[:B, c - 1] = torch.complex(s[:, 3], s[:, 4]) / torch.sum(
-                E * E.conj())
+        position_sums(c - 1)
+        check(lib.tike_eigen_dsum(A.ptr(sums), B, P, A.ptr(small), st),
+              "eigen weight denominator")
+        if comm.collective:
+            comm.Allreduce(small[:1])
+        more = c + 1 < eigen_weights.shape[-2]
+        check(
+            lib.tike_eigen_weights(A.ptr(sums), B, P, A.ptr(small), count,
+                                   w_c.data_ptr(), row,
+                                   coefs[:, c - 1:].data_ptr() if more else
+                                   None, C, small[1:].data_ptr(), st),
+            "eigen weights")
     return eigen_probe, eigen_weights
 
 

@@ -106,13 +106,13 @@ def main():
             N * (2 * T + D))
     run("pass2_gradients", lambda: check(lib.tike_ifft2_pass2_gradients(
         p(mid), p(patches), p(probe), p(eig), p(w), C, Sm, p(objproj),
-        p(chi0), p(mpu), N, S, det, 1.0 / det, st)), N * (T + 3 * P))
+        p(chi0), p(mpu), 1.0, N, S, det, 1.0 / det, st)), N * (T + 3 * P))
     run("pass2_gradients (no eigen)", lambda: check(lib.tike_ifft2_pass2_gradients(
         p(mid), p(patches), p(probe), None, None, 0, 0, p(objproj),
-        p(chi0), p(mpu), N, S, det, 1.0 / det, st)), N * (T + 3 * P))
+        p(chi0), p(mpu), 1.0, N, S, det, 1.0 / det, st)), N * (T + 3 * P))
     run("pass2_gradients (probe only)", lambda: check(lib.tike_ifft2_pass2_gradients(
         p(mid), p(patches), None, None, None, 0, 0, None, None, p(mpu),
-        N, S, det, 1.0 / det, st)), N * (T + P))
+        1.0, N, S, det, 1.0 / det, st)), N * (T + P))
     run("lstsq_gradients (old)", lambda: check(lib.tike_lstsq_gradients(
         p(mid), p(scan), p(psi), p(probe), p(eig), p(w), C, Sm, None,
         p(patches), p(mpu), p(objproj), N, S, pw, HW, HW, st)), N * (T + 2 * P))

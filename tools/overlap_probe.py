@@ -52,7 +52,7 @@ def g1(st):
 def p2g(st):
     check(lib.tike_ifft2_pass2_gradients(p(midB), p(patches), p(probe), None,
                                          None, 0, 0, p(objproj), p(chi0),
-                                         p(mpu), N, S, det, 1.0 / det, st))
+                                         p(mpu), 1.0, N, S, det, 1.0 / det, st))
 
 
 def timed(fn, reps=10):
