@@ -313,9 +313,14 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
 
     # planar (real plane, imaginary plane) float32 accumulator of the object
     # gradient: the shape float atomics run fastest on; recombined below
-    obj_acc = (torch.zeros((2, H, W), dtype=torch.float32, device=dev)
-               if recover_psi else None)
-    m_probe_update = torch.zeros_like(probe) if recover_probe else None
+    # ... and it shares ONE flat buffer with the probe gradient, so that the
+    # two are all-reduced in place by a single collective (no packing copy)
+    n_obj = 2 * H * W if recover_psi else 0
+    n_prb = 2 * probe.numel() if recover_probe else 0
+    grads = torch.zeros(n_obj + n_prb, dtype=torch.float32, device=dev)
+    obj_acc = grads[:n_obj].view(2, H, W) if recover_psi else None
+    m_probe_update = (torch.view_as_complex(
+        grads[n_obj:].view(*probe.shape, 2)) if recover_probe else None)
     chi0 = None  # allocated below unless chi itself can be handed on
     patches = None
     pos_major = det in POSITION_MAJOR_SIZES
@@ -537,9 +542,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             chi0[blo:blo + n] = chi[:n, 0, 0]
 
     # complete the sums over positions across ranks
-    reduced = [t for t in (obj_acc, m_probe_update) if t is not None]
-    if comm.collective:
-        comm.Allreduce(*reduced)
+    if comm.collective and grads.numel():
+        comm.Allreduce(grads)
     count = global_count(comm, op, lo, hi)
     if recover_probe and not fused:
         m_probe_update = m_probe_update / num_batch  # (fused: in the kernel)

@@ -20,7 +20,16 @@ KERNELS = {
     "void ptycho_fwd_pos_kernel<256, false>": "tike_ptycho_fwd_gradient_scale",
     "void ptycho_fwd_pos_kernel<256, true>": "tike_ptycho_fwd_intensity",
     "void ptycho_fwd_pos_kernel<512": "tike_ptycho_fwd_intensity",
-    "void grad_ifft2_crop_kernel": "tike_grad_ifft2_crop",
+    "void fwd_pass1_kernel": "tike_fwd_pass1",
+    "void fwd_gradient_scale_kernel": "tike_fwd_gradient_scale",
+    "void grad_ifft2_crop_kernel<256, 1, false>": "tike_grad_ifft2_pass1",
+    "void grad_ifft2_crop_kernel<256, 2, false>": "tike_grad_ifft2_pass1",
+    "void grad_ifft2_crop_kernel<256, 1, true>": "tike_grad_ifft2_crop",
+    "void grad_ifft2_crop_kernel<256, 2, true>": "tike_grad_ifft2_crop",
+    "void ifft2_pass2_gradients_kernel": "tike_ifft2_pass2_gradients",
+    "void ifft2_crop_v2_kernel<128, 1, false>": "tike_ifft2_pass1_scaled",
+    "void ifft2_crop_v2_kernel<256, 1, false>": "tike_ifft2_pass1_scaled",
+    "void ifft2_crop_v2_kernel<512, 1, false>": "tike_ifft2_pass1_scaled",
     "void ifft2_crop_v2_kernel": "tike_ifft2_crop_scaled",
     "void probe_grad_kernel<true": "tike_lstsq_gradients",
     "void step_stats_kernel": "tike_lstsq_step_stats",
@@ -41,9 +50,10 @@ def collect(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             for prefix, entry in KERNELS.items():
-                if r["Kernel_Name"].startswith(prefix):
+                if r["Kernel_Name"].startswith(prefix):  # first match wins
                     rows[entry].append((int(r["Grid_Size"]),
                                         float(r["Counter_Value"])))
+                    break
     out = {}
     for entry, v in rows.items():
         g = max(x[0] for x in v)
@@ -75,6 +85,17 @@ def main():
             "launches": nf,
             "hbm_bytes_per_launch": (2 * f + w) * 1024,
         }
+    # one timed step = launches-per-step x bytes per launch, summed over the
+    # kernels seen (bench.py runs --steps 1 --warmup 0 under the counters, so
+    # the launch count of the largest-grid launches is the count per step)
+    # bench.py's set-up (`simulate`: the far-plane-storing forward operator)
+    # is not part of a step
+    setup = {"c3": ("tike_ptycho_fwd_intensity",),
+             "c2": ("tike_ptycho_fwd_intensity",)}.get(workload, ())
+    doc["setup_kernels_excluded_from_step"] = list(setup)
+    doc["hbm_bytes_per_step"] = sum(
+        k["hbm_bytes_per_launch"] * k["launches"]
+        for name, k in doc["kernels"].items() if name not in setup)
     json.dump(doc, open(out, "w"), indent=1)
     for k, v in doc["kernels"].items():
         print(f"{k:34s} read {2*v['fetch_kib_per_launch']/1048576:7.2f} GiB  "

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Evidence for profiles/: run on the MI355X box from the repo root.
-#   bash tools/profile_round.sh r01
+#   bash tools/profile_round.sh r02
 # Writes gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards
 # (tools/profile_round.sh does the copy into gpurun_out/profiles_<tag>/).
-tag=${1:-r01}
+tag=${1:-r02}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 o=gpurun_out
@@ -17,7 +17,7 @@ for w in fwd256x1 fwd256x8 fwd128x1; do
 done
 # 2. kernel-trace summary of the default command
 rm -rf $o/${tag}_prof_c3
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof_c3 -- python3 bench.py --no-cpu-baseline > $o/${tag}_prof_c3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/${tag}_prof_c3 -- python3 bench.py --no-cpu-baseline --no-secondary > $o/${tag}_prof_c3.log 2>&1
 f=$(find $o/${tag}_prof_c3 -name "*kernel_stats.csv" | head -1)
 python3 - "$f" $o/profiles_$tag/${tag}_rocprof_stats_c3.csv <<'PY'
 import csv, sys
@@ -31,7 +31,7 @@ PY
 # 3. HBM traffic counters, one pass per counter (no other tracing domains)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $o/${tag}_pmc_$c
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_pmc_$c -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_pmc_$c -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 > /dev/null 2>&1
 done
 python3 tools/pmc_traffic.py $o/${tag}_pmc_FETCH_SIZE $o/${tag}_pmc_WRITE_SIZE c3 1000 $o/profiles_$tag/${tag}_pmc_traffic_c3.json
 cat $o/profiles_$tag/${tag}_bench_c3.json
