@@ -361,6 +361,13 @@ int tike_position_sums(const void* patches, const void* chi, int chi_modes, cons
                        int eigen_modes, const float* taps, int radius, float* numerator,
                        float* denominator, int nscan, int S, int pw, void* stream);
 
+/* ---- FresnelSpectProp.fwd / .adj (operators/cupy/fresnelspectprop.py:52-113):
+ * out = IFFT2(FFT2(in) * propagator) (adjoint != 0: conj(propagator)) for ntile
+ * n x n tiles sharing one (n,n) c64 propagator; fwd_scale / inv_scale are the
+ * two transforms' normalisations (1/n each for 'ortho').  in may equal out. */
+int tike_fresnel_spect_prop(const void* in, void* out, const void* propagator, long ntile, int n,
+                            int adjoint, float fwd_scale, float inv_scale, void* stream);
+
 /* ---- small fused kernels of the lstsq_grad host loop (psi-, probe- or
  * (positions,)-sized work between the heavy kernels; sums that span all ranks
  * stay in small device buffers the caller all-reduces between two phases) ---- */

@@ -225,27 +225,126 @@ def propagation_adj(farplane, norm="ortho"):
 
 
 # --------------------------------------------------------------------------
-# Ptycho  (src/tike/operators/cupy/ptycho.py:114-204, multislice.py D == 1)
+# FresnelSpectProp  (src/tike/operators/cupy/fresnelspectprop.py:52-137) and
+# Multislice with several slices (multislice.py:69-194)
 # --------------------------------------------------------------------------
 
 
-def ptycho_fwd(probe, scan, psi, detector_shape, norm="ortho"):
-    """probe (N|1,1,S,pw,pw), scan (N,2), psi (1,H,W) -> (N,1,S,det,det).
+def fresnel_spectrum_propagator(N, probe_FOV, distance, wavelength):
+    """fresnelspectprop.py:115-137 (float64 grids, FFT-shifted, complex64)."""
+    xgrid = (0.5 + np.linspace(-0.5 * N[1], 0.5 * N[1] - 1, num=N[1])) / N[1]
+    ygrid = (0.5 + np.linspace(-0.5 * N[0], 0.5 * N[0] - 1, num=N[0])) / N[0]
+    kx = 2 * np.pi * N[1] * xgrid / probe_FOV[1]
+    ky = 2 * np.pi * N[0] * ygrid / probe_FOV[0]
+    Kx, Ky = np.meshgrid(kx, ky, indexing="xy")
+    prop = np.exp(1j * distance * np.sqrt((2 * np.pi / wavelength)**2 -
+                                          Kx**2 - Ky**2))
+    return np.fft.fftshift(prop).astype(np.complex64)
 
-    ptycho.py:114-129 -> multislice.py:69-92 (D == 1) -> convolution.py:58.
+
+def fresnel_fwd(nearplane, propagator, norm="ortho"):
+    """IFFT2(FFT2(x) * H)  (fresnelspectprop.py:52-82)."""
+    return propagation_adj(propagation_fwd(nearplane, norm) * propagator, norm)
+
+
+def fresnel_adj(farplane, propagator, norm="ortho"):
+    """IFFT2(FFT2(x) * conj(H))  (fresnelspectprop.py:84-113)."""
+    return propagation_adj(
+        propagation_fwd(farplane, norm) * np.conj(propagator), norm)
+
+
+def multislice_fwd(probe, scan, psi, propagator, norm="ortho"):
+    """probe (N|1,S,pw,pw), psi (D,H,W) -> exit wave (N,S,pw,pw)
+    (multislice.py:69-92; detector = probe shape)."""
+    exitwave = convolution_fwd(psi[0], scan, probe)
+    for s in range(1, len(psi)):
+        exitwave = convolution_fwd(psi[s], scan,
+                                   fresnel_fwd(exitwave, propagator, norm))
+    return exitwave
+
+
+def multislice_fwd_intermediate(probe, scan, psi, propagator, norm="ortho"):
+    """(exit wave, probes incident on every slice (D,N,S,pw,pw))
+    (multislice.py:97-141)."""
+    N = scan.shape[-2]
+    probes = np.zeros((psi.shape[0], N, *probe.shape[-3:]), dtype=probe.dtype)
+    probes[0] = probe
+    exitwave = None
+    for t in range(len(psi)):
+        exitwave = convolution_fwd(psi[t], scan, probes[t])
+        if t == len(psi) - 1:
+            break
+        probes[t + 1] = fresnel_fwd(exitwave, propagator, norm)
+    return exitwave, probes
+
+
+def multislice_adj(nearplane, probe, scan, psi, propagator, norm="ortho"):
+    """(psi_adj (D,H,W) / D, probe_adj (N,S,pw,pw))  (multislice.py:144-194)."""
+    D = len(psi)
+    probes = [None] * D
+    probes[0] = probe
+    for s in range(1, D):
+        probes[s] = fresnel_fwd(convolution_fwd(psi[s - 1], scan, probes[s - 1]),
+                                propagator, norm)
+    psi_adj = np.zeros_like(psi)
+    psi_adj[D - 1] = convolution_adj(nearplane, scan, probes[D - 1],
+                                     psi.shape[-2], psi.shape[-1])
+    probe_adj = convolution_adj_probe(nearplane, scan, psi[D - 1],
+                                      probe.shape[-1])
+    for s in range(D - 2, -1, -1):
+        probe_adj = fresnel_adj(probe_adj, propagator, norm)
+        psi_adj[s] = convolution_adj(probe_adj, scan, probes[s], psi.shape[-2],
+                                     psi.shape[-1])
+        probe_adj = convolution_adj_probe(probe_adj, scan, psi[s],
+                                          probe.shape[-1])
+    return psi_adj / D, probe_adj
+
+
+# --------------------------------------------------------------------------
+# Ptycho  (src/tike/operators/cupy/ptycho.py:114-204)
+# --------------------------------------------------------------------------
+
+
+def ptycho_fwd(probe, scan, psi, detector_shape, norm="ortho",
+               propagator=None):
+    """probe (N|1,1,S,pw,pw), scan (N,2), psi (D,H,W) -> (N,1,S,det,det).
+
+    ptycho.py:114-129 -> multislice.py:69-92 -> convolution.py:58.  D > 1
+    needs the Fresnel `propagator` (and det == pw).
     """
-    assert psi.ndim == 3 and psi.shape[0] == 1, "oracle covers D == 1 only"
-    near = convolution_fwd(psi[0], scan, probe[..., 0, :, :, :],
-                           detector_shape)
+    assert psi.ndim == 3
+    if psi.shape[0] == 1:
+        near = convolution_fwd(psi[0], scan, probe[..., 0, :, :, :],
+                               detector_shape)
+    else:
+        near = multislice_fwd(probe[..., 0, :, :, :], scan, psi, propagator,
+                              norm)
     return propagation_fwd(near, norm)[..., None, :, :, :]
 
 
-def ptycho_adj(farplane, probe, scan, psi, norm="ortho"):
-    """Returns (psi_adj (1,H,W), probe_adj (N,1,S,pw,pw)); ptycho.py:156-176,
-    multislice.py:144-194 with nslices == 1 (the /nslices is /1)."""
-    assert psi.ndim == 3 and psi.shape[0] == 1, "oracle covers D == 1 only"
+def ptycho_fwd_intermediate(probe, scan, psi, propagator, norm="ortho"):
+    """ptycho.py:131-146: (farplane (N,1,S,pw,pw), probes (D,N,S,pw,pw))."""
+    if psi.shape[0] == 1:
+        p = probe[..., 0, :, :, :]
+        N = scan.shape[-2]
+        probes = np.broadcast_to(p, (N, *p.shape[-3:]))[None].copy()
+        near = convolution_fwd(psi[0], scan, p)
+    else:
+        near, probes = multislice_fwd_intermediate(probe[..., 0, :, :, :], scan,
+                                                   psi, propagator, norm)
+    return propagation_fwd(near, norm)[..., None, :, :, :], probes
+
+
+def ptycho_adj(farplane, probe, scan, psi, norm="ortho", propagator=None):
+    """Returns (psi_adj (D,H,W), probe_adj (N,1,S,pw,pw)); ptycho.py:156-176,
+    multislice.py:144-194 (psi_adj divided by the number of slices)."""
+    assert psi.ndim == 3
     near = propagation_adj(farplane, norm)[..., 0, :, :, :]
     p = probe[..., 0, :, :, :]
+    if psi.shape[0] > 1:
+        psi_adj, probe_adj = multislice_adj(near, p, scan, psi, propagator,
+                                            norm)
+        return psi_adj, probe_adj[..., None, :, :, :]
     psi_adj = convolution_adj(near, scan, p, psi.shape[-2], psi.shape[-1])
     probe_adj = convolution_adj_probe(near, scan, psi[0], p.shape[-1])
     return psi_adj[None], probe_adj[..., None, :, :, :]

@@ -262,7 +262,50 @@ def lstsq_parts(tag, N, pw, det, S, eigen, slim=False, rng=None):
          probe_precond=probe_pre, **extra, **out)
 
 
+def multislice_fixture():
+    """Multislice / FresnelSpectProp / Ptycho with D = 3 object slices, run by
+    the reference (tests/operators/test_multislice.py shapes, scaled down)."""
+    r = np.random.default_rng(7)
+    D, N, S, pw, HW = 3, 5, 2, 16, 40
+    scan_ = (r.random((N, 2), dtype=np.float32) * (HW - pw - 3) + 1).astype(
+        np.float32)
+    probe_ = rc(r, N, S, pw, pw)
+    psi_ = rc(r, D, HW, HW)
+    near_ = rc(r, N, S, pw, pw)
+    far_ = rc(r, N, 1, S, pw, pw)
+    with tike.operators.Multislice(probe_shape=pw, detector_shape=pw, nz=HW,
+                                   n=HW, **PHYS) as op:
+        prop = op.propagation._create_fresnel_spectrum_propagator(
+            (pw, pw), op.propagation.probe_FOV, op.propagation.distance,
+            op.propagation.wavelength)
+        fresnel_f = op.propagation.fwd(A(near_))
+        fresnel_a = op.propagation.adj(A(near_))
+        ms_fwd = op.fwd(probe=A(probe_), scan=A(scan_), psi=A(psi_))
+        ms_psi_adj, ms_probe_adj = op.adj(nearplane=A(near_), probe=A(probe_),
+                                          scan=A(scan_), psi=A(psi_))
+        ms_exit, ms_probes = op.fwd_return_intermediate_probes(
+            probe=A(probe_[:, None]), scan=A(scan_), psi=A(psi_))
+    with tike.operators.Ptycho(probe_shape=pw, detector_shape=pw, nz=HW,
+                               n=HW, **PHYS) as op:
+        pt_fwd = op.fwd(probe=A(probe_[:, None]), scan=A(scan_), psi=A(psi_))
+        pt_psi_adj, pt_probe_adj = op.adj(farplane=A(far_),
+                                          probe=A(probe_[:, None]),
+                                          scan=A(scan_), psi=A(psi_))
+    save("op_multislice.npz", scan=scan_, probe=probe_, psi=psi_,
+         nearplane_in=near_, farplane_in=far_, propagator=prop,
+         fresnel_fwd=fresnel_f, fresnel_adj=fresnel_a, ms_fwd=ms_fwd,
+         ms_psi_adj=ms_psi_adj, ms_probe_adj=ms_probe_adj, ms_exit=ms_exit,
+         ms_probes=ms_probes, pt_fwd=pt_fwd, pt_psi_adj=pt_psi_adj,
+         pt_probe_adj=pt_probe_adj,
+         phys=np.array([PHYS["probe_wavelength"], PHYS["probe_FOV_lengths"][0],
+                        PHYS["probe_FOV_lengths"][1],
+                        PHYS["multislice_propagation_distance"]]))
+
+
 ONLY = os.environ.get("TIKE_FIXTURES_ONLY")  # e.g. "big": new fixtures only
+if ONLY == "multislice":
+    multislice_fixture()
+    sys.exit(0)
 if ONLY == "big":
     # the tile sizes of the fused FFT kernels (v2 engine, position-major
     # forward, far-plane-free inverse): one minibatch each, own generators so

@@ -312,3 +312,33 @@ def test_cgrad_vs_reference_composition(golden):
         np.testing.assert_allclose(state["costs"][-1][0], g["costs"][i + 1],
                                    rtol=2e-3)
         assert relerr(state["psi"], g["psis"][i]) < 2e-3
+
+
+def test_multislice_vs_reference(golden):
+    """FresnelSpectProp, Multislice (3 slices) and Ptycho over it, against
+    the reference's own outputs (operators/cupy/multislice.py:69-194,
+    fresnelspectprop.py:52-137, ptycho.py:114-176)."""
+    g = golden("op_multislice.npz")
+    wl, fy, fx, dist = (float(v) for v in g["phys"])
+    pw = g["probe"].shape[-1]
+    H = ops.fresnel_spectrum_propagator((pw, pw), (fy, fx), dist, wl)
+    assert_close(H, g["propagator"], what="propagator")
+    assert_close(ops.fresnel_fwd(g["nearplane_in"], H), g["fresnel_fwd"],
+                 what="fresnel fwd")
+    assert_close(ops.fresnel_adj(g["nearplane_in"], H), g["fresnel_adj"],
+                 what="fresnel adj")
+    probe, scan, psi = g["probe"], g["scan"], g["psi"]
+    assert_close(ops.multislice_fwd(probe, scan, psi, H), g["ms_fwd"],
+                 what="multislice fwd")
+    exitw, probes = ops.multislice_fwd_intermediate(probe, scan, psi, H)
+    assert_close(exitw, g["ms_exit"], what="multislice exit wave")
+    assert_close(probes, g["ms_probes"], what="intermediate probes")
+    pa, qa = ops.multislice_adj(g["nearplane_in"], probe, scan, psi, H)
+    assert_close(pa, g["ms_psi_adj"], what="multislice psi_adj")
+    assert_close(qa, g["ms_probe_adj"], what="multislice probe_adj")
+    assert_close(ops.ptycho_fwd(probe[:, None], scan, psi, pw, propagator=H),
+                 g["pt_fwd"], what="ptycho fwd (3 slices)")
+    pa, qa = ops.ptycho_adj(g["farplane_in"], probe[:, None], scan, psi,
+                            propagator=H)
+    assert_close(pa, g["pt_psi_adj"], what="ptycho psi_adj (3 slices)")
+    assert_close(qa, g["pt_probe_adj"], what="ptycho probe_adj (3 slices)")

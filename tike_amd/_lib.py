@@ -45,6 +45,7 @@ _PROTOTYPES = {
     "tike_conv_adj": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "tike_conv_adj_probe": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "tike_fft2": [_p, _p, _l, _i, _i, _f, _p],
+    "tike_fresnel_spect_prop": [_p, _p, _p, _l, _i, _i, _f, _f, _p],
     "tike_ptycho_fwd": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i,
                         _i, _i, _f, _p],
     "tike_ifft2_crop": [_p, _p, _p, _l, _i, _i, _f, _p],

@@ -220,3 +220,36 @@ extern "C" int tike_fft2(const void* in, void* out, long ntile, int n, int inver
   TK_ENTER();
   return tk_fft2((const cf*)in, (cf*)out, ntile, n, inverse, scale, (hipStream_t)stream);
 }
+
+// ---------------------------------------------- Fresnel spectrum propagation
+// out = IFFT2( FFT2(in) * H )  (adjoint: conj(H)) for `ntile` n x n tiles
+// sharing the propagator H (n, n) -- the near-field step between the slices
+// of a multislice object (reference operators/cupy/fresnelspectprop.py:52-113).
+__global__ __launch_bounds__(256) void spectrum_multiply_kernel(cf* __restrict__ x,
+                                                                const cf* __restrict__ h,
+                                                                long ntile, long npix,
+                                                                int conjugate) {
+  const long total = ntile * npix;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    cf w = h[i % npix];
+    if (conjugate) w = conjf(w);
+    x[i] = x[i] * w;
+  }
+}
+
+extern "C" int tike_fresnel_spect_prop(const void* in, void* out, const void* propagator,
+                                       long ntile, int n, int adjoint, float fwd_scale,
+                                       float inv_scale, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && n >= 1);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(in && out && propagator);
+  int rc = tk_fft2((const cf*)in, (cf*)out, ntile, n, 0, fwd_scale, stream);
+  if (rc) return rc;
+  const long npix = (long)n * n;
+  hipLaunchKernelGGL(spectrum_multiply_kernel, dim3(tk_grid((ntile * npix + 255) / 256, 8)),
+                     dim3(256), 0, stream, (cf*)out, (const cf*)propagator, ntile, npix, adjoint);
+  TK_LAUNCH_CHECK();
+  return tk_fft2((const cf*)out, (cf*)out, ntile, n, 1, inv_scale, stream);
+}

@@ -102,7 +102,26 @@ class Ptycho(Operator):
         scan = A.to_device(scan, np.float32)
         probe = A.to_device(probe, np.complex64)
         assert probe.ndim == 5 and probe.shape[1] == 1, probe.shape
+        if psi.shape[0] > 1:
+            # several object slices (ptycho.py:114-129 over multislice.py:
+            # 69-92): slice-by-slice composition, then the far-field transform
+            far = self.propagation.fwd(self.diffraction.fwd(
+                psi=psi, scan=scan, probe=probe[..., 0, :, :, :]),
+                                       overwrite=True)[..., None, :, :, :]
+            return A.like_input(far, kind)
         return A.like_input(self.fwd_device(probe, scan, psi), kind)
+
+    def fwd_return_intermediate_probes(self, probe, scan, psi, **kwargs):
+        """(farplane, probes incident on every slice) -- ptycho.py:131-146."""
+        kind = psi
+        psi = A.to_device(psi, np.complex64)
+        scan = A.to_device(scan, np.float32)
+        probe = A.to_device(probe, np.complex64)
+        exitwave, probes = self.diffraction.fwd_return_intermediate_probes(
+            psi=psi, scan=scan, probe=probe)
+        far = self.propagation.fwd(nearplane=exitwave,
+                                   overwrite=True)[..., None, :, :, :]
+        return A.like_input(far, kind), A.like_input(probes, kind)
 
     def adj(self, farplane, probe, scan, psi, overwrite=False, **kwargs):
         kind = farplane
@@ -111,7 +130,13 @@ class Ptycho(Operator):
         psi = A.to_device(psi, np.complex64)
         scan = A.to_device(scan, np.float32)
         probe = A.to_device(probe, np.complex64)
-        Multislice._one_slice(psi)
+        if psi.shape[0] > 1:  # ptycho.py:148-176 over multislice.py:144-194
+            psi_adj, probe_adj = self.diffraction.adj(
+                nearplane=self.propagation.adj(
+                    farplane, overwrite=False)[..., 0, :, :, :],
+                probe=probe[..., 0, :, :, :], scan=scan, psi=psi)
+            return (A.like_input(psi_adj, kind),
+                    A.like_input(probe_adj[..., None, :, :, :], kind))
         N, S = scan.shape[0], farplane.shape[-3]
         pw, det = self.probe_shape, self.detector_shape
         assert tuple(farplane.shape) == (N, 1, S, det, det), farplane.shape
