@@ -181,11 +181,20 @@ def remove_object_ambiguity(psi, probe, preconditioner):
 # --------------------------------------------------------------------------
 
 
-def psi_preconditioner(psi, probe, scan):
-    """Sum_s |probe_s|^2 scattered at every position (K = 1 broadcast)."""
+def psi_preconditioner(psi, probe, scan, propagator=None):
+    """Sum_s |probe_s|^2 scattered at every position (K = 1 broadcast); for
+    the slices behind the first, the probe propagated through the slices in
+    front of it (_preconditioner.py:48-104)."""
     out = np.zeros(psi.shape, dtype=psi.dtype)
     probe_amp = np.sum(probe * probe.conj(), axis=-3)[:, 0]  # (1, pw, pw)
     out[0] = ops.patch_adj(patches=probe_amp, images=out[0], positions=scan)
+    probe1 = probe[:, 0]
+    for i in range(1, len(psi)):
+        probe1 = ops.fresnel_fwd(ops.convolution_fwd(psi[i - 1], scan, probe1),
+                                 propagator)
+        probe_amp = np.sum(probe1 * probe1.conj(), axis=-3)
+        out[i] = ops.patch_adj(patches=probe_amp, images=out[i],
+                               positions=scan)
     return out
 
 
@@ -551,17 +560,200 @@ def lstsq_grad(state, data, batches, *, epoch, detector_shape,
 
 
 # --------------------------------------------------------------------------
+# rpie (src/tike/ptycho/solvers/rpie.py:26-612), as this snapshot has it:
+# the probe numerator is re-zeroed by every minibatch (:349), the probe step is
+# alpha * max(preconditioner) only (:271-280), position correction is
+# commented out, and the object gradient is divided by the number of modes
+# (:466).  Multislice objects go through fwd_return_intermediate_probes.
+# --------------------------------------------------------------------------
+
+
+def rpie_gradients(data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi,
+                   psi_num, *, detector_shape, measured_pixels,
+                   propagator=None, noise_model="gaussian",
+                   unmeasured_pixels_scaling=1.0, norm="ortho",
+                   recover_psi=True, recover_probe=True,
+                   step_length_start=0.5, step_length_usemodes="all_modes",
+                   step_length_weight=0.5):
+    """rpie.py:310-548 for one minibatch [lo, hi)."""
+    pw = probe.shape[-1]
+    pad = (detector_shape - pw) // 2
+    end = pad + pw
+    S = probe.shape[-3]
+    unique_probe = get_varying_probe(
+        probe, eigen_probe,
+        eigen_weights[lo:hi] if eigen_weights is not None else None)
+    if unique_probe.shape[0] == 1 and hi - lo > 1:
+        unique_probe = np.broadcast_to(
+            unique_probe, (hi - lo, *unique_probe.shape[1:])).copy()
+    if psi.shape[0] == 1:
+        farplane = ops.ptycho_fwd(unique_probe, scan[lo:hi], psi,
+                                  detector_shape, norm)
+        probes = unique_probe[None, :, 0]
+    else:
+        farplane, probes = ops.ptycho_fwd_intermediate(
+            unique_probe, scan[lo:hi], psi, propagator, norm)
+    intensity = np.sum(np.square(np.abs(farplane)),
+                       axis=tuple(range(1, farplane.ndim - 2)))
+    d = data[lo:hi].astype(np.float32)
+    each = getattr(ops, f"{noise_model}_each_pattern")
+    costs = each(d[:, measured_pixels][:, None, :],
+                 intensity[:, measured_pixels][:, None, :])
+    if noise_model == "poisson":
+        with np.errstate(invalid="ignore", divide="ignore"):
+            xi = (1 - d / intensity)[:, None, None, ...]
+            grad_cost = farplane * xi
+            step = np.full((farplane.shape[0], 1, farplane.shape[2], 1, 1),
+                           np.float32(step_length_start), dtype=np.float32)
+            if step_length_usemodes == "dominant_mode":
+                step = poisson_steplength_dominant_mode(
+                    xi, intensity, d, measured_pixels, step,
+                    step_length_weight)
+            else:
+                step = poisson_steplength_all_modes(
+                    xi, np.square(np.abs(farplane)), intensity, d,
+                    measured_pixels, step, step_length_weight)
+            farplane[..., measured_pixels] = (
+                -step * grad_cost)[..., measured_pixels]
+    else:
+        grad = ops.gaussian_grad(d, farplane, intensity)
+        farplane[..., measured_pixels] = -grad[..., measured_pixels]
+    farplane[..., np.logical_not(measured_pixels)] *= np.float32(
+        unmeasured_pixels_scaling - 1.0)
+    diff = np.ascontiguousarray(
+        ops.propagation_adj(farplane, norm)[..., pad:end, pad:end])
+    N = hi - lo
+    probe_num = np.zeros((psi.shape[0], *probe.shape), dtype=probe.dtype)
+    if recover_psi:
+        for tt in range(len(psi) - 1, -1, -1):
+            grad_psi = (np.conj(probes[tt][:, None]) * diff / S).reshape(
+                N * S, pw, pw)
+            psi_num[tt] = ops.patch_adj(patches=grad_psi, images=psi_num[tt],
+                                        positions=scan[lo:hi], nrepeat=S)
+            patches = ops.patch_fwd(psi[tt], scan[lo:hi],
+                                    patch_width=pw)[..., None, None, :, :]
+            probe_num[tt] += np.sum(np.conj(patches) * diff, axis=-5,
+                                    keepdims=True)
+            if tt == 0:
+                break
+            diff = ops.fresnel_adj(diff, propagator, norm)
+    patches = ops.patch_fwd(psi[0], scan[lo:hi],
+                            patch_width=pw)[..., None, None, :, :]
+    if recover_probe and eigen_weights is not None:
+        m = 0
+        OP = patches * probe[..., m:m + 1, :, :]
+        num = np.sum(np.real(np.conj(OP) * diff[..., m:m + 1, :, :]),
+                     axis=(-1, -2))
+        den = np.sum(np.abs(OP)**2, axis=(-1, -2))
+        eigen_weights[lo:hi, 0:1, m:m + 1] += 0.1 * (num / den)
+    return costs, psi_num, probe_num, eigen_weights
+
+
+def rpie_update(state, psi_num, probe_num, *, alpha, recover_psi,
+                recover_probe, errors=None, object_adaptive_moment=False,
+                probe_adaptive_moment=False, object_mdecay=0.9,
+                probe_mdecay=0.9, vdecay=0.999):
+    """rpie.py:217-307."""
+    psi, probe = state["psi"], state["probe"]
+    if recover_psi:
+        P = state["psi_precond"]
+        deno = (1 - alpha) * P + alpha * P.real.max(axis=(-2, -1),
+                                                    keepdims=True)
+        dpsi = psi_num
+        psi = psi + dpsi / deno
+        if object_adaptive_moment:
+            if errors:
+                dpsi, state["object_v"], state["object_m"] = momentum_checked(
+                    g=dpsi, v=state.get("object_v"), m=state.get("object_m"),
+                    mdecay=object_mdecay, errors=errors, memory_length=3)
+            else:
+                dpsi, state["object_v"], state["object_m"] = opos.adam(
+                    dpsi, state.get("object_v"), state.get("object_m"),
+                    vdecay=vdecay, mdecay=object_mdecay)
+            psi = psi + dpsi / deno
+    if recover_probe:
+        dprobe = probe_num[0]
+        deno = alpha * state["probe_precond"][0].real.max(axis=(-2, -1),
+                                                          keepdims=True)
+        probe = probe + dprobe / deno
+        if probe_adaptive_moment:
+            mode = 0
+            if errors:
+                (dprobe[0, 0, mode], state["probe_v"],
+                 state["probe_m"]) = momentum_checked(
+                     g=dprobe[0, 0, mode], v=state.get("probe_v"),
+                     m=state.get("probe_m"), mdecay=probe_mdecay,
+                     errors=errors, memory_length=3)
+            else:
+                (dprobe[0, 0, mode], state["probe_v"],
+                 state["probe_m"]) = opos.adam(
+                     dprobe[0, 0, mode], state.get("probe_v"),
+                     state.get("probe_m"), vdecay=vdecay, mdecay=probe_mdecay)
+            probe = probe + dprobe / deno
+    state["psi"] = psi.astype(np.complex64)
+    state["probe"] = probe.astype(np.complex64)
+    return state
+
+
+def rpie(state, data, batches, *, epoch, detector_shape, alpha=0.05,
+         batch_method="compact", measured_pixels=None, rng=None,
+         recover_psi=True, recover_probe=True, probe_update_start=0,
+         object_adaptive_moment=False, probe_adaptive_moment=False,
+         propagator=None, **kw):
+    """One epoch of rpie.py:26-214."""
+    num_batch = len(batches)
+    if measured_pixels is None:
+        measured_pixels = np.ones((detector_shape, detector_shape), dtype=bool)
+    recover_probe = recover_probe and epoch >= probe_update_start
+    if batch_method == "compact":
+        order = range(num_batch)
+    else:
+        order = (rng or np.random.default_rng()).permutation(num_batch)
+    psi_num = probe_num = None
+    batch_cost = np.empty(num_batch, dtype=np.float32)
+    upd = dict(alpha=alpha, recover_psi=recover_psi,
+               recover_probe=recover_probe,
+               object_adaptive_moment=object_adaptive_moment,
+               probe_adaptive_moment=probe_adaptive_moment)
+    for n in order:
+        lo = int(batches[n][0])
+        hi = lo + len(batches[n])
+        if psi_num is None:
+            psi_num = np.zeros_like(state["psi"])
+        costs, psi_num, probe_num, state["eigen_weights"] = rpie_gradients(
+            data, state["psi"], state["scan"], state["probe"],
+            state.get("eigen_probe"), state.get("eigen_weights"), lo, hi,
+            psi_num, detector_shape=detector_shape,
+            measured_pixels=measured_pixels, propagator=propagator,
+            recover_psi=recover_psi, recover_probe=recover_probe, **kw)
+        batch_cost[n] = np.mean(costs)
+        if batch_method != "compact":
+            state = rpie_update(state, psi_num, probe_num, **upd)
+            psi_num = probe_num = None
+    state["costs"].append([float(batch_cost.mean())])
+    if batch_method == "compact":
+        state = rpie_update(
+            state, psi_num, probe_num,
+            errors=[float(x[0]) for x in state["costs"][-3:]], **upd)
+    if state.get("eigen_weights") is not None:
+        w = state["eigen_weights"]
+        state["eigen_weights"] = (w / mnorm(w, axis=-3, keepdims=True)).astype(
+            np.float32)
+    return state
+
+
+# --------------------------------------------------------------------------
 # epoch driver (src/tike/ptycho/ptycho.py:431-564, 723-808, 873-972)
 # --------------------------------------------------------------------------
 
 
 def rescale_probe(state, data, detector_shape, measured_pixels=None,
-                  norm="ortho"):
+                  norm="ortho", propagator=None):
     """ptycho.py:873-972: probe *= sqrt(sum(data) / sum(intensity))."""
     if measured_pixels is None:
         measured_pixels = np.ones((detector_shape, detector_shape), dtype=bool)
     far = ops.ptycho_fwd(state["probe"], state["scan"], state["psi"],
-                         detector_shape, norm)
+                         detector_shape, norm, propagator=propagator)
     intensity = ops.intensity_from_farplane(far)
     n0 = np.sum(data[:, measured_pixels], dtype=np.double)
     n1 = np.sum(intensity[:, measured_pixels], dtype=np.double)
@@ -593,9 +785,9 @@ def iterate(state, data, batches, num_iter, *, detector_shape,
                 state["eigen_probe"], state[
                     "eigen_weights"] = constrain_variable_probe(
                         state["eigen_probe"], state["eigen_weights"])
-        state["psi_precond"] = psi_preconditioner(state["psi"],
-                                                  state["probe"],
-                                                  state["scan"])
+        state["psi_precond"] = psi_preconditioner(
+            state["psi"], state["probe"], state["scan"],
+            propagator=kw.get("propagator"))
         state["probe_precond"] = probe_preconditioner(state["psi"],
                                                       state["probe"],
                                                       state["scan"])
@@ -605,6 +797,9 @@ def iterate(state, data, batches, num_iter, *, detector_shape,
         elif solver == "cgrad":
             state = cgrad(state, data, batches, detector_shape=detector_shape,
                           **kw)
+        elif solver == "rpie":
+            state = rpie(state, data, batches, epoch=epoch,
+                         detector_shape=detector_shape, **kw)
         else:
             raise ValueError(solver)
         if (state.get("psi_precond") is not None

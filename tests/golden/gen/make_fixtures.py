@@ -54,6 +54,10 @@ PHYS = dict(probe_wavelength=1e-10, probe_FOV_lengths=(1e-5, 1e-5),
             multislice_propagation_distance=1e-8)
 
 
+PHYS_PROBE = {}
+PHYS_OBJECT = {}
+
+
 def rc(rng, *shape):
     """uniform [-0.5, 0.5) complex64 like tike.random.numpy_complex."""
     return (rng.random((*shape, 2), dtype=np.float32) - 0.5).view(
@@ -324,11 +328,18 @@ lstsq_parts("eigen", N=24, pw=16, det=24, S=3, eigen=2)
 def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
           adaptive=False, orth=False, rng=None, noise_model="gaussian",
           usemodes="all_modes", mask_frac=0.0, scaling=1.0, positions=None,
-          position_error=0.0, psi_true_start=False, algo="lstsq"):
+          position_error=0.0, psi_true_start=False, algo="lstsq", alpha=None,
+          no_probe=False, depth=1):
     rng = globals()["rng"] if rng is None else rng
     p = make_problem(rng, N, pw, det, S, eigen=eigen,
                      margin=8 if positions else 0,
                      position_error=position_error)
+    if depth > 1:
+        # multislice object: every slice starts from the same guess, slightly
+        # perturbed so that the slices are distinguishable
+        p["psi0"] = (np.repeat(p["psi0"], depth, axis=0) *
+                     (1 + 0.05 * rc(rng, depth, *p["psi0"].shape[1:]))).astype(
+                         np.complex64)
     if psi_true_start:
         # position correction needs object structure to lock on to
         p["psi0"] = (p["psi_true"] * (1 + 0.05 * rc(rng, *p["psi_true"].shape))
@@ -349,13 +360,18 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
         p["eigen_probe"].copy(),
         eigen_weights=None if p["eigen_weights"] is None else
         p["eigen_weights"].copy(),
-        algorithm_options=(tike.ptycho.RpieOptions if algo == "rpie" else
-                           tike.ptycho.LstsqOptions)(
-            num_batch=num_batch, batch_method=batch_method, num_iter=epochs),
+        algorithm_options=(tike.ptycho.RpieOptions(
+            num_batch=num_batch, batch_method=batch_method, num_iter=epochs,
+            **({} if alpha is None else dict(alpha=alpha)))
+                           if algo == "rpie" else tike.ptycho.LstsqOptions(
+            num_batch=num_batch, batch_method=batch_method, num_iter=epochs)),
+        # (the reference reads the wavelength from probe_options, so "no
+        # probe recovery" is a start epoch that is never reached)
         probe_options=tike.ptycho.ProbeOptions(
-            force_orthogonality=orth, use_adaptive_moment=adaptive),
+            force_orthogonality=orth, use_adaptive_moment=adaptive,
+            update_start=10**6 if no_probe else 0, **PHYS_PROBE),
         object_options=tike.ptycho.ObjectOptions(
-            use_adaptive_moment=adaptive),
+            use_adaptive_moment=adaptive, **PHYS_OBJECT),
         exitwave_options=tike.ptycho.ExitWaveOptions(
             measured_pixels=measured, noise_model=noise_model,
             step_length_usemodes=usemodes,
@@ -403,12 +419,37 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
          num_batch=num_batch, batch_method=batch_method, epochs=epochs,
          adaptive=adaptive, orth=orth, measured=measured,
          noise_model=noise_model, usemodes=usemodes, scaling=scaling,
+         alpha=-1.0 if alpha is None else alpha, no_probe=no_probe,
+         phys=np.array([PHYS_PROBE.get("probe_wavelength", np.nan),
+                        *PHYS_PROBE.get("probe_FOV_lengths", (np.nan, np.nan)),
+                        PHYS_OBJECT.get("multislice_propagation_distance",
+                                        1e-9)]),
          psi_1=r1.psi, probe_1=r1.probe,
          costs_1=np.array(r1.algorithm_options.costs[:epochs]),
          costs_2=np.array(r2.algorithm_options.costs), psi_2=r2.psi,
          probe_2=r2.probe, **extra)
     print(tag, "costs:", np.array(r2.algorithm_options.costs).ravel())
 
+
+if ONLY == "rpie":
+    # rpie (solvers/rpie.py:26-612).  With the default
+    # alpha = 0.05 the probe step of this snapshot (denominator alpha *
+    # max(preconditioner), rpie.py:271-280) diverges, so the
+    # fixtures pin (a) alpha = 1 (ePIE: object + probe), (b) the default alpha
+    # with the object alone, (c) a two-slice object through the multislice
+    # forward model (own generators: the other fixtures stay bit-identical).
+    recon("epie", N=40, pw=24, det=32, S=2, eigen=0, num_batch=2,
+          batch_method="compact", epochs=3, orth=True, algo="rpie", alpha=1.0,
+          rng=np.random.default_rng(99))
+    recon("object", N=36, pw=16, det=16, S=1, eigen=0, num_batch=3,
+          batch_method="wobbly_center", epochs=3, algo="rpie", no_probe=True,
+          rng=np.random.default_rng(98), mask_frac=0.1, scaling=0.9)
+    PHYS_PROBE.update(probe_wavelength=1e-10, probe_FOV_lengths=(1e-5, 1e-5))
+    PHYS_OBJECT.update(multislice_propagation_distance=2e-4)
+    recon("twoslice", N=30, pw=16, det=16, S=2, eigen=0, num_batch=2,
+          batch_method="compact", epochs=2, algo="rpie", alpha=1.0, depth=2,
+          rng=np.random.default_rng(97))
+    sys.exit(0)
 
 recon("compact", N=48, pw=24, det=32, S=2, eigen=0, num_batch=2,
       batch_method="compact", epochs=3, adaptive=True, orth=True)

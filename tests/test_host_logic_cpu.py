@@ -160,9 +160,13 @@ def test_unsupported_features_fail_loudly():
         probe=np.ones((1, 1, 1, 8, 8), np.complex64),
         psi=np.ones((1, 32, 32), np.complex64),
         scan=np.full((4, 2), 4, np.float32),
-        algorithm_options=tp.RpieOptions())
+        algorithm_options=tp.LstsqOptions())
+    # multislice objects are reconstructed by rpie only, as in the reference
+    deep = tp.PtychoParameters(
+        probe=params.probe, psi=np.ones((2, 32, 32), np.complex64),
+        scan=params.scan, algorithm_options=tp.LstsqOptions())
     with pytest.raises(NotImplementedError):
-        tp.Reconstruction(np.ones((4, 8, 8), np.float32), params)
+        tp.Reconstruction(np.ones((4, 8, 8), np.float32), deep)
     with pytest.raises(ValueError):
         tp.Reconstruction(np.ones((3, 8, 8), np.float32),
                           tp.PtychoParameters(

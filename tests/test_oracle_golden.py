@@ -196,7 +196,7 @@ def test_lstsq_parts_vs_reference(golden, tag):
     np.testing.assert_allclose(bp, g["beta_probe"], rtol=1e-3)
 
 
-def _replay(g, second=False):
+def _replay(g, second=False, solver="lstsq_grad"):
     """Replay the reference reconstruction with the oracle epoch driver."""
     det = int(g["det"])
     order = g["order"]
@@ -226,7 +226,21 @@ def _replay(g, second=False):
               step_length_usemodes=str(g["usemodes"]),
               unmeasured_pixels_scaling=float(g["scaling"]))
     epochs = int(g["epochs"])
-    state = sol.rescale_probe(state, data, det, measured_pixels=measured)
+    rescale_kw = {}
+    if solver == "rpie":
+        kw.update(solver="rpie", recover_probe=not bool(g["no_probe"]))
+        kw.pop("object_adaptive_moment")
+        kw.pop("probe_adaptive_moment")
+        if float(g["alpha"]) >= 0:
+            kw["alpha"] = float(g["alpha"])
+        if g["psi0"].shape[0] > 1:
+            wl, fy, fx, dist = (float(v) for v in g["phys"])
+            pw = g["probe0"].shape[-1]
+            kw["propagator"] = ops.fresnel_spectrum_propagator(
+                (pw, pw), (fy, fx), dist, wl)
+            rescale_kw["propagator"] = kw["propagator"]
+    state = sol.rescale_probe(state, data, det, measured_pixels=measured,
+                              **rescale_kw)
     state = sol.iterate(state, data, batches, epochs, **kw)
     first = {k: (None if v is None else np.array(v, copy=True))
              for k, v in state.items() if k in ("psi", "probe", "eigen_probe",
@@ -251,7 +265,8 @@ def _replay(g, second=False):
             batches = [np.arange(e - s, e)
                        for s, e in zip(g["batch_sizes_2"], ends2)]
             order = order2
-        state = sol.rescale_probe(state, data, det, measured_pixels=measured)
+        state = sol.rescale_probe(state, data, det, measured_pixels=measured,
+                                  **rescale_kw)
         state = sol.iterate(state, data, batches, epochs, **kw)
     return first, state, order
 
@@ -342,3 +357,25 @@ def test_multislice_vs_reference(golden):
                             propagator=H)
     assert_close(pa, g["pt_psi_adj"], what="ptycho psi_adj (3 slices)")
     assert_close(qa, g["pt_probe_adj"], what="ptycho probe_adj (3 slices)")
+
+
+@pytest.mark.parametrize("tag", ["epie", "object", "twoslice"])
+def test_rpie_reconstruction_vs_reference(golden, tag):
+    """The oracle's rpie (solvers/rpie.py:26-612 as this snapshot has it)
+    replays the reference's own runs: alpha = 1 (ePIE) with object and probe,
+    the default alpha with the object alone and NaN-masked data, and a
+    two-slice object through the multislice forward model."""
+    g = golden(f"rpie_recon_{tag}.npz")
+    first, state, order = _replay(g, second=True, solver="rpie")
+    np.testing.assert_allclose(np.array(first["costs"]), g["costs_1"],
+                               rtol=1e-3)
+    assert_close(first["psi"], g["psi_1"], normwise=1e-3, maxabs=1e-2,
+                 what="psi after call 1")
+    assert_close(first["probe"], g["probe_1"], normwise=1e-3, maxabs=1e-2,
+                 what="probe after call 1")
+    np.testing.assert_allclose(np.array(state["costs"]), g["costs_2"],
+                               rtol=5e-3)
+    assert_close(state["psi"], g["psi_2"], normwise=5e-3, maxabs=5e-2,
+                 what="psi after call 2")
+    assert_close(state["probe"], g["probe_2"], normwise=5e-3, maxabs=5e-2,
+                 what="probe after call 2")

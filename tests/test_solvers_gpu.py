@@ -103,7 +103,7 @@ def test_lstsq_minibatch_kernels_vs_reference(tp, golden, tag):
                                    rtol=1e-3)
 
 
-def _reconstruct_like_reference(tp, g, second):
+def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
     import tike_amd.random
     det = int(g["det"])
     sizes = g["batch_sizes"]
@@ -116,12 +116,25 @@ def _reconstruct_like_reference(tp, g, second):
         eigen_probe=g["eigen_probe"].copy() if "eigen_probe" in g else None,
         eigen_weights=g["eigen_weights"].copy()
         if "eigen_weights" in g else None,
-        algorithm_options=tp.LstsqOptions(
+        algorithm_options=(tp.RpieOptions(
             num_batch=int(g["num_batch"]),
-            batch_method=str(g["batch_method"]), num_iter=int(g["epochs"])),
-        probe_options=tp.ProbeOptions(force_orthogonality=orth,
-                                      use_adaptive_moment=adaptive),
-        object_options=tp.ObjectOptions(use_adaptive_moment=adaptive),
+            batch_method=str(g["batch_method"]), num_iter=int(g["epochs"]),
+            **({} if float(g["alpha"]) < 0 else dict(alpha=float(g["alpha"]))))
+                           if algo == "rpie" else tp.LstsqOptions(
+            num_batch=int(g["num_batch"]),
+            batch_method=str(g["batch_method"]), num_iter=int(g["epochs"]))),
+        probe_options=tp.ProbeOptions(
+            force_orthogonality=orth, use_adaptive_moment=adaptive,
+            **(dict(update_start=10**6) if algo == "rpie" and bool(
+                g["no_probe"]) else {}),
+            **(dict(probe_wavelength=float(g["phys"][0]),
+                    probe_FOV_lengths=(float(g["phys"][1]),
+                                       float(g["phys"][2])))
+               if algo == "rpie" and g["psi0"].shape[0] > 1 else {})),
+        object_options=tp.ObjectOptions(
+            use_adaptive_moment=adaptive,
+            **(dict(multislice_propagation_distance=float(g["phys"][3]))
+               if algo == "rpie" and g["psi0"].shape[0] > 1 else {})),
         exitwave_options=tp.ExitWaveOptions(
             measured_pixels=g["measured"].astype(bool),
             noise_model=str(g["noise_model"]),
@@ -718,3 +731,79 @@ def test_bench_rccl_path_through_the_launcher():
     assert line["n_gpus"] == 1 and line["value"] > 0
     assert line["allreduce"]["calls_per_step"] >= 10
     assert 0 < line["roofline"]["iteration_hbm_frac"] < 1
+
+
+@pytest.mark.parametrize("tag", ["epie", "object", "twoslice"])
+def test_rpie_reconstruct_twice_vs_reference(tp, golden, tag):
+    """rpie (solvers/rpie.py:26-612) against the reference's own runs:
+    alpha = 1 (ePIE, object + probe, compact batches), the default alpha with
+    the object alone on NaN-masked data (wobbly_center batches), and a
+    two-slice object through Multislice / FresnelSpectProp."""
+    import warnings
+    g = golden(f"rpie_recon_{tag}.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # NaN in masked data warns
+        r1, r2 = _reconstruct_like_reference(tp, g, second=True, algo="rpie")
+    epochs = int(g["epochs"])
+    np.testing.assert_allclose(
+        np.array(r1.algorithm_options.costs[:epochs]), g["costs_1"],
+        rtol=1e-3)
+    assert r1.psi.shape == g["psi_1"].shape
+    assert_close(r1.psi, g["psi_1"], normwise=SOLVER_NORMWISE, maxabs=1e-2,
+                 what="psi after call 1")
+    assert_close(r1.probe, g["probe_1"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe after call 1")
+    np.testing.assert_allclose(np.array(r2.algorithm_options.costs),
+                               g["costs_2"], rtol=5e-3)
+    assert_close(r2.psi, g["psi_2"], normwise=5e-3, maxabs=5e-2,
+                 what="psi after call 2")
+    assert_close(r2.probe, g["probe_2"], normwise=5e-3, maxabs=5e-2,
+                 what="probe after call 2")
+
+
+@pytest.mark.parametrize("det,S,N,eigen", [(256, 8, 12, True), (128, 2, 10, False)])
+def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
+    """rpie on the fused-kernel sizes (256^2 with 8 modes and eigen-probe
+    weights: the far-plane-free pipeline) against the CPU oracle."""
+    import tike_amd.random
+    from oracle import solvers as osol
+    scan, psi_true, probe0, ep, ew, data = _headline_problem(
+        tp, det, S, N, seed=7 * det + S, eigen=eigen)
+    psi0 = np.full_like(psi_true, 0.5)
+    batches = np.array_split(np.arange(N), 2)
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
+        eigen_probe=None if ep is None else ep.copy(),
+        eigen_weights=None if ew is None else ew.copy(),
+        algorithm_options=tp.RpieOptions(num_batch=2, num_iter=2,
+                                         batch_method="compact", alpha=1.0),
+        probe_options=tp.ProbeOptions(force_orthogonality=True),
+        object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    with tp.Reconstruction(data, params, order=np.arange(N), batches=batches,
+                           spatial_sort=False) as ctx:
+        ctx.iterate(2)
+        got = ctx.get_result()
+    state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
+                 costs=[], eigen_probe=None if ep is None else ep.copy(),
+                 eigen_weights=None if ew is None else ew.copy())
+    state = osol.rescale_probe(state, data, det)
+    state = osol.iterate(state, data, batches, 2, detector_shape=det,
+                         solver="rpie", alpha=1.0, batch_method="compact",
+                         force_orthogonality=True)
+    np.testing.assert_allclose(np.array(got.algorithm_options.costs),
+                               np.array(state["costs"]), rtol=1e-3)
+    assert_close(got.psi, state["psi"], normwise=SOLVER_NORMWISE, maxabs=1e-2,
+                 what="psi")
+    assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe")
+    if eigen:
+        # rpie.py:209-214 divides by the rms over positions: the columns of
+        # modes without eigen probes are 0 / 0 = NaN in the reference too
+        want = state["eigen_weights"]
+        finite = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got.eigen_weights), finite)
+        assert finite[:, 0, :].all()
+        np.testing.assert_allclose(got.eigen_weights[finite], want[finite],
+                                   rtol=5e-3, atol=1e-4)

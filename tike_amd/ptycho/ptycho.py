@@ -51,7 +51,11 @@ def _intensity_chunks(operator, psi, scan, probe, eigen_probe=None,
     for lo in range(0, N, chunk):
         hi = min(N, lo + chunk)
         w = None if eigen_weights is None else eigen_weights[lo:hi]
-        far = operator.fwd_device(probe, scan[lo:hi], psi, eigen_probe, w)
+        if psi.shape[0] > 1:  # several slices: the Multislice composition
+            far = operator.fwd(probe=get_varying_probe(probe, eigen_probe, w),
+                               scan=scan[lo:hi], psi=psi).contiguous()
+        else:
+            far = operator.fwd_device(probe, scan[lo:hi], psi, eigen_probe, w)
         inten = torch.empty((hi - lo, det, det), dtype=torch.float32,
                             device=psi.device)
         check(
@@ -201,7 +205,11 @@ class Reconstruction():
         if not hasattr(solvers, name):
             raise NotImplementedError(
                 f"solver {name!r} is not available in tike_amd "
-                "(accelerated: lstsq_grad, cgrad)")
+                "(available: lstsq_grad, rpie, cgrad)")
+        if parameters.psi.shape[0] > 1 and name != "rpie":
+            raise NotImplementedError(
+                "multislice objects (psi.shape[0] > 1) are reconstructed by "
+                "rpie only, as in the reference")
         if use_mpi:
             raise NotImplementedError(
                 "multi-node MPI is out of scope; launch one process per GPU "

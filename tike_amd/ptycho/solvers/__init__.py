@@ -2,6 +2,7 @@
 from ._preconditioner import update_preconditioners
 from .cgrad import cgrad
 from .lstsq import lstsq_grad
+from .rpie import rpie
 from .options import (CgradOptions, IterativeOptions, LstsqOptions,
                       crop_fourier_space, pad_fourier_space, _resize_fft,
                       _resize_spline,
@@ -9,5 +10,5 @@ from .options import (CgradOptions, IterativeOptions, LstsqOptions,
 
 __all__ = [
     "cgrad", "CgradOptions", "IterativeOptions", "lstsq_grad", "LstsqOptions",
-    "PtychoParameters", "RpieOptions", "update_preconditioners",
+    "PtychoParameters", "rpie", "RpieOptions", "update_preconditioners",
 ]

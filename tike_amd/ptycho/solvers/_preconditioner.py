@@ -15,7 +15,8 @@ from ..._lib import check, lib
 def _psi_preconditioner(parameters, operator):
     """sum_s |probe_s|^2 scattered at every position (:48-104)."""
     psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
-    assert psi.shape[0] == 1, "single-slice objects only"
+    if psi.shape[0] > 1:
+        return _psi_preconditioner_multislice(parameters, operator)
     out = torch.zeros(tuple(psi.shape), dtype=torch.float32, device=psi.device)
     pw = probe.shape[-1]
     # sum_s |probe_s|^2 (probe-sized; _preconditioner.py:40-45)
@@ -28,17 +29,40 @@ def _psi_preconditioner(parameters, operator):
     return out
 
 
+def _psi_preconditioner_multislice(parameters, operator):
+    """Several object slices: slice i sees the probe propagated through the
+    slices in front of it (:82-95), so its illumination differs per position
+    (Patch.adj of one patch per position)."""
+    psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
+    pw = probe.shape[-1]
+    patch = operator.diffraction.patch
+    out = torch.zeros(tuple(psi.shape), dtype=torch.complex64,
+                      device=psi.device)
+    probe1 = probe[:, 0]  # (1, S, pw, pw)
+    amp = torch.sum(probe1 * probe1.conj(), dim=-3)  # (1, pw, pw)
+    patch.adj(positions=scan, patches=amp, images=out[0], patch_width=pw)
+    for i in range(1, len(psi)):
+        probe1 = operator.diffraction.propagation.fwd(
+            operator.diffraction.diffraction.fwd(probe=probe1, scan=scan,
+                                                 psi=psi[i - 1]))
+        amp = torch.sum(probe1 * probe1.conj(), dim=-3).contiguous()
+        patch.adj(positions=scan, patches=amp, images=out[i], patch_width=pw)
+    return out.real.contiguous()
+
+
 def _probe_preconditioner(parameters, operator):
     """sum_n |patch_n(psi)|^2 -> (D, pw, pw) complex (:116-167)."""
     psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
     pw = probe.shape[-1]
     out = torch.zeros((psi.shape[0], pw, pw), dtype=probe.dtype,
                       device=probe.device)
-    check(
-        lib.tike_probe_preconditioner(A.ptr(scan), A.ptr(psi), A.ptr(out),
-                                      scan.shape[0], pw, psi.shape[-2],
-                                      psi.shape[-1], A.stream_ptr()),
-        "probe preconditioner")
+    for i in range(psi.shape[0]):  # every slice (:136-144)
+        check(
+            lib.tike_probe_preconditioner(A.ptr(scan), A.ptr(psi[i]),
+                                          A.ptr(out[i]), scan.shape[0], pw,
+                                          psi.shape[-2], psi.shape[-1],
+                                          A.stream_ptr()),
+            "probe preconditioner")
     return out
 
 

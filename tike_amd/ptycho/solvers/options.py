@@ -43,7 +43,7 @@ class LstsqOptions(IterativeOptions):
 
 @dataclasses.dataclass
 class RpieOptions(IterativeOptions):
-    """Accepted for API compatibility; the rpie solver is not accelerated."""
+    """Options of the rpie solver (options.py:82-90): `alpha` = 1 is ePIE."""
     name: str = dataclasses.field(default="rpie", init=False)
     num_batch: int = 5
     alpha: float = 0.05

@@ -1,0 +1,274 @@
+"""Regularised ptychographical iterative engine
+(reference src/tike/ptycho/solvers/rpie.py:26-612, as that snapshot has it).
+
+The gradients of a minibatch are the ones ``lstsq_grad`` needs --
+``psi_update_numerator`` is its object gradient divided by the number of
+modes (rpie.py:466) and ``probe_update_numerator`` its un-normalised probe
+gradient -- so a single-slice object runs through the same fused HIP kernels
+(position-major forward, far-plane-free gradient + inverse, pixel-major
+pass 2 with both gradients, grouped footprint scatter).  A multislice object
+(``len(psi) > 1``) goes slice by slice through ``Multislice`` /
+``FresnelSpectProp`` (rpie.py:464-495).
+
+Quirks of the reference kept on purpose, because the bar is its iterates:
+the probe numerator is re-zeroed by every minibatch (rpie.py:349), so in
+'compact' mode only the last minibatch moves the probe; it is only formed
+when the object is recovered (:462); the probe step is ``alpha *
+max(preconditioner)`` alone (:271-280); position correction is commented out
+(:163-176, 521-563).
+"""
+import logging
+
+import numpy as np
+import torch
+
+from ... import _arrays as A
+from ... import linalg
+from ... import opt
+from ... import random as trandom
+from ..._lib import check, lib
+from ...operators.propagation import fft_scales
+from ..probe import get_varying_probe
+from . import lstsq as L
+
+logger = logging.getLogger(__name__)
+
+
+def rpie(parameters, data, batches, comm, *, op, epoch):
+    """Advance psi / probe / eigen weights by one epoch (rpie.py:26-214)."""
+    o = parameters.algorithm_options
+    psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
+    eigen_probe, eigen_weights = parameters.eigen_probe, parameters.eigen_weights
+    exitwave_options = parameters.exitwave_options
+    object_options = parameters.object_options
+    probe_options = parameters.probe_options
+    if exitwave_options.noise_model not in L._MODELS:
+        raise ValueError(
+            f"unknown noise model {exitwave_options.noise_model!r}")
+    recover_probe = (probe_options is not None
+                     and epoch >= probe_options.update_start)
+    recover_psi = object_options is not None
+    compact = o.batch_method == "compact"
+    order = (range(o.num_batch) if compact else
+             trandom.randomizer_np.permutation(o.num_batch))
+    dev = psi.device
+    psi_num = probe_num = None
+    batch_cost = torch.zeros(o.num_batch, dtype=torch.float32, device=dev)
+    for n in order:
+        lo = int(batches[n][0]) if len(batches[n]) else 0
+        hi = lo + len(batches[n])
+        if psi_num is None:
+            psi_num = torch.zeros_like(psi)
+        cost, probe_num = _get_nearplane_gradients(
+            data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi, comm,
+            psi_num, op=op, exitwave_options=exitwave_options,
+            recover_psi=recover_psi, recover_probe=recover_probe)
+        batch_cost[n] = cost
+        if not compact:
+            psi, probe = _update(psi, probe, psi_num, probe_num,
+                                 object_options, probe_options, recover_probe,
+                                 o)
+            psi_num = probe_num = None
+    # one device->host scalar per epoch, as in the reference (rpie.py:161)
+    o.costs.append([float(batch_cost.mean().item())])
+    if compact:
+        psi, probe = _update(psi, probe, psi_num, probe_num, object_options,
+                             probe_options, recover_probe, o,
+                             errors=[float(x[0]) for x in o.costs[-3:]])
+    if eigen_weights is not None:
+        # rpie.py:209-214 (mean over the positions of ALL ranks)
+        sq = torch.sum(eigen_weights * eigen_weights, dim=-3, keepdim=True)
+        n_local = torch.tensor(float(eigen_weights.shape[0]),
+                               dtype=torch.float32, device=dev)
+        if comm.collective:
+            packed = torch.cat([sq.reshape(-1), n_local.reshape(1)])
+            comm.Allreduce(packed)
+            sq, n_local = packed[:-1].reshape(sq.shape), packed[-1]
+        eigen_weights = eigen_weights / torch.sqrt(sq / n_local)
+    parameters.psi, parameters.probe = psi, probe
+    parameters.eigen_weights = eigen_weights
+    return parameters
+
+
+def _update(psi, probe, psi_num, probe_num, object_options, probe_options,
+            recover_probe, o, errors=None):
+    """rpie.py:217-307."""
+    if object_options:
+        P = object_options.preconditioner
+        deno = ((1 - o.alpha) * P + o.alpha *
+                torch.amax(P.real, dim=(-2, -1), keepdim=True))
+        dpsi = psi_num
+        psi = psi + dpsi / deno
+        if object_options.use_adaptive_moment:
+            if errors:
+                dpsi, object_options.v, object_options.m = L._momentum_checked(
+                    g=dpsi, v=object_options.v, m=object_options.m,
+                    mdecay=object_options.mdecay, errors=errors,
+                    memory_length=3)
+            else:
+                dpsi, object_options.v, object_options.m = opt.adam(
+                    g=dpsi, v=object_options.v, m=object_options.m,
+                    vdecay=object_options.vdecay,
+                    mdecay=object_options.mdecay)
+            psi = psi + dpsi / deno
+    if recover_probe:
+        dprobe = probe_num[0]  # (1, 1, S, pw, pw) of the first slice
+        deno = o.alpha * torch.amax(probe_options.preconditioner[0].real,
+                                    dim=(-2, -1), keepdim=True)
+        probe = probe + dprobe / deno
+        if probe_options.use_adaptive_moment:
+            mode = 0  # ptychoshelves only applies momentum to the main probe
+            if errors:
+                (dprobe[0, 0, mode], probe_options.v,
+                 probe_options.m) = L._momentum_checked(
+                     g=dprobe[0, 0, mode], v=probe_options.v,
+                     m=probe_options.m, mdecay=probe_options.mdecay,
+                     errors=errors, memory_length=3)
+            else:
+                (dprobe[0, 0, mode], probe_options.v,
+                 probe_options.m) = opt.adam(
+                     g=dprobe[0, 0, mode], v=probe_options.v,
+                     m=probe_options.m, vdecay=probe_options.vdecay,
+                     mdecay=probe_options.mdecay)
+            probe = probe + dprobe / deno
+    return psi, probe.contiguous()
+
+
+def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
+                             eigen_weights, lo, hi, comm, psi_num, *, op,
+                             exitwave_options, recover_psi, recover_probe):
+    """Cost of the minibatch; psi_num (accumulated in place) and a fresh
+    probe numerator (D, 1, 1, S, pw, pw) (rpie.py:310-548)."""
+    dev = psi.device
+    D = psi.shape[0]
+    S = probe.shape[-3]
+    probe_num = torch.zeros((D, *probe.shape), dtype=probe.dtype, device=dev)
+    count = L.global_count(comm, op, lo, hi)
+    if D == 1:
+        # the lstsq_grad kernels: object gradient (planar accumulator), the
+        # un-normalised probe gradient (num_batch = 1), costs, O_n, chi mode 0
+        g = L._get_nearplane_gradients(
+            data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi, comm,
+            num_batch=1, exitwave_options=exitwave_options, op=op,
+            recover_psi=recover_psi, recover_probe=recover_psi)
+        if recover_psi:
+            psi_num += L.object_upd_sum(g) / S
+            probe_num[0] = g["m_probe_update"]
+        costs, chi0, chi_modes, patches = (g["costs"], g["chi0"],
+                                           g["chi_modes"], g["patches"])
+    else:
+        costs, chi0, patches = _gradients_multislice(
+            data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi, comm,
+            psi_num, probe_num, op=op, exitwave_options=exitwave_options,
+            recover_psi=recover_psi)
+        chi_modes = 1
+    if recover_probe and eigen_weights is not None:
+        # weights of the shared probe, mode 0 (rpie.py:505-519): the last two
+        # sums of the step-statistics kernel, with no update directions
+        B = hi - lo
+        stats = torch.empty((max(B, 1), 8), dtype=torch.float32, device=dev)
+        ep, w_old, C, Sm = L._eigen_args(eigen_probe, eigen_weights[lo:hi])
+        check(
+            lib.tike_lstsq_step_stats(
+                A.ptr(chi0), A.ptr(scan[lo:hi]), A.ptr(psi[:1]), None,
+                A.ptr(probe), A.ptr(ep), A.ptr(w_old), C, Sm, None, None,
+                A.ptr(patches), A.ptr(stats), B, S, chi_modes,
+                probe.shape[-1], psi.shape[-2], psi.shape[-1], None, None,
+                A.stream_ptr()), "eigen weight sums")
+        Cw = eigen_weights.shape[-2] - 1
+        norms = torch.empty(max(Cw, 1), dtype=torch.float32, device=dev)
+        check(
+            lib.tike_eigen_weights0(A.ptr(eigen_weights[lo:hi]), A.ptr(stats),
+                                    B, Cw, S, 0, A.ptr(norms),
+                                    A.stream_ptr()), "eigen weights")
+    tot = comm.Allreduce_scalars([costs.sum()], dev)
+    return (tot[0] / count).to(torch.float32), probe_num
+
+
+def _gradients_multislice(data, psi, scan, probe, eigen_probe, eigen_weights,
+                          lo, hi, comm, psi_num, probe_num, *, op,
+                          exitwave_options, recover_psi):
+    """rpie.py:367-495 for an object of several slices, slice by slice."""
+    dev = psi.device
+    B = hi - lo
+    D = psi.shape[0]
+    S, pw = probe.shape[-3], probe.shape[-1]
+    det = op.detector_shape
+    H, W = psi.shape[-2:]
+    st = A.stream_ptr()
+    _, inv_scale = fft_scales(det, op.norm)
+    nmeasured, mask_u8 = L.mask_info(exitwave_options, det)
+    model = L._MODELS[exitwave_options.noise_model]
+    poisson = exitwave_options.noise_model == "poisson"
+    unmeasured = float(exitwave_options.unmeasured_pixels_scaling)
+    costs = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
+    chi0 = torch.empty((max(B, 1), pw, pw), dtype=torch.complex64, device=dev)
+    patches0 = torch.empty_like(chi0)
+    chunk = L.chunk_positions(S * D, det)
+    acc = torch.zeros_like(psi) if recover_psi else None
+    pacc = (torch.zeros((D, S, pw, pw), dtype=torch.complex64, device=dev)
+            if recover_psi else None)
+    for clo in range(lo, hi, chunk):
+        chi_hi = min(hi, clo + chunk)
+        n = chi_hi - clo
+        blo = clo - lo
+        sc = scan[clo:chi_hi]
+        w_c = None if eigen_weights is None else eigen_weights[clo:chi_hi]
+        unique = get_varying_probe(probe, eigen_probe, w_c)
+        far, probes = op.fwd_return_intermediate_probes(probe=unique, scan=sc,
+                                                        psi=psi)
+        far = far.contiguous()
+        if poisson:
+            inten = torch.empty((n, det, det), dtype=torch.float32,
+                                device=dev)
+            steps = torch.empty((n, S), dtype=torch.float32, device=dev)
+            check(lib.tike_intensity(A.ptr(far), A.ptr(inten), n, S,
+                                     det * det, st), "intensity")
+            check(
+                lib.tike_poisson_steps(
+                    A.ptr(far), A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                    A.ptr(mask_u8), A.ptr(steps), n, S, det,
+                    float(exitwave_options.step_length_start),
+                    float(exitwave_options.step_length_weight),
+                    int(exitwave_options.step_length_usemodes ==
+                        "dominant_mode"), st), "poisson step lengths")
+        check(
+            lib.tike_farplane_gradient(
+                A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), None,
+                A.ptr(costs[blo:blo + n]), n, S, det, model, 1, unmeasured,
+                nmeasured, st), "farplane gradient")
+        if poisson:
+            check(lib.tike_scale_modes(A.ptr(far), A.ptr(steps),
+                                       A.ptr(mask_u8), n * S, det, st),
+                  "poisson step scaling")
+        # diff = propagation.adj(farplane)[..., pad:end, pad:end]; a
+        # multislice object has pad = 0
+        diff = op.propagation.adj(far, overwrite=True)[:, 0].contiguous()
+        for tt in range(D - 1, -1, -1):
+            if recover_psi:
+                # psi numerator: sum_s conj(probe_tt) diff scattered (1/S below)
+                check(
+                    lib.tike_conv_adj(A.ptr(diff), A.ptr(sc),
+                                      A.ptr(probes[tt].contiguous()), 1,
+                                      A.ptr(acc[tt]), n, S, pw, pw, H, W, st),
+                    "object numerator")
+                # probe numerator: sum_n conj(patch_n(psi_tt)) diff
+                check(
+                    lib.tike_probe_grad(
+                        A.ptr(diff), A.ptr(sc), A.ptr(psi[tt]),
+                        A.ptr(patches0[blo:blo + n]) if tt == 0 else None,
+                        A.ptr(pacc[tt]), n, S, pw, H, W, st),
+                    "probe numerator")
+            if tt == 0:
+                break
+            diff = op.diffraction.propagation.adj(diff)
+        if not recover_psi:
+            patches0[blo:blo + n] = op.diffraction.patch.fwd(
+                images=psi[0], positions=sc, patch_width=pw)
+        chi0[blo:blo + n] = diff[:, 0]
+    if recover_psi:
+        if comm.collective:
+            comm.Allreduce(acc, pacc)
+        psi_num += acc / S
+        probe_num[:, 0, 0] = pacc
+    return costs[:B], chi0[:B], patches0[:B]
