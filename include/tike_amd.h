@@ -127,12 +127,14 @@ int tike_ptycho_fwd_gradient_scale(const void* psi, const float* scan, const voi
  * tike_fwd_gradient_scale: streams that scratch once, forms F = scale *
  * (column pass) in registers, I = sum_s |F_s|^2, and emits gscale, the costs
  * (may be NULL) and optionally the intensity (may be NULL) -- operands as
- * tike_ptycho_fwd_gradient_scale. */
+ * tike_ptycho_fwd_gradient_scale; data is float32, or uint16 when data_u16 != 0
+ * (detector counts that arrived as <= 16-bit integers stay 16-bit in HBM,
+ * ptycho.py:383-390). */
 int tike_fwd_pass1(const void* psi, const float* scan, const void* probe, int probe_per_scan,
                    const void* unique_probe, const void* eigen_probe,
                    const float* eigen_weights, int num_eigen, int eigen_modes, void* scratch,
                    void* patches, int nscan, int S, int pw, int det, int H, int W, void* stream);
-int tike_fwd_gradient_scale(const void* scratch, const float* data,
+int tike_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
                             const unsigned char* measured, float* gscale, float* intensity,
                             float* costs, int nscan, int S, int det, float scale, int model,
                             float unmeasured_scaling, long num_measured, void* stream);

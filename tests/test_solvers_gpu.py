@@ -807,3 +807,37 @@ def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
         assert finite[:, 0, :].all()
         np.testing.assert_allclose(got.eigen_weights[finite], want[finite],
                                    rtol=5e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("det,S", [(256, 2), (64, 1)])
+def test_uint16_data_stays_16_bit_and_matches_float(tp, det, S):
+    """Detector counts arriving as uint16 are kept as uint16 in HBM (reference
+    ptycho.py:383-390) and give the iterates of the same counts as float32
+    (256^2: the 16-bit loader of the streamed column pass; 64^2: the
+    converted-chunk path)."""
+    import torch
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, 8, seed=det + 11, eigen=False)
+    counts = np.round(data * (20000.0 / data.max())).astype(np.uint16)
+    results = []
+    for d in (counts, counts.astype(np.float32)):
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+            scan=scan.copy(),
+            algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
+                                              batch_method="compact"),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions(),
+            exitwave_options=tp.ExitWaveOptions(
+                measured_pixels=np.ones((det, det), dtype=bool)))
+        with tp.Reconstruction(d, params, order=np.arange(8),
+                               batches=np.array_split(np.arange(8), 2)) as ctx:
+            assert ctx.data.dtype == (torch.uint16 if d.dtype == np.uint16
+                                      else torch.float32)
+            ctx.iterate(2)
+            results.append(ctx.get_result())
+    a, b = results
+    np.testing.assert_allclose(np.array(a.algorithm_options.costs),
+                               np.array(b.algorithm_options.costs), rtol=1e-5)
+    assert_close(a.psi, b.psi, normwise=1e-5, maxabs=1e-4, what="psi")
+    assert_close(a.probe, b.probe, normwise=1e-5, maxabs=1e-4, what="probe")

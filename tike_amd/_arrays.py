@@ -60,6 +60,50 @@ def to_device(x, dtype=None, device=None):
     return t.contiguous()
 
 
+def is_small_integer(dtype):
+    """Detector counts that arrive as <= 16-bit integers stay 16-bit in HBM
+    (reference ptycho.py:383-390 keeps `itemsize <= 2` data as it is)."""
+    if isinstance(dtype, torch.dtype):
+        return dtype in (torch.uint8, torch.int8, torch.int16, torch.uint16)
+    dtype = np.dtype(dtype)
+    return dtype.kind in "iu" and dtype.itemsize <= 2
+
+
+def data_to_device(x, order=None, device=None):
+    """The diffraction patterns in HBM, rows permuted by `order`: uint16 when
+    they arrived as <= 16-bit integers, float32 otherwise."""
+    if device is None:
+        device = current_device()
+    small = is_small_integer(x.dtype)
+    if isinstance(x, torch.Tensor):
+        t = x.to(device)
+        if order is not None:
+            idx = torch.as_tensor(order, device=t.device)
+            if t.dtype == torch.uint16:  # no index kernels for uint16
+                t = t.view(torch.int16).index_select(0, idx).view(torch.uint16)
+            else:
+                t = t.index_select(0, idx)
+        if small:
+            if t.dtype != torch.uint16:
+                t = t.to(torch.int32).clamp_(min=0).to(torch.uint16)
+            return t.contiguous()
+        return t.to(torch.float32).contiguous()
+    a = np.asarray(x)
+    if order is not None:
+        a = a[order]
+    if small:
+        a = np.ascontiguousarray(np.clip(a, 0, None).astype(np.uint16))
+        return torch.from_numpy(a.view(np.int16)).to(device).view(torch.uint16)
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+def data_f32(data, lo, hi):
+    """Rows [lo, hi) of the resident data as float32 (a copy when the data is
+    kept as uint16; kernels without a 16-bit loader take this)."""
+    d = data[lo:hi]
+    return d if d.dtype == torch.float32 else d.to(torch.float32)
+
+
 def to_host(x):
     if isinstance(x, torch.Tensor):
         return x.detach().cpu().numpy()

@@ -708,9 +708,11 @@ extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* pr
 // 16 r + k1 of the hand-off), accumulates I = sum_s |F_s|^2 and emits the
 // gradient factor and the cost share of those 16 rows (objective.py:11-124,
 // lstsq.py:444-502).  costs must be zero on entry (accumulated by atomics).
-template <int MODEL>
+// DT: float, or unsigned short for detector counts kept as they arrived
+// (16-bit data stays 16-bit in HBM, reference ptycho.py:383-390).
+template <int MODEL, class DT>
 __global__ __launch_bounds__(256, 4) void fwd_gradient_scale_kernel(
-    const cf* __restrict__ colin, const float* __restrict__ data,
+    const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, float* __restrict__ gscale,
     float* __restrict__ intensity, float* __restrict__ costs, long nitem, int S, float scale,
     float unmeasured_scaling, float inv_nmeasured) {
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(256, 4) void fwd_gradient_scale_kernel(
       if (intensity) tk_st_stream(intensity + n * (long)N * N + p, I[k2]);
       float g = unmeasured_scaling - 1.0f;
       if (mask == nullptr || mask[p]) {
-        const float dv = data[n * (long)N * N + p];
+        const float dv = (float)data[n * (long)N * N + p];
         if (MODEL == 0) {
           const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
           const float diff = sI - sd;
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(256, 4) void fwd_gradient_scale_kernel(
 
 // scratch: from tike_fwd_pass1 (UNSCALED column-pass input; `scale` is the
 // forward FFT normalisation applied here).  intensity / costs may be NULL.
-extern "C" int tike_fwd_gradient_scale(const void* scratch, const float* data,
+extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
                                        const unsigned char* measured, float* gscale,
                                        float* intensity, float* costs, int nscan, int S, int det,
                                        float scale, int model, float unmeasured_scaling,
@@ -781,14 +783,19 @@ extern "C" int tike_fwd_gradient_scale(const void* scratch, const float* data,
   const long nitem = (long)nscan * 16;
   const float inv = 1.0f / (float)num_measured;
   const dim3 grid(tk_grid(nitem, 16)), block(256);
-  if (model == 0)
-    hipLaunchKernelGGL((fwd_gradient_scale_kernel<0>), grid, block, 0, stream, (const cf*)scratch,
-                       data, measured, gscale, intensity, costs, nitem, S, scale,
-                       unmeasured_scaling, inv);
+#define TK_FGS(M, DT)                                                                        \
+  hipLaunchKernelGGL((fwd_gradient_scale_kernel<M, DT>), grid, block, 0, stream,                \
+                     (const cf*)scratch, (const DT*)data, measured, gscale, intensity, costs,   \
+                     nitem, S, scale, unmeasured_scaling, inv)
+  if (model == 0 && data_u16)
+    TK_FGS(0, unsigned short);
+  else if (model == 0)
+    TK_FGS(0, float);
+  else if (data_u16)
+    TK_FGS(1, unsigned short);
   else
-    hipLaunchKernelGGL((fwd_gradient_scale_kernel<1>), grid, block, 0, stream, (const cf*)scratch,
-                       data, measured, gscale, intensity, costs, nitem, S, scale,
-                       unmeasured_scaling, inv);
+    TK_FGS(1, float);
+#undef TK_FGS
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -291,12 +291,10 @@ class Reconstruction():
             self.comm.sync_random()
         self.order, self.local_order, self.batches = self._shard(
             data.shape[0])
-        # HBM-resident data in batch-contiguous order (float32)
-        if A.is_device(data):
-            idx = torch.as_tensor(self.local_order, device=data.device)
-            self.data = data.index_select(0, idx).to(torch.float32)
-        else:
-            self.data = A.to_device(host[self.local_order], np.float32)
+        # HBM-resident data in batch-contiguous order: float32, or uint16 when
+        # it arrived as <= 16-bit integers (ptycho.py:383-390)
+        self.data = A.data_to_device(data if A.is_device(data) else host,
+                                     order=self.local_order)
         self.parameters = solvers.PtychoParameters.split(
             self.local_order,
             x=self._host_parameters()).copy_to_device()
@@ -497,7 +495,7 @@ def _rescale_probe(operator, comm, data, parameters):
     sums = torch.zeros(2, dtype=torch.float64, device=parameters.psi.device)
     for lo, hi, inten in _intensity_chunks(operator, parameters.psi,
                                            parameters.scan, parameters.probe):
-        d = data[lo:hi]
+        d = A.data_f32(data, lo, hi)
         if mask_u8 is not None:
             m = mask_u8.bool()
             sums[0] += d[:, m].sum(dtype=torch.float64)

@@ -107,6 +107,8 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, *, want_psi, want_probe,
 def cgrad(parameters, data, batches, comm, *, op, epoch):
     """One epoch: for every minibatch, `cg_iter` CG iterations on psi and
     then (when probe recovery is on) on the probe."""
+    if data.dtype != torch.float32:
+        data = data.to(torch.float32)  # 16-bit resident data: cgrad reads f32
     o = parameters.algorithm_options
     if parameters.eigen_probe is not None or parameters.eigen_weights is not None:
         raise NotImplementedError("cgrad does not support eigen probes")

@@ -393,6 +393,11 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                 "varying probe")
         model = _MODELS[exitwave_options.noise_model]
         unmeasured = float(exitwave_options.unmeasured_pixels_scaling)
+        # float32 view of the chunk for the kernels without a 16-bit loader
+        # (the 256^2 gaussian hot path reads uint16 directly)
+        dchunk = None
+        if not (pos_major and no_farplane and not poisson):
+            dchunk = A.data_f32(data, clo, chi_hi)
         if pos_major and no_farplane:
             # the far-plane waves never reach memory: the forward kernel forms
             # them in registers for the intensity and leaves the input of its
@@ -408,7 +413,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     det, H, W, st), "forward pass 1")
             check(
                 lib.tike_fwd_gradient_scale(
-                    A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8),
+                    A.ptr(far), A.ptr(data[clo:chi_hi]),
+                    int(data.dtype == torch.uint16), A.ptr(mask_u8),
                     A.ptr(gscale), A.ptr(inten) if poisson else None,
                     A.ptr(costs[blo:blo + n]), n, S, det, fwd_scale, model,
                     unmeasured, nmeasured, st),
@@ -416,7 +422,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             if poisson:  # dominant mode: the steps need no far-plane waves
                 check(
                     lib.tike_poisson_steps(
-                        None, A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                        None, A.ptr(inten), A.ptr(dchunk),
                         A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
                         step_weight, 1, st), "poisson step lengths")
             if fused:
@@ -445,7 +451,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     A.ptr(patches[blo:blo + n]) if fused else None, n, S, pw,
                     det, H, W, fwd_scale, st), "forward + intensity")
             check(
-                lib.tike_gradient_scale(A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                lib.tike_gradient_scale(A.ptr(inten), A.ptr(dchunk),
                                         A.ptr(mask_u8), A.ptr(gscale),
                                         A.ptr(costs[blo:blo + n]), n, det,
                                         model, unmeasured, nmeasured, st),
@@ -453,7 +459,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             if poisson:
                 check(
                     lib.tike_poisson_steps(
-                        A.ptr(far), A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                        A.ptr(far), A.ptr(inten), A.ptr(dchunk),
                         A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
                         step_weight, dominant, st), "poisson step lengths")
             if fused:
@@ -484,12 +490,12 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                                        det * det, st), "intensity")
                 check(
                     lib.tike_poisson_steps(
-                        A.ptr(far), A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                        A.ptr(far), A.ptr(inten), A.ptr(dchunk),
                         A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
                         step_weight, dominant, st), "poisson step lengths")
             check(
                 lib.tike_farplane_gradient(
-                    A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), None,
+                    A.ptr(far), A.ptr(dchunk), A.ptr(mask_u8), None,
                     A.ptr(costs[blo:blo + n]), n, S, det, model, 1, unmeasured,
                     nmeasured, st), "farplane gradient")
             if poisson:

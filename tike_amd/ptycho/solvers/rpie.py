@@ -218,6 +218,7 @@ def _gradients_multislice(data, psi, scan, probe, eigen_probe, eigen_weights,
         far, probes = op.fwd_return_intermediate_probes(probe=unique, scan=sc,
                                                         psi=psi)
         far = far.contiguous()
+        dchunk = A.data_f32(data, clo, chi_hi)
         if poisson:
             inten = torch.empty((n, det, det), dtype=torch.float32,
                                 device=dev)
@@ -226,7 +227,7 @@ def _gradients_multislice(data, psi, scan, probe, eigen_probe, eigen_weights,
                                      det * det, st), "intensity")
             check(
                 lib.tike_poisson_steps(
-                    A.ptr(far), A.ptr(inten), A.ptr(data[clo:chi_hi]),
+                    A.ptr(far), A.ptr(inten), A.ptr(dchunk),
                     A.ptr(mask_u8), A.ptr(steps), n, S, det,
                     float(exitwave_options.step_length_start),
                     float(exitwave_options.step_length_weight),
@@ -234,7 +235,7 @@ def _gradients_multislice(data, psi, scan, probe, eigen_probe, eigen_weights,
                         "dominant_mode"), st), "poisson step lengths")
         check(
             lib.tike_farplane_gradient(
-                A.ptr(far), A.ptr(data[clo:chi_hi]), A.ptr(mask_u8), None,
+                A.ptr(far), A.ptr(dchunk), A.ptr(mask_u8), None,
                 A.ptr(costs[blo:blo + n]), n, S, det, model, 1, unmeasured,
                 nmeasured, st), "farplane gradient")
         if poisson:
