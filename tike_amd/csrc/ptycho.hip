@@ -800,6 +800,206 @@ extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, in
   return TK_OK;
 }
 
+// ------------------------------------------- 128^2: the whole tile in LDS
+// A 128 x 128 complex tile is 128 KiB: it fits the 160 KiB LDS of a CU, so the
+// 2-D transform needs NO intermediate in memory -- the only HBM traffic of the
+// forward operator is its output, written once, straight from registers.
+// One workgroup of 1024 threads (one per CU) per position; per mode:
+//   rows     thread (row, j) gathers its 16 pixels (bilinear taps * probe)
+//            straight into the FFT register layout, runs the 128-point row
+//            transform (radix 16 x 8, the exchange stays inside its wave) and
+//            leaves the row spectrum in the LDS tile;
+//   columns  128 = 16 x 8 as in fft_engine2.h: thread (t, r) takes the radix-16
+//            stage of rows {r + 8 y2} of column t in registers (twiddle
+//            w_128^(r k1), uniform per wave) and puts it back as rows 16 r + k1;
+//            thread (t, k1) then finishes rows {16 r + k1} with a radix-8 and
+//            stores rows k1 + 16 k2 of the far plane -- 512-byte row segments
+//            per wave, coalesced, from registers.
+// The intensity sum_s |F_s|^2 accumulates in registers across the modes.
+// LDS row stride: 136 elements = 272 dwords = 16 (mod 64 banks), so the four
+// rows a 32-lane read group touches (8 lanes x 16 dwords each) tile the 64
+// banks exactly; 136 also holds the padded row (127 + 127/16 = 134).
+constexpr int TK_L128_LS = 136;
+
+template <bool WITH_I>
+__global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    cf* __restrict__ farplane, float* __restrict__ intensity, int nscan, int S, int H, int W,
+    float scale, const cf* __restrict__ twtab) {
+  constexpr int N = 128, T = 8, LS = TK_L128_LS;
+  static_assert(FftPlan<N>::E == 16 && LS >= N + N / 16, "row plan: 16 elements x 8 threads");
+  __shared__ cf lds[N * LS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + N * LS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  typedef float tk_v4f __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  int line = tid / T, j = tid % T;
+  asm volatile("" : "+v"(line), "+v"(j));
+  const FftTwLds<N> tw{twl, j};
+  const int t = tid & (N - 1);
+  const int r = __builtin_amdgcn_readfirstlane(tid >> 7);  // 0..7, uniform per wave
+  const long PP = (long)N * N;
+  const long total = (long)H * W;
+  auto at = [](const cf* base, unsigned byte_off) -> const cf* {
+    return reinterpret_cast<const cf*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  for (long n = blockIdx.x; n < nscan; n += gridDim.x) {
+    const TkCorner c = tk_corner(scan, n);
+    const bool interior = c.sy >= 0 && c.sx >= 0 && c.sy + N < H && c.sx + N < W &&
+                          total < (1L << 28);
+    // ---- bilinear patch of row `line`, elements e = j + 8 i
+    cf pv[16];
+    if (interior) {
+      // One 8-byte load per pixel and row: the tap to the right (x + 1) is the
+      // neighbouring lane's pixel (lane + 1 holds x + 1 for j < 7; for j == 7
+      // it is slot i + 1 of the lane with j = 0, seven lanes down), fetched
+      // with DPP row shifts.  Slot 16 is the pixel x = 128 + j that closes the
+      // row (only j = 0's is used).  Two batches of loads: row y, then row y+1.
+      const unsigned g0 = (unsigned)((c.sy + line) * W + c.sx + j) * (unsigned)sizeof(cf);
+      const unsigned g1 = g0 + (unsigned)W * (unsigned)sizeof(cf);
+      // slot 16 of the lanes j > 0 would lie past x = 128: read x = 128 too
+      const unsigned gx = (unsigned)(128 - j) * (unsigned)sizeof(cf);
+      auto right = [&](const cf (&a)[17], int i) {
+        // value of pixel x + 1 for slot i
+        auto dpp = [](float v, int ctrl_shl) {
+          return ctrl_shl
+                     ? __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                                     0, __builtin_bit_cast(int, v), 0x101, 0xF,
+                                                     0xF, true))   // row_shl:1  (lane + 1)
+                     : __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                                                     0, __builtin_bit_cast(int, v), 0x117, 0xF,
+                                                     0xF, true));  // row_shr:7  (lane - 7)
+        };
+        const cf nx = mk(dpp(a[i].x, 1), dpp(a[i].y, 1));
+        const cf wr = mk(dpp(a[i + 1].x, 0), dpp(a[i + 1].y, 0));
+        return j < 7 ? nx : wr;
+      };
+      cf up[17], lo[17];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) up[i] = *at(psi, g0 + 64 * i);
+      up[16] = *at(psi, g0 + gx);
+      asm volatile(""
+                   : "+v"(up[0].x), "+v"(up[1].x), "+v"(up[2].x), "+v"(up[3].x), "+v"(up[4].x),
+                     "+v"(up[5].x), "+v"(up[6].x), "+v"(up[7].x), "+v"(up[8].x), "+v"(up[9].x),
+                     "+v"(up[10].x), "+v"(up[11].x), "+v"(up[12].x), "+v"(up[13].x),
+                     "+v"(up[14].x), "+v"(up[15].x), "+v"(up[16].x));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lo[i] = *at(psi, g1 + 64 * i);
+      lo[16] = *at(psi, g1 + gx);
+      asm volatile(""
+                   : "+v"(lo[0].x), "+v"(lo[1].x), "+v"(lo[2].x), "+v"(lo[3].x), "+v"(lo[4].x),
+                     "+v"(lo[5].x), "+v"(lo[6].x), "+v"(lo[7].x), "+v"(lo[8].x), "+v"(lo[9].x),
+                     "+v"(lo[10].x), "+v"(lo[11].x), "+v"(lo[12].x), "+v"(lo[13].x),
+                     "+v"(lo[14].x), "+v"(lo[15].x), "+v"(lo[16].x));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const cf b = right(up, i), e = right(lo, i);
+        cf o = mk(up[i].x * c.w00, up[i].y * c.w00);
+        o.x += b.x * c.w01;
+        o.y += b.y * c.w01;
+        o.x += lo[i].x * c.w10;
+        o.y += lo[i].y * c.w10;
+        o.x += e.x * c.w11;
+        o.y += e.y * c.w11;
+        pv[i] = o;
+      }
+    } else {
+      const int y = c.sy + line;
+      const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int x = c.sx + j + i * T;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+        const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+        const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
+        pv[i] = ok ? o : mk(0.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);  // rare path: one element in flight
+      }
+    }
+    float I[2][8];
+    if (WITH_I) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) I[h][k] = 0.f;
+    }
+    const unsigned pbo = (unsigned)(line * N + j) * (unsigned)sizeof(cf);
+    for (int s = 0; s < S; ++s) {
+      // probe of (position, mode)
+      const cf* __restrict__ Pn = probe.probe + n * probe.pos_stride + s * PP;
+      float w0 = 1.0f;
+      if (probe.weights != nullptr) {
+        if (probe.unique != nullptr && s < probe.Sm)
+          Pn = probe.unique + (n * probe.Sm + s) * PP;
+        else
+          w0 = probe.weights[n * (long)(probe.C + 1) * probe.S + s];
+      }
+      cf v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = pv[i] * (*at(Pn, pbo + 64 * i) * w0);
+      // ---- row transform, spectrum into the tile
+      cf* lbase = lds + line * LS;
+      FftStageWave<N, false, 0>::run(v, lbase, j, tw);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lbase[tk_pad16(j + i * T)] = v[i];
+      __syncthreads();
+      // ---- columns, radix-16 stage: rows {r + 8 y2} -> rows 16 r + k1
+      const cf* col = lds + tk_pad16(t);
+#pragma unroll
+      for (int y2 = 0; y2 < 16; ++y2) v[y2] = col[(r + 8 * y2) * LS];
+      Dft<16, false>::run(v);
+#pragma unroll
+      for (int k1 = 1; k1 < 16; ++k1) v[k1] = mul_tw<false>(v[k1], twtab[N + r * k1]);
+      __syncthreads();
+      cf* colw = lds + tk_pad16(t);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) colw[(16 * r + k1) * LS] = v[k1];
+      __syncthreads();
+      // ---- columns, radix-8 stage: rows {16 q + k1} -> far-plane rows k1 + 16 k2
+      cf* __restrict__ dst = farplane + (n * S + s) * PP + t;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int k1 = r + 8 * h;
+        cf u[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u[q] = col[(16 * q + k1) * LS];
+        Dft<8, false>::run(u);
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) {
+          const cf o = u[k2] * scale;
+          if (farplane != nullptr) tk_st_stream(dst + (long)(k1 + 16 * k2) * N, o);
+          if (WITH_I) I[h][k2] += norm2(o);
+        }
+      }
+      __syncthreads();  // the next mode's rows overwrite the tile
+    }
+    if (WITH_I) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2)
+          tk_st_stream(intensity + n * PP + (long)(r + 8 * h + 16 * k2) * N + t, I[h][k2]);
+    }
+  }
+}
+
+static int launch_fwd128_lds(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
+                             float* intensity, int nscan, int S, int H, int W, float scale,
+                             hipStream_t stream) {
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  const dim3 grid(tk_grid(nscan, 1)), block(1024);
+  if (intensity)
+    hipLaunchKernelGGL((fwd128_lds_kernel<true>), grid, block, 0, stream, psi, scan, probe,
+                       farplane, intensity, nscan, S, H, W, scale, tw);
+  else
+    hipLaunchKernelGGL((fwd128_lds_kernel<false>), grid, block, 0, stream, psi, scan, probe,
+                       farplane, intensity, nscan, S, H, W, scale, tw);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 template <int N>
 static int launch_fwd_v2(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                          long ntile, int S, int pw, int H, int W, float scale,
@@ -840,6 +1040,8 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
   const long ntile = (long)nscan * S;
   const cf* psi_ = (const cf*)psi;
   cf* far = (cf*)farplane;
+  if (det == 128 && pw == 128 && !(eigen_weights && eigen_modes > 0))
+    return launch_fwd128_lds(psi_, scan, P, far, nullptr, nscan, S, H, W, scale, stream);
   if (S > 1 && !(eigen_weights && eigen_modes > 0)) {
     // position-major kernel (patch gathered once per position and shared by
     // the modes, straight-line loader; with a single mode there is nothing to

@@ -1,0 +1,23 @@
+#!/bin/bash
+# SQ stall counters of an arbitrary command (run on the GPU box):
+#   bash tools/pmc_cmd.sh <kernel-substring> python3 bench.py --workload fwd128x1 ...
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+pat=$1; shift
+o=gpurun_out/pmc_cmd
+rm -rf $o
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $o -- "$@" > $o.log 2>&1
+rm -rf ${o}2
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d ${o}2 -- "$@" > ${o}2.log 2>&1
+for d in $o ${o}2; do
+f=$(find $d -name "*counter_collection.csv" | head -1)
+python3 - "$f" "$pat" <<'PY'
+import csv, sys, collections
+agg = collections.defaultdict(float); n = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    if sys.argv[2] in r["Kernel_Name"]:
+        agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+for k, v in agg.items():
+    print(f"{k:28s} {v / n[k]:16.0f} per launch ({n[k]} launches)")
+PY
+done
