@@ -118,7 +118,7 @@ int tike_ptycho_fwd_gradient_scale(const void* psi, const float* scan, const voi
                                    int H, int W, float scale, int model, float unmeasured_scaling,
                                    long num_measured, void* stream);
 
-/* ---- the same, split in two launches (det = 256).  tike_fwd_pass1: bilinear
+/* ---- the same, split in two launches (det = 256 or 512).  tike_fwd_pass1: bilinear
  * gather * probe -> row transforms -> radix-16 column stage; scratch
  * (nscan,S,det,det) receives the UNSCALED input of the column pass of every
  * tile, patches (nscan,pw,pw, may be NULL) the object patches O_n.  The varying
@@ -129,15 +129,18 @@ int tike_ptycho_fwd_gradient_scale(const void* psi, const float* scan, const voi
  * (may be NULL) and optionally the intensity (may be NULL) -- operands as
  * tike_ptycho_fwd_gradient_scale; data is float32, or uint16 when data_u16 != 0
  * (detector counts that arrived as <= 16-bit integers stay 16-bit in HBM,
- * ptycho.py:383-390). */
+ * ptycho.py:383-390).  farplane (nscan,S,det,det), if not NULL, also receives
+ * the far-plane waves F themselves (for the pipelines that keep them: poisson
+ * per-mode steps, the 512^2 inverse); it must not alias scratch. */
 int tike_fwd_pass1(const void* psi, const float* scan, const void* probe, int probe_per_scan,
                    const void* unique_probe, const void* eigen_probe,
                    const float* eigen_weights, int num_eigen, int eigen_modes, void* scratch,
                    void* patches, int nscan, int S, int pw, int det, int H, int W, void* stream);
 int tike_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
                             const unsigned char* measured, float* gscale, float* intensity,
-                            float* costs, int nscan, int S, int det, float scale, int model,
-                            float unmeasured_scaling, long num_measured, void* stream);
+                            float* costs, void* farplane, int nscan, int S, int det, float scale,
+                            int model, float unmeasured_scaling, long num_measured,
+                            void* stream);
 
 /* ---- far-plane gradient + IFFT2 + crop from that scratch (lstsq.py:491-507):
  * chi = crop(IFFT2(F * gscale [* mode_scale on measured pixels])) * inv_scale

@@ -501,7 +501,8 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
                      normwise=1e-6, maxabs=1e-5, what="scratch (eigen on the fly)")
         check(lib.tike_fwd_gradient_scale(
             A.ptr(scratch3), A.ptr(d_d), 0, A.ptr(m_d), A.ptr(g3), A.ptr(I3),
-            A.ptr(costs3), N, S, det, 1.0 / det, 0, 0.5, int(mask.sum()), st))
+            A.ptr(costs3), None, N, S, det, 1.0 / det, 0, 0.5, int(mask.sum()),
+            st))
         assert_close(pat3.cpu().numpy(), pat.cpu().numpy(), normwise=1e-6,
                      maxabs=1e-6, what="patches (split forward)")
         assert_close(scratch3.cpu().numpy(), scratch.cpu().numpy(),
@@ -603,7 +604,7 @@ def test_abi_edge_cases():
     assert lib.tike_grad_ifft2_pass1(z, z, z, z, 2, z, 0, 256, 1.0, st) == 0
     assert lib.tike_fwd_pass1(z, z, z, 0, z, z, z, 0, 0, z, z, 0, 2, 256, 256,
                               400, 400, st) == 0
-    assert lib.tike_fwd_gradient_scale(z, z, 0, z, z, z, z, 0, 2, 256, 1.0, 0,
+    assert lib.tike_fwd_gradient_scale(z, z, 0, z, z, z, z, z, 0, 2, 256, 1.0, 0,
                                        1.0, 65536, st) == 0
     assert lib.tike_ifft2_pass1_scaled(z, z, z, z, 2, z, 0, 128, st) == 0
     assert lib.tike_ifft2_pass2_gradients(z, z, z, z, z, 0, 0, z, z, z, 1.0, 0,

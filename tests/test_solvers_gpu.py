@@ -378,6 +378,8 @@ def _oracle_state(g_psi, g_probe, scan, order):
     (256, 256, 2, 10, 1, False, "poisson:dominant_mode"),
     (48, 32, 2, 12, 2, True, "poisson:all_modes"),        # generic path: tike_scale_modes
     (512, 512, 2, 6, 2, True, "gaussian"),                # config-5 size: 512^2 position-major
+    (256, 256, 3, 8, 2, True, "poisson:all_modes"),       # 256^2 with the far plane kept (split forward)
+    (512, 512, 4, 5, 1, False, "poisson:dominant_mode"),
 ])
 def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
     """Two lstsq_grad epochs against the CPU oracle on seeded problems that
@@ -431,9 +433,10 @@ def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
                          noise_model=model.split(":")[0],
                          step_length_usemodes=(model.split(":") +
                                                ["all_modes"])[1])
+    # (the poisson cost mean(I - d log I) cancels heavily: a looser bound)
     np.testing.assert_allclose(
         np.array(got.algorithm_options.costs), np.array(state["costs"]),
-        rtol=1e-3)
+        rtol=2e-3 if model.startswith("poisson") else 1e-3)
     assert_close(got.psi, state["psi"], normwise=SOLVER_NORMWISE, maxabs=1e-2,
                  what="psi")
     assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,

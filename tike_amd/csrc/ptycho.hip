@@ -502,14 +502,14 @@ extern "C" int tike_ptycho_fwd_gradient_scale(
 // counter retires in issue order, so a load issued behind the stores would
 // wait for them and every mode would pay a full store round trip.
 // FULL: probe window = detector (pw == N, no padding): every probe / patch
-// access of a thread is `uniform base + one 32-bit lane offset + 128 i`.
+// access of a thread is `uniform base + one 32-bit lane offset + 8 T i` bytes.
 template <int N, bool FULL>
 __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ scratch, cf* __restrict__ patches, int nscan, int S, int pw, int H, int W,
     const cf* __restrict__ twtab) {
   using G2 = Fft2Geom<N>;
-  static_assert(G2::RB == 16, "16 row groups of 16 rows");
+  constexpr unsigned EB = G2::T * sizeof(cf);  // bytes between a thread's elements
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
   cf* twl = lds + G2::LDS_ELEMS;
   FftTwLds<N>::fill(twl, twtab);
@@ -559,8 +559,8 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
           tk_v4f u[8], l[8];  // upper row (a, b), lower row (d, e)
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            u[i] = ld4(psi, g0 + 128 * (h + i));
-            l[i] = ld4(psi, g1 + 128 * (h + i));
+            u[i] = ld4(psi, g0 + EB * (h + i));
+            l[i] = ld4(psi, g1 + EB * (h + i));
           }
           asm volatile(""
                        : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]),
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
         for (int i = 0; i < 16; ++i) {
           const int px = j + i * G2::T - pad;
           if (FULL)
-            tk_st_stream(const_cast<cf*>(at(On, pbo + 128 * i)), pv[i]);
+            tk_st_stream(const_cast<cf*>(at(On, pbo + EB * i)), pv[i]);
           else if (px >= 0 && px < pw)
             tk_st_stream(On + (long)py * pw + px, pv[i]);
         }
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
           }
         }
         auto pix = [&](const cf* base, int i) {
-          if (FULL) return *at(base, pbo + 128 * i);
+          if (FULL) return *at(base, pbo + EB * i);
           const int px = j + i * G2::T - pad;
           const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
           return base[pyc * pw + pxc];
@@ -686,19 +686,24 @@ extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* pr
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(psi && scan && probe && scratch);
   TK_CHECK_ARG(!(eigen_weights && eigen_modes > 0 && !unique_probe && !eigen_probe));
-  if (det != 256) return TK_ERR_UNSUPPORTED;
+  if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   const TkProbe P = tk_make_probe(probe, probe_per_scan, unique_probe ? nullptr : eigen_probe,
                                   eigen_weights, num_eigen, eigen_modes, S, pw, unique_probe);
-  if (pw == det)
-    hipLaunchKernelGGL((fwd_pass1_kernel<256, true>), dim3(tk_grid(nscan, 2)), dim3(256), 0,
-                       stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches, nscan, S, pw,
-                       H, W, tw);
+#define TK_F1(N, FULL)                                                                          \
+  hipLaunchKernelGGL((fwd_pass1_kernel<N, FULL>), dim3(tk_grid(nscan, N == 256 ? 2 : 1)),       \
+                     dim3(N), 0, stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches,   \
+                     nscan, S, pw, H, W, tw)
+  if (det == 256 && pw == det)
+    TK_F1(256, true);
+  else if (det == 256)
+    TK_F1(256, false);
+  else if (pw == det)
+    TK_F1(512, true);
   else
-    hipLaunchKernelGGL((fwd_pass1_kernel<256, false>), dim3(tk_grid(nscan, 2)), dim3(256), 0,
-                       stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches, nscan, S, pw,
-                       H, W, tw);
+    TK_F1(512, false);
+#undef TK_F1
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -710,34 +715,43 @@ extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* pr
 // lstsq.py:444-502).  costs must be zero on entry (accumulated by atomics).
 // DT: float, or unsigned short for detector counts kept as they arrived
 // (16-bit data stays 16-bit in HBM, reference ptycho.py:383-390).
-template <int MODEL, class DT>
-__global__ __launch_bounds__(256, 4) void fwd_gradient_scale_kernel(
+template <int N, int MODEL, class DT>
+__global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, float* __restrict__ gscale,
-    float* __restrict__ intensity, float* __restrict__ costs, long nitem, int S, float scale,
-    float unmeasured_scaling, float inv_nmeasured) {
-  constexpr int N = 256;
+    float* __restrict__ intensity, float* __restrict__ costs, cf* __restrict__ farplane,
+    long nitem, int S, float scale, float unmeasured_scaling, float inv_nmeasured) {
+  constexpr int RB = N / 16;    // radix of the column pass
+  constexpr int NH = N / 256;   // 256-column blocks per row
   __shared__ float red[4];
-  const int t = threadIdx.x;
   const float s2 = scale * scale;
   for (long v = blockIdx.x; v < nitem; v += gridDim.x) {
-    const long n = v >> 4;
-    const int k1 = (int)(v & 15);
-    float I[16];
+    // item = (position, k1, column block)
+    const int hb = (int)(v % NH);
+    const int k1 = (int)((v / NH) & 15);
+    const long n = v / (16 * NH);
+    const int t = hb * 256 + threadIdx.x;
+    float I[RB];
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) I[k2] = 0.f;
+    for (int k2 = 0; k2 < RB; ++k2) I[k2] = 0.f;
     for (int s = 0; s < S; ++s) {
       const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
-      cf u[16];
+      cf u[RB];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(src + (long)(16 * r) * N);
-      Dft<16, false>::run(u);
+      for (int r = 0; r < RB; ++r) u[r] = tk_ld_stream(src + (long)(16 * r) * N);
+      Dft<RB, false>::run(u);
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) I[k2] += norm2(u[k2]) * s2;
+      for (int k2 = 0; k2 < RB; ++k2) I[k2] += norm2(u[k2]) * s2;
+      if (farplane != nullptr) {
+        // the far-plane wave itself, for the pipelines that keep it
+        cf* __restrict__ dst = farplane + (n * S + s) * (long)N * N + k1 * N + t;
+#pragma unroll
+        for (int k2 = 0; k2 < RB; ++k2) tk_st_stream(dst + (long)(16 * k2) * N, u[k2] * scale);
+      }
     }
     float cost = 0.f;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) {
+    for (int k2 = 0; k2 < RB; ++k2) {
       const long p = (long)(k1 + 16 * k2) * N + t;
       if (intensity) tk_st_stream(intensity + n * (long)N * N + p, I[k2]);
       float g = unmeasured_scaling - 1.0f;
@@ -757,7 +771,7 @@ __global__ __launch_bounds__(256, 4) void fwd_gradient_scale_kernel(
     }
     if (costs) {
       cost = tk_block_sum256(cost, red);
-      if (t == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+      if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
     }
   }
 }
@@ -766,35 +780,44 @@ __global__ __launch_bounds__(256, 4) void fwd_gradient_scale_kernel(
 // forward FFT normalisation applied here).  intensity / costs may be NULL.
 extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
                                        const unsigned char* measured, float* gscale,
-                                       float* intensity, float* costs, int nscan, int S, int det,
-                                       float scale, int model, float unmeasured_scaling,
-                                       long num_measured, void* stream_) {
+                                       float* intensity, float* costs, void* farplane, int nscan,
+                                       int S, int det, float scale, int model,
+                                       float unmeasured_scaling, long num_measured,
+                                       void* stream_) {
   TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1 && (model == 0 || model == 1) &&
                num_measured > 0);
   if (nscan == 0) return TK_OK;
-  TK_CHECK_ARG(scratch && data && gscale);
-  if (det != 256) return TK_ERR_UNSUPPORTED;
+  TK_CHECK_ARG(scratch && data && gscale && farplane != scratch);
+  if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
   if (costs) {
     hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
     if (e != hipSuccess) return (int)e;
   }
-  const long nitem = (long)nscan * 16;
+  const long nitem = (long)nscan * 16 * (det / 256);
   const float inv = 1.0f / (float)num_measured;
   const dim3 grid(tk_grid(nitem, 16)), block(256);
-#define TK_FGS(M, DT)                                                                        \
-  hipLaunchKernelGGL((fwd_gradient_scale_kernel<M, DT>), grid, block, 0, stream,                \
+#define TK_FGS(N, M, DT)                                                                     \
+  hipLaunchKernelGGL((fwd_gradient_scale_kernel<N, M, DT>), grid, block, 0, stream,             \
                      (const cf*)scratch, (const DT*)data, measured, gscale, intensity, costs,   \
-                     nitem, S, scale, unmeasured_scaling, inv)
-  if (model == 0 && data_u16)
-    TK_FGS(0, unsigned short);
-  else if (model == 0)
-    TK_FGS(0, float);
-  else if (data_u16)
-    TK_FGS(1, unsigned short);
+                     (cf*)farplane, nitem, S, scale, unmeasured_scaling, inv)
+#define TK_FGS_N(N)                     \
+  do {                                  \
+    if (model == 0 && data_u16)         \
+      TK_FGS(N, 0, unsigned short);     \
+    else if (model == 0)                \
+      TK_FGS(N, 0, float);              \
+    else if (data_u16)                  \
+      TK_FGS(N, 1, unsigned short);     \
+    else                                \
+      TK_FGS(N, 1, float);              \
+  } while (0)
+  if (det == 256)
+    TK_FGS_N(256);
   else
-    TK_FGS(1, float);
+    TK_FGS_N(512);
+#undef TK_FGS_N
 #undef TK_FGS
   TK_LAUNCH_CHECK();
   return TK_OK;

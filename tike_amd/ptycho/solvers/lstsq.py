@@ -60,6 +60,7 @@ def _workspace(op):
 
 POSITION_MAJOR_SIZES = (128, 256, 512)
 NO_FARPLANE_SIZES = (256,)
+SPLIT_FORWARD_SIZES = (256, 512)
 """Detector sizes served by the position-major forward kernel
 (tike_ptycho_fwd_intensity) and the gradient-scaled inverse."""
 
@@ -373,6 +374,9 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # mode 0 of chi is read again after the whole minibatch (step sizes,
     # eigen probes).  When the minibatch is one chunk, chi is still intact
     # then and is handed on with a mode stride; otherwise mode 0 is packed.
+    # 256^2 / 512^2 with the far plane kept: split forward, intermediate in `far`
+    split_kept = (pos_major and fused and not no_farplane
+                  and det in SPLIT_FORWARD_SIZES)
     single_chunk = B <= chunk and not fused
     if not single_chunk:
         chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
@@ -416,8 +420,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     A.ptr(far), A.ptr(data[clo:chi_hi]),
                     int(data.dtype == torch.uint16), A.ptr(mask_u8),
                     A.ptr(gscale), A.ptr(inten) if poisson else None,
-                    A.ptr(costs[blo:blo + n]), n, S, det, fwd_scale, model,
-                    unmeasured, nmeasured, st),
+                    A.ptr(costs[blo:blo + n]), None, n, S, det, fwd_scale,
+                    model, unmeasured, nmeasured, st),
                 "forward pass 2 + gradient scale")
             if poisson:  # dominant mode: the steps need no far-plane waves
                 check(
@@ -441,6 +445,36 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                         A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
                         A.ptr(chi), n * S, det, pw, fwd_scale, inv_scale, st),
                     "gradient + ifft2 + crop")
+        elif pos_major and fused and det in SPLIT_FORWARD_SIZES:
+            # the far plane is kept (512^2; per-mode poisson steps at 256^2):
+            # forward pass 1 -> streamed column pass that stores the far-plane
+            # waves (in `mid`) next to the gradient factor -> inverse pass 1
+            # back into `far` -> pass 2 + gradients
+            check(
+                lib.tike_fwd_pass1(
+                    A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
+                    A.ptr(uq), None, A.ptr(w_c), C, Sm, A.ptr(far),
+                    A.ptr(patches[blo:blo + n]), n, S, pw, det, H, W, st),
+                "forward pass 1")
+            check(
+                lib.tike_fwd_gradient_scale(
+                    A.ptr(far), A.ptr(dchunk), 0, A.ptr(mask_u8),
+                    A.ptr(gscale), A.ptr(inten) if poisson else None,
+                    A.ptr(costs[blo:blo + n]), A.ptr(mid), n, S, det,
+                    fwd_scale, model, unmeasured, nmeasured, st),
+                "forward pass 2 + gradient scale")
+            if poisson:
+                check(
+                    lib.tike_poisson_steps(
+                        A.ptr(mid), A.ptr(inten), A.ptr(dchunk),
+                        A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
+                        step_weight, dominant, st), "poisson step lengths")
+            check(
+                lib.tike_ifft2_pass1_scaled(
+                    A.ptr(mid), A.ptr(gscale),
+                    A.ptr(steps) if poisson else None,
+                    A.ptr(mask_u8) if poisson else None, S, A.ptr(far),
+                    n * S, det, st), "scaled inverse pass 1")
         elif pos_major:
             # forward + intensity in one kernel; the gradient factor is a
             # per-pixel table applied while the inverse transform loads rows
@@ -511,7 +545,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             # pixel-major kernel (chi itself never exists in memory)
             check(
                 lib.tike_ifft2_pass2_gradients(
-                    A.ptr(mid), A.ptr(patches[blo:blo + n]), A.ptr(probe),
+                    A.ptr(far if split_kept else mid),
+                    A.ptr(patches[blo:blo + n]), A.ptr(probe),
                     A.ptr(ep), A.ptr(w_c), C, Sm,
                     A.ptr(objproj) if recover_psi else None,
                     A.ptr(chi0[blo:blo + n]), A.ptr(m_probe_update),

@@ -87,7 +87,7 @@ def main():
             p(psi), p(scan), p(probe), 0, None, p(eig), p(w), C, Sm, p(far),
             p(patches), N, S, pw, det, HW, HW, st)), N * (T + 2 * P))
         run("fwd_gradient_scale (split)", lambda: check(lib.tike_fwd_gradient_scale(
-            p(far), p(data), 0, None, p(gscale), None, p(costs), N, S, det,
+            p(far), p(data), 0, None, p(gscale), None, p(costs), None, N, S, det,
             1.0 / det, 0, 1.0, det * det, st)), N * (T + 2 * D))
         run("grad_ifft2_pass1", lambda: check(lib.tike_grad_ifft2_pass1(
             p(far), p(gscale), None, None, S, p(mid), N * S, det, 1.0 / det,

@@ -40,7 +40,7 @@ def f1(st):
 
 def f2(st):
     check(lib.tike_fwd_gradient_scale(p(farB), p(data), 0, None, p(gscale), None,
-                                      None, N, S, det, 1.0 / det, 0, 1.0,
+                                      None, None, N, S, det, 1.0 / det, 0, 1.0,
                                       det * det, st))
 
 
