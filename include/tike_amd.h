@@ -29,6 +29,8 @@ extern "C" {
 
 #define TIKE_ERR_ARG 1000001
 #define TIKE_ERR_UNSUPPORTED 1000002
+#define TIKE_ERR_COMM 2000000 /* + ncclResult_t of a failed RCCL call */
+#define TIKE_COMM_ID_BYTES 128
 
 /* Create the per-device constant tables (FFT twiddles).  Allocates; call once
  * per device before capturing graphs.  Every other call does it lazily. */
@@ -425,6 +427,26 @@ int tike_eigen_dsum(const float* sums, int B, long P, float* dsum, void* stream)
 int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, double count,
                        float* weights_c, long weights_row, void* coefs_c, int coef_stride,
                        const float* esum, void* stream);
+
+/* ---- collectives: the per-minibatch gradient all-reduce over RCCL / xGMI,
+ * one process (or thread) per GPU.  Replaces the serial peer-copy reduction of
+ * communicators/pool.py:300-395 (reduce_gpu / allreduce) as composed by
+ * communicators/comm.py:96-136.  librccl.so.1 is bound at the first call;
+ * TIKE_ERR_UNSUPPORTED if it cannot be loaded; a failed RCCL call returns
+ * TIKE_ERR_COMM + its ncclResult_t.
+ * tike_comm_unique_id: one rank fills a HOST buffer of TIKE_COMM_ID_BYTES and
+ *   hands it to the others out of band (file, socket, MPI, torch store).
+ * tike_comm_create: collective over the nranks callers, each on its own device
+ *   (blocks until all have joined); *comm is the opaque handle of the others.
+ * tike_comm_allreduce_sum: buf[0..count) of float32 (f64 = 0) or float64
+ *   (f64 = 1) summed over the ranks IN PLACE, asynchronously on `stream`;
+ *   complex64 arrays are reduced as 2*numel float32.
+ * tike_comm_broadcast: nbytes of rank `root`'s buf to every rank's buf. */
+int tike_comm_unique_id(void* id);
+int tike_comm_create(const void* id, int nranks, int rank, void** comm);
+int tike_comm_destroy(void* comm);
+int tike_comm_allreduce_sum(void* comm, void* buf, long count, int f64, void* stream);
+int tike_comm_broadcast(void* comm, void* buf, long nbytes, int root, void* stream);
 
 #ifdef __cplusplus
 }

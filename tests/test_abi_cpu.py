@@ -52,3 +52,18 @@ def test_every_entry_point_is_documented():
     assert names, "no entry points found"
     missing = [n for n in names if n not in doc]
     assert not missing, missing
+
+
+def test_comm_entries_reject_bad_arguments_without_a_gpu():
+    """Argument validation of the collective entries happens before RCCL is
+    bound, so it can be checked on a CPU-only host."""
+    comm = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(L.COMM_ID_BYTES)
+    lib = L.lib
+    assert lib.tike_comm_unique_id(None) == L.ERR_ARG
+    assert lib.tike_comm_create(None, 1, 0, ctypes.byref(comm)) == L.ERR_ARG
+    assert lib.tike_comm_create(ident, 2, 2, ctypes.byref(comm)) == L.ERR_ARG
+    assert lib.tike_comm_create(ident, 0, 0, ctypes.byref(comm)) == L.ERR_ARG
+    assert lib.tike_comm_allreduce_sum(None, None, 4, 0, None) == L.ERR_ARG
+    assert lib.tike_comm_broadcast(None, None, 4, 0, None) == L.ERR_ARG
+    assert lib.tike_comm_destroy(None) == 0

@@ -118,12 +118,13 @@ def test_two_ranks_match_one_rank(eigen, method, positions):
                          what=f"eigen weights rank {rank}")
 
 
-def _rccl_worker(port, ret):
+def _rccl_worker(port, ret, backend=""):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["TIKE_FORCE_COLLECTIVES"] = "1"
+    os.environ["TIKE_COMM_BACKEND"] = backend
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
@@ -135,16 +136,18 @@ def _rccl_worker(port, ret):
         dist.destroy_process_group()
 
 
-def test_rccl_collectives_single_rank():
+@pytest.mark.parametrize("backend", ["", "cabi"])
+def test_rccl_collectives_single_rank(backend):
     """The production backend: every collective of the solver (packed f32
     all-reduce, f64 scalar all-reduces, max all-reduce, row all-gather,
     position gather) issued through RCCL ("nccl") on a one-rank group must
-    leave the result unchanged."""
+    leave the result unchanged.  backend "cabi": the float32 all-reduces go
+    through tike_comm_allreduce_sum (the library's own RCCL communicator)."""
     import torch.multiprocessing as mp
     single = _reconstruct(True, "wobbly_center", positions=True)
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
-    p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret))
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), ret, backend))
     p.start()
     p.join(300)
     assert p.exitcode == 0

@@ -646,6 +646,46 @@ def test_abi_edge_cases():
                                       1.0, st) == L.ERR_ARG
 
 
+def test_comm_abi_single_rank():
+    """The RCCL entries of the C ABI on a one-rank communicator: sum
+    all-reduce (f32 / f64) and broadcast leave the buffers unchanged, are
+    asynchronous on the caller's stream, and argument errors are reported."""
+    import ctypes
+    import torch
+    import tike_amd._arrays as A
+    import tike_amd._lib as L
+    lib = L.lib
+    ident = ctypes.create_string_buffer(L.COMM_ID_BYTES)
+    L.check(lib.tike_comm_unique_id(ident), "unique_id")
+    comm = ctypes.c_void_p()
+    assert lib.tike_comm_create(ident.raw, 1, 1, ctypes.byref(comm)) == L.ERR_ARG
+    assert lib.tike_comm_create(None, 1, 0, ctypes.byref(comm)) == L.ERR_ARG
+    L.check(lib.tike_comm_create(ident.raw, 1, 0, ctypes.byref(comm)), "create")
+    assert comm.value
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(1 << 20, device="cuda", generator=g)
+    c = torch.randn(3, 100, 100, dtype=torch.complex64, device="cuda")
+    d = torch.randn(5, dtype=torch.float64, device="cuda")
+    x0, c0, d0 = x.clone(), c.clone(), d.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        st = A.stream_ptr()
+        L.check(lib.tike_comm_allreduce_sum(comm, x.data_ptr(), x.numel(), 0, st))
+        L.check(lib.tike_comm_allreduce_sum(comm, c.data_ptr(), 2 * c.numel(), 0,
+                                            st))
+        L.check(lib.tike_comm_allreduce_sum(comm, d.data_ptr(), d.numel(), 1, st))
+        L.check(lib.tike_comm_broadcast(comm, x.data_ptr(), 4 * x.numel(), 0, st))
+        assert lib.tike_comm_allreduce_sum(comm, None, 0, 0, st) == 0
+        assert lib.tike_comm_allreduce_sum(comm, None, 4, 0, st) == L.ERR_ARG
+        assert lib.tike_comm_allreduce_sum(None, x.data_ptr(), 4, 0,
+                                           st) == L.ERR_ARG
+    side.synchronize()
+    assert torch.equal(x, x0) and torch.equal(c, c0) and torch.equal(d, d0)
+    L.check(lib.tike_comm_destroy(comm), "destroy")
+    assert lib.tike_comm_destroy(None) == 0
+
+
 def test_multislice_vs_reference_fixture(ops, golden):
     """FresnelSpectProp / Multislice (3 slices) / Ptycho over it on the GPU
     against the reference's own outputs."""

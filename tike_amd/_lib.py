@@ -22,6 +22,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
 ERR_ARG = 1000001
 ERR_UNSUPPORTED = 1000002
+ERR_COMM = 2000000
+COMM_ID_BYTES = 128
 
 if not os.path.isfile(LIB_PATH):
     raise ImportError(
@@ -101,6 +103,11 @@ _PROTOTYPES = {
     "tike_psi_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_lstsq_step_stats": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p,
                               _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
+    "tike_comm_unique_id": [_p],
+    "tike_comm_create": [_p, _i, _i, ctypes.POINTER(_p)],
+    "tike_comm_destroy": [_p],
+    "tike_comm_allreduce_sum": [_p, _p, _l, _i, _p],
+    "tike_comm_broadcast": [_p, _p, _l, _i, _p],
 }
 
 
@@ -125,4 +132,6 @@ def check(rc, what=""):
         raise ValueError(f"{what}: incompatible shapes / arguments")
     if rc == ERR_UNSUPPORTED:
         raise ValueError(f"{what}: unsupported size for the HIP path")
+    if rc >= ERR_COMM:
+        raise RuntimeError(f"{what}: RCCL error {rc - ERR_COMM}")
     raise RuntimeError(f"{what}: HIP error {rc}")

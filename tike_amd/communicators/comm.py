@@ -26,12 +26,51 @@ class Comm:
         # issues them anyway (used to exercise RCCL on a one-GPU test box)
         self.collective = self.size > 1 or (
             self.enabled and os.environ.get("TIKE_FORCE_COLLECTIVES") == "1")
+        # TIKE_COMM_BACKEND=cabi: the float32 sum all-reduces (the gradient
+        # buffers of every minibatch) go through the library's own RCCL entry
+        # (tike_comm_allreduce_sum, include/tike_amd.h) instead of
+        # torch.distributed; the process group only hands out the unique id.
+        self._cabi = None
+        if self.collective and os.environ.get("TIKE_COMM_BACKEND") == "cabi":
+            self._cabi = self._create_cabi()
+
+    def _create_cabi(self):
+        import ctypes
+        from .. import _lib
+        ident = [None]
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+            _lib.check(_lib.lib.tike_comm_unique_id(buf), "tike_comm_unique_id")
+            ident[0] = buf.raw
+        dist.broadcast_object_list(ident, src=0, group=self.group)
+        handle = ctypes.c_void_p()
+        _lib.check(
+            _lib.lib.tike_comm_create(ident[0], self.size, self.rank,
+                                      ctypes.byref(handle)),
+            "tike_comm_create")
+        return handle
+
+    def _allreduce_f32(self, flat):
+        if self._cabi is not None and flat.is_cuda:
+            from .. import _lib
+            _lib.check(
+                _lib.lib.tike_comm_allreduce_sum(
+                    self._cabi, flat.data_ptr(), flat.numel(), 0,
+                    torch.cuda.current_stream(flat.device).cuda_stream),
+                "tike_comm_allreduce_sum")
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def __enter__(self):
         return self
 
     def __exit__(self, type, value, traceback):
-        pass
+        if self._cabi is not None:
+            from .. import _lib
+            torch.cuda.synchronize()
+            _lib.check(_lib.lib.tike_comm_destroy(self._cabi),
+                       "tike_comm_destroy")
+            self._cabi = None
 
     def Allreduce(self, *tensors):
         """Sum the tensors across ranks IN PLACE; complex tensors are reduced
@@ -42,11 +81,14 @@ class Comm:
         views = [
             torch.view_as_real(t) if t.is_complex() else t for t in tensors
         ]
-        if len(views) == 1 and views[0].is_contiguous():
+        if (len(views) == 1 and views[0].is_contiguous()
+                and views[0].dtype == torch.float32):
+            self._allreduce_f32(views[0])
+        elif len(views) == 1 and views[0].is_contiguous():
             dist.all_reduce(views[0], op=dist.ReduceOp.SUM, group=self.group)
         else:
             flat = torch.cat([v.reshape(-1).to(torch.float32) for v in views])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            self._allreduce_f32(flat)
             off = 0
             for v in views:
                 n = v.numel()

@@ -10,7 +10,8 @@ from .probe import (ProbeOptions, add_modes_random_phase, adjust_probe_power,
 from .ptycho import (Reconstruction, reconstruct, reconstruct_multigrid,
                      simulate)
 from .solvers import (CgradOptions, LstsqOptions, PtychoParameters,
-                      RpieOptions, cgrad, lstsq_grad, update_preconditioners)
+                      RpieOptions, cgrad, lstsq_grad, rpie,
+                      update_preconditioners)
 from . import probe, object, position, exitwave, solvers  # noqa: F401,A004
 
 __all__ = [
@@ -18,6 +19,6 @@ __all__ = [
     "AffineTransform", "PositionOptions", "affine_position_regularization",
     "ProbeOptions", "PtychoParameters", "Reconstruction",
     "RpieOptions", "cgrad", "check_allowed_positions", "lstsq_grad",
-    "reconstruct", "reconstruct_multigrid", "simulate",
+    "reconstruct", "reconstruct_multigrid", "rpie", "simulate",
     "update_preconditioners",
 ]
