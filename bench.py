@@ -101,6 +101,10 @@ def synthetic(N_total, S, det, lo, hi, seed=1234):
 
 
 # ------------------------------------------------------ per-kernel HIP events
+# entry -> index of the output argument whose absence marks a cost-only launch
+COST_ONLY_ARG = {"tike_fwd_pass1": 10, "tike_fwd_gradient_scale": 4}
+
+
 class KernelTimers:
     """Brackets every C-ABI launch with HIP events on the launch stream
     (torch's current stream, which is the stream handed to the C ABI).  The
@@ -122,6 +126,11 @@ class KernelTimers:
                 e0.record()
                 rc = _fn(*args)
                 e1.record()
+                # cost-only launches (cgrad's line search: no patches / no
+                # gradient factor stored) move fewer bytes: own line
+                out = COST_ONLY_ARG.get(_name)
+                if out is not None and args[out] is None:
+                    _name = _name + ":cost_only"
                 self.events[_name].append((e0, e1))
                 return rc
 
@@ -238,6 +247,9 @@ def algorithmic_bytes(name, n, S, det, pw, C):
         # column pass -> intensity -> gradient factor: reads the hand-off and
         # the data, writes the factor
         "tike_fwd_gradient_scale": n * (T + 2 * D),
+        # line-search probes: no patches / no gradient factor stored
+        "tike_fwd_pass1:cost_only": n * (T + P + 8) + (S + C) * P,
+        "tike_fwd_gradient_scale:cost_only": n * (T + D + 4),
         "tike_ptycho_fwd_gradient_scale":
         n * (T + P + 2 * D + 8) + (S + C) * P,
         "tike_ptycho_fwd_intensity": n * (T + P + D + 8) + (S + C) * P,

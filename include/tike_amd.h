@@ -128,7 +128,8 @@ int tike_ptycho_fwd_gradient_scale(const void* psi, const float* scan, const voi
  * otherwise formed on the fly from eigen_probe (probe.py:272-303).
  * tike_fwd_gradient_scale: streams that scratch once, forms F = scale *
  * (column pass) in registers, I = sum_s |F_s|^2, and emits gscale, the costs
- * (may be NULL) and optionally the intensity (may be NULL) -- operands as
+ * (either may be NULL, not both: a cost-only call is a line-search probe of
+ * cgrad) and optionally the intensity (may be NULL) -- operands as
  * tike_ptycho_fwd_gradient_scale; data is float32, or uint16 when data_u16 != 0
  * (detector counts that arrived as <= 16-bit integers stay 16-bit in HBM,
  * ptycho.py:383-390).  farplane (nscan,S,det,det), if not NULL, also receives

@@ -288,11 +288,14 @@ def test_cgrad_vs_reference_composition(tp, golden):
 
 
 @pytest.mark.parametrize("det,pw,S,N", [(256, 256, 1, 6), (256, 192, 2, 5),
-                                        (128, 128, 1, 8)])
+                                        (128, 128, 1, 8), (512, 512, 2, 3),
+                                        (64, 48, 2, 9)])
 def test_cgrad_vs_oracle(tp, det, pw, S, N):
     """cgrad (object then probe, 2 CG iterations each) against the oracle's
-    composition at the sizes with fused kernels: 256 takes the far-plane-free
-    forward / gradient+inverse pair, 128 the stored-far-plane path."""
+    composition: the gradients are lstsq_grad's pipelines (far-plane-free at
+    256, split forward + kept far plane at 512, whole-tile kernels at 128,
+    generic below), the line-search costs the split forward with nothing but
+    the costs stored (256 / 512)."""
     from oracle import solvers as osol
     rng = np.random.default_rng(det + N)
     side = int(np.ceil(np.sqrt(N)))

@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kern
           g = -(1.0f - dv / (I[k2] + 1e-9f));
         }
       }
-      gscale[n * (long)N * N + p] = g;
+      if (gscale) gscale[n * (long)N * N + p] = g;
     }
     if (costs) {
       cost = tk_block_sum256(cost, red);
@@ -777,7 +777,8 @@ __global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kern
 }
 
 // scratch: from tike_fwd_pass1 (UNSCALED column-pass input; `scale` is the
-// forward FFT normalisation applied here).  intensity / costs may be NULL.
+// forward FFT normalisation applied here).  intensity / costs may be NULL, and
+// so may gscale when only the costs are wanted (a line-search probe).
 extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
                                        const unsigned char* measured, float* gscale,
                                        float* intensity, float* costs, void* farplane, int nscan,
@@ -789,7 +790,7 @@ extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, in
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1 && (model == 0 || model == 1) &&
                num_measured > 0);
   if (nscan == 0) return TK_OK;
-  TK_CHECK_ARG(scratch && data && gscale && farplane != scratch);
+  TK_CHECK_ARG(scratch && data && (gscale || costs) && farplane != scratch);
   if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
   if (costs) {
     hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
