@@ -327,9 +327,14 @@ class Reconstruction():
             logger.info(f"{o.name} epoch {total_epochs:,d}")
             self.parameters = _apply_probe_constraints(self.parameters,
                                                        epoch=total_epochs)
+            # cgrad reads no preconditioner while it iterates; the object's is
+            # needed only by the ambiguity rescale that follows some epochs
+            lean = o.name == "cgrad"
             self.parameters = solvers.update_preconditioners(
                 comm=self.comm, parameters=self.parameters,
-                operator=self.operator)
+                operator=self.operator, probe=not lean,
+                psi=not lean or (o.rescale_method == "mean_of_abs_object" and
+                                 (len(o.costs) + 1) % o.rescale_period == 0))
             self.parameters = getattr(solvers, o.name)(
                 self.parameters, self.data, self.batches, self.comm,
                 op=self.operator, epoch=total_epochs)

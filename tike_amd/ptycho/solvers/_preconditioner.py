@@ -66,14 +66,16 @@ def _probe_preconditioner(parameters, operator):
     return out
 
 
-def update_preconditioners(comm, parameters, operator):
-    """Refresh both preconditioners once per epoch (:170-209)."""
-    if parameters.object_options:
+def update_preconditioners(comm, parameters, operator, *, psi=True,
+                           probe=True):
+    """Refresh both preconditioners once per epoch (:170-209).  `psi` /
+    `probe` = False skips one (cgrad reads neither while it iterates)."""
+    if parameters.object_options and psi:
         # accumulated as float32 (real-valued), stored complex64 like the
         # reference's array (object.py:69-72)
         parameters.object_options.preconditioner = comm.Allreduce(
             _psi_preconditioner(parameters, operator)).to(torch.complex64)
-    if parameters.probe_options:
+    if parameters.probe_options and probe:
         parameters.probe_options.preconditioner = comm.Allreduce(
             _probe_preconditioner(parameters, operator))
     return parameters
