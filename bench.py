@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true",
                    help="skip the short forward-operator legs")
+    p.add_argument("--data-on-host", action="store_true",
+                   help="stream the patterns from pinned host memory (the "
+                        "PCIe-inclusive rate; never the headline value)")
     p.add_argument("--breakdown", action="store_true",
                    help="print the per-kernel time breakdown to stderr")
     return p.parse_args()
@@ -423,10 +426,11 @@ def main():
             position_options=tp.PositionOptions(
                 p["scan"].copy(), use_adaptive_moment=True,
                 update_magnitude_limit=1.0) if a.workload == "c5" else None)
-        ctx = tp.Reconstruction(data_dev, params, presharded=True,
-                                order=np.arange(N),
+        ctx = tp.Reconstruction(data if a.data_on_host else data_dev, params,
+                                presharded=True, order=np.arange(N),
                                 batches=np.array_split(np.arange(N),
-                                                       num_batch))
+                                                       num_batch),
+                                data_on_host=a.data_on_host)
         ctx.__enter__()
         # the gradient all-reduce of every minibatch, timed like a kernel
         timers.wrap_method(ctx.comm, "Allreduce", "allreduce(gradients)")
@@ -445,6 +449,8 @@ def main():
                         else "lstsq_grad",
                         num_batch=num_batch, chunk_positions=launch_n,
                         position_correction=a.workload == "c5")
+        if a.data_on_host:
+            workload["data_residency"] = "pinned host, streamed per chunk"
     else:
         raise SystemExit(f"unknown workload {a.workload}")
 

@@ -847,3 +847,51 @@ def test_uint16_data_stays_16_bit_and_matches_float(tp, det, S):
                                np.array(b.algorithm_options.costs), rtol=1e-5)
     assert_close(a.psi, b.psi, normwise=1e-5, maxabs=1e-4, what="psi")
     assert_close(a.probe, b.probe, normwise=1e-5, maxabs=1e-4, what="probe")
+
+
+@pytest.mark.parametrize("det,S,u16,solver", [(256, 2, True, "lstsq_grad"),
+                                              (64, 1, False, "lstsq_grad"),
+                                              (128, 1, False, "rpie"),
+                                              (256, 1, True, "cgrad")])
+def test_data_streamed_from_pinned_host_matches_resident(tp, monkeypatch, det,
+                                                         S, u16, solver):
+    """`data_on_host=True` (datasets larger than HBM; the reference's
+    stream_and_modify2, communicators/stream.py:285-404): the patterns stay in
+    pinned host memory and reach the kernels chunk by chunk, prefetched on a
+    copy stream.  Same kernels, same numbers: the iterates must agree with the
+    HBM-resident run to summation order, and most chunks must have been on
+    their way before they were asked for."""
+    import tike_amd.ptycho.solvers.lstsq as L
+    monkeypatch.setattr(L, "CHUNK_POSITIONS_OVERRIDE", 3)
+    N = 16
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=det + 5, eigen=False)
+    if u16:
+        data = np.round(data * (20000.0 / data.max())).astype(np.uint16)
+    options = dict(lstsq_grad=tp.LstsqOptions, rpie=tp.RpieOptions,
+                   cgrad=tp.CgradOptions)[solver]
+    results = []
+    for on_host in (False, True):
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+            scan=scan.copy(),
+            algorithm_options=options(num_batch=2, num_iter=2,
+                                      batch_method="compact"),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions(),
+            exitwave_options=tp.ExitWaveOptions(
+                measured_pixels=np.ones((det, det), dtype=bool)))
+        with tp.Reconstruction(data, params, order=np.arange(N),
+                               batches=np.array_split(np.arange(N), 2),
+                               data_on_host=on_host) as ctx:
+            ctx.iterate(2)
+            results.append(ctx.get_result())
+            if on_host:
+                assert type(ctx.data).__name__ == "PinnedData"
+                assert ctx.data.copies > 0
+                assert ctx.data.hits >= ctx.data.copies // 3
+    a, b = results
+    np.testing.assert_allclose(np.array(a.algorithm_options.costs),
+                               np.array(b.algorithm_options.costs), rtol=1e-5)
+    assert_close(a.psi, b.psi, normwise=1e-5, maxabs=1e-4, what="psi")
+    assert_close(a.probe, b.probe, normwise=1e-5, maxabs=1e-4, what="probe")

@@ -1,0 +1,113 @@
+"""Diffraction patterns that stay in pinned host memory.
+
+The reference keeps `data` in pinned host memory and copies 64-position
+chunks to the GPU on two CUDA streams while the previous chunk is worked on
+(src/tike/communicators/stream.py:285-404 `stream_and_modify2`, called from
+ptycho/solvers/lstsq.py:367-602).  Here the data is HBM-resident by default
+(288 GB per GPU hold every BASELINE configuration); `PinnedData` is the
+out-of-core alternative for datasets that do not fit: it looks like the
+resident tensor to the solvers -- `data[lo:hi]` returns a device tensor -- and
+hides the PCIe copy of the NEXT chunk behind the kernels of the current one
+(one copy stream, two device slots, HIP events both ways; no host
+synchronisation).
+"""
+import numpy as np
+import torch
+
+
+class PinnedData:
+    """Rows of a (N, det, det) array in pinned host memory, sliced onto the
+    GPU on demand.  Only contiguous row slices are supported (what the solvers
+    take); the chunk after the one just handed out is prefetched."""
+
+    def __init__(self, host, device=None):
+        if isinstance(host, torch.Tensor):
+            host = host.detach().cpu().numpy()
+        host = np.ascontiguousarray(host)
+        if host.dtype == np.uint16:
+            # torch has no copy kernels for uint16: move it as int16 bits
+            self._host = torch.from_numpy(host.view(np.int16))
+            self.dtype = torch.uint16
+        elif host.dtype == np.float32:
+            self._host = torch.from_numpy(host)
+            self.dtype = torch.float32
+        else:
+            raise TypeError(f"PinnedData holds uint16 or float32, not {host.dtype}")
+        self._host = self._host.pin_memory()
+        self.device = torch.device(
+            "cuda", torch.cuda.current_device()) if device is None else device
+        self.shape = tuple(self._host.shape)
+        self.ndim = self._host.ndim
+        self._copy = torch.cuda.Stream(self.device)
+        self._slots = [None, None]
+        self._free = [None, None]  # event after which a slot may be overwritten
+        self._ready = None  # (lo, hi, slot, event) of the prefetched chunk
+        self._last = None  # (lo, hi, slot) handed out last
+        self.copies = 0  # host-to-device copies issued
+        self.hits = 0  # chunks that were already on their way when asked for
+
+    def __len__(self):
+        return self.shape[0]
+
+    def _slot(self, s, n):
+        buf = self._slots[s]
+        if buf is None or buf.shape[0] < n:
+            if buf is not None:
+                torch.cuda.synchronize(self.device)  # rare: a larger chunk
+            buf = torch.empty((n, *self.shape[1:]), dtype=self._host.dtype,
+                              device=self.device)
+            buf.record_stream(self._copy)
+            self._slots[s] = buf
+            self._free[s] = None
+        return buf
+
+    def _issue(self, lo, hi, s):
+        """Start copying rows [lo, hi) into slot s on the copy stream."""
+        buf = self._slot(s, hi - lo)
+        if self._free[s] is not None:
+            self._copy.wait_event(self._free[s])
+        with torch.cuda.stream(self._copy):
+            buf[:hi - lo].copy_(self._host[lo:hi], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._copy)
+        self.copies += 1
+        return done
+
+    def __getitem__(self, key):
+        if not isinstance(key, slice) or key.step not in (None, 1):
+            raise TypeError("PinnedData supports contiguous row slices only")
+        lo, hi, _ = key.indices(self.shape[0])
+        hi = max(hi, lo)
+        n = hi - lo
+        if n == 0:
+            return torch.empty((0, *self.shape[1:]), dtype=self.dtype,
+                               device=self.device)
+        if self._last is not None and self._last[:2] == (lo, hi):
+            s = self._last[2]  # asked for twice in one chunk iteration
+            return self._view(s, n)
+        cur = torch.cuda.current_stream(self.device)
+        if self._ready is not None and self._ready[:2] == (lo, hi):
+            _, _, s, done = self._ready
+            self.hits += 1
+        else:
+            # not predicted: into the slot that was NOT handed out last (its
+            # kernels may still be queued); a stale prefetch there is dropped
+            s = 0 if self._last is None else 1 - self._last[2]
+            done = self._issue(lo, hi, s)
+        self._ready = None
+        cur.wait_event(done)
+        # everything queued so far has finished with the other slot
+        other = 1 - s
+        free = torch.cuda.Event()
+        free.record(cur)
+        self._free[other] = free
+        self._last = (lo, hi, s)
+        # the solvers walk a minibatch chunk by chunk: fetch the next one now
+        nlo, nhi = hi, min(self.shape[0], hi + n)
+        if nhi > nlo:
+            self._ready = (nlo, nhi, other, self._issue(nlo, nhi, other))
+        return self._view(s, n)
+
+    def _view(self, s, n):
+        buf = self._slots[s][:n]
+        return buf.view(torch.uint16) if self.dtype == torch.uint16 else buf

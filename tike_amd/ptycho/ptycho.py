@@ -93,14 +93,16 @@ def simulate(detector_shape, probe, scan, psi, fly=1, eigen_probe=None,
         return operator.asnumpy(out)
 
 
-def reconstruct(data, parameters, num_gpu=1, use_mpi=False):
+def reconstruct(data, parameters, num_gpu=1, use_mpi=False, **kwargs):
     """Solve the ptychography problem (ptycho.py:182-262).
 
     data (FRAME, WIDE, HIGH): measured intensities, FFT-shifted so that the
     diffraction peak is at the corners.  Returns the updated
     ``PtychoParameters`` (host arrays), which can be passed back in to resume.
+    Extra keyword arguments go to `Reconstruction` (e.g. ``data_on_host``).
     """
-    with Reconstruction(data, parameters, num_gpu, use_mpi) as context:
+    with Reconstruction(data, parameters, num_gpu, use_mpi,
+                        **kwargs) as context:
         context.iterate(parameters.algorithm_options.num_iter)
         result = context.get_result()
     return result
@@ -170,11 +172,15 @@ class Reconstruction():
       spatial_sort: list the positions of every minibatch along a Z-order
         curve (default) so that the grouped scatter kernels find neighbours
         next to each other; results change only by summation order.
+      data_on_host: keep the diffraction patterns in pinned host memory and
+        stream them to the GPU chunk by chunk (datasets larger than HBM; what
+        the reference always does, communicators/stream.py:285-404) instead
+        of holding them in HBM.  Results are identical.
     """
 
     def __init__(self, data, parameters, num_gpu=1, use_mpi=False, *,
                  presharded=False, order=None, batches=None,
-                 spatial_sort=True):
+                 spatial_sort=True, data_on_host=False):
         if (np.any(np.asarray(data.shape) < 1) or data.ndim != 3
                 or data.shape[-2] != data.shape[-1]):
             raise ValueError(
@@ -218,6 +224,7 @@ class Reconstruction():
         self._data_in = data
         self._parameters_in = parameters
         self._presharded = presharded
+        self._data_on_host = bool(data_on_host)
         self._order_in = order
         self._batches_in = batches
         self._spatial_sort = spatial_sort
@@ -293,8 +300,16 @@ class Reconstruction():
             data.shape[0])
         # HBM-resident data in batch-contiguous order: float32, or uint16 when
         # it arrived as <= 16-bit integers (ptycho.py:383-390)
-        self.data = A.data_to_device(data if A.is_device(data) else host,
-                                     order=self.local_order)
+        if self._data_on_host:
+            from ..communicators.stream import PinnedData
+            rows = (A.to_host(data) if host is None else host)[self.local_order]
+            rows = (np.clip(rows, 0, None).astype(np.uint16)
+                    if A.is_small_integer(rows.dtype) else
+                    rows.astype(np.float32, copy=False))
+            self.data = PinnedData(rows)
+        else:
+            self.data = A.data_to_device(data if A.is_device(data) else host,
+                                         order=self.local_order)
         self.parameters = solvers.PtychoParameters.split(
             self.local_order,
             x=self._host_parameters()).copy_to_device()
