@@ -12,7 +12,7 @@ from .ptycho import (Reconstruction, reconstruct, reconstruct_multigrid,
 from .solvers import (CgradOptions, LstsqOptions, PtychoParameters,
                       RpieOptions, cgrad, lstsq_grad, rpie,
                       update_preconditioners)
-from . import probe, object, position, exitwave, solvers  # noqa: F401,A004
+from . import probe, object, position, exitwave, solvers, io  # noqa: F401,A004
 
 __all__ = [
     "CgradOptions", "ExitWaveOptions", "LstsqOptions", "ObjectOptions",
