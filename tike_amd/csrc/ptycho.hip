@@ -521,7 +521,11 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
   auto at = [](const cf* base, unsigned byte_off) -> const cf* {
     return reinterpret_cast<const cf*>(reinterpret_cast<const char*>(base) + byte_off);
   };
-  for (long n = blockIdx.x; n < nscan; n += gridDim.x) {
+  // work item = (position, 16-row group): small launches (the sub-chunked
+  // pipeline keeps the hand-off inside the Infinity Cache) still fill the chip
+  for (long item = blockIdx.x; item < (long)nscan * G2::RB; item += gridDim.x) {
+    const long n = item / G2::RB;
+    const int r = (int)(item % G2::RB);
     const TkCorner c = tk_corner(scan, n);
     cf* __restrict__ dst0 = scratch + n * S * (long)N * N;
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
     // passes check_allowed_positions) and 32-bit byte offsets suffice
     const bool interior = FULL && c.sy >= 0 && c.sx >= 0 && c.sy + pw < H && c.sx + pw < W &&
                           total < (1L << 28);
-    for (int r = 0; r < G2::RB; ++r) {
+    {
       // patch values of row y = r + RB*line in the FFT register layout
       // (element e = j + i*T), gathered once and shared by all S modes
       const int py = r + G2::RB * line - pad;
@@ -692,7 +696,8 @@ extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* pr
   const TkProbe P = tk_make_probe(probe, probe_per_scan, unique_probe ? nullptr : eigen_probe,
                                   eigen_weights, num_eigen, eigen_modes, S, pw, unique_probe);
 #define TK_F1(N, FULL)                                                                          \
-  hipLaunchKernelGGL((fwd_pass1_kernel<N, FULL>), dim3(tk_grid(nscan, N == 256 ? 2 : 1)),       \
+  hipLaunchKernelGGL((fwd_pass1_kernel<N, FULL>),                                              \
+                     dim3(tk_grid((long)nscan * (N / 16), N == 256 ? 2 : 1)),                  \
                      dim3(N), 0, stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches,   \
                      nscan, S, pw, H, W, tw)
   if (det == 256 && pw == det)
@@ -1492,7 +1497,8 @@ template <int N, int MODE, bool PASS2 = true>
 __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
     const cf* __restrict__ colin, cf* work, cf* chi, long ntile, int pw, float fwd_scale,
     float inv_scale, const cf* __restrict__ twtab, const float* __restrict__ gscale, int S,
-    const float* __restrict__ mode_scale, const unsigned char* __restrict__ measured) {
+    const float* __restrict__ mode_scale, const unsigned char* __restrict__ measured,
+    int ksplit) {
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
   cf* twl = lds + G2::LDS_ELEMS;
@@ -1501,8 +1507,13 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
   const int pad = (N - pw) / 2;
   const int t = threadIdx.x;
   const long nscan = ntile / S;
+  // work item = (tile, group of 16 / ksplit values of k1); ksplit > 1 (only
+  // without pass 2) lets a small launch fill the chip
   const long nvirt = ((nscan + 7) / 8) * 8 * S;
-  for (long v = blockIdx.x; v < nvirt; v += gridDim.x) {
+  const int kn = 16 / ksplit;
+  for (long w = blockIdx.x; w < nvirt * ksplit; w += gridDim.x) {
+    const long v = w % nvirt;
+    const int kbeg = (int)(w / nvirt) * kn;
     const long tile = tk_xcd_tile(v, S, nscan);
     if (tile < 0) continue;  // uniform
     const cf* __restrict__ src = colin + tile * (long)N * N;
@@ -1513,7 +1524,7 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
     const FftTwLds<N> tw{twl, j};
-    for (int k1 = 0; k1 < 16; ++k1) {
+    for (int k1 = kbeg; k1 < kbeg + kn; ++k1) {
       cf u[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(src + (16 * r + k1) * N + t);
@@ -1552,11 +1563,17 @@ static int launch_grad_ifft2(const void* colin, const float* gscale, const float
   constexpr int N = 256;
   // a multiple of 8 workgroups keeps "virtual block % 8" equal to the XCD of
   // the workgroup across the grid-stride loop
-  const int grid8 = (tk_grid(((ntile / S + 7) / 8) * 8 * S, 4) + 7) / 8 * 8;
+  const long nvirt = ((ntile / S + 7) / 8) * 8 * S;
+  // without pass 2 the 16 values of k1 of a tile are independent: split them
+  // when there are fewer tiles than the chip holds workgroups
+  int ksplit = 1;
+  if (!pass2)
+    while (ksplit < 16 && nvirt * ksplit < 2048) ksplit *= 2;
+  const int grid8 = (tk_grid(nvirt * ksplit, 4) + 7) / 8 * 8;
 #define TK_GINV(MODE, P2)                                                                      \
   hipLaunchKernelGGL((grad_ifft2_crop_kernel<N, MODE, P2>), dim3(grid8), dim3(N), 0,            \
                      stream, (const cf*)colin, (cf*)work, (cf*)chi, ntile, pw, fwd_scale,      \
-                     inv_scale, tw, gscale, S, mode_scale, measured)
+                     inv_scale, tw, gscale, S, mode_scale, measured, ksplit)
   if (mode_scale && pass2)
     TK_GINV(2, true);
   else if (mode_scale)
