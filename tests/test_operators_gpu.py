@@ -757,3 +757,33 @@ def test_multislice_adjoint_and_oracle(ops, oracle, depth, pw, distance):
     c = np.vdot(m1, probe)
     np.testing.assert_allclose([a.real, a.imag], [b.real, b.imag], rtol=1e-3)
     np.testing.assert_allclose([a.real, a.imag], [c.real, c.imag], rtol=1e-3)
+
+
+def test_extract_patches_and_probe_constraints_on_device(golden):
+    """tike.ptycho.learn.extract_patches through the Patch kernel (vs the
+    oracle's bilinear patches), and the probe constraints on CUDA tensors
+    against the reference-run fixture."""
+    import torch
+    import tike_amd.ptycho as tp
+    from oracle import operators as oop
+    rng = np.random.default_rng(9)
+    psi = (rng.random((40, 44)) + 1j * rng.random((40, 44))).astype(np.complex64)
+    scan = (1 + rng.random((7, 2)) * (20, 24)).astype(np.float32)
+    got = tp.learn.extract_patches(psi, scan, 16)
+    want = oop.patch_fwd(psi, scan, patch_width=16)
+    assert got.shape == (7, 16, 16)
+    assert_close(got, want, normwise=1e-6, maxabs=1e-5, what="extract_patches")
+    with pytest.raises(ValueError):
+        tp.learn.extract_patches(psi, scan + 30, 16)
+    g = golden("probe_constraints.npz")
+    dev = lambda a: torch.from_numpy(a.copy()).cuda()
+    for case in "abcd":
+        out = tp.constrain_center_peak(dev(g[f"center_in_{case}"]))
+        assert out.is_cuda
+        np.testing.assert_array_equal(out.cpu().numpy(),
+                                      g[f"center_out_{case}"])
+    out = tp.apply_median_filter_abs_probe(dev(g["median_in"]), (2, 4))
+    np.testing.assert_allclose(out.cpu().numpy(), g["median_out_2_4"],
+                               rtol=2e-6, atol=1e-7)
+    out = tp.constrain_probe_sparsity(dev(g["sparse_in"]), 0.6)
+    np.testing.assert_array_equal(out.cpu().numpy(), g["sparse_out_60"])

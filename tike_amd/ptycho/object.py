@@ -113,3 +113,21 @@ def remove_object_ambiguity(psi, probe, preconditioner):
     W = W / linalg.mnorm(W)
     object_norm = 2 * torch.sqrt(torch.mean(torch.square(psi.abs()) * W))
     return psi / object_norm, probe * object_norm
+
+
+def get_absorbtion_image(data, scan, *, rescale=1.0, method="cubic"):
+    """Approximate scanning-transmission image: the total counts of every
+    diffraction pattern interpolated (scipy.interpolate.griddata) onto the
+    unit grid spanned by the rescaled scan positions (object.py:281-322)."""
+    import scipy.interpolate
+    data, scan = np.asarray(A.to_host(data)), np.asarray(A.to_host(scan))
+    rescaled = scan * rescale
+    axes = [np.arange(np.floor(rescaled[:, k].min()),
+                      np.ceil(rescaled[:, k].max())) for k in (0, 1)]
+    coord0, coord1 = np.meshgrid(*axes, indexing="ij")
+    values = np.sum(np.abs(data.astype(np.float64))**2, axis=(-2, -1))
+    image = scipy.interpolate.griddata(
+        points=rescaled, values=values,
+        xi=(coord0.ravel(), coord1.ravel()), method=method,
+        fill_value=np.amax(values))
+    return image.reshape(coord0.shape)

@@ -174,6 +174,26 @@ def gaussian_derivative_taps(sigma=0.333, truncate=6.0):
     return (-(d / (sigma * sigma)) * phi).astype(np.float32), r
 
 
+def gaussian_gradient(x, sigma=0.333):
+    """First-order Gaussian derivatives of `x` along its last two axes
+    (position.py:779-810): ``gaussian_filter1d(-x, sigma, order=1,
+    mode='nearest', truncate=6)`` per axis.  The solver applies the same taps
+    inside ``tike_position_sums``; this is the array-level form."""
+    t, was_numpy = (x, False) if isinstance(x, torch.Tensor) else (
+        torch.from_numpy(np.ascontiguousarray(x)), True)
+    taps, r = gaussian_derivative_taps(sigma)
+    taps = torch.from_numpy(taps).to(t.device)
+    out = []
+    for axis in (-2, -1):
+        n = t.shape[axis]
+        g = torch.zeros_like(t)
+        for d in range(-r, r + 1):
+            idx = torch.clamp(torch.arange(n, device=t.device) + d, 0, n - 1)
+            g = g + taps[d + r] * t.index_select(axis % t.ndim, idx)
+        out.append(g.cpu().numpy() if was_numpy else g)
+    return tuple(out)
+
+
 # -------------------------------------------------------------------- options
 @dataclasses.dataclass
 class PositionOptions:

@@ -259,3 +259,147 @@ def rescale_probe_using_fixed_intensity_photons(probe, Nphotons,
         probe_power_fraction = photons / torch.sum(photons)
     return probe * torch.sqrt(probe_power_fraction * Nphotons /
                               photons)[..., None, None]
+
+
+# ---------------------------------------------------------- probe constraints
+def _gaussian_taps(sigma, truncate, device):
+    """Normalised taps of scipy.ndimage's gaussian_filter1d (radius =
+    int(truncate * sigma + 0.5))."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = torch.arange(-radius, radius + 1, dtype=torch.float64, device=device)
+    w = torch.exp(-0.5 * x * x / float(sigma)**2)
+    return (w / w.sum()), radius
+
+
+def _smooth_intensity(intensity, sigma, *, wrap, truncate):
+    """Separable Gaussian blur of a real (H, W) image, in float64 like
+    scipy.ndimage.gaussian_filter on a float32 input accumulates; borders:
+    zeros (mode='constant') or periodic (mode='wrap')."""
+    img = intensity.to(torch.float64)
+    for axis, s in ((0, sigma[0]), (1, sigma[1])):
+        w, radius = _gaussian_taps(s, truncate, img.device)
+        rows = img if axis == 1 else img.T
+        if wrap:
+            n = rows.shape[1]
+            idx = torch.arange(-radius, n + radius, device=img.device) % n
+            padded = rows[:, idx]
+        else:
+            padded = torch.nn.functional.pad(rows, (radius, radius))
+        out = torch.nn.functional.conv1d(padded[:, None, :], w[None, None, :])[:, 0]
+        img = out if axis == 1 else out.T
+    return img.to(intensity.dtype)
+
+
+def constrain_center_peak(probe):
+    """Move the peak of the smoothed combined intensity towards the centre of
+    the probe grid, one pixel per call (probe.py:817-856): blur with sigma =
+    half / 3 (zero borders, 6 sigma), centre of mass, integer step of at most
+    one pixel along each axis, vacated pixels zero."""
+    p, was = _t(probe)
+    h, w = p.shape[-2:]
+    half = (h // 2, w // 2)
+    stack = p.reshape(-1, h, w)
+    intensity = _smooth_intensity(
+        torch.sum(stack.abs()**2, dim=0), (half[0] / 3, half[1] / 3),
+        wrap=False, truncate=6.0)
+    total = intensity.sum()
+    cy = torch.round((intensity.sum(1) * torch.arange(
+        h, device=p.device, dtype=intensity.dtype)).sum() / total)
+    cx = torch.round((intensity.sum(0) * torch.arange(
+        w, device=p.device, dtype=intensity.dtype)).sum() / total)
+    sy = int(min(1, max(-1, half[0] - float(cy))))
+    sx = int(min(1, max(-1, half[1] - float(cx))))
+    shifted = torch.zeros_like(stack)
+    src_y = slice(max(0, -sy), h - max(0, sy))
+    dst_y = slice(max(0, sy), h - max(0, -sy))
+    src_x = slice(max(0, -sx), w - max(0, sx))
+    dst_x = slice(max(0, sx), w - max(0, -sx))
+    shifted[:, dst_y, dst_x] = stack[:, src_y, src_x]
+    return _back(shifted.reshape(p.shape).contiguous(), was)
+
+
+def apply_median_filter_abs_probe(probe, med_filt_px):
+    """Median-filter the amplitude of every shared mode, keep the phase
+    (probe.py:859-893).  Window (a, b) pixels (integers, as CuPy's
+    median_filter takes its size), zero borders; for an even window the upper
+    of the two middle values, as scipy / CuPy rank filters pick."""
+    p, was = _t(probe)
+    a, b = (max(1, int(v)) for v in med_filt_px)
+    modes = p[0, 0]
+    amp = modes.abs()
+    S, h, w = amp.shape
+    # window of pixel i: [i - a // 2, i - a // 2 + a)
+    padded = torch.nn.functional.pad(amp, (b // 2, b - 1 - b // 2, a // 2,
+                                           a - 1 - a // 2))
+    windows = padded.unfold(1, a, 1).unfold(2, b, 1).reshape(S, h, w, a * b)
+    filtered = torch.kthvalue(windows, (a * b) // 2 + 1, dim=-1).values
+    out = p.clone()
+    out[0, 0] = torch.polar(filtered, torch.angle(modes))
+    return _back(out, was)
+
+
+def constrain_probe_sparsity(probe, f):
+    """Zero, in every mode, the fraction `f` of pixels where the smoothed
+    combined intensity is smallest (probe.py:896-916; blur sigma = size / 8,
+    periodic borders)."""
+    if f == 0:
+        return probe
+    p, was = _t(probe)
+    h, w = p.shape[-2:]
+    intensity = _smooth_intensity(
+        torch.sum(p.reshape(-1, h, w).abs()**2, dim=0), (h / 8, w / 8),
+        wrap=True, truncate=4.0)
+    k = int(f * h * w)
+    out = p.clone()
+    if k > 0:
+        smallest = torch.topk(intensity.reshape(-1), k, largest=False).indices
+        out.reshape(*p.shape[:-2], h * w)[..., smallest] = 0
+    return _back(out, was)
+
+
+def add_modes_cartesian_hermite(probe, nmodes):
+    """More probe modes from one: the probe times 2-D Cartesian Hermite-like
+    polynomials about its intensity centroid (Gaussian-windowed with its
+    second moments), Gram-Schmidt orthonormalised in order (probe.py:534-644;
+    Odstrcil et al., Opt. Express 2018).  Host arrays."""
+    if nmodes < 1:
+        raise ValueError(f"nmodes cannot be less than 1. It was {nmodes}.")
+    if probe.ndim < 3:
+        raise ValueError("probe is incorrect shape is should be "
+                         f" (..., 1, W, H) not {probe.shape}.")
+    probe = np.asarray(probe)
+    M = int(np.ceil(np.sqrt(nmodes)))
+    N = int(np.ceil(nmodes / M))
+    off = probe.shape[-2] // 2 - 1
+    X, Y = np.meshgrid(np.arange(probe.shape[-2]) - off,
+                       np.arange(probe.shape[-1]) - off, indexing="xy")
+    weight = np.abs(probe)**2
+    total = weight.sum(axis=(-2, -1), keepdims=True)
+    moment = lambda g: (g * weight).sum(axis=(-2, -1), keepdims=True) / total
+    dx, dy = X - moment(X), Y - moment(Y)
+    window = np.exp(-dx**2 / (2 * moment(dx**2)) - dy**2 / (2 * moment(dy**2)))
+    norm = lambda a: np.sqrt(
+        np.sum(np.abs(a)**2, axis=(-2, -1), keepdims=True))
+    modes = []
+    for count in range(nmodes):
+        ny, mx = divmod(count, M)
+        assert ny < N
+        basis = dx**mx * dy**ny * probe
+        if count:
+            basis = basis * window
+        basis = basis / norm(basis)
+        for earlier in modes:
+            basis = basis - earlier * np.sum(
+                np.conj(earlier) * basis, axis=(-2, -1), keepdims=True)
+        modes.append(basis / norm(basis))
+    return np.concatenate(modes, axis=-3)
+
+
+def simulate_varying_weights(scan, eigen_probe):
+    """Random sinusoidal eigen-probe weights along the scan: amplitude 1,
+    random phase, period at most one scan (probe.py:647-657)."""
+    N = scan.shape[1]
+    x = np.arange(N)[..., :, None, None]
+    period = N * np.random.rand(*eigen_probe.shape[:-2])
+    phase = 2 * np.pi * np.random.rand(*eigen_probe.shape[:-2])
+    return np.sin(2 * np.pi / period * x - phase)

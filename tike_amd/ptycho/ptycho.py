@@ -32,8 +32,10 @@ from .object import (positivity_constraint, remove_object_ambiguity,
                      smoothness_constraint)
 from .position import (affine_position_regularization,
                        check_allowed_positions)
-from .probe import (constrain_variable_probe, finite_probe_support,
-                    get_varying_probe, orthogonalize_eig, power as probe_power,
+from .probe import (apply_median_filter_abs_probe, constrain_center_peak,
+                    constrain_probe_sparsity, constrain_variable_probe,
+                    finite_probe_support, get_varying_probe, orthogonalize_eig,
+                    power as probe_power,
                     rescale_probe_using_fixed_intensity_photons)
 from .solvers.lstsq import chunk_positions, mask_info
 from .._lib import check, lib
@@ -440,8 +442,7 @@ class Reconstruction():
 
 
 def _apply_probe_constraints(parameters, *, epoch):
-    """ptycho.py:723-808 (median filter, centring and sparsity constraints are
-    host-side utilities outside the accelerated scope)."""
+    """ptycho.py:723-808."""
     po = parameters.probe_options
     if po is None:
         return parameters
@@ -458,13 +459,14 @@ def _apply_probe_constraints(parameters, *, epoch):
                 device=parameters.probe.device)[..., None, None]
             parameters.probe = parameters.probe - b1 * torch.conj(
                 b1 * parameters.probe)
-        for flag in ("median_filter_abs_probe", "force_centered_intensity"):
-            if getattr(po, flag):
-                raise NotImplementedError(
-                    f"ProbeOptions.{flag} is outside the accelerated scope")
-        if po.force_sparsity not in (0, 0.0, 1, 1.0):
-            raise NotImplementedError(
-                "ProbeOptions.force_sparsity is outside the accelerated scope")
+        if po.median_filter_abs_probe:
+            parameters.probe = apply_median_filter_abs_probe(
+                parameters.probe, med_filt_px=po.median_filter_abs_probe_px)
+        if po.force_centered_intensity:
+            parameters.probe = constrain_center_peak(parameters.probe)
+        if po.force_sparsity < 1:
+            parameters.probe = constrain_probe_sparsity(parameters.probe,
+                                                        f=po.force_sparsity)
         if po.force_orthogonality:
             parameters.probe, pwr = orthogonalize_eig(parameters.probe)
             parameters.probe = parameters.probe.contiguous()
