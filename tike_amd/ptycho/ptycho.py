@@ -296,8 +296,9 @@ class Reconstruction():
             warnings.warn(
                 "Diffraction patterns contain invalid data. "
                 "All data should be non-negative and finite.", UserWarning)
-        if not self._presharded:
-            self.comm.sync_random()
+        # every rank draws the same minibatch permutation / RANSAC subsets
+        # (also when the caller sharded the data itself)
+        self.comm.sync_random()
         self.order, self.local_order, self.batches = self._shard(
             data.shape[0])
         # HBM-resident data in batch-contiguous order: float32, or uint16 when
