@@ -159,7 +159,7 @@ int tike_grad_ifft2_crop(const void* colin, const float* gscale, const float* mo
 /* ---- the inverse transform split for the gradient pass (lstsq.py:504-539).
  * Pass 1 only: `work` (ntile,det,det) receives the INPUT of the inverse column
  * pass of every tile (rows 16 k + ya of fft_engine2.h) -- from the forward
- * kernel's scratch (tike_grad_ifft2_pass1, det = 256; operands as
+ * kernel's scratch (tike_grad_ifft2_pass1, det = 256 or 512; operands as
  * tike_grad_ifft2_crop) or from a stored far plane times gscale
  * [* mode_scale on measured pixels] (tike_ifft2_pass1_scaled, det in
  * {128,256,512}; operands as tike_ifft2_crop_scaled_modes, mode_scale /

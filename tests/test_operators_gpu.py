@@ -456,6 +456,38 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
         check(lib.tike_ifft2_pass1_scaled(A.ptr(far), A.ptr(g), None, None, S,
                                           A.ptr(work), N * S, det, st))
         fused_gradients(work, "stored far plane")
+    if det == 512 and pw == det and S <= 4:
+        # far-plane free at 512^2: split forward, then gradient + inverse pass 1
+        # straight from the hand-off (radix-32 column pass re-formed in
+        # registers), finished by the fused pass 2
+        scratch = torch.empty_like(far)
+        g5, costs5 = torch.empty_like(g), torch.empty_like(costs)
+        check(lib.tike_fwd_pass1(
+            A.ptr(psi_d), A.ptr(scan_d), A.ptr(probe_d), 0, None, A.ptr(eig_d),
+            A.ptr(w_d), C, 1, A.ptr(scratch), None, N, S, pw, det, HW, HW, st))
+        check(lib.tike_fwd_gradient_scale(
+            A.ptr(scratch), A.ptr(d_d), 0, A.ptr(m_d), A.ptr(g5), None,
+            A.ptr(costs5), None, N, S, det, 1.0 / det, 0, 0.5, int(mask.sum()),
+            st))
+        np.testing.assert_allclose(costs5.cpu().numpy(), want_cost,
+                                   rtol=COST_RTOL)
+        work = torch.empty_like(far)
+        check(lib.tike_grad_ifft2_pass1(A.ptr(scratch), A.ptr(g), None, None, S,
+                                        A.ptr(work), N * S, det, 1.0 / det, st))
+        fused_gradients(work, "no far plane, 512")
+        # ... and the same intermediate as the stored-far-plane pass 1, also
+        # with per-mode steps on measured pixels (poisson form)
+        steps = torch.rand((N, S), dtype=torch.float32, device=dev) + 0.5
+        for sp, mp in ((None, None), (steps, m_d)):
+            w_ref = torch.empty_like(far)
+            check(lib.tike_ifft2_pass1_scaled(A.ptr(far), A.ptr(g), A.ptr(sp),
+                                              A.ptr(mp), S, A.ptr(w_ref), N * S,
+                                              det, st))
+            check(lib.tike_grad_ifft2_pass1(A.ptr(scratch), A.ptr(g), A.ptr(sp),
+                                            A.ptr(mp), S, A.ptr(work), N * S,
+                                            det, 1.0 / det, st))
+            assert_close(work.cpu().numpy(), w_ref.cpu().numpy(), normwise=1e-5,
+                         maxabs=1e-4, what="inverse intermediate at 512")
     if det == 256:
         # the far-plane-free pipeline: forward for the intensity only, then the
         # gradient and the inverse transform from the column-pass scratch

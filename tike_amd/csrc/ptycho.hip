@@ -1554,6 +1554,63 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
   }
 }
 
+// The same at 512^2 (RB = 32): per tile and k1 a thread owns one column,
+//   F[k1 + 16 k2] = radix-32 over r of rows 16 r + k1 of the hand-off, times g;
+// the 32 rows it then holds are exactly TWO input groups of the inverse's pass
+// 1 (rows of residue k1 and k1 + 16 mod 32: k2 even / odd), so they go through
+// LDS into the row layout and through fft2_pass1 -- the result is the
+// intermediate tike_ifft2_pass1_scaled would have produced from a stored far
+// plane, which tike_ifft2_pass2_gradients finishes.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void grad_ifft2_pass1_512_kernel(
+    const cf* __restrict__ colin, cf* __restrict__ work, long ntile, float fwd_scale,
+    const cf* __restrict__ twtab, const float* __restrict__ gscale, int S,
+    const float* __restrict__ mode_scale, const unsigned char* __restrict__ measured) {
+  constexpr int N = 512;
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int t = threadIdx.x;
+  const long nscan = ntile / S;
+  const long nvirt = ((nscan + 7) / 8) * 8 * S;
+  for (long w = blockIdx.x; w < nvirt * 16; w += gridDim.x) {
+    const long tile = tk_xcd_tile(w % nvirt, S, nscan);
+    const int k1 = (int)(w / nvirt);
+    if (tile < 0) continue;  // uniform
+    const cf* __restrict__ src = colin + tile * (long)N * N;
+    cf* __restrict__ mid = work + tile * (long)N * N;
+    const float* __restrict__ gs = gscale + (tile / S) * (long)N * N;
+    const float ms = MODE == 2 ? mode_scale[tile] : 1.0f;
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    cf u[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) u[r] = tk_ld_stream(src + (16 * r + k1) * N + t);
+    Dft<32, false>::run(u);
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) {
+      const int p = (k1 + 16 * k2) * N + t;
+      float g = gs[p] * fwd_scale;
+      if (MODE == 2 && (measured == nullptr || measured[p])) g *= ms;
+      u[k2] = u[k2] * g;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // rows k1 + 16 h + 32 y2 (column t) -> row layout of pass-1 group k1 + 16 h
+#pragma unroll
+      for (int y2 = 0; y2 < 16; ++y2) lds[y2 * G2::LS + tk_pad16(t)] = u[2 * y2 + h];
+      __syncthreads();
+      const cf* __restrict__ lrow = lds + line * G2::LS;
+      fft2_pass1<N, true, true>(
+          lds, twtab, tw, line, j, k1 + 16 * h,
+          [&](int, int e, auto) { return lrow[tk_pad16(e)]; }, mid);
+    }
+  }
+}
+
 static int launch_grad_ifft2(const void* colin, const float* gscale, const float* mode_scale,
                              const unsigned char* measured, int S, void* work, void* chi,
                              long ntile, int pw, float fwd_scale, float inv_scale,
@@ -1613,6 +1670,22 @@ extern "C" int tike_grad_ifft2_pass1(const void* colin, const float* gscale,
   TK_CHECK_ARG(ntile >= 0 && S >= 1 && det >= 1);
   if (ntile == 0) return TK_OK;
   TK_CHECK_ARG(colin && gscale && work && work != colin && ntile % S == 0);
+  if (det == 512) {
+    const cf* tw = tk_twiddles();
+    if (!tw) return (int)hipErrorNotInitialized;
+    const long nvirt = ((ntile / S + 7) / 8) * 8 * S;
+    const int grid8 = (tk_grid(nvirt * 16, 2) + 7) / 8 * 8;
+    if (mode_scale)
+      hipLaunchKernelGGL((grad_ifft2_pass1_512_kernel<2>), dim3(grid8), dim3(512), 0, stream,
+                         (const cf*)colin, (cf*)work, ntile, fwd_scale, tw, gscale, S, mode_scale,
+                         measured);
+    else
+      hipLaunchKernelGGL((grad_ifft2_pass1_512_kernel<1>), dim3(grid8), dim3(512), 0, stream,
+                         (const cf*)colin, (cf*)work, ntile, fwd_scale, tw, gscale, S, mode_scale,
+                         measured);
+    TK_LAUNCH_CHECK();
+    return TK_OK;
+  }
   if (det != 256) return TK_ERR_UNSUPPORTED;
   return launch_grad_ifft2(colin, gscale, mode_scale, measured, S, work, work, ntile, det,
                            fwd_scale, 1.0f, stream, false);

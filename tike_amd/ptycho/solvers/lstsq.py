@@ -344,7 +344,10 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                         torch.float32, dev)
     # detector sizes with the far-plane-free pipeline (the per-mode poisson
     # steps of 'all_modes' need |F_s|^2 and keep the stored far plane)
-    no_farplane = (pos_major and det in NO_FARPLANE_SIZES
+    # (512^2: only together with the fused pass 2, the generic gradient +
+    # inverse + crop kernel exists at 256^2 only)
+    no_farplane = (pos_major
+                   and (det in NO_FARPLANE_SIZES or (det == 512 and fused))
                    and not (poisson and exitwave_options.step_length_usemodes
                             != "dominant_mode"))
     if poisson:
