@@ -895,3 +895,128 @@ def test_data_streamed_from_pinned_host_matches_resident(tp, monkeypatch, det,
                                np.array(b.algorithm_options.costs), rtol=1e-5)
     assert_close(a.psi, b.psi, normwise=1e-5, maxabs=1e-4, what="psi")
     assert_close(a.probe, b.probe, normwise=1e-5, maxabs=1e-4, what="probe")
+
+
+@pytest.mark.parametrize("det,S,N", [(256, 8, 1000), (512, 4, 400)])
+def test_full_size_fused_gradient_adjoint(tp, det, S, N):
+    """The bench's launch sizes (c3: 1000 positions x 8 modes x 256^2; c5: 400
+    x 4 x 512^2), checked through a size-independent property: the fused
+    gradient kernels (inverse pass 1 -> pass 2 + both gradients -> grouped
+    scatter) are the adjoint of the forward operator,
+        <A(psi) , G> = <psi , A^H G>   and   <A(probe) , G> = <probe , A^H G>,
+    for a random far-plane array G (gradient factor 1)."""
+    import torch
+    import tike_amd._arrays as A
+    import tike_amd.operators as ops
+    from tike_amd._lib import check, lib
+    from tike_amd import cluster
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(det)
+    pw = det
+    side = int(np.ceil(np.sqrt(N)))
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"),
+                  -1).reshape(-1, 2)[:N]
+    scan_np = (1 + 8.0 * ij + rng.random((N, 2))).astype(np.float32)
+    scan_np = scan_np[cluster.spatial_order(scan_np)]
+    HW = int(np.ceil((8 * (side - 1) + pw + 4) / 32.0) * 32)
+    g = torch.Generator(device=dev).manual_seed(det)
+    rc = lambda *s: torch.view_as_complex(
+        torch.rand(*s, 2, device=dev, generator=g) - 0.5)
+    psi, probe = rc(1, HW, HW), rc(1, 1, S, pw, pw)
+    scan = A.to_device(scan_np)
+    G = rc(N, 1, S, det, det)
+    st = A.stream_ptr()
+    with ops.Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+        far = torch.empty_like(G)
+        op.fwd_device(probe, scan, psi, out=far)
+    lhs = (far * G.conj()).sum()
+    del far
+    ones = torch.ones(N, det, det, device=dev)
+    work = torch.empty_like(G)
+    check(lib.tike_ifft2_pass1_scaled(A.ptr(G), A.ptr(ones), None, None, S,
+                                      A.ptr(work), N * S, det, st))
+    patches = torch.empty(N, pw, pw, dtype=torch.complex64, device=dev)
+    scratch = torch.empty_like(G)
+    check(lib.tike_fwd_pass1(A.ptr(psi), A.ptr(scan), A.ptr(probe), 0, None,
+                             None, None, 0, 0, A.ptr(scratch), A.ptr(patches),
+                             N, S, pw, det, HW, HW, st))
+    del scratch
+    objproj = torch.empty_like(patches)
+    chi0 = torch.empty_like(patches)
+    mpu = torch.zeros(1, 1, S, pw, pw, dtype=torch.complex64, device=dev)
+    check(lib.tike_ifft2_pass2_gradients(
+        A.ptr(work), A.ptr(patches), A.ptr(probe), None, None, 0, 0,
+        A.ptr(objproj), A.ptr(chi0), A.ptr(mpu), 1.0, N, S, det, 1.0 / det, st))
+    acc = torch.zeros(2, HW, HW, device=dev)
+    check(lib.tike_scatter_patches(A.ptr(objproj), A.ptr(scan), A.ptr(acc), N,
+                                   pw, HW, HW, st))
+    adj_psi = torch.complex(acc[0], acc[1])
+    rhs_psi = (psi[0] * adj_psi.conj()).sum()
+    rhs_probe = (probe * mpu.conj()).sum()
+    scale = float(lhs.abs())
+    for name, rhs in (("psi", rhs_psi), ("probe", rhs_probe)):
+        err = float((lhs - rhs).abs()) / scale
+        assert err < 2e-4, (name, err, complex(lhs), complex(rhs))
+
+
+@pytest.mark.parametrize("det,S,N", [(256, 8, 1000), (512, 4, 400)])
+def test_full_size_far_plane_free_chain_matches_stored_far_plane(tp, det, S, N):
+    """At the bench's launch sizes the far-plane-free chain (forward pass 1 ->
+    streamed column pass + gradient factor -> gradient + inverse pass 1) hands
+    pass 2 the same intermediate, costs and factor as the stored-far-plane
+    kernels (forward operator -> gradient scale -> scaled inverse pass 1), and
+    the costs are the gaussian objective of the stored far plane."""
+    import torch
+    import tike_amd._arrays as A
+    import tike_amd.operators as ops
+    from tike_amd._lib import check, lib
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(det + 1)
+    pw = det
+    side = int(np.ceil(np.sqrt(N)))
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"),
+                  -1).reshape(-1, 2)[:N]
+    scan = A.to_device((1 + 8.0 * ij + rng.random((N, 2))).astype(np.float32))
+    HW = int(np.ceil((8 * (side - 1) + pw + 4) / 32.0) * 32)
+    g = torch.Generator(device=dev).manual_seed(det)
+    rc = lambda *s: torch.view_as_complex(
+        torch.rand(*s, 2, device=dev, generator=g) - 0.5)
+    psi, probe = rc(1, HW, HW) + 1, rc(1, 1, S, pw, pw)
+    data = torch.rand(N, det, det, device=dev, generator=g) * 50
+    st = A.stream_ptr()
+    with ops.Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+        far = torch.empty(N, 1, S, det, det, dtype=torch.complex64, device=dev)
+        op.fwd_device(probe, scan, psi, out=far)
+    inten = (far.abs()**2).sum(dim=(1, 2))
+    want_cost = ((inten.sqrt() - data.sqrt())**2).mean(dim=(-2, -1))
+    scratch = torch.empty_like(far)
+    gs = torch.empty(N, det, det, device=dev)
+    costs = torch.empty(N, device=dev)
+    check(lib.tike_fwd_pass1(A.ptr(psi), A.ptr(scan), A.ptr(probe), 0, None,
+                             None, None, 0, 0, A.ptr(scratch), None, N, S, pw,
+                             det, HW, HW, st))
+    check(lib.tike_fwd_gradient_scale(A.ptr(scratch), A.ptr(data), 0, None,
+                                      A.ptr(gs), None, A.ptr(costs), None, N, S,
+                                      det, 1.0 / det, 0, 1.0, det * det, st))
+    torch.testing.assert_close(costs, want_cost, rtol=2e-4, atol=1e-6)
+    work = torch.empty_like(far)
+    check(lib.tike_grad_ifft2_pass1(A.ptr(scratch), A.ptr(gs), None, None, S,
+                                    A.ptr(work), N * S, det, 1.0 / det, st))
+    del scratch
+    ref = torch.empty_like(far)
+    check(lib.tike_ifft2_pass1_scaled(A.ptr(far), A.ptr(gs), None, None, S,
+                                      A.ptr(ref), N * S, det, st))
+    if det == 256:
+        # different (equivalent) factorisations of the inverse at 256^2: the
+        # intermediates differ, what pass 2 makes of them must not
+        outs = []
+        patches = torch.zeros(N, pw, pw, dtype=torch.complex64, device=dev)
+        for w in (work, ref):
+            chi0 = torch.empty_like(patches)
+            check(lib.tike_ifft2_pass2_gradients(
+                A.ptr(w), A.ptr(patches), None, None, None, 0, 0, None,
+                A.ptr(chi0), None, 1.0, N, S, det, 1.0 / det, st))
+            outs.append(chi0)
+        work, ref = outs
+    err = float((work - ref).abs().max()) / float(ref.abs().max())
+    assert err < 2e-5, err
