@@ -412,7 +412,8 @@ int tike_probe_update(void* probe, void* combined, const void* mpu, const float*
  *   norms[c-1] = sum_n weights[n][c][m]^2 for c = 1..C (local; all-reduce).
  * tike_eigen_proj_mean: pm[n] = (first[n*first_stride] / P + weights_c[n*row]) / norm[0].
  * tike_eigen_normalise: E <- E + beta u / mnorm(u), u = update / count, then
- *   E <- E / mnorm(E); esum[0] = sum |E|^2 (may be NULL).
+ *   E <- E / mnorm(E); esum[0] = sum |E|^2 (may be NULL); work: 4 floats of device
+ *   scratch (the sums both norms follow from).
  * tike_eigen_dsum: dsum[0] = sum_n sums[n][2] / P (local; all-reduce).
  * tike_eigen_weights: weights_c[n*row] += (sums[n][1]/P) / (sums[n][2]/P + 0.1
  *   dsum[0] / count); coefs_c[n*coef_stride] = (sums[n][3] + i sums[n][4]) / esum[0]
@@ -423,7 +424,7 @@ int tike_eigen_proj_mean(const float* first, int first_stride, const float* weig
                          long weights_row, const float* norm, long P, int B, float* pm,
                          void* stream);
 int tike_eigen_normalise(void* eigen, const void* update, double count, float beta, int npix,
-                         float* esum, void* stream);
+                         float* esum, float* work, void* stream);
 int tike_eigen_dsum(const float* sums, int B, long P, float* dsum, void* stream);
 int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, double count,
                        float* weights_c, long weights_row, void* coefs_c, int coef_stride,

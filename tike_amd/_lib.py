@@ -78,7 +78,7 @@ _PROTOTYPES = {
     "tike_probe_update": [_p, _p, _p, _p, _f, _l, _p],
     "tike_eigen_weights0": [_p, _p, _i, _i, _i, _i, _p, _p],
     "tike_eigen_proj_mean": [_p, _i, _p, _l, _p, _l, _i, _p, _p],
-    "tike_eigen_normalise": [_p, _p, _d, _f, _i, _p, _p],
+    "tike_eigen_normalise": [_p, _p, _d, _f, _i, _p, _p, _p],
     "tike_eigen_dsum": [_p, _i, _l, _p, _p],
     "tike_eigen_weights": [_p, _i, _l, _p, _d, _p, _l, _p, _i, _p, _p],
     "tike_grad_ifft2_crop": [_p, _p, _p, _p, _i, _p, _p, _l, _i, _i, _f, _f,

@@ -232,52 +232,72 @@ extern "C" int tike_eigen_proj_mean(const float* first, int first_stride, const 
 }
 
 // E <- normalise(E + beta * u / mnorm(u)),  u = update / count  (probe.py:440-448;
-// mnorm = sqrt(mean |.|^2)).  esum[0] = sum |E_new|^2.  One workgroup of 1024.
-__global__ __launch_bounds__(1024) void eigen_normalise_kernel(cf* __restrict__ E,
-                                                               const cf* __restrict__ update,
-                                                               float inv_count, float beta,
-                                                               int npix,
-                                                               float* __restrict__ esum) {
-  __shared__ float red[16];
-  __shared__ float bc;
-  auto block_sum = [&](float v) {
-    v = tk_wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-    for (int w = 0; w < 16; ++w) t += red[w];
-    return t;
-  };
-  float a = 0.f;
-  for (int i = threadIdx.x; i < npix; i += 1024) a += norm2(update[i] * inv_count);
-  const float mu = sqrtf(block_sum(a) / (float)npix);
-  const float k = beta / mu * inv_count;
-  float b = 0.f;
-  for (int i = threadIdx.x; i < npix; i += 1024) {
-    const cf e = E[i] + update[i] * k;
-    E[i] = e;
-    b += norm2(e);
+// mnorm = sqrt(mean |.|^2)).  esum[0] = sum |E_new|^2.  Two launches over many
+// workgroups instead of three dependent sweeps of one: the first forms
+// sum |update|^2, sum |E|^2 and sum Re(conj(E) update), from which both norms
+// follow (|E + k u|^2 = |E|^2 + 2 k Re(conj(E) u) + k^2 |u|^2); the second
+// applies the update and the normalisation and accumulates esum.
+// acc: 4 floats { sum|update|^2, sum|E|^2, sum Re(conj(E) update), esum }, zeroed.
+__global__ __launch_bounds__(256) void eigen_normalise_sums_kernel(const cf* __restrict__ E,
+                                                                   const cf* __restrict__ update,
+                                                                   int npix,
+                                                                   float* __restrict__ acc) {
+  __shared__ float red[4];
+  float uu = 0.f, ee = 0.f, eu = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const cf e = E[i], u = update[i];
+    uu += norm2(u);
+    ee += norm2(e);
+    eu += e.x * u.x + e.y * u.y;
   }
-  const float me = sqrtf(block_sum(b) / (float)npix);
-  const float inv = 1.0f / me;
+  uu = tk_block_sum256(uu, red);
+  ee = tk_block_sum256(ee, red);
+  eu = tk_block_sum256(eu, red);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(&acc[0], uu);
+    unsafeAtomicAdd(&acc[1], ee);
+    unsafeAtomicAdd(&acc[2], eu);
+  }
+}
+
+__global__ __launch_bounds__(256) void eigen_normalise_apply_kernel(cf* __restrict__ E,
+                                                                    const cf* __restrict__ update,
+                                                                    float inv_count, float beta,
+                                                                    int npix,
+                                                                    float* __restrict__ acc) {
+  __shared__ float red[4];
+  const float uu = acc[0], ee = acc[1], eu = acc[2];
+  const float mu = sqrtf(uu * inv_count * inv_count / (float)npix);
+  const float k = beta / mu * inv_count;
+  const float inv = 1.0f / sqrtf((ee + 2.0f * k * eu + k * k * uu) / (float)npix);
   float c = 0.f;
-  for (int i = threadIdx.x; i < npix; i += 1024) {
-    const cf e = E[i] * inv;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const cf e = (E[i] + update[i] * k) * inv;
     E[i] = e;
     c += norm2(e);
   }
-  c = block_sum(c);
-  if (threadIdx.x == 0 && esum) esum[0] = c;
-  (void)bc;
+  c = tk_block_sum256(c, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(&acc[3], c);
+}
+
+__global__ void eigen_normalise_finish_kernel(const float* __restrict__ acc,
+                                              float* __restrict__ esum) {
+  esum[0] = acc[3];
 }
 
 extern "C" int tike_eigen_normalise(void* eigen, const void* update, double count, float beta,
-                                    int npix, float* esum, void* stream) {
+                                    int npix, float* esum, float* work, void* stream) {
   TK_ENTER();
-  TK_CHECK_ARG(npix >= 1 && eigen && update && count > 0);
-  hipLaunchKernelGGL(eigen_normalise_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream,
-                     (cf*)eigen, (const cf*)update, (float)(1.0 / count), beta, npix, esum);
+  TK_CHECK_ARG(npix >= 1 && eigen && update && work && count > 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(work, 0, 4 * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  const int grid = npix >= 256 * 64 ? 64 : (npix + 255) / 256;
+  hipLaunchKernelGGL(eigen_normalise_sums_kernel, dim3(grid), dim3(256), 0, st, (const cf*)eigen,
+                     (const cf*)update, npix, work);
+  hipLaunchKernelGGL(eigen_normalise_apply_kernel, dim3(grid), dim3(256), 0, st, (cf*)eigen,
+                     (const cf*)update, (float)(1.0 / count), beta, npix, work);
+  if (esum) hipLaunchKernelGGL(eigen_normalise_finish_kernel, dim3(1), dim3(1), 0, st, work, esum);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -716,6 +716,7 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
     coefs = torch.zeros((max(B, 1), C), dtype=torch.complex64, device=dev)
     pm = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
     small = torch.empty(2, dtype=torch.float32, device=dev)  # dsum, esum
+    nwork = torch.empty(4, dtype=torch.float32, device=dev)
     ep = eigen_probe  # (1, C, Sm, pw, pw), updated in place, read by kernels
 
     def position_sums(c):
@@ -753,7 +754,7 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
         E = ep[0, c - 1, m]  # (pw, pw) view, contiguous
         check(
             lib.tike_eigen_normalise(A.ptr(E), A.ptr(update), count, beta, P,
-                                     small[1:].data_ptr(), st),
+                                     small[1:].data_ptr(), A.ptr(nwork), st),
             "eigen probe normalisation")
         # new weights for the updated eigen probe (and the projection of the
         # residual onto it, removed before the next eigen probe)
