@@ -722,8 +722,15 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
   if (det == 128 && MW == 1) MW = 2;  // a 128-wide tile has only two 64-column waves
   const int MPW = S > 4 ? 2 : 1;
   const int nslice = 16 * (det / (64 * (4 / MW)));
-  // enough (slice, chunk) workgroups to fill the chip about three times
+  // enough (slice, chunk) workgroups to fill the chip about four times -- and
+  // in WHOLE rounds: the kernel holds two workgroups per CU (512 at a time) and
+  // every workgroup walks the same number of positions, so 4.5 rounds cost 5
   int nchunk = (2304 + nslice - 1) / nslice;
+  {
+    int unit = 512, a = nslice;  // unit = 512 / gcd(512, nslice)
+    while (a % 2 == 0 && unit > 1) { a /= 2; unit /= 2; }
+    if (nchunk >= unit) nchunk = nchunk / unit * unit;
+  }
   int chunk = (nscan + nchunk - 1) / nchunk;
   if (chunk < 8) chunk = 8;
   nchunk = (nscan + chunk - 1) / chunk;
