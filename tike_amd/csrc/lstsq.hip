@@ -520,7 +520,10 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
   const int v = blockIdx.x;
   constexpr int per = NSLICE / 8;
   const int slice = (v & 7) * per + (v >> 3) % per;
-  const int b0 = ((v >> 3) / per) * chunk;
+  // chunks in DESCENDING order: the inverse pass 1 wrote the intermediate in
+  // ascending position order, its tail is still in the Infinity Cache
+  const int nchunk_ = (nscan + chunk - 1) / chunk;
+  const int b0 = (nchunk_ - 1 - ((v >> 3) / per)) * chunk;
   const int b1 = min(nscan, b0 + chunk);
   const int ya = slice / NCB, cb = slice % NCB;
   // the wave index is uniform: say so, so that everything derived from it

@@ -734,7 +734,11 @@ __global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kern
     // item = (position, k1, column block)
     const int hb = (int)(v % NH);
     const int k1 = (int)((v / NH) & 15);
-    const long n = v / (16 * NH);
+    // positions in DESCENDING order: the last hand-off tiles forward pass 1
+    // wrote (ascending) are still in the 256 MB Infinity Cache when this
+    // kernel starts, and the ones read last here are the first the next
+    // kernel (ascending again) asks for
+    const long n = nitem / (16 * NH) - 1 - v / (16 * NH);
     const int t = hb * 256 + threadIdx.x;
     float I[RB];
 #pragma unroll
