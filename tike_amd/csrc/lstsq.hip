@@ -725,10 +725,10 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
   if (det == 128 && MW == 1) MW = 2;  // a 128-wide tile has only two 64-column waves
   const int MPW = S > 4 ? 2 : 1;
   const int nslice = 16 * (det / (64 * (4 / MW)));
-  // enough (slice, chunk) workgroups to fill the chip about four times -- and
+  // enough (slice, chunk) workgroups to fill the chip about twice -- and
   // in WHOLE rounds: the kernel holds two workgroups per CU (512 at a time) and
   // every workgroup walks the same number of positions, so 4.5 rounds cost 5
-  int nchunk = (2304 + nslice - 1) / nslice;
+  int nchunk = (1024 + nslice - 1) / nslice;
   {
     int unit = 512, a = nslice;  // unit = 512 / gcd(512, nslice)
     while (a % 2 == 0 && unit > 1) { a /= 2; unit /= 2; }
@@ -812,11 +812,16 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
     const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
     const cf* __restrict__ gobj, const TkProbe probe, const cf* __restrict__ mpu,
     const cf* __restrict__ patches, float* __restrict__ stats, int nscan, int chi_modes, int pw,
-    int H, int W, const cf* __restrict__ eigen0, float* __restrict__ eigen_proj) {
+    int H, int W, const cf* __restrict__ eigen0, float* __restrict__ eigen_proj, int nsplit) {
   __shared__ float red[4];
   const long P = (long)pw * pw;
   const long total = (long)H * W;
-  for (int n = blockIdx.x; n < nscan; n += gridDim.x) {
+  // work item = (position, 1 / nsplit of its pixels): a minibatch of a few
+  // hundred positions would otherwise leave most of the chip idle; with
+  // nsplit > 1 the sums are accumulated into the (zeroed) tables by atomics
+  const int plen = (int)(P / nsplit);
+  for (int v = blockIdx.x; v < nscan * nsplit; v += gridDim.x) {
+    const int n = v / nsplit, part = v % nsplit;
     const TkCorner c = tk_corner(scan, n);
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ep = 0.f;  // sum Re(conj(R_n) E_0), R_n = conj(O_n) chi_n,0 - mpu_0
@@ -825,9 +830,11 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
     // (row, column) of the pixel advance with the stride instead of a
     // division per pixel
     const int qstep = (int)blockDim.x / pw, rstep = (int)blockDim.x % pw;
-    int py = (int)threadIdx.x / pw, px = (int)threadIdx.x % pw;
+    const int pbeg = part * plen + (int)threadIdx.x;
+    const int pend = part + 1 == nsplit ? (int)P : (part + 1) * plen;
+    int py = pbeg / pw, px = pbeg % pw;
 #pragma unroll 2
-    for (int p = threadIdx.x; p < (int)P; p += blockDim.x) {
+    for (int p = pbeg; p < pend; p += blockDim.x) {
       const int y = c.sy + py, x = c.sx + px;
       const bool ok = y >= 0 && y < H && x >= 0 && x < W;
       const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
@@ -867,12 +874,22 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float v = tk_block_sum256(a[k], red);
-      if (threadIdx.x == 0) stats[(long)n * 8 + k] = v;
+      const float t = tk_block_sum256(a[k], red);
+      if (threadIdx.x == 0) {
+        if (nsplit > 1)
+          unsafeAtomicAdd(&stats[(long)n * 8 + k], t);
+        else
+          stats[(long)n * 8 + k] = t;
+      }
     }
     if (eigen_proj) {
-      const float v = tk_block_sum256(ep, red);
-      if (threadIdx.x == 0) eigen_proj[n] = v;
+      const float t = tk_block_sum256(ep, red);
+      if (threadIdx.x == 0) {
+        if (nsplit > 1)
+          unsafeAtomicAdd(&eigen_proj[n], t);
+        else
+          eigen_proj[n] = t;
+      }
     }
   }
 }
@@ -891,12 +908,24 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
   TK_CHECK_ARG(!eigen_proj || (eigen0 && m_probe_update));
   const TkProbe pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
                                    S, pw, unique_probe);
+  // split the pixels of a position over several workgroups until the launch
+  // holds ~4096 of them (probe windows that are a multiple of 1024 pixels)
+  int nsplit = 1;
+  while (nsplit < 16 && (long)nscan * nsplit * 2 <= 4096 && ((long)pw * pw) % (2048L * nsplit) == 0)
+    nsplit *= 2;
+  if (nsplit > 1) {
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 8 * (size_t)nscan, (hipStream_t)stream);
+    if (e == hipSuccess && eigen_proj)
+      e = hipMemsetAsync(eigen_proj, 0, sizeof(float) * (size_t)nscan, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
 #define TK_SS(HP, HG)                                                                         \
-  hipLaunchKernelGGL((step_stats_kernel<HP, HG>), dim3(tk_grid(nscan, 16)), dim3(256), 0,     \
+  hipLaunchKernelGGL((step_stats_kernel<HP, HG>), dim3(tk_grid((long)nscan * nsplit, 16)),    \
+                     dim3(256), 0,                                                            \
                      (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,               \
                      (const cf*)object_update_precond, pr, (const cf*)m_probe_update,         \
                      (const cf*)patches, stats, nscan, chi_modes, pw, H, W, (const cf*)eigen0, \
-                     eigen_proj)
+                     eigen_proj, nsplit)
   if (patches && object_update_precond) TK_SS(true, true);
   else if (patches) TK_SS(true, false);
   else if (object_update_precond) TK_SS(false, true);
@@ -1083,16 +1112,20 @@ struct TkTaps {
 __global__ __launch_bounds__(256) void position_sums_kernel(
     const cf* __restrict__ patches, const cf* __restrict__ chi, int chi_modes,
     const TkProbe probe, const TkTaps taps, float* __restrict__ num, float* __restrict__ den,
-    int pw) {
+    int pw, int nsplit) {
   __shared__ float red[4];
-  const long n = blockIdx.x;
+  // work item = (position, 1 / nsplit of the window): see step_stats_kernel
+  const long n = blockIdx.x / nsplit;
+  const int part = blockIdx.x % nsplit;
   const long P = (long)pw * pw;
   const cf* __restrict__ O = patches + n * P;
   const cf* __restrict__ X = chi + n * chi_modes * P;
   const int crop = pw / 4;
   const int w = pw - 2 * crop;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < w * w; i += blockDim.x) {
+  const int ilen = (w * w + nsplit - 1) / nsplit;
+  const int iend = min(w * w, (part + 1) * ilen);
+  for (int i = part * ilen + threadIdx.x; i < iend; i += blockDim.x) {
     const int y = crop + i / w, x = crop + i % w;
     cf gx = mk(0.f, 0.f), gy = mk(0.f, 0.f);
     for (int d = -taps.r; d <= taps.r; ++d) {
@@ -1117,10 +1150,17 @@ __global__ __launch_bounds__(256) void position_sums_kernel(
   }
   for (int k = 0; k < 4; ++k) a[k] = tk_block_sum256(a[k], red);
   if (threadIdx.x == 0) {
-    num[2 * n] = a[0];
-    num[2 * n + 1] = a[1];
-    den[2 * n] = a[2];
-    den[2 * n + 1] = a[3];
+    if (nsplit > 1) {
+      unsafeAtomicAdd(&num[2 * n], a[0]);
+      unsafeAtomicAdd(&num[2 * n + 1], a[1]);
+      unsafeAtomicAdd(&den[2 * n], a[2]);
+      unsafeAtomicAdd(&den[2 * n + 1], a[3]);
+    } else {
+      num[2 * n] = a[0];
+      num[2 * n + 1] = a[1];
+      den[2 * n] = a[2];
+      den[2 * n + 1] = a[3];
+    }
   }
 }
 
@@ -1138,9 +1178,18 @@ extern "C" int tike_position_sums(const void* patches, const void* chi, int chi_
   for (int k = 0; k < 9; ++k) taps.t[k] = k <= 2 * radius ? taps_host[k] : 0.f;
   const TkProbe pr =
       tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes, S, pw);
-  hipLaunchKernelGGL(position_sums_kernel, dim3(nscan), dim3(256), 0, (hipStream_t)stream,
-                     (const cf*)patches, (const cf*)chi, chi_modes, pr, taps, numerator,
-                     denominator, pw);
+  int nsplit = 1;
+  while (nsplit < 16 && (long)nscan * nsplit * 2 <= 4096 && pw >= 64) nsplit *= 2;
+  if (nsplit > 1) {
+    hipError_t e = hipMemsetAsync(numerator, 0, sizeof(float) * 2 * (size_t)nscan,
+                                  (hipStream_t)stream);
+    if (e == hipSuccess)
+      e = hipMemsetAsync(denominator, 0, sizeof(float) * 2 * (size_t)nscan, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(position_sums_kernel, dim3((unsigned)nscan * nsplit), dim3(256), 0,
+                     (hipStream_t)stream, (const cf*)patches, (const cf*)chi, chi_modes, pr, taps,
+                     numerator, denominator, pw, nsplit);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -697,7 +697,7 @@ extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* pr
                                   eigen_weights, num_eigen, eigen_modes, S, pw, unique_probe);
 #define TK_F1(N, FULL)                                                                          \
   hipLaunchKernelGGL((fwd_pass1_kernel<N, FULL>),                                              \
-                     dim3(tk_grid((long)nscan * (N / 16), N == 256 ? 2 : 1)),                  \
+                     dim3(tk_grid((long)nscan * (N / 16), N == 256 ? 8 : 1)),                  \
                      dim3(N), 0, stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches,   \
                      nscan, S, pw, H, W, tw)
   if (det == 256 && pw == det)
@@ -807,7 +807,7 @@ extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, in
   }
   const long nitem = (long)nscan * 16 * (det / 256);
   const float inv = 1.0f / (float)num_measured;
-  const dim3 grid(tk_grid(nitem, 16)), block(256);
+  const dim3 grid(tk_grid(nitem, 32)), block(256);
 #define TK_FGS(N, M, DT)                                                                     \
   hipLaunchKernelGGL((fwd_gradient_scale_kernel<N, M, DT>), grid, block, 0, stream,             \
                      (const cf*)scratch, (const DT*)data, measured, gscale, intensity, costs,   \
