@@ -10,6 +10,8 @@
 // to the probe window), P_n,s the probe at position n (shared probe plus
 // eigen probes synthesised on the fly) and O_n the bilinear object patch.
 #include "fft_engine2.h"
+#include <type_traits>
+
 #include "internal.h"
 #include "tike_amd.h"
 
@@ -823,6 +825,24 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
   for (int v = blockIdx.x; v < nscan * nsplit; v += gridDim.x) {
     const int n = v / nsplit, part = v % nsplit;
     const TkCorner c = tk_corner(scan, n);
+    // the varying probe of mode 0 (probe.py:272-303): weights and bases are
+    // per position, hoisted here (TkProbe::at re-read them for every pixel)
+    const cf* __restrict__ pbase = probe.probe + n * probe.pos_stride;
+    float pw0 = 1.0f, pw1 = 0.f;
+    int nE = 0;
+    const float* __restrict__ wn = nullptr;
+    if (probe.weights != nullptr) {
+      if (probe.unique != nullptr && 0 < probe.Sm) {
+        pbase = probe.unique + (long)n * probe.Sm * P;
+      } else {
+        wn = probe.weights + n * (long)(probe.C + 1) * probe.S;
+        pw0 = wn[0];
+        if (probe.eigen != nullptr && 0 < probe.Sm) {
+          nE = probe.C;
+          pw1 = wn[probe.S];
+        }
+      }
+    }
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ep = 0.f;  // sum Re(conj(R_n) E_0), R_n = conj(O_n) chi_n,0 - mpu_0
     // branch-free body (clamped addresses, results zeroed by select) so that
@@ -833,45 +853,91 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
     const int pbeg = part * plen + (int)threadIdx.x;
     const int pend = part + 1 == nsplit ? (int)P : (part + 1) * plen;
     int py = pbeg / pw, px = pbeg % pw;
+    // interior position (every tap of every pixel inside the image): the two
+    // taps of a row are adjacent complex values, fetched with one 16-byte load
+    const bool interior = HAVE_GOBJ && c.sy >= 0 && c.sx >= 0 && c.sy + pw < H && c.sx + pw < W &&
+                          total < (1L << 28);
+    // E_0 of the first eigen probe is the array the varying probe adds: one load
+    const bool same_e = eigen_proj != nullptr && nE > 0 && eigen0 == probe.eigen;
+    auto body = [&](auto fast_tag) {
+      constexpr bool FAST = decltype(fast_tag)::value;
 #pragma unroll 2
-    for (int p = pbeg; p < pend; p += blockDim.x) {
-      const int y = c.sy + py, x = c.sx + px;
-      const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-      const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
-      const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
-      const long ii = (long)yc * W + xc;
-      // O_n: the patch stored by tike_lstsq_gradients when available
-      cf o = HAVE_PATCHES ? patches[n * P + p] : tk_gather(psi, ii, W, total, c);
-      cf g = HAVE_GOBJ ? tk_gather(gobj, ii, W, total, c) : mk(0.f, 0.f);
-      if (!ok) {
-        if (!HAVE_PATCHES) o = mk(0.f, 0.f);
-        g = mk(0.f, 0.f);
+      for (int p = pbeg; p < pend; p += blockDim.x) {
+        cf o, g;
+        if (FAST) {
+          typedef float tk_v4f __attribute__((ext_vector_type(4)));
+          const unsigned off =
+              (unsigned)((c.sy + py) * W + c.sx + px) * (unsigned)sizeof(cf);
+          tk_v4f u, l;
+          __builtin_memcpy(&u, reinterpret_cast<const char*>(gobj) + off, sizeof(u));
+          __builtin_memcpy(&l, reinterpret_cast<const char*>(gobj) + off + (unsigned)W * 8u,
+                           sizeof(l));
+          o = patches[n * P + p];
+          g = mk(u.x * c.w00, u.y * c.w00);
+          g.x += u.z * c.w01;
+          g.y += u.w * c.w01;
+          g.x += l.x * c.w10;
+          g.y += l.y * c.w10;
+          g.x += l.z * c.w11;
+          g.y += l.w * c.w11;
+        } else {
+          const int y = c.sy + py, x = c.sx + px;
+          const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+          const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+          const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+          const long ii = (long)yc * W + xc;
+          // O_n: the patch stored by tike_lstsq_gradients when available
+          o = HAVE_PATCHES ? patches[n * P + p] : tk_gather(psi, ii, W, total, c);
+          g = HAVE_GOBJ ? tk_gather(gobj, ii, W, total, c) : mk(0.f, 0.f);
+          if (!ok) {
+            if (!HAVE_PATCHES) o = mk(0.f, 0.f);
+            g = mk(0.f, 0.f);
+          }
+        }
+        const cf x0 = chi[((long)n * chi_modes) * P + p];
+        cf pn = pbase[p] * pw0;
+        cf e1 = mk(0.f, 0.f);
+        if (nE > 0) {
+          e1 = probe.eigen[p];
+          pn.x += pw1 * e1.x;
+          pn.y += pw1 * e1.y;
+          for (int e = 1; e < nE; ++e) {  // uniform, rare
+            const cf ee = probe.eigen[(long)e * probe.Sm * P + p];
+            const float we = wn[(e + 1) * probe.S];
+            pn.x += we * ee.x;
+            pn.y += we * ee.y;
+          }
+        }
+        const cf dOP = g * pn;
+        const cf m0 = mpu ? mpu[p] : mk(0.f, 0.f);
+        const cf dPO = m0 * o;
+        const cf OP = o * probe.probe[p];
+        a[0] += norm2(dOP);
+        a[1] += norm2(dPO);
+        const cf a2 = dOP * conjf(dPO);
+        a[2] += a2.x;
+        a[3] += a2.y;
+        a[4] += dOP.x * x0.x + dOP.y * x0.y;
+        a[5] += dPO.x * x0.x + dPO.y * x0.y;
+        a[6] += OP.x * x0.x + OP.y * x0.y;
+        a[7] += norm2(OP);
+        if (eigen_proj) {
+          const cf r = conjf(o) * x0 - m0;
+          const cf e = same_e ? e1 : eigen0[p];
+          ep += r.x * e.x + r.y * e.y;
+        }
+        py += qstep;
+        px += rstep;
+        if (px >= pw) {
+          px -= pw;
+          ++py;
+        }
       }
-      const cf x0 = chi[((long)n * chi_modes) * P + p];
-      const cf dOP = g * probe.at(n, 0, p);
-      const cf dPO = mpu ? mpu[p] * o : mk(0.f, 0.f);
-      const cf OP = o * probe.probe[p];
-      a[0] += norm2(dOP);
-      a[1] += norm2(dPO);
-      const cf a2 = dOP * conjf(dPO);
-      a[2] += a2.x;
-      a[3] += a2.y;
-      a[4] += dOP.x * x0.x + dOP.y * x0.y;
-      a[5] += dPO.x * x0.x + dPO.y * x0.y;
-      a[6] += OP.x * x0.x + OP.y * x0.y;
-      a[7] += norm2(OP);
-      if (eigen_proj) {
-        const cf r = conjf(o) * x0 - mpu[p];
-        const cf e = eigen0[p];
-        ep += r.x * e.x + r.y * e.y;
-      }
-      py += qstep;
-      px += rstep;
-      if (px >= pw) {
-        px -= pw;
-        ++py;
-      }
-    }
+    };
+    if (HAVE_PATCHES && interior)
+      body(std::true_type{});
+    else
+      body(std::false_type{});
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float t = tk_block_sum256(a[k], red);

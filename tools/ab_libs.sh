@@ -4,7 +4,7 @@
 reps=$1; shift
 for rep in $(seq $reps); do
   for l in "$@"; do
-    TIKE_AMD_LIB=$PWD/tools/probe/_lib/lib_$l.so python3 bench.py --no-cpu-baseline --no-secondary --breakdown --steps 10 2>&1 |
+    TIKE_AMD_LIB=$PWD/tools/probe/_lib/lib_$l.so python3 bench.py --no-cpu-baseline --no-secondary --breakdown --steps ${STEPS:-10} ${WL:+--workload $WL} 2>&1 |
       python3 -c "
 import sys, json, re
 k = {}
