@@ -126,7 +126,7 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
 // every minibatch spatially); a group whose box is wider than the LDS strip
 // falls back to the per-position atomics, so any order gives the same sums.
 constexpr int TK_GROUP = 8;
-constexpr int TK_GROWS = 16;    // image rows per workgroup
+constexpr int TK_GROWS = 8;     // image rows per workgroup (A/B: 8 beats 4, 6, 16, 32)
 constexpr int TK_GSPREAD = 112;  // extra box width and height beyond one footprint
 
 struct TkGroupBox {
