@@ -32,7 +32,7 @@ def _gaussian_options(det):
 
 
 def _cost_and_grad(op, comm, data, psi, scan, probe, lo, hi, *, want_psi,
-                   want_probe, want_grad):
+                   want_probe, want_grad, read_cost=True):
     """Global gaussian cost (mean over all positions and pixels) of the
     minibatch [lo, hi) and, optionally, d cost / d psi and d cost / d probe
     (unnormalised adjoints).
@@ -49,7 +49,7 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, lo, hi, *, want_psi,
         g = _get_nearplane_gradients(
             data, psi, scan, probe, None, None, lo, hi, comm, num_batch=1,
             exitwave_options=_gaussian_options(det), op=op,
-            recover_psi=want_psi, recover_probe=want_probe)
+            recover_psi=want_psi, recover_probe=want_probe, need_chi0=False)
         costs = g["costs"]
         gpsi = gprobe = None
         if want_psi:
@@ -89,9 +89,41 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, lo, hi, *, want_psi,
                         A.ptr(far), A.ptr(A.data_f32(data, clo, chi)), None,
                         None, A.ptr(costs[clo - lo:chi - lo]), n, S, det, 0, 0,
                         1.0, det * det, st), "cgrad cost")
-    tot = comm.Allreduce_scalars([costs.sum()], dev)
-    cost = float((tot[0] / global_count(comm, op, lo, hi)).item())
-    return cost, gpsi, gprobe
+    total = costs.sum(dtype=torch.float64)  # device scalar (this rank)
+    if read_cost:
+        return _finish_cost(total, comm, op, lo, hi), gpsi, gprobe
+    return total, gpsi, gprobe
+
+
+def _finish_cost(total, comm, op, lo, hi):
+    """Mean cost over the positions of ALL ranks, on the host: one (all-)
+    reduction and one read-back."""
+    if comm.collective:
+        total = comm.Allreduce_scalars([total], total.device)[0]
+    return float(total.item()) / global_count(comm, op, lo, hi)
+
+
+class _Evaluator:
+    """cost / gradient callbacks of one conjugate-gradient call.  The gradient
+    pass forms the cost of its argument as well: it is kept ON THE DEVICE and
+    read back only if the line search asks for the cost of that very array
+    (opt.line_search does, for its starting point) -- which then costs neither
+    a forward pass nor, for the other gradient evaluations, a host
+    synchronisation."""
+
+    def __init__(self, run, finish):
+        self._run, self._finish = run, finish
+        self._x = self._total = None
+
+    def cost(self, x):
+        if x is self._x:
+            return self._finish(self._total)
+        return self._finish(self._run(x, False)[0])
+
+    def grad(self, x):
+        total, g = self._run(x, True)
+        self._x, self._total = x, total
+        return [g]
 
 
 def cgrad(parameters, data, batches, comm, *, op, epoch):
@@ -110,26 +142,27 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
         hi = lo + len(b)
         d, s = data, scan
         cost = None
+        finish = lambda total: _finish_cost(total, comm, op, lo, hi)
         if recover_psi:
+            def run(x, want_grad):
+                r = _cost_and_grad(op, comm, d, x, s, probe, lo, hi,
+                                   want_psi=True, want_probe=False,
+                                   want_grad=want_grad, read_cost=False)
+                return r[0], r[1]
+            ev = _Evaluator(run, finish)
             psi, cost = opt.conjugate_gradient(
-                torch, x=psi,
-                cost_function=lambda x: _cost_and_grad(
-                    op, comm, d, x, s, probe, lo, hi, want_psi=True, want_probe=False,
-                    want_grad=False)[0],
-                grad=lambda x: [_cost_and_grad(
-                    op, comm, d, x, s, probe, lo, hi, want_psi=True, want_probe=False,
-                    want_grad=True)[1]],
+                torch, x=psi, cost_function=ev.cost, grad=ev.grad,
                 dir_multi=lambda x: x[0], num_iter=o.cg_iter,
                 step_length=o.step_length)
         if recover_probe:
+            def run(x, want_grad):
+                r = _cost_and_grad(op, comm, d, psi, s, x, lo, hi,
+                                   want_psi=False, want_probe=True,
+                                   want_grad=want_grad, read_cost=False)
+                return r[0], r[2]
+            ev = _Evaluator(run, finish)
             probe, cost = opt.conjugate_gradient(
-                torch, x=probe,
-                cost_function=lambda x: _cost_and_grad(
-                    op, comm, d, psi, s, x, lo, hi, want_psi=False, want_probe=True,
-                    want_grad=False)[0],
-                grad=lambda x: [_cost_and_grad(
-                    op, comm, d, psi, s, x, lo, hi, want_psi=False, want_probe=True,
-                    want_grad=True)[2]],
+                torch, x=probe, cost_function=ev.cost, grad=ev.grad,
                 dir_multi=lambda x: x[0], num_iter=o.cg_iter,
                 step_length=o.step_length)
         if cost is None:

@@ -293,8 +293,10 @@ def _eigen_args(eigen_probe, weights):
 def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                              eigen_weights, lo, hi, comm, *, num_batch,
                              exitwave_options, op, recover_psi, recover_probe,
-                             position_terms=None):
-    """Object / probe gradients of one minibatch (lstsq.py:367-602)."""
+                             position_terms=None, need_chi0=True):
+    """Object / probe gradients of one minibatch (lstsq.py:367-602).
+    need_chi0=False (cgrad: no step statistics follow) skips the store of
+    mode 0 of chi where the fused pass 2 would be its only producer."""
     dev = psi.device
     B = hi - lo
     S, pw = probe.shape[-3], probe.shape[-1]
@@ -552,7 +554,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     A.ptr(patches[blo:blo + n]), A.ptr(probe),
                     A.ptr(ep), A.ptr(w_c), C, Sm,
                     A.ptr(objproj) if recover_psi else None,
-                    A.ptr(chi0[blo:blo + n]), A.ptr(m_probe_update),
+                    A.ptr(chi0[blo:blo + n]) if need_chi0 else None,
+                    A.ptr(m_probe_update),
                     1.0 / num_batch, n, S, det, inv_scale, st),
                 "inverse pass 2 + gradients")
         else:
