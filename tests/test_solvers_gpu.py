@@ -289,7 +289,8 @@ def test_cgrad_vs_reference_composition(tp, golden):
 
 @pytest.mark.parametrize("det,pw,S,N", [(256, 256, 1, 6), (256, 192, 2, 5),
                                         (128, 128, 1, 8), (512, 512, 2, 3),
-                                        (64, 48, 2, 9)])
+                                        (64, 48, 2, 9),
+                                        (128, 128, 1, 256)])  # BASELINE configs[0]
 def test_cgrad_vs_oracle(tp, det, pw, S, N):
     """cgrad (object then probe, 2 CG iterations each) against the oracle's
     composition: the gradients are lstsq_grad's pipelines (far-plane-free at
