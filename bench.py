@@ -7,6 +7,7 @@ One "step" = one pass of the hot path over the whole synthetic dataset:
   c3 (default, the configuration BASELINE.json's metric is quoted on):
      one lstsq_grad epoch over 10 000 scan positions per GPU, 256x256
      detector, 8 probe modes + eigen-probe correction, 10 minibatches;
+  c1: BASELINE configs[0] (256 positions, 128x128, 1 mode, cgrad);
   c2: 1 probe mode, cgrad;  c5: 512x512, 4 modes, position correction;
   fwdDxS: one launch of the fused forward operator (D = detector, S = modes).
 Inputs are HBM-resident before the timed region.  Rank 0 prints ONE JSON line.
@@ -213,6 +214,26 @@ def cpu_baseline_epoch(p, data_np, S, det, n=256):
                 f"{det}x{det}, scipy.fft workers={cores}")
 
 
+def cpu_baseline_c1(p, data_np, det):
+    """BASELINE configs[0] IN FULL on the host: one oracle cgrad epoch (cg_iter
+    = 4, object then probe) over all 256 positions."""
+    from oracle import operators as oops
+    from oracle import solvers as osol
+    cores = os.cpu_count() or 1
+    oops.set_workers(cores)
+    n = len(p["scan"])
+    state = dict(psi=np.full_like(p["psi"], 0.5 + 0j), probe=p["probe"].copy(),
+                 scan=p["scan"].copy(), costs=[])
+    t0 = time.perf_counter()
+    osol.cgrad(state, data_np, [np.arange(n)], detector_shape=det, cg_iter=4,
+               recover_probe=True)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="patterns/s", cores=cores, kind="port",
+                cpu=cpu_model(), seconds=dt,
+                sample=f"oracle cgrad epoch (cg_iter=4, object + probe) over all "
+                f"{n} positions, 1 mode {det}x{det}, scipy.fft workers={cores}")
+
+
 def cpu_baseline_fwd(p, S, det, seconds=10.0):
     from oracle import operators as oops
     cores = os.cpu_count() or 1
@@ -383,13 +404,15 @@ def main():
             cpu = cpu_baseline_fwd(p, S, det)
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, solver=None)
-    elif a.workload in ("c2", "c3", "c5"):
+    elif a.workload in ("c1", "c2", "c3", "c5"):
         # c2: 1 mode; c3 (default, = one GPU's share of c4): 8 modes + eigen
         # probes; c5: 512x512, 4 modes, position correction on
-        det = 512 if a.workload == "c5" else 256
-        S = {"c2": 1, "c3": 8, "c5": 4}[a.workload]
-        N = a.positions or (4000 if a.workload == "c5" else 10000)
-        num_batch = 10
+        # c1 = BASELINE configs[0], the reference's CPU-runnable case: 256
+        # positions, 128x128, 1 mode, cgrad (one minibatch)
+        det = {"c1": 128, "c5": 512}.get(a.workload, 256)
+        S = {"c1": 1, "c2": 1, "c3": 8, "c5": 4}[a.workload]
+        N = a.positions or {"c1": 256, "c5": 4000}.get(a.workload, 10000)
+        num_batch = 1 if a.workload == "c1" else 10
         # global problem: N*world positions; this rank's share of every
         # global minibatch, concatenated (see Reconstruction(presharded=True))
         Ng = N * world
@@ -418,7 +441,7 @@ def main():
             eigen_probe=eigen_probe, eigen_weights=eigen_weights,
             # BASELINE configs[1] names the conjugate-gradient solver
             algorithm_options=(tp.CgradOptions(num_batch=num_batch, cg_iter=4)
-                               if a.workload == "c2" else
+                               if a.workload in ("c1", "c2") else
                                tp.LstsqOptions(num_batch=num_batch,
                                                batch_method="compact")),
             probe_options=tp.ProbeOptions(force_orthogonality=True),
@@ -442,10 +465,11 @@ def main():
         launch_n = min(chunk_positions(S, det, True), N // num_batch)
         dominant = None
         if rank == 0 and not a.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline_epoch(p, data, S, det)
+            cpu = (cpu_baseline_c1(p, data, det) if a.workload == "c1" else
+                   cpu_baseline_epoch(p, data, S, det))
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, eigen_probes=C,
-                        solver="cgrad (cg_iter=4)" if a.workload == "c2"
+                        solver="cgrad (cg_iter=4)" if a.workload in ("c1", "c2")
                         else "lstsq_grad",
                         num_batch=num_batch, chunk_positions=launch_n,
                         position_correction=a.workload == "c5")
