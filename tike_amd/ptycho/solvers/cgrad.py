@@ -31,8 +31,68 @@ def _gaussian_options(det):
     return _GAUSSIAN[det]
 
 
+class _CostPlan:
+    """Everything a line-search probe (cost only) of one minibatch needs that
+    does not change between probes: workspaces, chunk bounds, raw pointers of
+    the scan / data / cost slices.  A probe is then two C-ABI calls per chunk
+    and one reduction -- at BASELINE configs[0] (256 positions of 128^2) the
+    Python between the launches was most of the epoch."""
+
+    def __init__(self, op, data, scan, lo, hi, S, pw, H, W, dev):
+        det = op.detector_shape
+        N = hi - lo
+        ws = _workspace(op)
+        self.split = det in SPLIT_FORWARD_SIZES
+        chunk = chunk_positions(S, det, self.split)
+        self.far = ws.get("far", (min(chunk, max(N, 1)), 1, S, det, det),
+                          torch.complex64, dev)
+        self.costs = ws.get("costs", (max(N, 1),), torch.float32, dev)[:N]
+        self.fwd_scale = fft_scales(det, op.norm)[0]
+        self.dims = (S, pw, det, H, W)
+        self.u16 = int(data.dtype == torch.uint16)
+        # resident data that the cost kernel of this size reads as it is
+        direct = isinstance(data, torch.Tensor) and (
+            self.split or data.dtype == torch.float32)
+        self.chunks = []
+        for clo in range(lo, hi, chunk):
+            chi = min(hi, clo + chunk)
+            self.chunks.append(
+                (clo, chi, scan[clo:chi], data[clo:chi] if direct else None,
+                 self.costs[clo - lo:chi - lo]))
+
+    def run(self, data, psi, probe):
+        S, pw, det, H, W = self.dims
+        st = A.stream_ptr()
+        ppsi, pprobe, pfar = A.ptr(psi), A.ptr(probe), A.ptr(self.far)
+        for clo, chi, sc, d, cost in self.chunks:
+            n = chi - clo
+            if d is None:  # streamed from the host, or 16-bit counts at 128^2
+                d = data[clo:chi] if self.split else A.data_f32(data, clo, chi)
+            if self.split:
+                check(
+                    lib.tike_fwd_pass1(ppsi, sc.data_ptr(), pprobe, 0, None,
+                                       None, None, 0, 0, pfar, None, n, S, pw,
+                                       det, H, W, st), "cgrad forward pass 1")
+                check(
+                    lib.tike_fwd_gradient_scale(
+                        pfar, d.data_ptr(), self.u16, None, None, None,
+                        cost.data_ptr(), None, n, S, det, self.fwd_scale, 0,
+                        1.0, det * det, st), "cgrad forward pass 2 + cost")
+            else:
+                check(
+                    lib.tike_ptycho_fwd(ppsi, sc.data_ptr(), pprobe, 0, None,
+                                        None, 0, 0, pfar, n, S, pw, det, H, W,
+                                        self.fwd_scale, st), "cgrad forward")
+                check(
+                    lib.tike_farplane_gradient(pfar, d.data_ptr(), None, None,
+                                               cost.data_ptr(), n, S, det, 0,
+                                               0, 1.0, det * det, st),
+                    "cgrad cost")
+        return self.costs
+
+
 def _cost_and_grad(op, comm, data, psi, scan, probe, lo, hi, *, want_psi,
-                   want_probe, want_grad, read_cost=True):
+                   want_probe, want_grad, read_cost=True, plan=None):
     """Global gaussian cost (mean over all positions and pixels) of the
     minibatch [lo, hi) and, optionally, d cost / d psi and d cost / d probe
     (unnormalised adjoints).
@@ -58,37 +118,8 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, lo, hi, *, want_psi,
             gprobe = -g["m_probe_update"]
     else:
         gpsi = gprobe = None
-        ws = _workspace(op)
-        st = A.stream_ptr()
-        fwd_scale, _ = fft_scales(det, op.norm)
-        split = det in SPLIT_FORWARD_SIZES
-        chunk = chunk_positions(S, det, split)
-        far = ws.get("far", (min(chunk, max(N, 1)), 1, S, det, det),
-                     torch.complex64, dev)
-        costs = ws.get("costs", (max(N, 1),), torch.float32, dev)[:N]
-        for clo in range(lo, hi, chunk):
-            chi = min(hi, clo + chunk)
-            n = chi - clo
-            if split:
-                check(
-                    lib.tike_fwd_pass1(A.ptr(psi), A.ptr(scan[clo:chi]),
-                                       A.ptr(probe), 0, None, None, None, 0, 0,
-                                       A.ptr(far), None, n, S, pw, det, H, W,
-                                       st), "cgrad forward pass 1")
-                check(
-                    lib.tike_fwd_gradient_scale(
-                        A.ptr(far), A.ptr(data[clo:chi]),
-                        int(data.dtype == torch.uint16), None, None, None,
-                        A.ptr(costs[clo - lo:chi - lo]), None, n, S, det,
-                        fwd_scale, 0, 1.0, det * det, st),
-                    "cgrad forward pass 2 + cost")
-            else:
-                op.fwd_device(probe, scan[clo:chi], psi, out=far[:n])
-                check(
-                    lib.tike_farplane_gradient(
-                        A.ptr(far), A.ptr(A.data_f32(data, clo, chi)), None,
-                        None, A.ptr(costs[clo - lo:chi - lo]), n, S, det, 0, 0,
-                        1.0, det * det, st), "cgrad cost")
+        plan = plan or _CostPlan(op, data, scan, lo, hi, S, pw, H, W, dev)
+        costs = plan.run(data, psi, probe)
     total = costs.sum(dtype=torch.float64)  # device scalar (this rank)
     if read_cost:
         return _finish_cost(total, comm, op, lo, hi), gpsi, gprobe
@@ -143,11 +174,14 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
         d, s = data, scan
         cost = None
         finish = lambda total: _finish_cost(total, comm, op, lo, hi)
+        plan = _CostPlan(op, d, s, lo, hi, probe.shape[-3], probe.shape[-1],
+                         psi.shape[-2], psi.shape[-1], psi.device)
         if recover_psi:
             def run(x, want_grad):
                 r = _cost_and_grad(op, comm, d, x, s, probe, lo, hi,
                                    want_psi=True, want_probe=False,
-                                   want_grad=want_grad, read_cost=False)
+                                   want_grad=want_grad, read_cost=False,
+                                   plan=plan)
                 return r[0], r[1]
             ev = _Evaluator(run, finish)
             psi, cost = opt.conjugate_gradient(
@@ -158,7 +192,8 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
             def run(x, want_grad):
                 r = _cost_and_grad(op, comm, d, psi, s, x, lo, hi,
                                    want_psi=False, want_probe=True,
-                                   want_grad=want_grad, read_cost=False)
+                                   want_grad=want_grad, read_cost=False,
+                                   plan=plan)
                 return r[0], r[2]
             ev = _Evaluator(run, finish)
             probe, cost = opt.conjugate_gradient(
