@@ -22,6 +22,7 @@ KERNELS = {
     "void ptycho_fwd_pos_kernel<512": "tike_ptycho_fwd_intensity",
     "void fwd_pass1_kernel": "tike_fwd_pass1",
     "void fwd_gradient_scale_kernel": "tike_fwd_gradient_scale",
+    "void grad_ifft2_pass1_512_kernel": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 1, false>": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 2, false>": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 1, true>": "tike_grad_ifft2_crop",
@@ -91,7 +92,8 @@ def main():
     # bench.py's set-up (`simulate`: the far-plane-storing forward operator)
     # is not part of a step
     setup = {"c3": ("tike_ptycho_fwd_intensity",),
-             "c2": ("tike_ptycho_fwd_intensity",)}.get(workload, ())
+             "c2": ("tike_ptycho_fwd_intensity",),
+             "c5": ("tike_ptycho_fwd_intensity",)}.get(workload, ())
     doc["setup_kernels_excluded_from_step"] = list(setup)
     doc["hbm_bytes_per_step"] = sum(
         k["hbm_bytes_per_launch"] * k["launches"]
