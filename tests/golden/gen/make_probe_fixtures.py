@@ -9,6 +9,9 @@
   seeded probes.  CuPy's median_filter converts its window size to integers
   (cupyx/scipy/ndimage/_filters_core.py `_fix_sequence_arg(size, ndim, 'size',
   int)`); SciPy refuses floats, so the window is handed over as integers.
+* `fresnel_probes.npz`: the REFERENCE's single_probe / MW_probe
+  (tike.ptycho.fresnel) for custom and preset zone plates, forward and
+  backward propagation, a Gaussian line and a supplied spectrum.
 * `ref_hermite.npz`: tests/ptycho/hermite.mat (the data file of the
   reference's own test_hermite_modes) re-encoded.
 """
@@ -85,6 +88,27 @@ gy, gx = ref_position.gaussian_gradient(cp.asarray(x))
 out["gradient_y"], out["gradient_x"] = np.asarray(gy), np.asarray(gx)
 path = os.path.join(OUT, "probe_constraints.npz")
 np.savez_compressed(path, **out)
+print(path, os.path.getsize(path) / 1e6, "MB")
+
+# Fresnel zone-plate probes (tike.ptycho.fresnel): pure NumPy in the reference
+import tike.ptycho.fresnel as ref_fresnel  # noqa: E402
+lam = 1.24e-9 / 10
+dx = lam * 2 / 64 / 75e-6
+plate = dict(radius=150e-6 / 2, outmost=50e-9, beamstop=60e-6)
+spec = np.stack([lam * (1 + 0.002 * np.arange(-4, 5)),
+                 np.exp(-np.arange(-4, 5)**2 / 8.0)], 1)
+fres = dict(
+    params=np.array([lam, dx]), spectrum=spec,
+    single=ref_fresnel.single_probe(64, lam, dx, 800e-6, zone_plate_params=plate),
+    single_velo_back=ref_fresnel.single_probe(48, lam, dx, -300e-6,
+                                              zone_plate_params="velo"),
+    mw_2idd=ref_fresnel.MW_probe(64, lam, dx, 800e-6, zone_plate_params="2idd",
+                                 energy=5, bandwidth=0.01),
+    mw_lamni_spectrum=ref_fresnel.MW_probe(64, lam, dx, 800e-6,
+                                           zone_plate_params="lamni", energy=3,
+                                           spectrum=spec.copy()))
+path = os.path.join(OUT, "fresnel_probes.npz")
+np.savez_compressed(path, **fres)
 print(path, os.path.getsize(path) / 1e6, "MB")
 
 m = scipy.io.loadmat(f"{REF}/tests/ptycho/hermite.mat")

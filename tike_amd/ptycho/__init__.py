@@ -1,5 +1,6 @@
 """Ptychography solvers and helpers (mirror of ``tike.ptycho``)."""
 from .exitwave import ExitWaveOptions
+from .fresnel import MW_probe, single_probe
 from .object import (ObjectOptions, get_absorbtion_image, get_padded_object,
                      positivity_constraint,
                      remove_object_ambiguity, smoothness_constraint)
@@ -16,7 +17,7 @@ from .ptycho import (Reconstruction, reconstruct, reconstruct_multigrid,
 from .solvers import (CgradOptions, LstsqOptions, PtychoParameters,
                       RpieOptions, cgrad, lstsq_grad, rpie,
                       update_preconditioners)
-from . import probe, object, position, exitwave, solvers, io, learn  # noqa: F401,A004
+from . import probe, object, position, exitwave, solvers, io, learn, fresnel  # noqa: F401,A004
 
 __all__ = [
     "CgradOptions", "ExitWaveOptions", "LstsqOptions", "ObjectOptions",
