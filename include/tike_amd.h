@@ -430,6 +430,33 @@ int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, doub
                        float* weights_c, long weights_row, void* coefs_c, int coef_stride,
                        const float* esum, void* stream);
 
+/* ---- the chunk body of _get_nearplane_gradients (lstsq.py:422-579) in ONE call:
+ * the far-plane-free pipeline for a chunk of nscan positions,
+ *   tike_fwd_pass1 -> tike_fwd_gradient_scale -> tike_grad_ifft2_pass1 ->
+ *   tike_ifft2_pass2_gradients -> tike_scatter_patches,
+ * for callers that do not need the stages separately (a level-B binding of
+ * lstsq.py's chunk loop).  Inputs as in those entries (psi, scan, probe, the
+ * eigen probes applied on the fly, data f32 or uint16, optional mask);
+ * workspaces scratch and work (nscan,S,det,det) c64 each and gscale
+ * (nscan,det,det) f32 are the caller's, must not alias and hold no result
+ * afterwards.  Outputs: patches, chi0 (nscan,det,det) c64 and costs (nscan)
+ * are overwritten; m_probe_update (S,det,det) c64 += mpu_scale * sum_n ...,
+ * object_acc (2,H,W) planar f32 += scatter_n(sum_s conj(P_n,s) chi_n,s) via
+ * objproj (nscan,det,det) c64 (overwritten); object_acc / objproj may both be
+ * NULL (probe gradient only), m_probe_update and chi0 may be NULL.
+ * Probe window = detector; det = 256 with S <= 8, or det = 512 with S <= 4;
+ * model 0 gaussian / 1 poisson (without per-mode step lengths):
+ * TIKE_ERR_UNSUPPORTED otherwise -- compose the stages yourself. */
+int tike_lstsq_chunk_gradients(const void* psi, const float* scan, const void* probe,
+                               const void* eigen_probe, const float* eigen_weights,
+                               int num_eigen, int eigen_modes, const void* data, int data_u16,
+                               const unsigned char* measured, int model,
+                               float unmeasured_scaling, long num_measured, void* scratch,
+                               void* work, float* gscale, void* patches, float* costs,
+                               void* objproj, void* chi0, void* m_probe_update,
+                               float mpu_scale, float* object_acc, int nscan, int S, int det,
+                               int H, int W, float fwd_scale, float inv_scale, void* stream);
+
 /* ---- collectives: the per-minibatch gradient all-reduce over RCCL / xGMI,
  * one process (or thread) per GPU.  Replaces the serial peer-copy reduction of
  * communicators/pool.py:300-395 (reduce_gpu / allreduce) as composed by

@@ -1021,3 +1021,69 @@ def test_full_size_far_plane_free_chain_matches_stored_far_plane(tp, det, S, N):
         work, ref = outs
     err = float((work - ref).abs().max()) / float(ref.abs().max())
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("det,S,N,eigen,u16", [(256, 3, 7, True, False),
+                                               (256, 8, 5, False, True),
+                                               (512, 2, 4, False, False)])
+def test_chunk_gradients_entry_matches_the_staged_pipeline(tp, det, S, N, eigen,
+                                                           u16):
+    """tike_lstsq_chunk_gradients (the chunk body of _get_nearplane_gradients,
+    lstsq.py:422-579, in one C call) == the five stage entries as the solver
+    issues them (themselves checked against the oracle and the reference)."""
+    import torch
+    import tike_amd._arrays as A
+    import tike_amd.ptycho.solvers.lstsq as L
+    from tike_amd._lib import check, lib
+    from tike_amd.communicators import Comm
+    from tike_amd.operators import Ptycho
+    from tike_amd.operators.propagation import fft_scales
+    scan, psi_true, probe0, ep, ew, data = _headline_problem(
+        tp, det, S, N, seed=det + S, eigen=eigen)
+    if u16:
+        data = np.round(data * (20000.0 / data.max())).astype(np.uint16)
+    dev = torch.device("cuda", 0)
+    psi = A.to_device(np.full_like(psi_true, 0.5) + 0.1 * psi_true)
+    probe, scan_d = A.to_device(probe0), A.to_device(scan)
+    data_d = A.data_to_device(data)
+    ep_d = None if ep is None else A.to_device(ep)
+    ew_d = None if ew is None else A.to_device(ew.astype(np.float32))
+    H, W = psi.shape[-2:]
+    opts = tp.ExitWaveOptions(measured_pixels=np.ones((det, det), dtype=bool))
+    with Ptycho(probe_shape=det, detector_shape=det, nz=H, n=W) as op:
+        g = L._get_nearplane_gradients(
+            data_d, psi, scan_d, probe, ep_d, ew_d, 0, N, Comm(), num_batch=2,
+            exitwave_options=opts, op=op, recover_psi=True, recover_probe=True)
+        want = {k: g[k].clone() for k in ("object_acc", "m_probe_update",
+                                          "costs", "chi0")}
+    c64 = lambda *s: torch.empty(*s, dtype=torch.complex64, device=dev)
+    scratch, work = c64(N, 1, S, det, det), c64(N, 1, S, det, det)
+    gscale = torch.empty(N, det, det, device=dev)
+    patches, objproj, chi0 = c64(N, det, det), c64(N, det, det), c64(N, det, det)
+    costs = torch.empty(N, device=dev)
+    mpu = torch.zeros(1, 1, S, det, det, dtype=torch.complex64, device=dev)
+    acc = torch.zeros(2, H, W, device=dev)
+    C = Sm = 0
+    if ep_d is not None:
+        C, Sm = ep_d.shape[-4], ep_d.shape[-3]
+    fwd_scale, inv_scale = fft_scales(det, "ortho")
+    check(lib.tike_lstsq_chunk_gradients(
+        A.ptr(psi), A.ptr(scan_d), A.ptr(probe), A.ptr(ep_d), A.ptr(ew_d), C, Sm,
+        A.ptr(data_d), int(u16), None, 0, 1.0, det * det, A.ptr(scratch),
+        A.ptr(work), A.ptr(gscale), A.ptr(patches), A.ptr(costs),
+        A.ptr(objproj), A.ptr(chi0), A.ptr(mpu), 0.5, A.ptr(acc), N, S, det, H,
+        W, fwd_scale, inv_scale, A.stream_ptr()), "chunk gradients")
+    torch.testing.assert_close(costs, want["costs"], rtol=1e-5, atol=1e-7)
+    assert_close(acc.cpu().numpy(), want["object_acc"].cpu().numpy(),
+                 normwise=1e-5, maxabs=1e-4, what="object gradient")
+    assert_close(mpu.cpu().numpy(), want["m_probe_update"].cpu().numpy(),
+                 normwise=1e-5, maxabs=1e-4, what="probe gradient")
+    assert_close(chi0.cpu().numpy(), want["chi0"].cpu().numpy(), normwise=1e-6,
+                 maxabs=1e-5, what="chi0")
+    # unsupported shapes are refused, not mis-computed
+    assert lib.tike_lstsq_chunk_gradients(
+        A.ptr(psi), A.ptr(scan_d), A.ptr(probe), None, None, 0, 0,
+        A.ptr(data_d), int(u16), None, 0, 1.0, det * det, A.ptr(scratch),
+        A.ptr(work), A.ptr(gscale), A.ptr(patches), A.ptr(costs),
+        A.ptr(objproj), A.ptr(chi0), A.ptr(mpu), 0.5, A.ptr(acc), N, 9, det, H,
+        W, fwd_scale, inv_scale, A.stream_ptr()) == 1000002

@@ -103,6 +103,9 @@ _PROTOTYPES = {
     "tike_psi_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_lstsq_step_stats": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p,
                               _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
+    "tike_lstsq_chunk_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i,
+                                   _f, _l, _p, _p, _p, _p, _p, _p, _p, _p, _f,
+                                   _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "tike_comm_unique_id": [_p],
     "tike_comm_create": [_p, _i, _i, ctypes.POINTER(_p)],
     "tike_comm_destroy": [_p],

@@ -357,3 +357,36 @@ extern "C" int tike_eigen_weights(const float* sums, int B, long P, const float*
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
+
+// ------------------------------------------- the whole chunk body in one call
+// (lstsq.py:422-579): the five stage entries, stream-ordered.
+extern "C" int tike_lstsq_chunk_gradients(
+    const void* psi, const float* scan, const void* probe, const void* eigen_probe,
+    const float* eigen_weights, int num_eigen, int eigen_modes, const void* data, int data_u16,
+    const unsigned char* measured, int model, float unmeasured_scaling, long num_measured,
+    void* scratch, void* work, float* gscale, void* patches, float* costs, void* objproj,
+    void* chi0, void* m_probe_update, float mpu_scale, float* object_acc, int nscan, int S,
+    int det, int H, int W, float fwd_scale, float inv_scale, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && H >= 1 && W >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(psi && scan && probe && data && scratch && work && gscale && patches);
+  TK_CHECK_ARG(scratch != work && (object_acc == nullptr) == (objproj == nullptr));
+  if (!((det == 256 && S <= 8) || (det == 512 && S <= 4))) return TK_ERR_UNSUPPORTED;
+  int rc = tike_fwd_pass1(psi, scan, probe, 0, nullptr, eigen_probe, eigen_weights, num_eigen,
+                          eigen_modes, scratch, patches, nscan, S, det, det, H, W, stream);
+  if (rc) return rc;
+  rc = tike_fwd_gradient_scale(scratch, data, data_u16, measured, gscale, nullptr, costs,
+                               nullptr, nscan, S, det, fwd_scale, model, unmeasured_scaling,
+                               num_measured, stream);
+  if (rc) return rc;
+  rc = tike_grad_ifft2_pass1(scratch, gscale, nullptr, nullptr, S, work, (long)nscan * S, det,
+                             fwd_scale, stream);
+  if (rc) return rc;
+  rc = tike_ifft2_pass2_gradients(work, patches, probe, eigen_probe, eigen_weights, num_eigen,
+                                  eigen_modes, objproj, chi0, m_probe_update, mpu_scale, nscan,
+                                  S, det, inv_scale, stream);
+  if (rc) return rc;
+  if (object_acc) rc = tike_scatter_patches(objproj, scan, object_acc, nscan, det, H, W, stream);
+  return rc;
+}
