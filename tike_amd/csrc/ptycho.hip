@@ -1057,6 +1057,30 @@ static int launch_fwd(const cf* psi, const float* scan, const TkProbe& probe, cf
   return TK_OK;
 }
 
+// The forward column pass alone, in place on the far-plane array: rows
+// {k1 + 16 r} of a tile in, the same rows out (fft_engine2.h pass 2), so a
+// tile written by forward pass 1 becomes the far plane without a second array.
+// Work item = (tile, k1, 256-column block); tiles in descending order (pass 1
+// wrote them ascending: its last tiles are still in the Infinity Cache).
+template <int N>
+__global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_colpass_inplace_kernel(
+    cf* far, long ntile, float scale) {
+  constexpr int RB = N / 16, NH = N / 256;
+  const long nitem = ntile * 16 * NH;
+  for (long v = blockIdx.x; v < nitem; v += gridDim.x) {
+    const int hb = (int)(v % NH);
+    const int k1 = (int)((v / NH) & 15);
+    const long tile = ntile - 1 - v / (16 * NH);
+    cf* p = far + tile * (long)N * N + (long)k1 * N + hb * 256 + threadIdx.x;
+    cf u[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) u[r] = p[(long)(16 * r) * N];
+    Dft<RB, false>::run(u);
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) tk_st_stream(p + (long)(16 * k2) * N, u[k2] * scale);
+  }
+}
+
 extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe,
                                int probe_per_scan, const void* eigen_probe,
                                const float* eigen_weights, int num_eigen, int eigen_modes,
@@ -1075,6 +1099,25 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
   cf* far = (cf*)farplane;
   if (det == 128 && pw == 128 && !(eigen_weights && eigen_modes > 0))
     return launch_fwd128_lds(psi_, scan, P, far, nullptr, nscan, S, H, W, scale, stream);
+  if ((det == 512 && S >= 2) || (det == 256 && S >= 4)) {
+    // many modes: forward pass 1 (the patch of a row group gathered once for
+    // all modes, eigen probes on the fly) straight into the far-plane array,
+    // then the column pass in place -- both streaming kernels; faster than the
+    // one-workgroup-per-position kernel below (512^2: 1.45x)
+    int rc = tike_fwd_pass1(psi, scan, probe, probe_per_scan, nullptr, eigen_probe, eigen_weights,
+                            num_eigen, eigen_modes, farplane, nullptr, nscan, S, pw, det, H, W,
+                            stream_);
+    if (rc) return rc;
+    const long nitem = ntile * 16 * (det / 256);
+    if (det == 256)
+      hipLaunchKernelGGL((fwd_colpass_inplace_kernel<256>), dim3(tk_grid(nitem, 32)), dim3(256),
+                         0, stream, far, ntile, scale);
+    else
+      hipLaunchKernelGGL((fwd_colpass_inplace_kernel<512>), dim3(tk_grid(nitem, 32)), dim3(256),
+                         0, stream, far, ntile, scale);
+    TK_LAUNCH_CHECK();
+    return TK_OK;
+  }
   if (S > 1 && !(eigen_weights && eigen_modes > 0)) {
     // position-major kernel (patch gathered once per position and shared by
     // the modes, straight-line loader; with a single mode there is nothing to
