@@ -407,6 +407,13 @@ static int launch_fwd_pos(const cf* psi, const float* scan, const TkProbe& probe
   return TK_OK;
 }
 
+#ifndef TK_LDS128_MAX_MODES
+#define TK_LDS128_MAX_MODES 8
+#endif
+static int launch_fwd128_lds(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
+                             float* intensity, int nscan, int S, int H, int W, float scale,
+                             hipStream_t stream, cf* patches);
+
 extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, const void* probe,
                                          int probe_per_scan, const void* unique_probe,
                                          const float* eigen_weights, int num_eigen,
@@ -424,6 +431,12 @@ extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, con
                                   eigen_modes, S, pw, unique_probe);
   switch (det) {
     case 128:
+      // probe window = detector: the whole-tile-in-LDS kernel (no intermediate
+      // in memory); a few modes only -- it re-reads nothing, but keeps the
+      // patch in registers across the modes at the 128-register cap
+      if (pw == 128 && intensity != nullptr && S <= TK_LDS128_MAX_MODES)
+        return launch_fwd128_lds((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, H,
+                                 W, scale, stream, (cf*)patches);
       return launch_fwd_pos<128>((const cf*)psi, scan, P, (cf*)farplane, intensity, nscan, S, pw,
                                  H, W, scale, stream, nullptr, (cf*)patches);
     case 256:
@@ -857,8 +870,8 @@ constexpr int TK_L128_LS = 136;
 template <bool WITH_I>
 __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
-    cf* __restrict__ farplane, float* __restrict__ intensity, int nscan, int S, int H, int W,
-    float scale, const cf* __restrict__ twtab) {
+    cf* __restrict__ farplane, float* __restrict__ intensity, cf* __restrict__ patches, int nscan,
+    int S, int H, int W, float scale, const cf* __restrict__ twtab) {
   constexpr int N = 128, T = 8, LS = TK_L128_LS;
   static_assert(FftPlan<N>::E == 16 && LS >= N + N / 16, "row plan: 16 elements x 8 threads");
   __shared__ cf lds[N * LS + FftTwLds<N>::ELEMS];
@@ -950,6 +963,12 @@ __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
         __builtin_amdgcn_sched_barrier(0);  // rare path: one element in flight
       }
     }
+    if (patches != nullptr) {
+      // O_n for the gradient kernels (uniform branch; the solver's 128^2 path)
+      cf* __restrict__ On = patches + n * PP + line * N + j;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tk_st_stream(On + i * T, pv[i]);
+    }
     float I[2][8];
     if (WITH_I) {
 #pragma unroll
@@ -1019,16 +1038,16 @@ __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
 
 static int launch_fwd128_lds(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                              float* intensity, int nscan, int S, int H, int W, float scale,
-                             hipStream_t stream) {
+                             hipStream_t stream, cf* patches) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   const dim3 grid(tk_grid(nscan, 1)), block(1024);
   if (intensity)
     hipLaunchKernelGGL((fwd128_lds_kernel<true>), grid, block, 0, stream, psi, scan, probe,
-                       farplane, intensity, nscan, S, H, W, scale, tw);
+                       farplane, intensity, patches, nscan, S, H, W, scale, tw);
   else
     hipLaunchKernelGGL((fwd128_lds_kernel<false>), grid, block, 0, stream, psi, scan, probe,
-                       farplane, intensity, nscan, S, H, W, scale, tw);
+                       farplane, intensity, patches, nscan, S, H, W, scale, tw);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -1098,7 +1117,7 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
   const cf* psi_ = (const cf*)psi;
   cf* far = (cf*)farplane;
   if (det == 128 && pw == 128 && !(eigen_weights && eigen_modes > 0))
-    return launch_fwd128_lds(psi_, scan, P, far, nullptr, nscan, S, H, W, scale, stream);
+    return launch_fwd128_lds(psi_, scan, P, far, nullptr, nscan, S, H, W, scale, stream, nullptr);
   if ((det == 512 && S >= 2) || (det == 256 && S >= 4)) {
     // many modes: forward pass 1 (the patch of a row group gathered once for
     // all modes, eigen probes on the fly) straight into the far-plane array,
