@@ -17,7 +17,7 @@ from ..._lib import check, lib
 from ...operators.propagation import fft_scales
 from ..exitwave import ExitWaveOptions
 from .lstsq import (SPLIT_FORWARD_SIZES, _get_nearplane_gradients, _workspace,
-                    chunk_positions, global_count)
+                    chunk_positions, fused_gradients, global_count)
 
 
 _GAUSSIAN = {}
@@ -90,6 +90,50 @@ class _CostPlan:
                     "cgrad cost")
         return self.costs
 
+    def supports_gradients(self):
+        """The far-plane-free sizes, probe window = detector: the gradient of a
+        chunk is ONE C-ABI call (tike_lstsq_chunk_gradients)."""
+        S, pw, det, _, _ = self.dims
+        return (self.split and pw == det and fused_gradients(S, pw, det)
+                and all(c[3] is not None for c in self.chunks))
+
+    def gradients(self, op, comm, psi, probe, want_psi, want_probe):
+        """(costs, -d cost / d psi or None, -d cost / d probe or None), the
+        sums over the positions of all ranks -- what _get_nearplane_gradients
+        returns for this case, without its per-call set-up."""
+        S, pw, det, H, W = self.dims
+        dev = psi.device
+        ws = _workspace(op)
+        n_max = self.far.shape[0]
+        mid = ws.get("mid", tuple(self.far.shape), torch.complex64, dev)
+        gscale = ws.get("gscale", (n_max, det, det), torch.float32, dev)
+        N = self.costs.shape[0]
+        patches = ws.get("patches", (max(N, 1), pw, pw), torch.complex64, dev)
+        objproj = ws.get("objproj", (n_max, pw, pw), torch.complex64, dev)
+        n_obj = 2 * H * W if want_psi else 0
+        n_prb = 2 * probe.numel() if want_probe else 0
+        grads = torch.zeros(n_obj + n_prb, dtype=torch.float32, device=dev)
+        acc = grads[:n_obj].view(2, H, W) if want_psi else None
+        mpu = (torch.view_as_complex(grads[n_obj:].view(*probe.shape, 2))
+               if want_probe else None)
+        _, inv_scale = fft_scales(det, op.norm)
+        st = A.stream_ptr()
+        lo = self.chunks[0][0]
+        for clo, chi, sc, d, cost in self.chunks:
+            n = chi - clo
+            check(
+                lib.tike_lstsq_chunk_gradients(
+                    A.ptr(psi), sc.data_ptr(), A.ptr(probe), None, None, 0, 0,
+                    d.data_ptr(), self.u16, None, 0, 1.0, det * det,
+                    A.ptr(self.far), A.ptr(mid), A.ptr(gscale),
+                    A.ptr(patches[clo - lo:chi - lo]), cost.data_ptr(),
+                    A.ptr(objproj) if want_psi else None, None, A.ptr(mpu), 1.0,
+                    A.ptr(acc), n, S, det, H, W, self.fwd_scale, inv_scale,
+                    st), "cgrad gradients")
+        if comm.collective and grads.numel():
+            comm.Allreduce(grads)
+        return self.costs, acc, mpu
+
 
 def _cost_and_grad(op, comm, data, psi, scan, probe, lo, hi, *, want_psi,
                    want_probe, want_grad, read_cost=True, plan=None):
@@ -105,7 +149,12 @@ def _cost_and_grad(op, comm, data, psi, scan, probe, lo, hi, *, want_psi,
     S, pw = probe.shape[-3], probe.shape[-1]
     det = op.detector_shape
     H, W = psi.shape[-2:]
-    if want_grad:
+    if want_grad and plan is not None and plan.supports_gradients():
+        costs, acc, mpu = plan.gradients(op, comm, psi, probe, want_psi,
+                                         want_probe)
+        gpsi = -torch.complex(acc[0], acc[1])[None] if want_psi else None
+        gprobe = -mpu if want_probe else None
+    elif want_grad:
         g = _get_nearplane_gradients(
             data, psi, scan, probe, None, None, lo, hi, comm, num_batch=1,
             exitwave_options=_gaussian_options(det), op=op,
