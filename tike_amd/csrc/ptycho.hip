@@ -509,15 +509,16 @@ extern "C" int tike_ptycho_fwd_gradient_scale(
 // ---- the 256^2 forward split in two launches (both far-plane free) ----------
 // Pass 1 alone: bilinear gather * probe -> row transforms -> radix-16 column
 // stage; `scratch` receives the column-pass input of every tile and `patches`
-// the object patches.  One workgroup owns all S modes of a position (the patch
-// is gathered once per 16-row group and shared by the modes).  The probe values
-// of mode s+1 are requested BEFORE the rows of mode s are stored: the memory
-// counter retires in issue order, so a load issued behind the stores would
-// wait for them and every mode would pay a full store round trip.
+// the object patches.  A work item is (position, 16-row group) and covers all S
+// modes (the patch of the group is gathered once and shared by the modes).
+// 167 VGPRs at 256^2: three waves per SIMD hide the probe loads of a mode behind
+// the other waves' butterflies and stores (an earlier version requested the
+// next mode's probe values ahead of the stores instead, at 255 VGPRs and two
+// waves: 13 % slower).
 // FULL: probe window = detector (pw == N, no padding): every probe / patch
 // access of a thread is `uniform base + one 32-bit lane offset + 8 T i` bytes.
 template <int N, bool FULL>
-__global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
+__global__ __launch_bounds__(N, N == 256 ? 3 : 2) void fwd_pass1_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ scratch, cf* __restrict__ patches, int nscan, int S, int pw, int H, int W,
     const cf* __restrict__ twtab) {
@@ -659,9 +660,12 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
           }
         }
       };
-      cf pn[16];
-      load_probe(0, pn);
       for (int s = 0; s < S; ++s) {
+        // (requesting the next mode's probe values ahead of this mode's stores
+        // hid one load latency but cost 32 registers: without it the kernel
+        // fits 167 VGPRs = 3 waves/SIMD at 256^2 and runs 13 % faster)
+        cf pn[16];
+        load_probe(s, pn);
         cf v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = pv[i] * pn[i];
@@ -669,9 +673,6 @@ __global__ __launch_bounds__(N, 2) void fwd_pass1_kernel(
         FftStageWave<N, false, 0>::run(v, lbase, j, tw);
 #pragma unroll
         for (int i = 0; i < 16; ++i) lbase[tk_pad16(j + i * G2::T)] = v[i];
-        // next mode's probe values: in flight across the transpose, the column
-        // butterflies and -- the point -- ahead of this mode's stores
-        if (s + 1 < S) load_probe(s + 1, pn);
         __syncthreads();
 #pragma unroll
         for (int y2 = 0; y2 < 16; ++y2) v[y2] = lds[y2 * G2::LS + tk_pad16(t)];
