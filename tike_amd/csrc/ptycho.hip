@@ -1614,10 +1614,20 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
     const FftTwLds<N> tw{twl, j};
+    // software pipelined over k1: the 16 rows of k1 + 1 are requested before
+    // the butterflies of k1 (1.64 -> 1.60 ms; 7 registers go to scratch at the
+    // 128-register cap, a third wave less per SIMD would cost more)
+    cf un[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) un[r] = tk_ld_stream(src + (16 * r + kbeg) * N + t);
     for (int k1 = kbeg; k1 < kbeg + kn; ++k1) {
       cf u[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(src + (16 * r + k1) * N + t);
+      for (int r = 0; r < 16; ++r) u[r] = un[r];
+      if (k1 + 1 < kbeg + kn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) un[r] = tk_ld_stream(src + (16 * r + k1 + 1) * N + t);
+      }
       Dft<16, false>::run(u);
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) {
