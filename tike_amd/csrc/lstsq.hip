@@ -975,9 +975,9 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
   const TkProbe pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
                                    S, pw, unique_probe);
   // split the pixels of a position over several workgroups until the launch
-  // holds ~4096 of them (probe windows that are a multiple of 1024 pixels)
+  // holds ~8192 of them (probe windows that are a multiple of 1024 pixels)
   int nsplit = 1;
-  while (nsplit < 16 && (long)nscan * nsplit * 2 <= 4096 && ((long)pw * pw) % (2048L * nsplit) == 0)
+  while (nsplit < 16 && (long)nscan * nsplit * 2 <= 8192 && ((long)pw * pw) % (2048L * nsplit) == 0)
     nsplit *= 2;
   if (nsplit > 1) {
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 8 * (size_t)nscan, (hipStream_t)stream);
@@ -1245,7 +1245,7 @@ extern "C" int tike_position_sums(const void* patches, const void* chi, int chi_
   const TkProbe pr =
       tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes, S, pw);
   int nsplit = 1;
-  while (nsplit < 16 && (long)nscan * nsplit * 2 <= 4096 && pw >= 64) nsplit *= 2;
+  while (nsplit < 16 && (long)nscan * nsplit * 2 <= 8192 && pw >= 64) nsplit *= 2;
   if (nsplit > 1) {
     hipError_t e = hipMemsetAsync(numerator, 0, sizeof(float) * 2 * (size_t)nscan,
                                   (hipStream_t)stream);
