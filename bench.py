@@ -282,6 +282,10 @@ def algorithmic_bytes(name, n, S, det, pw, C):
         "tike_grad_ifft2_crop": n * (T + S * P + D),
         # gradient + inverse pass 1: hand-off in, intermediate out
         "tike_grad_ifft2_pass1": n * (2 * T + D),
+        # column pass + gradient factor + inverse pass 1 in one launch: the
+        # hand-off and the data in, the intermediate out (it reads the
+        # hand-off twice; the second read is not algorithmic)
+        "tike_fwd_grad_ifft2_pass1": n * (2 * T + D),
         # inverse pass 2 + both gradients: intermediate + patches in,
         # objproj + chi0 out (+ the probe gradient, probe-sized)
         "tike_ifft2_pass2_gradients": n * (T + 3 * P) + S * P,

@@ -164,6 +164,19 @@ int tike_grad_ifft2_crop(const void* colin, const float* gscale, const float* mo
  * [* mode_scale on measured pixels] (tike_ifft2_pass1_scaled, det in
  * {128,256,512}; operands as tike_ifft2_crop_scaled_modes, mode_scale /
  * measured may be NULL).  work must not alias the input. */
+/* The column pass + gradient factor + inverse pass 1 in ONE launch (det = 256;
+ * gaussian, or poisson without per-mode step lengths): what
+ * tike_fwd_gradient_scale followed by tike_grad_ifft2_pass1 compute, without
+ * the factor going through memory (a work item = (position, k1) sweeps the
+ * hand-off rows of all S modes twice: for the intensity, then -- newest first --
+ * for the gradient and the inverse's pass 1).  scratch (nscan,S,det,det) from
+ * tike_fwd_pass1; data f32 or uint16; measured may be NULL; costs (nscan, may be
+ * NULL) overwritten; work (nscan,S,det,det) != scratch receives the input of
+ * tike_ifft2_pass2_gradients. */
+int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, int data_u16,
+                              const unsigned char* measured, float* costs, void* work,
+                              int nscan, int S, int det, float fwd_scale, int model,
+                              float unmeasured_scaling, long num_measured, void* stream);
 int tike_grad_ifft2_pass1(const void* colin, const float* gscale, const float* mode_scale,
                           const unsigned char* measured, int S, void* work, long ntile, int det,
                           float fwd_scale, void* stream);

@@ -69,6 +69,8 @@ _PROTOTYPES = {
     "tike_fwd_gradient_scale": [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _f,
                                 _i, _f, _l, _p],
     "tike_grad_ifft2_pass1": [_p, _p, _p, _p, _i, _p, _l, _i, _f, _p],
+    "tike_fwd_grad_ifft2_pass1": [_p, _p, _i, _p, _p, _p, _i, _i, _i, _f, _i, _f,
+                                  _l, _p],
     "tike_ifft2_pass1_scaled": [_p, _p, _p, _p, _i, _p, _l, _i, _p],
     "tike_ifft2_pass2_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _f,
                                    _i, _i, _i, _f, _p],

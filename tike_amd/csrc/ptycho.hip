@@ -1654,6 +1654,109 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
   }
 }
 
+// ---- column pass + gradient factor + inverse pass 1 in ONE kernel (256^2)
+// tike_fwd_gradient_scale and tike_grad_ifft2_pass1 both stream the hand-off:
+// the factor g of rows {k1 + 16 k2} needs |F_s|^2 of ALL modes of exactly those
+// rows, and the inverse's pass 1 for (tile, k1) needs exactly that g -- so one
+// work item (position, k1) can do both: sweep A re-forms F_s row by row for
+// the intensity (F discarded), g stays in 16 registers, sweep B re-reads the
+// same 16 rows of every mode -- newest first, they are the likeliest to be
+// cached still -- re-forms F_s, scales, and runs the inverse's pass 1 on the
+// same registers.  The factor never goes through memory and the second read
+// of the hand-off is served partly by the caches.  Gaussian / poisson without
+// per-mode steps (those need the intensity between the two sweeps).
+template <int MODEL, class DT>
+__global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
+    const cf* __restrict__ colin, const DT* __restrict__ data,
+    const unsigned char* __restrict__ mask, float* __restrict__ costs, cf* __restrict__ work,
+    long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
+    const cf* __restrict__ twtab) {
+  constexpr int N = 256;
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  __shared__ float red[4];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int t = threadIdx.x;
+  const float s2 = fwd_scale * fwd_scale;
+  for (long v = blockIdx.x; v < nscan * 16; v += gridDim.x) {
+    const int k1 = (int)(v & 15);
+    const long n = nscan - 1 - (v >> 4);  // descending: see fwd_gradient_scale_kernel
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    // ---- sweep A: intensity of rows k1 + 16 k2, all modes (pipelined loads)
+    float I[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) I[k2] = 0.f;
+    cf un[16];
+    {
+      const cf* __restrict__ src0 = colin + (n * S) * (long)N * N + k1 * N + t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) un[r] = tk_ld_stream(src0 + (long)(16 * r) * N);
+    }
+    for (int s = 0; s < S; ++s) {
+      cf u[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = un[r];
+      // next: mode s + 1 of sweep A, or the first mode of sweep B (S - 1 again)
+      {
+        const int sn = s + 1 < S ? s + 1 : S - 1;
+        const cf* __restrict__ src = colin + (n * S + sn) * (long)N * N + k1 * N + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) un[r] = src[(long)(16 * r) * N];
+      }
+      Dft<16, false>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) I[k2] += norm2(u[k2]) * s2;
+    }
+    // ---- the factor (times the forward scale the inverse applies to F) and the cost
+    float cost = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      const long p = (long)(k1 + 16 * k2) * N + t;
+      float g = unmeasured_scaling - 1.0f;
+      if (mask == nullptr || mask[p]) {
+        const float dv = (float)data[n * (long)N * N + p];
+        if (MODEL == 0) {
+          const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
+          const float diff = sI - sd;
+          cost += diff * diff;
+          g = -(1.0f - sd / (sI + 1e-9f));
+        } else {
+          cost += I[k2] - dv * logf(I[k2] + 1e-9f);
+          g = -(1.0f - dv / (I[k2] + 1e-9f));
+        }
+      }
+      I[k2] = g * fwd_scale;
+    }
+    if (costs) {
+      cost = tk_block_sum256(cost, red);
+      if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+    }
+    // ---- sweep B: modes S - 1 .. 0, gradient and the inverse's pass 1
+    for (int s = S - 1; s >= 0; --s) {
+      cf u[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = un[r];
+      if (s > 0) {
+        const cf* __restrict__ src = colin + (n * S + s - 1) * (long)N * N + k1 * N + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) un[r] = src[(long)(16 * r) * N];
+      }
+      Dft<16, false>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) u[k2] = u[k2] * I[k2];
+      Dft<16, true>::run(u);
+#pragma unroll
+      for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
+      cf* mid = work + (n * S + s) * (long)N * N;
+      fft2_rows_from_columns<N, true, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
+    }
+  }
+}
+
 // The same at 512^2 (RB = 32): per tile and k1 a thread owns one column,
 //   F[k1 + 16 k2] = radix-32 over r of rows 16 r + k1 of the hand-off, times g;
 // the 32 rows it then holds are exactly TWO input groups of the inverse's pass
@@ -1761,6 +1864,45 @@ extern "C" int tike_grad_ifft2_crop(const void* colin, const float* gscale,
 
 // Pass 1 only of tike_grad_ifft2_crop: `work` receives the input of the inverse
 // column pass (rows 16 k1 + ya), consumed by tike_ifft2_pass2_gradients.
+// scratch: from tike_fwd_pass1.  costs (may be NULL) must not need zeroing by
+// the caller (done here); work must not alias scratch.  det = 256.
+extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, int data_u16,
+                                         const unsigned char* measured, float* costs,
+                                         void* work, int nscan, int S, int det, float fwd_scale,
+                                         int model, float unmeasured_scaling, long num_measured,
+                                         void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1 && (model == 0 || model == 1) &&
+               num_measured > 0);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(scratch && data && work && work != scratch);
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  if (costs) {
+    hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  const float inv = 1.0f / (float)num_measured;
+  const dim3 grid(tk_grid((long)nscan * 16, 12)), block(256);
+#define TK_FG(M, DT)                                                                          \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_kernel<M, DT>), grid, block, 0, stream,            \
+                     (const cf*)scratch, (const DT*)data, measured, costs, (cf*)work,         \
+                     (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
+  if (model == 0 && data_u16)
+    TK_FG(0, unsigned short);
+  else if (model == 0)
+    TK_FG(0, float);
+  else if (data_u16)
+    TK_FG(1, unsigned short);
+  else
+    TK_FG(1, float);
+#undef TK_FG
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 extern "C" int tike_grad_ifft2_pass1(const void* colin, const float* gscale,
                                      const float* mode_scale, const unsigned char* measured,
                                      int S, void* work, long ntile, int det, float fwd_scale,

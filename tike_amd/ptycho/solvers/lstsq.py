@@ -420,21 +420,36 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     None, A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(far),
                     A.ptr(patches[blo:blo + n]) if fused else None, n, S, pw,
                     det, H, W, st), "forward pass 1")
-            check(
-                lib.tike_fwd_gradient_scale(
-                    A.ptr(far), A.ptr(data[clo:chi_hi]),
-                    int(data.dtype == torch.uint16), A.ptr(mask_u8),
-                    A.ptr(gscale), A.ptr(inten) if poisson else None,
-                    A.ptr(costs[blo:blo + n]), None, n, S, det, fwd_scale,
-                    model, unmeasured, nmeasured, st),
-                "forward pass 2 + gradient scale")
+            # 256^2 without poisson step lengths: the column pass, the gradient
+            # factor and the inverse's pass 1 are ONE launch (the factor never
+            # goes through memory)
+            one_launch = fused and det == 256 and not poisson
+            if one_launch:
+                check(
+                    lib.tike_fwd_grad_ifft2_pass1(
+                        A.ptr(far), A.ptr(data[clo:chi_hi]),
+                        int(data.dtype == torch.uint16), A.ptr(mask_u8),
+                        A.ptr(costs[blo:blo + n]), A.ptr(mid), n, S, det,
+                        fwd_scale, model, unmeasured, nmeasured, st),
+                    "column pass + gradient + inverse pass 1")
+            else:
+                check(
+                    lib.tike_fwd_gradient_scale(
+                        A.ptr(far), A.ptr(data[clo:chi_hi]),
+                        int(data.dtype == torch.uint16), A.ptr(mask_u8),
+                        A.ptr(gscale), A.ptr(inten) if poisson else None,
+                        A.ptr(costs[blo:blo + n]), None, n, S, det, fwd_scale,
+                        model, unmeasured, nmeasured, st),
+                    "forward pass 2 + gradient scale")
             if poisson:  # dominant mode: the steps need no far-plane waves
                 check(
                     lib.tike_poisson_steps(
                         None, A.ptr(inten), A.ptr(dchunk),
                         A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
                         step_weight, 1, st), "poisson step lengths")
-            if fused:
+            if one_launch:
+                pass
+            elif fused:
                 check(
                     lib.tike_grad_ifft2_pass1(
                         A.ptr(far), A.ptr(gscale),
