@@ -292,7 +292,8 @@ def algorithmic_bytes(name, n, S, det, pw, C):
         # the five far-plane-free stages in one call (cgrad's gradient pass:
         # no chi0 stored)
         "tike_lstsq_chunk_gradients":
-        (n * (T + 2 * P + 8) + (S + C) * P) + n * (T + 2 * D) + n * (2 * T + D)
+        (n * (T + 2 * P + 8) + (S + C) * P)
+        + (n * (2 * T + D) if det == 256 else n * (T + 2 * D) + n * (2 * T + D))
         + (n * (T + 2 * P) + S * P) + n * (P + 8 * (pw + 1) * (pw + 1)),
         "tike_gradient_scale": n * 3 * D,
         "tike_farplane_gradient": n * (2 * T + D + 4),

@@ -445,13 +445,15 @@ int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, doub
 
 /* ---- the chunk body of _get_nearplane_gradients (lstsq.py:422-579) in ONE call:
  * the far-plane-free pipeline for a chunk of nscan positions,
- *   tike_fwd_pass1 -> tike_fwd_gradient_scale -> tike_grad_ifft2_pass1 ->
+ *   tike_fwd_pass1 -> tike_fwd_grad_ifft2_pass1 (256^2; at 512^2
+ *   tike_fwd_gradient_scale -> tike_grad_ifft2_pass1) ->
  *   tike_ifft2_pass2_gradients -> tike_scatter_patches,
  * for callers that do not need the stages separately (a level-B binding of
  * lstsq.py's chunk loop).  Inputs as in those entries (psi, scan, probe, the
  * eigen probes applied on the fly, data f32 or uint16, optional mask);
  * workspaces scratch and work (nscan,S,det,det) c64 each and gscale
- * (nscan,det,det) f32 are the caller's, must not alias and hold no result
+ * (nscan,det,det) f32 (512^2 only; may be NULL at 256^2, where the factor
+ * stays in registers) are the caller's, must not alias and hold no result
  * afterwards.  Outputs: patches, chi0 (nscan,det,det) c64 and costs (nscan)
  * are overwritten; m_probe_update (S,det,det) c64 += mpu_scale * sum_n ...,
  * object_acc (2,H,W) planar f32 += scatter_n(sum_s conj(P_n,s) chi_n,s) via

@@ -370,18 +370,24 @@ extern "C" int tike_lstsq_chunk_gradients(
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
-  TK_CHECK_ARG(psi && scan && probe && data && scratch && work && gscale && patches);
+  TK_CHECK_ARG(psi && scan && probe && data && scratch && work && patches);
   TK_CHECK_ARG(scratch != work && (object_acc == nullptr) == (objproj == nullptr));
   if (!((det == 256 && S <= 8) || (det == 512 && S <= 4))) return TK_ERR_UNSUPPORTED;
+  TK_CHECK_ARG(gscale || det == 256);  // 256^2: the factor stays in registers
   int rc = tike_fwd_pass1(psi, scan, probe, 0, nullptr, eigen_probe, eigen_weights, num_eigen,
                           eigen_modes, scratch, patches, nscan, S, det, det, H, W, stream);
   if (rc) return rc;
-  rc = tike_fwd_gradient_scale(scratch, data, data_u16, measured, gscale, nullptr, costs,
-                               nullptr, nscan, S, det, fwd_scale, model, unmeasured_scaling,
-                               num_measured, stream);
-  if (rc) return rc;
-  rc = tike_grad_ifft2_pass1(scratch, gscale, nullptr, nullptr, S, work, (long)nscan * S, det,
-                             fwd_scale, stream);
+  if (det == 256) {
+    rc = tike_fwd_grad_ifft2_pass1(scratch, data, data_u16, measured, costs, work, nscan, S, det,
+                                   fwd_scale, model, unmeasured_scaling, num_measured, stream);
+  } else {
+    rc = tike_fwd_gradient_scale(scratch, data, data_u16, measured, gscale, nullptr, costs,
+                                 nullptr, nscan, S, det, fwd_scale, model, unmeasured_scaling,
+                                 num_measured, stream);
+    if (rc) return rc;
+    rc = tike_grad_ifft2_pass1(scratch, gscale, nullptr, nullptr, S, work, (long)nscan * S, det,
+                               fwd_scale, stream);
+  }
   if (rc) return rc;
   rc = tike_ifft2_pass2_gradients(work, patches, probe, eigen_probe, eigen_weights, num_eigen,
                                   eigen_modes, objproj, chi0, m_probe_update, mpu_scale, nscan,
