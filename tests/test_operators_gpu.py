@@ -358,7 +358,9 @@ def test_full_size_roundtrip_property(ops):
                                       (512, 384, 1), (256, 192, 3),
                                       (256, 256, 8), (256, 256, 1),
                                       (256, 256, 5), (128, 128, 8),
-                                      (128, 128, 1), (512, 512, 4)])
+                                      (128, 128, 1), (512, 512, 4),
+                                      (256, 256, 3), (256, 256, 4),
+                                      (256, 256, 6), (256, 256, 7)])
 def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
     """tike_ptycho_fwd_intensity -> tike_gradient_scale ->
     tike_ifft2_crop_scaled == oracle fwd, intensity, per-pattern cost and
@@ -558,6 +560,17 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
                                             None, S, A.ptr(work), N * S, det,
                                             1.0 / det, st))
             fused_gradients(work, "no far plane")
+            # column pass + factor + inverse pass 1 in ONE launch (two sweeps
+            # for S <= 2, column-pass values resident in registers above)
+            work1 = torch.full_like(far, 3.0)
+            costs1 = torch.empty_like(costs)
+            check(lib.tike_fwd_grad_ifft2_pass1(
+                A.ptr(scratch), A.ptr(d_d), 0, A.ptr(m_d), A.ptr(costs1),
+                A.ptr(work1), N, S, det, 1.0 / det, 0, 0.5, int(mask.sum()),
+                st))
+            np.testing.assert_allclose(costs1.cpu().numpy(), want_cost,
+                                       rtol=COST_RTOL)
+            fused_gradients(work1, "one launch")
         # per-mode factor on measured pixels (poisson form)
         steps = torch.rand((N, S), dtype=torch.float32, device=dev) + 0.5
         check(lib.tike_grad_ifft2_crop(
@@ -569,6 +582,62 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
             A.ptr(chi3), N * S, det, pw, 1.0 / det, st))
         assert_close(chi2.cpu().numpy(), chi3.cpu().numpy(), normwise=1e-5,
                      maxabs=1e-4, what="chi with mode steps")
+
+
+@pytest.mark.parametrize("S", [1, 3, 4, 5, 8])
+@pytest.mark.parametrize("model,u16,masked", [(0, False, False), (0, True, True),
+                                               (1, False, True), (1, True, False)])
+def test_one_launch_gradient_pass_matches_the_two_launches(S, model, u16, masked):
+    """tike_fwd_grad_ifft2_pass1 == tike_fwd_gradient_scale +
+    tike_grad_ifft2_pass1 on the same hand-off, with enough positions that
+    every workgroup walks several work items (the register-resident kernel
+    requests the next item's rows while it finishes the current one): both
+    noise models, float / 16-bit counts, with and without a mask whose
+    unmeasured pixels hold garbage."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import lib, check
+    N, det = 300, 256
+    dev = A.current_device()
+    g = torch.Generator(device=dev).manual_seed(S + 10 * model)
+    scratch = torch.view_as_complex(
+        torch.rand(N, 1, S, det, det, 2, device=dev, generator=g) - 0.5)
+    counts = torch.rand(N, det, det, device=dev, generator=g) * 40 * S
+    mask = None
+    nmeas = det * det
+    if masked:
+        mask = (torch.rand(det, det, device=dev, generator=g) > 0.1).to(torch.uint8)
+        nmeas = int(mask.sum())
+    if u16:
+        data = counts.to(torch.int32).to(torch.uint16)
+        if masked:  # garbage where nothing was measured
+            data = torch.where(mask.bool(), data.to(torch.int32),
+                               torch.full_like(data, 65535, dtype=torch.int32)
+                               ).to(torch.uint16)
+    else:
+        data = counts
+        if masked:
+            data = torch.where(mask.bool(), data,
+                               torch.full_like(data, float("nan")))
+    st = A.stream_ptr()
+    gs = torch.empty(N, det, det, device=dev)
+    c_ref, c_one = torch.empty(N, device=dev), torch.empty(N, device=dev)
+    w_ref, w_one = torch.empty_like(scratch), torch.full_like(scratch, 5.0)
+    mp = A.ptr(mask) if masked else None
+    check(lib.tike_fwd_gradient_scale(
+        A.ptr(scratch), A.ptr(data), int(u16), mp, A.ptr(gs), None,
+        A.ptr(c_ref), None, N, S, det, 1.0 / det, model, 0.5, nmeas, st))
+    check(lib.tike_grad_ifft2_pass1(A.ptr(scratch), A.ptr(gs), None, None, S,
+                                    A.ptr(w_ref), N * S, det, 1.0 / det, st))
+    check(lib.tike_fwd_grad_ifft2_pass1(
+        A.ptr(scratch), A.ptr(data), int(u16), mp, A.ptr(c_one), A.ptr(w_one),
+        N, S, det, 1.0 / det, model, 0.5, nmeas, st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(torch.view_as_real(w_one)).all()
+    np.testing.assert_allclose(c_one.cpu().numpy(), c_ref.cpu().numpy(),
+                               rtol=1e-5)
+    assert_close(w_one.cpu().numpy(), w_ref.cpu().numpy(), normwise=2e-6,
+                 maxabs=2e-5, what="inverse column-pass input")
 
 
 @pytest.mark.parametrize("layout", ["neighbours", "far_apart", "tall_group",

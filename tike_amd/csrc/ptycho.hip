@@ -1654,6 +1654,55 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
   }
 }
 
+// Counts and mask bits of the 16 pixels (k1 + 16 k2, t) of position n of a
+// 256^2 pattern, requested TOGETHER and unconditionally (a branch per pixel
+// around its load makes 16 serial memory round trips of them); unmeasured
+// pixels may hold NaN: they are selected away by the mask bit, never multiplied.
+template <class DT>
+__device__ __forceinline__ void tk_request_data16(const DT* __restrict__ data,
+                                                  const unsigned char* __restrict__ mask, long n,
+                                                  int k1, int t, DT (&raw)[16], unsigned& bits) {
+  constexpr int N = 256;
+  const DT* __restrict__ d = data + n * (long)N * N + k1 * N + t;
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) raw[k2] = d[(long)(16 * k2) * N];
+  bits = 0xffffu;
+  if (mask) {  // uniform
+    unsigned char mb[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) mb[k2] = mask[(k1 + 16 * k2) * N + t];
+    bits = 0;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) bits |= (mb[k2] ? 1u : 0u) << k2;
+  }
+}
+
+// I[k2] (intensity) -> g * fwd_scale, returns this thread's cost terms.
+template <int MODEL, class DT>
+__device__ __forceinline__ float tk_gradient_factor16(float (&I)[16], const DT (&raw)[16],
+                                                      unsigned bits, float unmeasured_scaling,
+                                                      float fwd_scale) {
+  float cost = 0.f;
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) {
+    const bool meas = (bits >> k2) & 1u;
+    const float dv = (float)raw[k2];
+    float term, g;
+    if (MODEL == 0) {
+      const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
+      const float diff = sI - sd;
+      term = diff * diff;
+      g = -(1.0f - sd / (sI + 1e-9f));
+    } else {
+      term = I[k2] - dv * logf(I[k2] + 1e-9f);
+      g = -(1.0f - dv / (I[k2] + 1e-9f));
+    }
+    cost += meas ? term : 0.f;
+    I[k2] = (meas ? g : unmeasured_scaling - 1.0f) * fwd_scale;
+  }
+  return cost;
+}
+
 // ---- column pass + gradient factor + inverse pass 1 in ONE kernel (256^2)
 // tike_fwd_gradient_scale and tike_grad_ifft2_pass1 both stream the hand-off:
 // the factor g of rows {k1 + 16 k2} needs |F_s|^2 of ALL modes of exactly those
@@ -1665,6 +1714,8 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
 // same registers.  The factor never goes through memory and the second read
 // of the hand-off is served partly by the caches.  Gaussian / poisson without
 // per-mode steps (those need the intensity between the two sweeps).
+#define TK_FG_RESIDENT_MIN_MODES 3
+
 template <int MODEL, class DT>
 __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
@@ -1712,24 +1763,12 @@ __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
       for (int k2 = 0; k2 < 16; ++k2) I[k2] += norm2(u[k2]) * s2;
     }
     // ---- the factor (times the forward scale the inverse applies to F) and the cost
-    float cost = 0.f;
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) {
-      const long p = (long)(k1 + 16 * k2) * N + t;
-      float g = unmeasured_scaling - 1.0f;
-      if (mask == nullptr || mask[p]) {
-        const float dv = (float)data[n * (long)N * N + p];
-        if (MODEL == 0) {
-          const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
-          const float diff = sI - sd;
-          cost += diff * diff;
-          g = -(1.0f - sd / (sI + 1e-9f));
-        } else {
-          cost += I[k2] - dv * logf(I[k2] + 1e-9f);
-          g = -(1.0f - dv / (I[k2] + 1e-9f));
-        }
-      }
-      I[k2] = g * fwd_scale;
+    float cost;
+    {
+      DT raw[16];
+      unsigned bits;
+      tk_request_data16(data, mask, n, k1, t, raw, bits);
+      cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
     }
     if (costs) {
       cost = tk_block_sum256(cost, red);
@@ -1753,6 +1792,130 @@ __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
       for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
       cf* mid = work + (n * S + s) * (long)N * N;
       fft2_rows_from_columns<N, true, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
+    }
+  }
+}
+
+// ---- the same with the column-pass values RESIDENT IN REGISTERS (256^2)
+// The kernel above streams the hand-off twice, and its second sweep misses L2
+// (96 work items x 256 KiB per XCD).  Here a 512-thread workgroup -- one per
+// CU, 2 waves/SIMD, the whole register file -- owns a work item (position,
+// k1): half h of the workgroup holds F of modes [h*MH, h*MH + MH) of its
+// column, 32 registers per mode; the halves exchange their partial
+// intensities through LDS, form the same g, and each sends its modes through
+// the inverse's pass 1 in its own LDS transpose region.  The hand-off is read
+// ONCE.  With a single workgroup per CU nothing else hides the memory
+// latency, so the loop is rotated: as soon as mode m of this work item has
+// left its registers, the rows of mode m of the NEXT work item are requested
+// into them -- a full work item (256 KiB per CU) is always in flight.
+template <int N, bool INV, class Tw>
+__device__ __forceinline__ void fft2_rows_from_columns_half(cf* __restrict__ lds, const Tw& tw,
+                                                            int t, int line, int j, cf (&a)[16],
+                                                            cf* __restrict__ rows, bool store) {
+  using G2 = Fft2Geom<N>;
+#pragma unroll
+  for (int ya = 0; ya < 16; ++ya) lds[ya * G2::LS + tk_pad16(t)] = a[ya];
+  __syncthreads();
+  cf v[16];
+  cf* lbase = lds + line * G2::LS;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = lbase[tk_pad16(j + i * G2::T)];
+  FftStageWave<N, INV, 0>::run(v, lbase, j, tw);
+  if (store) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tk_st_stream(rows + line * N + j + i * G2::T, v[i]);
+  }
+  __syncthreads();
+}
+
+template <int MH, int MODEL, class DT>
+__global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
+    const cf* __restrict__ colin, const DT* __restrict__ data,
+    const unsigned char* __restrict__ mask, float* __restrict__ costs, cf* __restrict__ work,
+    long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
+    const cf* __restrict__ twtab) {
+  constexpr int N = 256;
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[2 * G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + 2 * G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int h = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int t = threadIdx.x & 255;
+  cf* const mylds = lds + h * G2::LDS_ELEMS;
+  int line = t / G2::T, j = t % G2::T;
+  asm volatile("" : "+v"(line), "+v"(j));
+  const FftTwLds<N> tw{twl, j};
+  const int m0 = h * MH;
+  const float s2 = fwd_scale * fwd_scale;
+  const long total = nscan * 16;
+  cf F[MH][16];
+  auto request = [&](long v, int m) {  // rows 16 r + k1 of mode m0 + m into F[m]
+    const int k1 = (int)(v & 15);
+    const long n = nscan - 1 - (v >> 4);
+    if (m0 + m < S) {
+      const cf* __restrict__ src = colin + (n * S + m0 + m) * (long)N * N + k1 * N + t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) F[m][r] = tk_ld_stream(src + (long)(16 * r) * N);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) F[m][r] = cf{0.f, 0.f};
+    }
+  };
+  long v = blockIdx.x;
+  if (v < total) {
+#pragma unroll
+    for (int m = 0; m < MH; ++m) request(v, m);
+  }
+  for (; v < total; v += gridDim.x) {
+    const int k1 = (int)(v & 15);
+    const long n = nscan - 1 - (v >> 4);  // descending: see fwd_gradient_scale_kernel
+    DT raw[16];
+    unsigned bits;
+    float I[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) I[k2] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+      // the counts: requested behind the last hand-off rows, used after the
+      // last butterfly and the exchange
+      if (m == MH - 1) tk_request_data16(data, mask, n, k1, t, raw, bits);
+      Dft<16, false>::run(F[m]);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) I[k2] += norm2(F[m][k2]) * s2;
+    }
+    {
+      float* const myI = reinterpret_cast<float*>(mylds);
+      const float* const otherI =
+          reinterpret_cast<const float*>(lds + (1 - h) * G2::LDS_ELEMS);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) myI[k2 * N + t] = I[k2];
+      __syncthreads();
+      // both halves add in the same order: they must form the SAME factor
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const float o = otherI[k2 * N + t];
+        I[k2] = h == 0 ? I[k2] + o : o + I[k2];
+      }
+      __syncthreads();
+    }
+    float cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
+    if (costs && h == 0) {
+      cost = tk_wave_sum(cost);
+      if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+    }
+    const long vn = v + gridDim.x;
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) F[m][k2] = F[m][k2] * I[k2];
+      Dft<16, true>::run(F[m]);
+#pragma unroll
+      for (int ya = 1; ya < 16; ++ya) F[m][ya] = mul_tw<true>(F[m][ya], twtab[N + k1 * ya]);
+      cf* mid = work + (n * S + m0 + m) * (long)N * N;
+      fft2_rows_from_columns_half<N, true>(mylds, tw, t, line, j, F[m], mid + (long)(16 * k1) * N,
+                                           m0 + m < S);
+      if (vn < total) request(vn, m);
     }
   }
 }
@@ -1885,6 +2048,34 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
     if (e != hipSuccess) return (int)e;
   }
   const float inv = 1.0f / (float)num_measured;
+  if (S >= TK_FG_RESIDENT_MIN_MODES && S <= 8) {
+    // one 512-thread workgroup per CU (it takes the whole register file)
+    const dim3 grid(tk_grid((long)nscan * 16, 1)), block(512);
+#define TK_FGR(MH, M, DT)                                                                     \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT>), grid, block, 0,       \
+                     stream, (const cf*)scratch, (const DT*)data, measured, costs, (cf*)work, \
+                     (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
+#define TK_FGR_M(MH)                                                                          \
+  do {                                                                                        \
+    if (model == 0 && data_u16)                                                               \
+      TK_FGR(MH, 0, unsigned short);                                                          \
+    else if (model == 0)                                                                      \
+      TK_FGR(MH, 0, float);                                                                   \
+    else if (data_u16)                                                                        \
+      TK_FGR(MH, 1, unsigned short);                                                          \
+    else                                                                                      \
+      TK_FGR(MH, 1, float);                                                                   \
+  } while (0)
+    switch ((S + 1) / 2) {
+      case 2: TK_FGR_M(2); break;
+      case 3: TK_FGR_M(3); break;
+      default: TK_FGR_M(4); break;
+    }
+#undef TK_FGR_M
+#undef TK_FGR
+    TK_LAUNCH_CHECK();
+    return TK_OK;
+  }
   const dim3 grid(tk_grid((long)nscan * 16, 12)), block(256);
 #define TK_FG(M, DT)                                                                          \
   hipLaunchKernelGGL((fwd_grad_ifft2_pass1_kernel<M, DT>), grid, block, 0, stream,            \
