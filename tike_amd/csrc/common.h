@@ -52,6 +52,28 @@ __device__ __forceinline__ void tk_st_stream(float* p, float v) {
   __builtin_nontemporal_store(v, p);
 }
 
+// Element `byte_off` bytes past a UNIFORM base pointer: written so that the
+// compiler selects the scalar-base addressing mode (SGPR pair + one 32-bit
+// VGPR offset shared by all rows of the slice) instead of a 64-bit address
+// pair per row.
+template <class T>
+__device__ __forceinline__ const T* tk_at(const T* base, unsigned byte_off) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class T>
+__device__ __forceinline__ T* tk_at(T* base, unsigned byte_off) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+// The same with the base pinned in scalar registers first: without it the
+// compiler folds (base + lane offset) once and then adds the row offsets as
+// 64-bit VECTOR additions (two instructions, a hazard nop and a register pair
+// per row).
+template <class T>
+__device__ __forceinline__ T* tk_at_pinned(T* base, unsigned byte_off) {
+  asm volatile("" : "+s"(base));
+  return tk_at(base, byte_off);
+}
+
 __device__ __forceinline__ float tk_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -485,19 +485,6 @@ struct TkModeProbe {  // probe of one (position, mode): uniform values
   int nE;             // eigen probes to add on the fly (0 when `base` is final)
 };
 
-// Element `byte_off` bytes past a UNIFORM base pointer: written so that the
-// compiler selects the scalar-base addressing mode (SGPR pair + one 32-bit
-// VGPR offset shared by all rows of the slice) instead of a 64-bit address
-// pair per row.
-template <class T>
-__device__ __forceinline__ const T* tk_at(const T* base, unsigned byte_off) {
-  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-}
-template <class T>
-__device__ __forceinline__ T* tk_at(T* base, unsigned byte_off) {
-  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
-}
-
 template <int N, int MW, int MPW, bool HAVE_PROJ>
 __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
     const cf* __restrict__ mid, const cf* __restrict__ patches, const TkProbe probe,

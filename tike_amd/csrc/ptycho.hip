@@ -1663,9 +1663,10 @@ __device__ __forceinline__ void tk_request_data16(const DT* __restrict__ data,
                                                   const unsigned char* __restrict__ mask, long n,
                                                   int k1, int t, DT (&raw)[16], unsigned& bits) {
   constexpr int N = 256;
-  const DT* __restrict__ d = data + n * (long)N * N + k1 * N + t;
+  const DT* __restrict__ d = data + n * (long)N * N + k1 * N;  // uniform
+  const unsigned lo = (unsigned)t * (unsigned)sizeof(DT);
 #pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) raw[k2] = d[(long)(16 * k2) * N];
+  for (int k2 = 0; k2 < 16; ++k2) raw[k2] = *tk_at_pinned(d + (16 * k2) * N, lo);
   bits = 0xffffu;
   if (mask) {  // uniform
     unsigned char mb[16];
@@ -1822,8 +1823,9 @@ __device__ __forceinline__ void fft2_rows_from_columns_half(cf* __restrict__ lds
   for (int i = 0; i < 16; ++i) v[i] = lbase[tk_pad16(j + i * G2::T)];
   FftStageWave<N, INV, 0>::run(v, lbase, j, tw);
   if (store) {
+    const unsigned lo = (unsigned)(line * N + j) * 8u;  // `rows` is uniform
 #pragma unroll
-    for (int i = 0; i < 16; ++i) tk_st_stream(rows + line * N + j + i * G2::T, v[i]);
+    for (int i = 0; i < 16; ++i) tk_st_stream(tk_at(rows + i * G2::T, lo), v[i]);
   }
   __syncthreads();
 }
@@ -1854,9 +1856,10 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
     const int k1 = (int)(v & 15);
     const long n = nscan - 1 - (v >> 4);
     if (m0 + m < S) {
-      const cf* __restrict__ src = colin + (n * S + m0 + m) * (long)N * N + k1 * N + t;
+      const cf* __restrict__ src = colin + (n * S + m0 + m) * (long)N * N + k1 * N;  // uniform
 #pragma unroll
-      for (int r = 0; r < 16; ++r) F[m][r] = tk_ld_stream(src + (long)(16 * r) * N);
+      for (int r = 0; r < 16; ++r)
+        F[m][r] = tk_ld_stream(tk_at_pinned(src + (16 * r) * N, t * 8u));
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) F[m][r] = cf{0.f, 0.f};

@@ -24,6 +24,7 @@ KERNELS = {
     "void fwd_colpass_inplace_kernel": "tike_ptycho_fwd",
     "void fwd_gradient_scale_kernel": "tike_fwd_gradient_scale",
     "void fwd_grad_ifft2_pass1_kernel": "tike_fwd_grad_ifft2_pass1",
+    "void fwd_grad_ifft2_pass1_resident_kernel": "tike_fwd_grad_ifft2_pass1",
     "void grad_ifft2_pass1_512_kernel": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 1, false>": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 2, false>": "tike_grad_ifft2_pass1",
@@ -51,6 +52,7 @@ KERNELS = {
 # whose kernels the solver uses too)
 SOLVER_ONLY = ("psi_precond_kernel", "void fwd_gradient_scale_kernel",
                "void fwd_grad_ifft2_pass1_kernel",
+               "void fwd_grad_ifft2_pass1_resident_kernel",
                "void step_stats_kernel", "void probe_grad_kernel",
                "void gradient_scale_kernel", "void farplane_gradient_kernel")
 
