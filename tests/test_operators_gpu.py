@@ -561,7 +561,7 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
                                             1.0 / det, st))
             fused_gradients(work, "no far plane")
             # column pass + factor + inverse pass 1 in ONE launch (two sweeps
-            # for S <= 2, column-pass values resident in registers above)
+            # for S <= 5, column-pass values resident in registers above)
             work1 = torch.full_like(far, 3.0)
             costs1 = torch.empty_like(costs)
             check(lib.tike_fwd_grad_ifft2_pass1(
@@ -584,7 +584,7 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
                      maxabs=1e-4, what="chi with mode steps")
 
 
-@pytest.mark.parametrize("S", [1, 3, 4, 5, 8])
+@pytest.mark.parametrize("S", [1, 4, 6, 7, 8])
 @pytest.mark.parametrize("model,u16,masked", [(0, False, False), (0, True, True),
                                                (1, False, True), (1, True, False)])
 def test_one_launch_gradient_pass_matches_the_two_launches(S, model, u16, masked):

@@ -1714,8 +1714,11 @@ __device__ __forceinline__ float tk_gradient_factor16(float (&I)[16], const DT (
 // cached still -- re-forms F_s, scales, and runs the inverse's pass 1 on the
 // same registers.  The factor never goes through memory and the second read
 // of the hand-off is served partly by the caches.  Gaussian / poisson without
-// per-mode steps (those need the intensity between the two sweeps).
-#define TK_FG_RESIDENT_MIN_MODES 3
+// per-mode steps (those need the intensity between the two sweeps).  The path
+// for S < TK_FG_RESIDENT_MIN_MODES; more modes: the resident kernel below.
+// measured (tools/fg_probe.py, 8000 tiles): S = 3 1.91 vs 2.22 ms, 4 1.87 / 1.89, 5 1.86 / 1.91,
+// 6 1.89 / 1.77, 7 1.86 / 1.78, 8 1.97 / 1.67 (two sweeps / resident)
+#define TK_FG_RESIDENT_MIN_MODES 6
 
 template <int MODEL, class DT>
 __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
@@ -2069,11 +2072,10 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
     else                                                                                      \
       TK_FGR(MH, 1, float);                                                                   \
   } while (0)
-    switch ((S + 1) / 2) {
-      case 2: TK_FGR_M(2); break;
-      case 3: TK_FGR_M(3); break;
-      default: TK_FGR_M(4); break;
-    }
+    if (S == 6)
+      TK_FGR_M(3);
+    else
+      TK_FGR_M(4);
 #undef TK_FGR_M
 #undef TK_FGR
     TK_LAUNCH_CHECK();

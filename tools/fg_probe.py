@@ -1,5 +1,6 @@
 """tike_fwd_grad_ifft2_pass1 vs tike_fwd_gradient_scale + tike_grad_ifft2_pass1:
-same intermediate and costs, and the time of each (1000 positions, 8 modes, 256^2)."""
+same intermediate and costs, and the time of each (8000 / S positions, S modes
+[argv 1, default 8], 256^2)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +8,8 @@ import torch
 import tike_amd._arrays as A
 from tike_amd._lib import check, lib
 
-N, S, det = 1000, 8, 256
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+N, det = 8000 // S, 256
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(1)
 scratch = torch.view_as_complex(torch.rand(N, 1, S, det, det, 2, device=dev, generator=g) - 0.5)
