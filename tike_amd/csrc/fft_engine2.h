@@ -97,9 +97,11 @@ struct FftStageWave {
   using G = FftGeom<N>;
   using P = FftPlan<N>;
   static constexpr int T = N / 16;
-  template <class Tw>
-  static __device__ __forceinline__ void run(cf (&v)[16], cf* __restrict__ lbase, int j,
-                                             const Tw& tw) {
+  // `at(e)`: LDS offset (from lbase) of element e of the line the T threads
+  // share -- tk_pad16 for a contiguous row, a strided map for a tile column
+  template <class Tw, class At>
+  static __device__ __forceinline__ void run_at(cf (&v)[16], cf* __restrict__ lbase, int j,
+                                                const Tw& tw, const At& at) {
     constexpr int R = P::R[S];
     constexpr int B = 16 / R;
     constexpr int Ns = G::ns(S);
@@ -121,7 +123,7 @@ struct FftStageWave {
         const int k = jj & (Ns - 1);
         const int j0 = (jj - k) * R + k;
 #pragma unroll
-        for (int r = 0; r < R; ++r) lbase[tk_pad16(j0 + r * Ns)] = u[r];
+        for (int r = 0; r < R; ++r) lbase[at(j0 + r * Ns)] = u[r];
       }
     }
     if constexpr (!LAST) {
@@ -129,11 +131,16 @@ struct FftStageWave {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = lbase[tk_pad16(j + i * T)];
+      for (int i = 0; i < 16; ++i) v[i] = lbase[at(j + i * T)];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      FftStageWave<N, INV, S + 1>::run(v, lbase, j, tw);
+      FftStageWave<N, INV, S + 1>::run_at(v, lbase, j, tw, at);
     }
+  }
+  template <class Tw>
+  static __device__ __forceinline__ void run(cf (&v)[16], cf* __restrict__ lbase, int j,
+                                             const Tw& tw) {
+    run_at(v, lbase, j, tw, [](int e) { return tk_pad16(e); });
   }
 };
 

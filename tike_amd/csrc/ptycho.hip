@@ -878,17 +878,30 @@ extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, in
 //            straight into the FFT register layout, runs the 128-point row
 //            transform (radix 16 x 8, the exchange stays inside its wave) and
 //            leaves the row spectrum in the LDS tile;
-//   columns  128 = 16 x 8 as in fft_engine2.h: thread (t, r) takes the radix-16
-//            stage of rows {r + 8 y2} of column t in registers (twiddle
-//            w_128^(r k1), uniform per wave) and puts it back as rows 16 r + k1;
-//            thread (t, k1) then finishes rows {16 r + k1} with a radix-8 and
-//            stores rows k1 + 16 k2 of the far plane -- 512-byte row segments
-//            per wave, coalesced, from registers.
+//   columns  the same 8 threads then own COLUMN `line`: its 128 elements
+//            (stride LS) go through the same in-wave radix 16 x 8 plan, the
+//            column itself being the exchange buffer -- no workgroup barrier
+//            and no second trip of the tile through LDS -- and leave for the
+//            far plane from registers (8 rows x 64 contiguous bytes per wave
+//            store; the neighbouring wave writes the other half of each line).
+//            Two workgroup barriers per mode (rows done / columns done).
 // The intensity sum_s |F_s|^2 accumulates in registers across the modes.
 // LDS row stride: 136 elements = 272 dwords = 16 (mod 64 banks), so the four
 // rows a 32-lane read group touches (8 lanes x 16 dwords each) tile the 64
 // banks exactly; 136 also holds the padded row (127 + 127/16 = 134).
 constexpr int TK_L128_LS = 136;
+// Column offset of row `row` inside the LDS tile (element (row, col) lives at
+// row * LS + ((col + swizzle(row)) & 127)), chosen so that BOTH transforms run
+// on the tile without bank conflicts, dword bank = 16 row + 2 col' (mod 64):
+//   rows     a 32-lane group = 4 consecutive rows x 8 lanes j: the rows share
+//            the swizzle, 16 row covers the four 16-bank quarters;
+//   columns  lanes j read rows j + 8 i (bit 2 of the row separates j from
+//            j + 4: + 8 banks) and exchange through rows 16 j + r (bits 4..6 of
+//            the row = j: + 8 j banks); 4 neighbouring columns fill the 8
+//            banks in between.
+__device__ __forceinline__ int tk_l128_swizzle(int row) {
+  return 4 * (((row >> 2) & 1) + ((row >> 4) & 7));
+}
 
 template <bool WITH_I>
 __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
@@ -906,8 +919,7 @@ __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
   int line = tid / T, j = tid % T;
   asm volatile("" : "+v"(line), "+v"(j));
   const FftTwLds<N> tw{twl, j};
-  const int t = tid & (N - 1);
-  const int r = __builtin_amdgcn_readfirstlane(tid >> 7);  // 0..7, uniform per wave
+  __builtin_assume(j >= 0 && j < T && line >= 0 && line < N);
   const long PP = (long)N * N;
   const long total = (long)H * W;
   auto at = [](const cf* base, unsigned byte_off) -> const cf* {
@@ -992,12 +1004,10 @@ __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) tk_st_stream(On + i * T, pv[i]);
     }
-    float I[2][8];
+    float I[16];
     if (WITH_I) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) I[h][k] = 0.f;
+      for (int i = 0; i < 16; ++i) I[i] = 0.f;
     }
     const unsigned pbo = (unsigned)(line * N + j) * (unsigned)sizeof(cf);
     for (int s = 0; s < S; ++s) {
@@ -1013,48 +1023,34 @@ __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
       cf v[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = pv[i] * (*at(Pn, pbo + 64 * i) * w0);
-      // ---- row transform, spectrum into the tile
+      // ---- row transform (the row of the tile is its own exchange buffer),
+      // spectrum into the tile at the swizzled columns
       cf* lbase = lds + line * LS;
       FftStageWave<N, false, 0>::run(v, lbase, j, tw);
+      const int rsw = tk_l128_swizzle(line);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) lbase[tk_pad16(j + i * T)] = v[i];
+      for (int i = 0; i < 16; ++i) lbase[(j + i * T + rsw) & (N - 1)] = v[i];
       __syncthreads();
-      // ---- columns, radix-16 stage: rows {r + 8 y2} -> rows 16 r + k1
-      const cf* col = lds + tk_pad16(t);
+      // ---- column transform: the 8 threads that shared row `line` now share
+      // COLUMN `line`; its 128 elements (stride LS) are their exchange buffer
+      const int col = line;
+      auto cat = [&](int e) { return e * LS + ((col + tk_l128_swizzle(e)) & (N - 1)); };
 #pragma unroll
-      for (int y2 = 0; y2 < 16; ++y2) v[y2] = col[(r + 8 * y2) * LS];
-      Dft<16, false>::run(v);
+      for (int i = 0; i < 16; ++i) v[i] = lds[cat(j + i * T)];
+      FftStageWave<N, false, 0>::run_at(v, lds, j, tw, cat);
+      cf* __restrict__ dst = farplane + (n * S + s) * PP + col;
 #pragma unroll
-      for (int k1 = 1; k1 < 16; ++k1) v[k1] = mul_tw<false>(v[k1], twtab[N + r * k1]);
-      __syncthreads();
-      cf* colw = lds + tk_pad16(t);
-#pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) colw[(16 * r + k1) * LS] = v[k1];
-      __syncthreads();
-      // ---- columns, radix-8 stage: rows {16 q + k1} -> far-plane rows k1 + 16 k2
-      cf* __restrict__ dst = farplane + (n * S + s) * PP + t;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int k1 = r + 8 * h;
-        cf u[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) u[q] = col[(16 * q + k1) * LS];
-        Dft<8, false>::run(u);
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2) {
-          const cf o = u[k2] * scale;
-          if (farplane != nullptr) tk_st_stream(dst + (long)(k1 + 16 * k2) * N, o);
-          if (WITH_I) I[h][k2] += norm2(o);
-        }
+      for (int i = 0; i < 16; ++i) {
+        const cf o = v[i] * scale;
+        if (farplane != nullptr) tk_st_stream(dst + (long)(j + i * T) * N, o);
+        if (WITH_I) I[i] += norm2(o);
       }
       __syncthreads();  // the next mode's rows overwrite the tile
     }
     if (WITH_I) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int k2 = 0; k2 < 8; ++k2)
-          tk_st_stream(intensity + n * PP + (long)(r + 8 * h + 16 * k2) * N + t, I[h][k2]);
+      for (int i = 0; i < 16; ++i)
+        tk_st_stream(intensity + n * PP + (long)(j + i * T) * N + line, I[i]);
     }
   }
 }
