@@ -1,11 +1,11 @@
 #!/bin/bash
 # SQ stall counters of the c3 minibatch kernels (run on the GPU box):
-#   bash tools/pmc_kernel.sh [script, default tools/kbench_c3.py]  -> gpurun_out/pmc_sq/*.csv summary on stdout
+#   bash tools/pmc_kernel.sh [script args..., default tools/kbench_c3.py]  -> gpurun_out/pmc_sq/*.csv summary on stdout
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 o=gpurun_out/pmc_sq
 rm -rf $o
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $o -- python3 ${1:-tools/kbench_c3.py} > $o.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $o -- python3 ${@:-tools/kbench_c3.py} > $o.log 2>&1
 f=$(find $o -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
