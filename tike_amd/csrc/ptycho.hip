@@ -727,6 +727,68 @@ extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* pr
   return TK_OK;
 }
 
+// Counts and mask bits of the RB pixels (k1 + 16 k2, t) of position n of an
+// N x N pattern, requested TOGETHER and unconditionally (a branch per pixel
+// around its load makes RB serial memory round trips of them); unmeasured
+// pixels may hold NaN: they are selected away by the mask bit, never multiplied.
+template <int N, int RB, class DT>
+__device__ __forceinline__ void tk_request_data(const DT* __restrict__ data,
+                                                const unsigned char* __restrict__ mask, long n,
+                                                int k1, int t, DT (&raw)[RB], unsigned& bits) {
+  static_assert(RB <= 32, "one mask bit per pixel");
+  const DT* __restrict__ d = data + n * (long)N * N + k1 * N;  // uniform
+  const unsigned lo = (unsigned)t * (unsigned)sizeof(DT);
+#pragma unroll
+  for (int k2 = 0; k2 < RB; ++k2) raw[k2] = *tk_at_pinned(d + (16 * k2) * N, lo);
+  bits = 0xffffffffu;
+  if (mask) {  // uniform
+    unsigned char mb[RB];
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) mb[k2] = mask[(k1 + 16 * k2) * N + t];
+    bits = 0;
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) bits |= (mb[k2] ? 1u : 0u) << k2;
+  }
+}
+template <class DT>
+__device__ __forceinline__ void tk_request_data16(const DT* __restrict__ data,
+                                                  const unsigned char* __restrict__ mask, long n,
+                                                  int k1, int t, DT (&raw)[16], unsigned& bits) {
+  tk_request_data<256, 16>(data, mask, n, k1, t, raw, bits);
+}
+
+// I[k2] (intensity) -> g * fwd_scale, returns this thread's cost terms.
+template <int MODEL, int RB, class DT>
+__device__ __forceinline__ float tk_gradient_factor(float (&I)[RB], const DT (&raw)[RB],
+                                                    unsigned bits, float unmeasured_scaling,
+                                                    float fwd_scale) {
+  float cost = 0.f;
+#pragma unroll
+  for (int k2 = 0; k2 < RB; ++k2) {
+    const bool meas = (bits >> k2) & 1u;
+    const float dv = (float)raw[k2];
+    float term, g;
+    if (MODEL == 0) {
+      const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
+      const float diff = sI - sd;
+      term = diff * diff;
+      g = -(1.0f - sd / (sI + 1e-9f));
+    } else {
+      term = I[k2] - dv * logf(I[k2] + 1e-9f);
+      g = -(1.0f - dv / (I[k2] + 1e-9f));
+    }
+    cost += meas ? term : 0.f;
+    I[k2] = (meas ? g : unmeasured_scaling - 1.0f) * fwd_scale;
+  }
+  return cost;
+}
+template <int MODEL, class DT>
+__device__ __forceinline__ float tk_gradient_factor16(float (&I)[16], const DT (&raw)[16],
+                                                      unsigned bits, float unmeasured_scaling,
+                                                      float fwd_scale) {
+  return tk_gradient_factor<MODEL, 16>(I, raw, bits, unmeasured_scaling, fwd_scale);
+}
+
 // The column pass as a pure read stream: one workgroup per (position, k1)
 // forms F[k1 + 16 k2] of every mode in registers (radix-16 over the rows
 // 16 r + k1 of the hand-off), accumulates I = sum_s |F_s|^2 and emits the
@@ -794,25 +856,20 @@ __global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kern
         for (int k2 = 0; k2 < RB; ++k2) tk_st_stream(dst + (long)(16 * k2) * N, u[k2] * scale);
       }
     }
-    float cost = 0.f;
+    // counts and mask requested together, the factor selected (not branched)
+    DT raw[RB];
+    unsigned bits;
+    tk_request_data<N, RB>(data, mask, n, k1, t, raw, bits);
+    if (intensity) {  // uniform
 #pragma unroll
-    for (int k2 = 0; k2 < RB; ++k2) {
-      const long p = (long)(k1 + 16 * k2) * N + t;
-      if (intensity) tk_st_stream(intensity + n * (long)N * N + p, I[k2]);
-      float g = unmeasured_scaling - 1.0f;
-      if (mask == nullptr || mask[p]) {
-        const float dv = (float)data[n * (long)N * N + p];
-        if (MODEL == 0) {
-          const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
-          const float diff = sI - sd;
-          cost += diff * diff;
-          g = -(1.0f - sd / (sI + 1e-9f));
-        } else {
-          cost += I[k2] - dv * logf(I[k2] + 1e-9f);
-          g = -(1.0f - dv / (I[k2] + 1e-9f));
-        }
-      }
-      if (gscale) gscale[n * (long)N * N + p] = g;
+      for (int k2 = 0; k2 < RB; ++k2)
+        tk_st_stream(intensity + n * (long)N * N + (long)(k1 + 16 * k2) * N + t, I[k2]);
+    }
+    float cost = tk_gradient_factor<MODEL, RB>(I, raw, bits, unmeasured_scaling, 1.0f);
+    if (gscale) {  // uniform
+#pragma unroll
+      for (int k2 = 0; k2 < RB; ++k2)
+        gscale[n * (long)N * N + (long)(k1 + 16 * k2) * N + t] = I[k2];
     }
     if (costs) {
       cost = tk_block_sum256(cost, red);
@@ -1648,56 +1705,6 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
       __syncthreads();
     }
   }
-}
-
-// Counts and mask bits of the 16 pixels (k1 + 16 k2, t) of position n of a
-// 256^2 pattern, requested TOGETHER and unconditionally (a branch per pixel
-// around its load makes 16 serial memory round trips of them); unmeasured
-// pixels may hold NaN: they are selected away by the mask bit, never multiplied.
-template <class DT>
-__device__ __forceinline__ void tk_request_data16(const DT* __restrict__ data,
-                                                  const unsigned char* __restrict__ mask, long n,
-                                                  int k1, int t, DT (&raw)[16], unsigned& bits) {
-  constexpr int N = 256;
-  const DT* __restrict__ d = data + n * (long)N * N + k1 * N;  // uniform
-  const unsigned lo = (unsigned)t * (unsigned)sizeof(DT);
-#pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) raw[k2] = *tk_at_pinned(d + (16 * k2) * N, lo);
-  bits = 0xffffu;
-  if (mask) {  // uniform
-    unsigned char mb[16];
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) mb[k2] = mask[(k1 + 16 * k2) * N + t];
-    bits = 0;
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) bits |= (mb[k2] ? 1u : 0u) << k2;
-  }
-}
-
-// I[k2] (intensity) -> g * fwd_scale, returns this thread's cost terms.
-template <int MODEL, class DT>
-__device__ __forceinline__ float tk_gradient_factor16(float (&I)[16], const DT (&raw)[16],
-                                                      unsigned bits, float unmeasured_scaling,
-                                                      float fwd_scale) {
-  float cost = 0.f;
-#pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) {
-    const bool meas = (bits >> k2) & 1u;
-    const float dv = (float)raw[k2];
-    float term, g;
-    if (MODEL == 0) {
-      const float sI = sqrtf(I[k2]), sd = sqrtf(dv);
-      const float diff = sI - sd;
-      term = diff * diff;
-      g = -(1.0f - sd / (sI + 1e-9f));
-    } else {
-      term = I[k2] - dv * logf(I[k2] + 1e-9f);
-      g = -(1.0f - dv / (I[k2] + 1e-9f));
-    }
-    cost += meas ? term : 0.f;
-    I[k2] = (meas ? g : unmeasured_scaling - 1.0f) * fwd_scale;
-  }
-  return cost;
 }
 
 // ---- column pass + gradient factor + inverse pass 1 in ONE kernel (256^2)
