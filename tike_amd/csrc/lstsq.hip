@@ -1191,6 +1191,8 @@ struct TkTaps {
   int r;
 };
 
+template <int RT>  // tap radius at compile time (-1: taps.r), so that the 2 (2 r + 1) tap
+                   // loads of a pixel are requested together with its probe and chi values
 __global__ __launch_bounds__(256) void position_sums_kernel(
     const cf* __restrict__ patches, const cf* __restrict__ chi, int chi_modes,
     const TkProbe probe, const TkTaps taps, float* __restrict__ num, float* __restrict__ den,
@@ -1210,8 +1212,11 @@ __global__ __launch_bounds__(256) void position_sums_kernel(
   for (int i = part * ilen + threadIdx.x; i < iend; i += blockDim.x) {
     const int y = crop + i / w, x = crop + i % w;
     cf gx = mk(0.f, 0.f), gy = mk(0.f, 0.f);
-    for (int d = -taps.r; d <= taps.r; ++d) {
-      const float t = taps.t[d + taps.r];
+    const long pix = (long)y * pw + x;
+    const cf Pm = probe.at(n, 0, pix);
+    const cf c = X[pix];
+    auto tap = [&](int d, int r) {
+      const float t = taps.t[d + r];
       int yy = y + d, xx = x + d;
       yy = yy < 0 ? 0 : (yy >= pw ? pw - 1 : yy);
       xx = xx < 0 ? 0 : (xx >= pw ? pw - 1 : xx);
@@ -1220,10 +1225,13 @@ __global__ __launch_bounds__(256) void position_sums_kernel(
       gx.y += t * oy.y;
       gy.x += t * ox.x;
       gy.y += t * ox.y;
+    };
+    if (RT >= 0) {
+#pragma unroll
+      for (int d = -RT; d <= RT; ++d) tap(d, RT);
+    } else {
+      for (int d = -taps.r; d <= taps.r; ++d) tap(d, taps.r);
     }
-    const long pix = (long)y * pw + x;
-    const cf Pm = probe.at(n, 0, pix);
-    const cf c = X[pix];
     const cf px = gx * Pm, py = gy * Pm;
     a[0] += px.x * c.x + px.y * c.y;
     a[1] += py.x * c.x + py.y * c.y;
@@ -1269,9 +1277,14 @@ extern "C" int tike_position_sums(const void* patches, const void* chi, int chi_
       e = hipMemsetAsync(denominator, 0, sizeof(float) * 2 * (size_t)nscan, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(position_sums_kernel, dim3((unsigned)nscan * nsplit), dim3(256), 0,
-                     (hipStream_t)stream, (const cf*)patches, (const cf*)chi, chi_modes, pr, taps,
-                     numerator, denominator, pw, nsplit);
+  if (radius == 2)  // position.py:779-810: sigma = 0.333, truncate 4 -> radius 2
+    hipLaunchKernelGGL(position_sums_kernel<2>, dim3((unsigned)nscan * nsplit), dim3(256), 0,
+                       (hipStream_t)stream, (const cf*)patches, (const cf*)chi, chi_modes, pr,
+                       taps, numerator, denominator, pw, nsplit);
+  else
+    hipLaunchKernelGGL(position_sums_kernel<-1>, dim3((unsigned)nscan * nsplit), dim3(256), 0,
+                       (hipStream_t)stream, (const cf*)patches, (const cf*)chi, chi_modes, pr,
+                       taps, numerator, denominator, pw, nsplit);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -1456,25 +1456,26 @@ __global__ __launch_bounds__(256) void farplane_gradient_kernel(
   const long p0 = (long)blockIdx.x * TK_FG_PIX;
   const long p1 = p0 + TK_FG_PIX < npix ? p0 + TK_FG_PIX : npix;
   for (long p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    // the count is requested WITH the wave values, not behind the mask test
+    // (a load inside a branch waits for everything in front of the branch);
+    // an unmeasured pixel may hold NaN: selected away, never multiplied
+    const float dv = d[p];
+    const bool measured = mask ? mask[p] != 0 : true;
     float I = 0.f;
     for (int s = 0; s < S; ++s) I += norm2(F[s * npix + p]);
     if (intensity) intensity[n * npix + p] = I;
-    const bool measured = mask ? mask[p] != 0 : true;
-    float g;
-    if (measured) {
-      const float dv = d[p];
-      if (MODEL == 0) {
-        const float sI = sqrtf(I), sd = sqrtf(dv);
-        const float diff = sI - sd;
-        cost += diff * diff;
-        g = -(1.0f - sd / (sI + 1e-9f));
-      } else {
-        cost += I - dv * logf(I + 1e-9f);
-        g = -(1.0f - dv / (I + 1e-9f));
-      }
+    float g, term;
+    if (MODEL == 0) {
+      const float sI = sqrtf(I), sd = sqrtf(dv);
+      const float diff = sI - sd;
+      term = diff * diff;
+      g = -(1.0f - sd / (sI + 1e-9f));
     } else {
-      g = unmeasured_scaling - 1.0f;
+      term = I - dv * logf(I + 1e-9f);
+      g = -(1.0f - dv / (I + 1e-9f));
     }
+    cost += measured ? term : 0.f;
+    g = measured ? g : unmeasured_scaling - 1.0f;
     if (GRAD)
       for (int s = 0; s < S; ++s) F[s * npix + p] = F[s * npix + p] * g;
   }
@@ -1532,23 +1533,20 @@ __global__ __launch_bounds__(256) void gradient_scale_kernel(
   const long p1 = p0 + TK_FG_PIX < npix ? p0 + TK_FG_PIX : npix;
   for (long p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
     const float I = intensity[n * npix + p];
+    const float dv = data[n * npix + p];  // with I, not behind the mask test
     const bool measured = mask ? mask[p] != 0 : true;
-    float g;
-    if (measured) {
-      const float dv = data[n * npix + p];
-      if (MODEL == 0) {
-        const float sI = sqrtf(I), sd = sqrtf(dv);
-        const float diff = sI - sd;
-        cost += diff * diff;
-        g = -(1.0f - sd / (sI + 1e-9f));
-      } else {
-        cost += I - dv * logf(I + 1e-9f);
-        g = -(1.0f - dv / (I + 1e-9f));
-      }
+    float g, term;
+    if (MODEL == 0) {
+      const float sI = sqrtf(I), sd = sqrtf(dv);
+      const float diff = sI - sd;
+      term = diff * diff;
+      g = -(1.0f - sd / (sI + 1e-9f));
     } else {
-      g = unmeasured_scaling - 1.0f;
+      term = I - dv * logf(I + 1e-9f);
+      g = -(1.0f - dv / (I + 1e-9f));
     }
-    gscale[n * npix + p] = g;
+    cost += measured ? term : 0.f;
+    gscale[n * npix + p] = measured ? g : unmeasured_scaling - 1.0f;
   }
   if (costs) {
     cost = tk_block_sum256(cost, red);
