@@ -347,8 +347,27 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
       for (int s = 0; s < SM; ++s)
         if (SC > 0 || s < S) xs[s] = tk_ld_stream(chi + ((long)b * S + s) * P + p);
     }
-    cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
-    if (!ok) o = mk(0.f, 0.f);
+    cf o;
+    // interior position (uniform): the two taps of a row are adjacent complex
+    // values, one 16-byte load each -- half the L1 requests of four 8-byte taps
+    if (!WITH_CHI && c.sy >= 0 && c.sx >= 0 && c.sy + pw < H && c.sx + pw < W &&
+        total < (1L << 28)) {
+      typedef float tk_v4f __attribute__((ext_vector_type(4)));
+      const unsigned off = (unsigned)(y * W + x) * (unsigned)sizeof(cf);
+      tk_v4f u, l;
+      __builtin_memcpy(&u, reinterpret_cast<const char*>(psi) + off, sizeof(u));
+      __builtin_memcpy(&l, reinterpret_cast<const char*>(psi) + off + (unsigned)W * 8u, sizeof(l));
+      o = mk(u.x * c.w00, u.y * c.w00);
+      o.x += u.z * c.w01;
+      o.y += u.w * c.w01;
+      o.x += l.x * c.w10;
+      o.y += l.y * c.w10;
+      o.x += l.z * c.w11;
+      o.y += l.w * c.w11;
+    } else {
+      o = tk_gather(psi, (long)yc * W + xc, W, total, c);
+      if (!ok) o = mk(0.f, 0.f);
+    }
     if (patches) patches[b * P + p] = o;
     if (WITH_CHI) {
       const cf oc = conjf(o);
