@@ -1801,6 +1801,57 @@ __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
   }
 }
 
+// ---- one mode: the column-pass values of the work item are 16 registers per
+// thread, so there is no second sweep at all (cgrad's gradient pass, S = 1)
+template <int MODEL, class DT>
+__global__ __launch_bounds__(256, 4) void fwd_grad_ifft2_pass1_single_kernel(
+    const cf* __restrict__ colin, const DT* __restrict__ data,
+    const unsigned char* __restrict__ mask, float* __restrict__ costs, cf* __restrict__ work,
+    long nscan, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
+    const cf* __restrict__ twtab) {
+  constexpr int N = 256;
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  __shared__ float red[4];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int t = threadIdx.x;
+  const float s2 = fwd_scale * fwd_scale;
+  for (long v = blockIdx.x; v < nscan * 16; v += gridDim.x) {
+    const int k1 = (int)(v & 15);
+    const long n = nscan - 1 - (v >> 4);  // descending: see fwd_gradient_scale_kernel
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    cf u[16];
+    {
+      const cf* __restrict__ src = colin + n * (long)N * N + k1 * N;  // uniform
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(tk_at_pinned(src + (16 * r) * N, t * 8u));
+    }
+    DT raw[16];
+    unsigned bits;
+    tk_request_data16(data, mask, n, k1, t, raw, bits);
+    Dft<16, false>::run(u);
+    float I[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) I[k2] = norm2(u[k2]) * s2;
+    float cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
+    if (costs) {
+      cost = tk_block_sum256(cost, red);
+      if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) u[k2] = u[k2] * I[k2];
+    Dft<16, true>::run(u);
+#pragma unroll
+    for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
+    cf* mid = work + n * (long)N * N;
+    fft2_rows_from_columns<N, true, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
+  }
+}
+
 // ---- the same with the column-pass values RESIDENT IN REGISTERS (256^2)
 // The kernel above streams the hand-off twice, and its second sweep misses L2
 // (96 work items x 256 KiB per XCD).  Here a 512-thread workgroup -- one per
@@ -2083,6 +2134,23 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
     return TK_OK;
   }
   const dim3 grid(tk_grid((long)nscan * 16, 12)), block(256);
+  if (S == 1) {
+#define TK_FG1(M, DT)                                                                         \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_single_kernel<M, DT>), grid, block, 0, stream,     \
+                     (const cf*)scratch, (const DT*)data, measured, costs, (cf*)work,         \
+                     (long)nscan, fwd_scale, unmeasured_scaling, inv, tw)
+    if (model == 0 && data_u16)
+      TK_FG1(0, unsigned short);
+    else if (model == 0)
+      TK_FG1(0, float);
+    else if (data_u16)
+      TK_FG1(1, unsigned short);
+    else
+      TK_FG1(1, float);
+#undef TK_FG1
+    TK_LAUNCH_CHECK();
+    return TK_OK;
+  }
 #define TK_FG(M, DT)                                                                          \
   hipLaunchKernelGGL((fwd_grad_ifft2_pass1_kernel<M, DT>), grid, block, 0, stream,            \
                      (const cf*)scratch, (const DT*)data, measured, costs, (cf*)work,         \
