@@ -1052,15 +1052,21 @@ struct TkResidual {
   int C, Sm, c;
   long P;
   long XS;  // elements between chi0 of consecutive positions (chi_modes * P)
+  // C0: the residual of the FIRST eigen probe (c == 0) has no projections to
+  // remove -- without that run-time loop in the body the callers' loops unroll
+  // and the loads of several pixels / positions are in flight together
+  template <bool C0>
   __device__ __forceinline__ cf at(long n, long p) const {
     cf r = conjf(patches[n * P + p]) * chi0[n * XS + p] - mpu0[p];
-    for (int k = 0; k < c; ++k) r = r - coefs[n * C + k] * eigen[((long)k * Sm) * P + p];
+    if (!C0)
+      for (int k = 0; k < c; ++k) r = r - coefs[n * C + k] * eigen[((long)k * Sm) * P + p];
     return r;
   }
 };
 
 // sums[n] = { sum Re(conj(R) E_c), sum Re(chi0 conj(O E_c)), sum |O E_c|^2,
 //             Re sum R conj(E_c), Im sum R conj(E_c) }
+template <bool C0>
 __global__ __launch_bounds__(256) void eigen_position_sums_kernel(const TkResidual R,
                                                                   float* __restrict__ sums,
                                                                   int nscan) {
@@ -1068,9 +1074,9 @@ __global__ __launch_bounds__(256) void eigen_position_sums_kernel(const TkResidu
   const cf* __restrict__ E = R.eigen + ((long)R.c * R.Sm) * R.P;
   for (int n = blockIdx.x; n < nscan; n += gridDim.x) {
     float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long p = threadIdx.x; p < R.P; p += blockDim.x) {
+    for (long p = threadIdx.x; p < R.P; p += blockDim.x) {  // (unrolled by 4: 0.217 -> 0.234 ms)
       const cf e = E[p];
-      const cf r = R.at(n, p);
+      const cf r = R.at<C0>(n, p);
       const cf phi = R.patches[n * R.P + p] * e;
       const cf x = R.chi0[n * R.XS + p];
       a[0] += r.x * e.x + r.y * e.y;
@@ -1089,6 +1095,7 @@ __global__ __launch_bounds__(256) void eigen_position_sums_kernel(const TkResidu
 }
 
 // update[p] += sum_n R_n[p] * pm[n]      (probe.py:432-436 before the mean)
+template <bool C0>
 __global__ __launch_bounds__(256) void eigen_pixel_update_kernel(const TkResidual R,
                                                                  const float* __restrict__ pm,
                                                                  float* __restrict__ update,
@@ -1098,8 +1105,9 @@ __global__ __launch_bounds__(256) void eigen_pixel_update_kernel(const TkResidua
   const int b0 = blockIdx.y * chunk;
   const int b1 = min(nscan, b0 + chunk);
   cf acc = mk(0.f, 0.f);
+#pragma unroll 4
   for (int n = b0; n < b1; ++n) {
-    const cf r = R.at(n, p);
+    const cf r = R.at<C0>(n, p);
     const float w = pm[n];
     acc.x += r.x * w;
     acc.y += r.y * w;
@@ -1134,11 +1142,14 @@ extern "C" int tike_eigen_position_sums(const void* patches, const void* chi0, c
                chi_modes >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen_probe && sums && (c == 0 || coefs));
-  hipLaunchKernelGGL(eigen_position_sums_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
-                     (hipStream_t)stream,
-                     make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
-                                   eigen_modes, c, pw, chi_modes),
-                     sums, nscan);
+  const TkResidual R = make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
+                                     eigen_modes, c, pw, chi_modes);
+  if (c == 0)
+    hipLaunchKernelGGL(eigen_position_sums_kernel<true>, dim3(tk_grid(nscan, 16)), dim3(256), 0,
+                       (hipStream_t)stream, R, sums, nscan);
+  else
+    hipLaunchKernelGGL(eigen_position_sums_kernel<false>, dim3(tk_grid(nscan, 16)), dim3(256),
+                       0, (hipStream_t)stream, R, sums, nscan);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -1156,10 +1167,14 @@ extern "C" int tike_eigen_pixel_update(const void* patches, const void* chi0, co
   const long P = (long)pw * pw;
   const int chunk = probe_chunk(nscan);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
-  hipLaunchKernelGGL(eigen_pixel_update_kernel, grid, dim3(256), 0, (hipStream_t)stream,
-                     make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
-                                   eigen_modes, c, pw, chi_modes),
-                     pm, (float*)update, nscan, chunk);
+  const TkResidual R = make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
+                                     eigen_modes, c, pw, chi_modes);
+  if (c == 0)
+    hipLaunchKernelGGL(eigen_pixel_update_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
+                       R, pm, (float*)update, nscan, chunk);
+  else
+    hipLaunchKernelGGL(eigen_pixel_update_kernel<false>, grid, dim3(256), 0,
+                       (hipStream_t)stream, R, pm, (float*)update, nscan, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
