@@ -53,6 +53,26 @@ TK_HD cf mul_tw(cf a, cf w) {
   return INV ? a * conjf(w) : a * w;
 }
 
+// rp = t + (-+i) d,  rm = t - (-+i) d   (the radix-4 cross terms).
+// Device: two packed FMAs on the half-swapped d with a (+-1, -+1) sign pair --
+// exact (a product with +-1 is exact, so this IS the sum), and without the
+// per-half moves the compiler needs to recombine `t + mk(d.y, -d.x)` from two
+// packed adds whose halves carry different signs.
+template <bool INV>
+TK_HD void addsub_mi(cf t, cf d, cf& rp, cf& rm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const tk_v2f T = __builtin_bit_cast(tk_v2f, t), D = __builtin_bit_cast(tk_v2f, d);
+  const tk_v2f sp = INV ? tk_v2f{-1.0f, 1.0f} : tk_v2f{1.0f, -1.0f};
+  const tk_v2f sm = INV ? tk_v2f{1.0f, -1.0f} : tk_v2f{-1.0f, 1.0f};
+  rp = __builtin_bit_cast(cf, __builtin_elementwise_fma(D.yx, sp, T));
+  rm = __builtin_bit_cast(cf, __builtin_elementwise_fma(D.yx, sm, T));
+#else
+  const cf r = mul_mi<INV>(d);
+  rp = t + r;
+  rm = t - r;
+#endif
+}
+
 template <int R, bool INV>
 struct Dft;
 
@@ -69,11 +89,10 @@ template <bool INV>
 struct Dft<4, INV> {
   static TK_HD void run(cf* v) {
     cf t0 = v[0] + v[2], t1 = v[0] - v[2];
-    cf t2 = v[1] + v[3], t3 = mul_mi<INV>(v[1] - v[3]);
+    cf t2 = v[1] + v[3], d = v[1] - v[3];
     v[0] = t0 + t2;
-    v[1] = t1 + t3;
     v[2] = t0 - t2;
-    v[3] = t1 - t3;
+    addsub_mi<INV>(t1, d, v[1], v[3]);
   }
 };
 
