@@ -107,15 +107,13 @@ struct Dft<8, INV> {
     // o[k] *= w8^k : w8 = (1 - i)/sqrt2 (forward)
     cf o1 = INV ? mk((o[1].x - o[1].y) * h, (o[1].x + o[1].y) * h)
                 : mk((o[1].x + o[1].y) * h, (o[1].y - o[1].x) * h);
-    cf o2 = mul_mi<INV>(o[2]);
     cf o3 = INV ? mk((-o[3].x - o[3].y) * h, (o[3].x - o[3].y) * h)
                 : mk((o[3].y - o[3].x) * h, (-o[3].x - o[3].y) * h);
     v[0] = e[0] + o[0];
     v[4] = e[0] - o[0];
     v[1] = e[1] + o1;
     v[5] = e[1] - o1;
-    v[2] = e[2] + o2;
-    v[6] = e[2] - o2;
+    addsub_mi<INV>(e[2], o[2], v[2], v[6]);
     v[3] = e[3] + o3;
     v[7] = e[3] - o3;
   }
@@ -143,7 +141,7 @@ struct Dft<16, INV> {
     a[1][2] = mul_tw<INV>(a[1][2], w2);
     a[1][3] = mul_tw<INV>(a[1][3], w3);
     a[2][1] = mul_tw<INV>(a[2][1], w2);
-    a[2][2] = mul_mi<INV>(a[2][2]);  // w16^4 = -i
+    // a[2][2] takes w16^4 = -i: folded into the k1 = 2 butterfly below
     a[2][3] = mul_tw<INV>(a[2][3], w6);
     a[3][1] = mul_tw<INV>(a[3][1], w3);
     a[3][2] = mul_tw<INV>(a[3][2], w6);
@@ -151,7 +149,17 @@ struct Dft<16, INV> {
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) {
       cf t[4] = {a[0][k1], a[1][k1], a[2][k1], a[3][k1]};
-      Dft<4, INV>::run(t);
+      if (k1 == 2) {
+        // radix 4 with t[2] still to be multiplied by -+i
+        cf t0, t1;
+        addsub_mi<INV>(t[0], t[2], t0, t1);
+        const cf t2 = t[1] + t[3], d = t[1] - t[3];
+        t[0] = t0 + t2;
+        t[2] = t0 - t2;
+        addsub_mi<INV>(t1, d, t[1], t[3]);
+      } else {
+        Dft<4, INV>::run(t);
+      }
 #pragma unroll
       for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = t[k2];
     }
