@@ -21,15 +21,22 @@ def _free_port():
     return port
 
 
-def _problem(eigen):
+SMALL = dict(N=64, S=2, pw=32, side=8, pitch=5.0)
+# the headline (c3) shape: 256^2 far-plane-free kernels, 8 modes + one eigen
+# probe, two minibatches of 64 positions = 32 per rank and minibatch
+C3 = dict(N=128, S=8, pw=256, side=12, pitch=8.0)
+
+
+def _problem(eigen, shape=SMALL):
     import tike_amd.ptycho as tp
     import tike_amd.random
     rng = np.random.default_rng(3)
-    N, S, pw, side = 64, 2, 32, 8
+    N, S, pw, side, pitch = (shape[k] for k in ("N", "S", "pw", "side",
+                                                "pitch"))
     ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
-                              indexing="ij"), -1).reshape(-1, 2)
-    scan = (2 + 5.0 * ij + rng.random((N, 2))).astype(np.float32)
-    HW = 5 * (side - 1) + pw + 8
+                              indexing="ij"), -1).reshape(-1, 2)[:N]
+    scan = (2 + pitch * ij + rng.random((N, 2))).astype(np.float32)
+    HW = int(pitch * (side - 1)) + pw + 8
     psi_true = ((0.75 + 0.25 * rng.random((1, HW, HW))) * np.exp(
         1j * np.pi * (rng.random((1, HW, HW)) - 0.5))).astype(np.complex64)
     w = tp.gaussian(pw, rin=0.6)
@@ -44,10 +51,11 @@ def _problem(eigen):
     return data, scan, probe, np.full_like(psi_true, 0.5), ep, ew
 
 
-def _reconstruct(eigen, method, positions=False, rank=0):
+def _reconstruct(eigen, method, positions=False, rank=0, shape=SMALL,
+                 num_iter=3):
     import tike_amd.ptycho as tp
     import tike_amd.random
-    data, scan, probe, psi0, ep, ew = _problem(eigen)
+    data, scan, probe, psi0, ep, ew = _problem(eigen, shape)
     # only rank 0 starts from the single-rank run's generator states: the
     # library must hand them to the other ranks (Comm.sync_random)
     np.random.seed(1 + 17 * rank)
@@ -55,7 +63,7 @@ def _reconstruct(eigen, method, positions=False, rank=0):
     params = tp.PtychoParameters(
         probe=probe.copy(), psi=psi0.copy(), scan=scan.copy(), eigen_probe=ep,
         eigen_weights=ew,
-        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=3,
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=num_iter,
                                           batch_method=method),
         probe_options=tp.ProbeOptions(force_orthogonality=True),
         object_options=tp.ObjectOptions(),
@@ -66,7 +74,8 @@ def _reconstruct(eigen, method, positions=False, rank=0):
     return tp.reconstruct(data, params)
 
 
-def _worker(rank, world, port, eigen, method, ret, positions=False):
+def _worker(rank, world, port, eigen, method, ret, positions=False,
+            shape=SMALL, num_iter=3):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -74,30 +83,38 @@ def _worker(rank, world, port, eigen, method, ret, positions=False):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        r = _reconstruct(eigen, method, positions, rank=rank)
+        r = _reconstruct(eigen, method, positions, rank=rank, shape=shape,
+                         num_iter=num_iter)
         ret[rank] = (r.psi, r.probe, r.eigen_weights, r.scan,
                      np.array(r.algorithm_options.costs))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("eigen,method,positions", [
-    (False, "compact", False), (True, "wobbly_center", False),
-    (False, "compact", True), (False, "wobbly_center", True)])
-def test_two_ranks_match_one_rank(eigen, method, positions):
+@pytest.mark.parametrize("eigen,method,positions,shape", [
+    (False, "compact", False, SMALL), (True, "wobbly_center", False, SMALL),
+    (False, "compact", True, SMALL), (False, "wobbly_center", True, SMALL),
+    # the kernels the headline number comes from (256^2 far-plane-free chain,
+    # grouped scatter on a sharded, spatially sorted minibatch, eigen path at
+    # S = 8), two epochs of two minibatches
+    (True, "compact", False, C3)])
+def test_two_ranks_match_one_rank(eigen, method, positions, shape):
     import torch.multiprocessing as mp
-    single = _reconstruct(eigen, method, positions)
+    num_iter = 2 if shape is C3 else 3
+    single = _reconstruct(eigen, method, positions, shape=shape,
+                          num_iter=num_iter)
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager()
     ret = mgr.dict()
     port = _free_port()
     procs = [ctx.Process(target=_worker,
-                         args=(r, 2, port, eigen, method, ret, positions))
+                         args=(r, 2, port, eigen, method, ret, positions,
+                               shape, num_iter))
              for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
+        p.join(600)
         assert p.exitcode == 0
     for rank in range(2):
         psi, probe, ew, scan, costs = ret[rank]
@@ -109,7 +126,7 @@ def test_two_ranks_match_one_rank(eigen, method, positions):
                      what=f"probe rank {rank}")
         if positions:
             # corrected positions (pixels); moved by up to ~1 px per epoch
-            assert np.abs(single.scan - _problem(eigen)[1]).max() > 0.05
+            assert np.abs(single.scan - _problem(eigen, shape)[1]).max() > 0.05
             np.testing.assert_allclose(scan, single.scan, atol=5e-3)
         else:
             np.testing.assert_allclose(scan, single.scan, atol=1e-5)

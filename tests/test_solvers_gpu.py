@@ -542,12 +542,14 @@ def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0):
     return scan, psi_true, probe0, ep, ew, data
 
 
+@pytest.mark.parametrize("spatial_sort", [False, True])
 @pytest.mark.parametrize("tag,det,S,N,num_batch", [
     ("c3", 256, 8, 20, 2),  # BASELINE configs[2]: 8 modes + eigen probe, far-plane-free
     ("c3-4modes", 256, 4, 12, 2),
     ("c5", 512, 4, 8, 2),   # BASELINE configs[4]: 512^2, 4 modes, position correction
 ])
-def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch):
+def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
+                                         spatial_sort):
     """The code path bench.py times (c3: 256^2, S = 8, one eigen probe,
     several minibatches; c5: 512^2, S = 4, position correction with ADAM and
     affine regularisation): two epochs against the CPU oracle."""
@@ -575,8 +577,11 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch):
         exitwave_options=tp.ExitWaveOptions(
             measured_pixels=np.ones((det, det), dtype=bool)))
     tike_amd.random.randomizer_np = np.random.default_rng(11)
+    # spatial_sort=True is the default and what the bench runs: the positions
+    # of a minibatch are re-listed along a space-filling curve (membership,
+    # and therefore every sum over the minibatch, unchanged)
     with tp.Reconstruction(data, params, order=order, batches=batches,
-                           spatial_sort=False) as ctx:
+                           spatial_sort=spatial_sort) as ctx:
         ctx.iterate(2)
         got = ctx.get_result()
     state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
@@ -789,7 +794,7 @@ def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
         exitwave_options=tp.ExitWaveOptions(
             measured_pixels=np.ones((det, det), dtype=bool)))
     with tp.Reconstruction(data, params, order=np.arange(N), batches=batches,
-                           spatial_sort=False) as ctx:
+                           spatial_sort=(det == 256)) as ctx:
         ctx.iterate(2)
         got = ctx.get_result()
     state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
@@ -1007,6 +1012,64 @@ def test_full_size_far_plane_free_chain_matches_stored_far_plane(tp, det, S, N):
     ref = torch.empty_like(far)
     check(lib.tike_ifft2_pass1_scaled(A.ptr(far), A.ptr(gs), None, None, S,
                                       A.ptr(ref), N * S, det, st))
+    if det == 256:
+        # The kernel of record -- tike_fwd_grad_ifft2_pass1, the one-launch
+        # column pass + gradient factor + inverse pass 1 the bench times -- at
+        # its bench launch size (N = 1000, S = 8: the register-resident kernel
+        # with the rotated prefetch), with float32 counts and no mask, and with
+        # uint16 counts and unmeasured pixels holding values that must never be
+        # read as data.  Its intermediate and costs must be those of the two
+        # launches above on the same hand-off, mask and counts.
+        scratch2 = torch.empty_like(far)
+        check(lib.tike_fwd_pass1(A.ptr(psi), A.ptr(scan), A.ptr(probe), 0, None,
+                                 None, None, 0, 0, A.ptr(scratch2), None, N, S,
+                                 pw, det, HW, HW, st))
+        mask = (torch.rand(det, det, device=dev, generator=g) > 0.1)
+        mask_u8 = mask.to(torch.uint8).contiguous()
+        nmeas = int(mask.sum().item())
+        counts = A.data_to_device(
+            np.round(data.cpu().numpy() * 400).astype(np.uint16))
+        assert counts.dtype == torch.uint16
+        counts_f = torch.from_numpy(
+            np.round(data.cpu().numpy() * 400).astype(np.float32)).to(dev)
+        for tag, d_k, d_f, u16, m_u8, nm in (
+                ("f32", data, data, 0, None, det * det),
+                ("u16+mask", counts, counts_f, 1, mask_u8, nmeas)):
+            one = torch.empty_like(far)
+            costs1 = torch.empty(N, device=dev)
+            check(lib.tike_fwd_grad_ifft2_pass1(
+                A.ptr(scratch2), A.ptr(d_k), u16, A.ptr(m_u8), A.ptr(costs1),
+                A.ptr(one), N, S, det, 1.0 / det, 0, 0.25, nm, st))
+            if m_u8 is None:
+                want_c, two = costs, work
+            else:
+                gs2 = torch.empty_like(gs)
+                want_c = torch.empty(N, device=dev)
+                check(lib.tike_fwd_gradient_scale(
+                    A.ptr(scratch2), A.ptr(d_k), u16, A.ptr(m_u8), A.ptr(gs2),
+                    None, A.ptr(want_c), None, N, S, det, 1.0 / det, 0, 0.25, nm,
+                    st))
+                two = torch.empty_like(far)
+                check(lib.tike_grad_ifft2_pass1(
+                    A.ptr(scratch2), A.ptr(gs2), None, None, S, A.ptr(two),
+                    N * S, det, 1.0 / det, st))
+                # ... and the masked costs / factor are the objective's
+                sq = (inten.sqrt() - d_f.sqrt())**2
+                torch.testing.assert_close(
+                    want_c, (sq * mask).sum(dim=(-2, -1)) / nmeas, rtol=2e-4,
+                    atol=1e-6)
+                g_want = torch.where(
+                    mask, -(1 - d_f.sqrt() / (inten.sqrt() + 1e-9)),
+                    torch.full_like(inten, 0.25 - 1.0))
+                torch.testing.assert_close(gs2, g_want, rtol=2e-4, atol=2e-5)
+                del gs2, g_want, sq
+            torch.testing.assert_close(costs1, want_c, rtol=1e-5, atol=1e-7)
+            err1 = float((one - two).abs().max()) / float(two.abs().max())
+            assert err1 < 2e-6, (tag, err1)
+            del one
+            if m_u8 is not None:
+                del two
+        del scratch2
     if det == 256:
         # different (equivalent) factorisations of the inverse at 256^2: the
         # intermediates differ, what pass 2 makes of them must not
