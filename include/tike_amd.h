@@ -443,6 +443,61 @@ int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, doub
                        float* weights_c, long weights_row, void* coefs_c, int coef_stride,
                        const float* esum, void* stream);
 
+/* ---- the packed minibatch tail: the arithmetic of tike_lstsq_step_sums / _solve,
+ * tike_probe_update and the tike_eigen_* entries above for the common case of ONE
+ * eigen probe (or none), in four launches after the step statistics and with two
+ * small all-reduces between them when several ranks share a minibatch
+ * (lstsq.py:136-205,297-364,641-761; probe.py:362-476):
+ *
+ *   tike_lstsq_step_stats                         stats, eigen_proj
+ *   tike_eigen_pixel_update1                      update += sum_n R_n pm[n]; sums3
+ *     [all-reduce { sums3 ; update }]
+ *   tike_lstsq_tail_mid                           tail3[0..1]; eigen0 <- E'
+ *   tike_eigen_position_sums1                     sums5, tail3[2] (dsum)
+ *     [all-reduce tail3]
+ *   tike_lstsq_tail_finish                        weights, probe, steps
+ * (no eigen probe: tike_lstsq_step_sums in place of tike_eigen_pixel_update1, no
+ * tike_eigen_position_sums1).
+ *
+ * tike_eigen_pixel_update1: as tike_eigen_pixel_update for the first eigen probe
+ *   with pm[n] = (eigen_proj[n] / P + weights_c[n*weights_row]) / norm[0] formed on
+ *   the fly (eigen_proj from tike_lstsq_step_stats; norm = sum over ALL ranks of the
+ *   minibatch's weights_c^2); eigen0 (pw,pw) c64: that eigen probe.  With sums3 not
+ *   NULL one extra workgroup also leaves sums3[0..2] = tike_lstsq_step_sums(stats,
+ *   costs, nscan, eps): the two share one all-reduce.
+ * tike_lstsq_tail_mid: the 2x2 solves of the B local positions with sums3 and
+ *   count over all ranks: tail3[0..1] = { sum 0.9 max(0, Re x1), sum 0.9 max(0, Re
+ *   x2) }; and, eigen0 not NULL, nacc[0..2] += { sum |update|^2, sum |eigen0|^2,
+ *   sum Re(conj(eigen0) update) } over npix pixels (nacc zero on entry), then
+ *   eigen0 <- normalise(eigen0 + beta_eigen u / mnorm(u)), u = update / count
+ *   (tike_eigen_normalise, probe.py:440-448).
+ * tike_eigen_position_sums1: sums5 (nscan,5) as tike_eigen_position_sums for the
+ *   first eigen probe, and dsum[0] += sum_n sums5[n][2] / P (zero on entry).
+ * tike_lstsq_tail_finish, with tail3 = { sum step_o, sum step_p, dsum } over all
+ *   ranks: steps[0..4] = { tail3[0], tail3[1], tail3[0]/count, tail3[1]/count,
+ *   sums3[2]/count }; probe += beta_probe mpu and combined += beta_probe mpu *
+ *   inv_num_batch over nprobe elements (probe NULL: skipped; combined may be NULL);
+ *   weights (B,C+1,S): [n][0][m] += 0.1 stats[n][6] / stats[n][7] and, with sums5
+ *   (npix = P), [n][1][m] += (s1/P) / (s2/P + 0.1 dsum / count) (weights NULL:
+ *   skipped). */
+int tike_eigen_pixel_update1(const void* patches, const void* chi0, const void* mpu0,
+                             const void* eigen0, const float* eigen_proj,
+                             const float* weights_c, long weights_row, const float* norm,
+                             void* update, int nscan, int pw, int chi_modes, const float* stats,
+                             const float* costs, float eps, float* sums3, void* stream);
+int tike_lstsq_tail_mid(void* eigen0, const void* update, int npix, float* nacc,
+                        float beta_eigen, const float* stats, int B, float eps,
+                        const float* sums3, double count, int recover_psi, int recover_probe,
+                        float* tail3, void* stream);
+int tike_eigen_position_sums1(const void* patches, const void* chi0, const void* mpu0,
+                              const void* eigen0, float* sums5, float* dsum, int nscan, int pw,
+                              int chi_modes, void* stream);
+int tike_lstsq_tail_finish(const float* tail3, const float* sums3, double count, float* steps,
+                           void* probe, void* combined, const void* mpu, float inv_num_batch,
+                           long nprobe, float* weights, long weights_row, int S, int m,
+                           const float* stats, const float* sums5, int B, int npix,
+                           void* stream);
+
 /* ---- the chunk body of _get_nearplane_gradients (lstsq.py:422-579) in ONE call:
  * the far-plane-free pipeline for a chunk of nscan positions,
  *   tike_fwd_pass1 -> tike_fwd_grad_ifft2_pass1 (256^2; at 512^2

@@ -101,6 +101,35 @@ def test_lstsq_minibatch_kernels_vs_reference(tp, golden, tag):
                                    rtol=1e-3)
         np.testing.assert_allclose(float(bp), g["beta_probe"].ravel()[0],
                                    rtol=1e-3)
+        if ep is None or ep.shape[-4] == 1:
+            # the packed tail lstsq_grad runs for at most one eigen probe,
+            # against the same outputs of the reference
+            ep3 = None if ep is None else ep.clone()
+            ew3 = None if ew is None else ew.clone()
+            probe3 = probe.clone()
+            steps_row = torch.zeros(5, dtype=torch.float32, device=psi.device)
+            norm = None
+            if ep is not None:
+                norm = torch.square(ew3[lo:hi, 1, 0]).sum().reshape(1)
+            bo3, bp3 = L._packed_tail(
+                out, psi, scan, probe3, ep3, ew3, precond, lo, hi, comm, op=op,
+                num_batch=2, recover_psi=True, recover_probe=True, norm=norm,
+                steps_row=steps_row,
+                probe_combined_update=torch.zeros_like(probe3))
+            np.testing.assert_allclose(float(bo3), g["beta_object"].ravel()[0],
+                                       rtol=1e-3)
+            np.testing.assert_allclose(float(bp3), g["beta_probe"].ravel()[0],
+                                       rtol=1e-3)
+            np.testing.assert_allclose(float(steps_row[4]), g["costs"].mean(),
+                                       rtol=COST_RTOL)
+            if ew is not None:
+                assert_close(ew3.cpu().numpy(), g["eigen_weights_out"],
+                             normwise=1e-4, maxabs=1e-3,
+                             what="eigen_weights (packed tail)")
+            if ep is not None:
+                assert_close(ep3.cpu().numpy(), g["eigen_probe_out"],
+                             normwise=1e-4, maxabs=1e-3,
+                             what="eigen_probe (packed tail)")
 
 
 def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
@@ -699,6 +728,36 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
                          what="eigen_probe")
             assert_close(ew2.cpu().numpy(), ew_o, normwise=1e-4, maxabs=1e-3,
                          what="eigen_weights")
+        # the packed tail (what lstsq_grad runs for at most one eigen probe):
+        # same statistics, eigen update, step lengths and probe update in five
+        # launches, against the same oracle values
+        import torch
+        ep3 = None if ep is None else d["ep"].clone()
+        ew3 = None if ew is None else d["ew"].clone()
+        probe3 = d["probe"].clone()
+        combined = torch.zeros_like(probe3)
+        steps_row = torch.zeros(5, dtype=torch.float32, device=probe3.device)
+        norm = None
+        if eigen:
+            norm = torch.square(ew3[:, 1, 0]).sum().reshape(1).contiguous()
+        bo3, bp3 = L._packed_tail(
+            out, d["psi"], d["scan"], probe3, ep3, ew3, precond, 0, N, comm,
+            op=op, num_batch=2, recover_psi=True, recover_probe=True,
+            norm=norm, steps_row=steps_row, probe_combined_update=combined)
+        np.testing.assert_allclose(float(bo3), np.ravel(bo_o)[0], rtol=1e-3)
+        np.testing.assert_allclose(float(bp3), np.ravel(bp_o)[0], rtol=1e-3)
+        np.testing.assert_allclose(float(steps_row[4]), o["costs"].mean(),
+                                   rtol=COST_RTOL)
+        want_probe = probe0 + np.ravel(bp_o)[0] * o["m_probe_update"]
+        assert_close(probe3.cpu().numpy(), want_probe, normwise=2e-5,
+                     what="probe after the packed tail")
+        assert_close(combined.cpu().numpy(), (want_probe - probe0) / 2,
+                     normwise=1e-3, what="combined probe update")
+        if eigen:
+            assert_close(ep3.cpu().numpy(), ep_o, normwise=1e-4, maxabs=1e-3,
+                         what="eigen_probe (packed tail)")
+            assert_close(ew3.cpu().numpy(), ew_o, normwise=1e-4, maxabs=1e-3,
+                         what="eigen_weights (packed tail)")
 
 
 def test_bench_launcher_refuses_more_gpus_than_visible():
@@ -741,7 +800,9 @@ def test_bench_rccl_path_through_the_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
+    # per minibatch: the gradient buffer + two small packed buffers
     assert line["allreduce"]["calls_per_step"] >= 10
+    assert line["allreduce"]["calls_per_minibatch"] <= 3
     assert 0 < line["roofline"]["iteration_hbm_frac"] < 1
 
 

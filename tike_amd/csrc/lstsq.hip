@@ -1116,6 +1116,87 @@ __global__ __launch_bounds__(256) void eigen_pixel_update_kernel(const TkResidua
   unsafeAtomicAdd(&update[2 * p + 1], acc.y);
 }
 
+// The packed tail (one eigen probe per mode, c = 0): the per-position factor
+// pm[n] = (eproj[n] / P + w[n]) / norm (probe.py:429-433) is formed on the fly
+// from the projection the step statistics left and the batch norm.
+// The one workgroup past the pixel blocks (blockIdx.x == gridDim.x - 1,
+// blockIdx.y == 0) forms sums3 = { sum(A1 + eps), sum(A4 + eps), sum(costs) }
+// of the step-statistics table (tike_lstsq_step_sums) -- the two go into one
+// all-reduce.
+__global__ __launch_bounds__(256) void eigen_pixel_update1_kernel(
+    const TkResidual R, const float* __restrict__ eproj, const float* __restrict__ weights_c,
+    long row, const float* __restrict__ norm, float inv_P, float* __restrict__ update, int nscan,
+    int chunk, const float* __restrict__ stats, const float* __restrict__ costs, float eps,
+    float* __restrict__ sums3) {
+  if (blockIdx.x + 1 == gridDim.x) {
+    if (blockIdx.y != 0 || sums3 == nullptr) return;
+    __shared__ float red[4];
+    float a1 = 0.f, a4 = 0.f, c = 0.f;
+    for (int n = threadIdx.x; n < nscan; n += 256) {
+      a1 += stats[8 * n] + eps;
+      a4 += stats[8 * n + 1] + eps;
+      c += costs[n];
+    }
+    a1 = tk_block_sum256(a1, red);
+    a4 = tk_block_sum256(a4, red);
+    c = tk_block_sum256(c, red);
+    if (threadIdx.x == 0) {
+      sums3[0] = a1;
+      sums3[1] = a4;
+      sums3[2] = c;
+    }
+    return;
+  }
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= R.P) return;
+  const int b0 = blockIdx.y * chunk;
+  const int b1 = min(nscan, b0 + chunk);
+  const float inv_norm = 1.0f / norm[0];
+  cf acc = mk(0.f, 0.f);
+#pragma unroll 4
+  for (int n = b0; n < b1; ++n) {
+    const cf r = R.at<true>(n, p);
+    const float w = (eproj[n] * inv_P + weights_c[n * row]) * inv_norm;
+    acc.x += r.x * w;
+    acc.y += r.y * w;
+  }
+  unsafeAtomicAdd(&update[2 * p], acc.x);
+  unsafeAtomicAdd(&update[2 * p + 1], acc.y);
+}
+
+// Position sums against the (already updated) first eigen probe, plus
+// dsum[0] += sum_n sums[n][2] / P (the denominator mean, probe.py:463-469).
+__global__ __launch_bounds__(256) void eigen_position_sums1_kernel(const TkResidual R,
+                                                                   float* __restrict__ sums,
+                                                                   float* __restrict__ dsum,
+                                                                   int nscan) {
+  __shared__ float red[4];
+  const cf* __restrict__ E = R.eigen;
+  for (int n = blockIdx.x; n < nscan; n += gridDim.x) {
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long p = threadIdx.x; p < R.P; p += blockDim.x) {
+      const cf e = E[p];
+      const cf r = R.at<true>(n, p);
+      const cf phi = R.patches[n * R.P + p] * e;
+      const cf x = R.chi0[n * R.XS + p];
+      a[0] += r.x * e.x + r.y * e.y;
+      a[1] += x.x * phi.x + x.y * phi.y;
+      a[2] += norm2(phi);
+      const cf re = r * conjf(e);
+      a[3] += re.x;
+      a[4] += re.y;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float v = tk_block_sum256(a[k], red);
+      if (threadIdx.x == 0) {
+        sums[(long)n * 5 + k] = v;
+        if (k == 2) unsafeAtomicAdd(dsum, v / (float)R.P);
+      }
+    }
+  }
+}
+
 static TkResidual make_residual(const void* patches, const void* chi0, const void* mpu0,
                                 const void* eigen, const void* coefs, int C, int Sm, int c,
                                 int pw, int chi_modes) {
@@ -1175,6 +1256,47 @@ extern "C" int tike_eigen_pixel_update(const void* patches, const void* chi0, co
   else
     hipLaunchKernelGGL(eigen_pixel_update_kernel<false>, grid, dim3(256), 0,
                        (hipStream_t)stream, R, pm, (float*)update, nscan, chunk);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_eigen_pixel_update1(const void* patches, const void* chi0,
+                                        const void* mpu0, const void* eigen0,
+                                        const float* eigen_proj, const float* weights_c,
+                                        long weights_row, const float* norm, void* update,
+                                        int nscan, int pw, int chi_modes, const float* stats,
+                                        const float* costs, float eps, float* sums3,
+                                        void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && chi_modes >= 1 && weights_row >= 1);
+  TK_CHECK_ARG(!sums3 || (stats && costs));
+  if (nscan == 0) {
+    if (sums3) return (int)hipMemsetAsync(sums3, 0, 3 * sizeof(float), (hipStream_t)stream);
+    return TK_OK;
+  }
+  TK_CHECK_ARG(patches && chi0 && mpu0 && eigen0 && eigen_proj && weights_c && norm && update);
+  const long P = (long)pw * pw;
+  const int chunk = probe_chunk(nscan);
+  dim3 grid((unsigned)((P + 255) / 256) + 1, (unsigned)((nscan + chunk - 1) / chunk));
+  const TkResidual R = make_residual(patches, chi0, mpu0, eigen0, nullptr, 1, 1, 0, pw, chi_modes);
+  hipLaunchKernelGGL(eigen_pixel_update1_kernel, grid, dim3(256), 0, (hipStream_t)stream, R,
+                     eigen_proj, weights_c, weights_row, norm, 1.0f / (float)P, (float*)update,
+                     nscan, chunk, stats, costs, eps, sums3);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_eigen_position_sums1(const void* patches, const void* chi0,
+                                         const void* mpu0, const void* eigen0, float* sums,
+                                         float* dsum, int nscan, int pw, int chi_modes,
+                                         void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && chi_modes >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(patches && chi0 && mpu0 && eigen0 && sums && dsum);
+  const TkResidual R = make_residual(patches, chi0, mpu0, eigen0, nullptr, 1, 1, 0, pw, chi_modes);
+  hipLaunchKernelGGL(eigen_position_sums1_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
+                     (hipStream_t)stream, R, sums, dsum, nscan);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

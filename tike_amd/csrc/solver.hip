@@ -358,6 +358,169 @@ extern "C" int tike_eigen_weights(const float* sums, int B, long P, const float*
   return TK_OK;
 }
 
+// ------------------------------------------------- the packed minibatch tail
+// The same arithmetic as the entries above, grouped so that a minibatch needs
+// three launches between the step statistics and the next forward pass, and
+// (several ranks) two small all-reduces besides the gradient's:
+//   tike_lstsq_step_stats  ->  tike_eigen_pixel_update1 (+ sums3)
+//     [all-reduce { sums3 ; update }]
+//   tike_lstsq_tail_mid     2x2 solves; the eigen probe updated and normalised
+//   tike_eigen_position_sums1
+//     [all-reduce { sum step_o, sum step_p, dsum }]
+//   tike_lstsq_tail_finish  weights, probe update, step lengths
+
+// Workgroups [0, gridDim.x - 1): nacc[0..2] += { sum |update|^2, sum |E|^2,
+// sum Re(conj(E) update) } (E == NULL: none).  Last workgroup: the 2x2 solves of
+// the minibatch (step_solve_kernel), with sums3 = { sum (A1 + eps), sum (A4 +
+// eps), sum cost } over ALL ranks: tail3[0..1] = { sum 0.9 max(0, Re x1),
+// sum 0.9 max(0, Re x2) } over the local positions.
+__global__ __launch_bounds__(256) void lstsq_tail_mid_kernel(
+    const cf* __restrict__ E, const cf* __restrict__ update, int npix, float* __restrict__ nacc,
+    const float* __restrict__ stats, int B, float eps, const float* __restrict__ sums3,
+    float inv_count, int recover_psi, int recover_probe, float* __restrict__ tail3) {
+  __shared__ float red[4];
+  if (blockIdx.x + 1 < gridDim.x) {
+    float uu = 0.f, ee = 0.f, eu = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += (gridDim.x - 1) * 256) {
+      const cf e = E[i], u = update[i];
+      uu += norm2(u);
+      ee += norm2(e);
+      eu += e.x * u.x + e.y * u.y;
+    }
+    uu = tk_block_sum256(uu, red);
+    ee = tk_block_sum256(ee, red);
+    eu = tk_block_sum256(eu, red);
+    if (threadIdx.x == 0) {
+      unsafeAtomicAdd(&nacc[0], uu);
+      unsafeAtomicAdd(&nacc[1], ee);
+      unsafeAtomicAdd(&nacc[2], eu);
+    }
+    return;
+  }
+  const float r1 = 0.5f * sums3[0] * inv_count, r4 = 0.5f * sums3[1] * inv_count;
+  float so = 0.f, sp = 0.f;
+  for (int n = threadIdx.x; n < B; n += 256) {
+    const float* s = stats + 8 * n;
+    const float A1 = s[0] + eps + r1, A4 = s[1] + eps + r4;
+    const float b1 = s[4], b2 = s[5];
+    float x1 = 0.f, x2 = 0.f;
+    if (recover_psi && recover_probe) {
+      const float det = A1 * A4 - (s[2] * s[2] + s[3] * s[3]);
+      x1 = -(s[2] * b2 - A4 * b1) / det;
+      x2 = (A1 * b2 - s[2] * b1) / det;
+    } else if (recover_psi) {
+      x1 = b1 / A1;
+    } else if (recover_probe) {
+      x2 = b2 / A4;
+    }
+    so += 0.9f * fmaxf(x1, 0.f);
+    sp += 0.9f * fmaxf(x2, 0.f);
+  }
+  so = tk_block_sum256(so, red);
+  sp = tk_block_sum256(sp, red);
+  if (threadIdx.x == 0) {
+    tail3[0] = so;
+    tail3[1] = sp;
+  }
+}
+
+// E <- (E + k update) / mnorm(.), k = beta / mnorm(update / count) / count
+// (probe.py:440-448), from nacc = { sum |update|^2, sum |E|^2, sum Re(conj(E) update) }
+__global__ __launch_bounds__(256) void eigen_apply1_kernel(cf* __restrict__ E,
+                                                           const cf* __restrict__ update,
+                                                           const float* __restrict__ nacc,
+                                                           float inv_count, float beta,
+                                                           int npix) {
+  const float uu = nacc[0], ee = nacc[1], eu = nacc[2];
+  const float mu = sqrtf(uu * inv_count * inv_count / (float)npix);
+  const float k = beta / mu * inv_count;
+  const float inv = 1.0f / sqrtf((ee + 2.0f * k * eu + k * k * uu) / (float)npix);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256)
+    E[i] = (E[i] + update[i] * k) * inv;
+}
+
+extern "C" int tike_lstsq_tail_mid(void* eigen0, const void* update, int npix, float* nacc,
+                                   float beta_eigen, const float* stats, int B, float eps,
+                                   const float* sums3, double count, int recover_psi,
+                                   int recover_probe, float* tail3, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(B >= 0 && count > 0 && sums3 && tail3 && (B == 0 || stats));
+  TK_CHECK_ARG(!eigen0 || (update && nacc && npix >= 1));
+  const int grid = !eigen0 ? 0 : (npix >= 256 * 64 ? 64 : (npix + 255) / 256);
+  hipLaunchKernelGGL(lstsq_tail_mid_kernel, dim3(grid + 1), dim3(256), 0, (hipStream_t)stream,
+                     (const cf*)eigen0, (const cf*)update, npix, nacc, stats, B, eps, sums3,
+                     (float)(1.0 / count), recover_psi, recover_probe, tail3);
+  if (eigen0)
+    hipLaunchKernelGGL(eigen_apply1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (cf*)eigen0, (const cf*)update, nacc, (float)(1.0 / count), beta_eigen,
+                       npix);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// Everything that closes a minibatch, element-wise over max(probe, pixels,
+// positions), with tail3 = { sum step_o, sum step_p, dsum } over ALL ranks:
+//   steps[0..4] = { tail3[0], tail3[1], beta_object, beta_probe, mean cost }
+//   probe += beta_probe mpu;  combined += beta_probe mpu / num_batch   (lstsq.py:177-181)
+//   weights[n][0][m] += 0.1 stats[n][6] / stats[n][7]               (lstsq.py:721-738)
+//   weights[n][1][m] += (s1 / P) / (s2 / P + 0.1 dsum / count)      (probe.py:450-476)
+__global__ __launch_bounds__(256) void lstsq_tail_finish_kernel(
+    const float* __restrict__ tail3, const float* __restrict__ sums3, float inv_count,
+    float* __restrict__ steps, cf* __restrict__ probe, cf* __restrict__ combined,
+    const cf* __restrict__ mpu, float inv_num_batch, long nprobe, float* __restrict__ weights,
+    long row, int S, int m, const float* __restrict__ stats, const float* __restrict__ sums5,
+    int B, int npix) {
+  const float bp = tail3[1] * inv_count;
+  const long stride = (long)gridDim.x * 256;
+  const long i0 = blockIdx.x * 256L + threadIdx.x;
+  if (i0 == 0) {
+    steps[0] = tail3[0];
+    steps[1] = tail3[1];
+    steps[2] = tail3[0] * inv_count;
+    steps[3] = bp;
+    steps[4] = sums3[2] * inv_count;
+  }
+  if (probe != nullptr) {
+    for (long i = i0; i < nprobe; i += stride) {
+      const cf d = mpu[i] * bp;
+      probe[i] = probe[i] + d;
+      if (combined) combined[i] = combined[i] + d * inv_num_batch;
+    }
+  }
+  if (weights != nullptr) {
+    const float inv_P = 1.0f / (float)npix;
+    const float d_mean = sums5 ? tail3[2] * inv_count : 0.f;
+    for (long n = i0; n < B; n += stride) {
+      weights[n * row + m] += 0.1f * stats[8 * n + 6] / stats[8 * n + 7];
+      if (sums5) {
+        const float* s = sums5 + 5 * n;
+        weights[n * row + S + m] += (s[1] * inv_P) / (s[2] * inv_P + 0.1f * d_mean);
+      }
+    }
+  }
+}
+
+extern "C" int tike_lstsq_tail_finish(const float* tail3, const float* sums3, double count,
+                                      float* steps, void* probe, void* combined, const void* mpu,
+                                      float inv_num_batch, long nprobe, float* weights,
+                                      long weights_row, int S, int m, const float* stats,
+                                      const float* sums5, int B, int npix, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(tail3 && sums3 && steps && count > 0 && B >= 0 && nprobe >= 0 && npix >= 0);
+  TK_CHECK_ARG(!probe || mpu);
+  TK_CHECK_ARG(!weights || (stats && weights_row >= 1 && S >= 1 && m >= 0 && m < S));
+  TK_CHECK_ARG(!sums5 || (weights && weights_row >= 2L * S && npix >= 1));
+  long work = 1;
+  if (probe && nprobe > work) work = nprobe;
+  if (weights && B > work) work = B;
+  hipLaunchKernelGGL(lstsq_tail_finish_kernel, dim3(tk_grid((work + 255) / 256, 8)), dim3(256), 0,
+                     (hipStream_t)stream, tail3, sums3, (float)(1.0 / count), steps, (cf*)probe,
+                     (cf*)combined, (const cf*)mpu, inv_num_batch, nprobe, weights, weights_row,
+                     S, m, stats, sums5, B, npix);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 // ------------------------------------------- the whole chunk body in one call
 // (lstsq.py:422-579): the five stage entries, stream-ordered.
 extern "C" int tike_lstsq_chunk_gradients(

@@ -164,10 +164,26 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
     if position_options is not None:
         # numerator / denominator of the shift estimate, all local positions
         position_terms = (torch.zeros_like(scan), torch.zeros_like(scan))
+    # the packed minibatch tail (three launches, two small all-reduces) serves
+    # every configuration with at most one eigen probe
+    packed = PACKED_TAIL and (eigen_probe is None
+                              or eigen_probe.shape[-4] == 1)
+    eigen_norms = None
+    if (packed and recover_probe and eigen_weights is not None
+            and eigen_probe is not None):
+        # sum over the positions of every minibatch of the eigen weights
+        # squared (probe.py:417-424), all ranks: the weights of a minibatch
+        # change only in its own update, so one table (and one all-reduce)
+        # per epoch serves them all
+        eigen_norms = torch.stack([
+            torch.square(eigen_weights[_lo_hi(b)[0]:_lo_hi(b)[1], 1, 0]).sum()
+            for b in batches
+        ]).to(torch.float32).contiguous()
+        if comm.collective:
+            comm.Allreduce(eigen_norms)
 
     for batch_index in order:
-        lo = int(batches[batch_index][0]) if len(batches[batch_index]) else 0
-        hi = lo + len(batches[batch_index])
+        lo, hi = _lo_hi(batches[batch_index])
         g = _get_nearplane_gradients(
             data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi, comm,
             num_batch=num_batch, exitwave_options=exitwave_options, op=op,
@@ -179,18 +195,29 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
             object_update_precond = _precondition_object_update(
                 g["object_acc"], object_options.preconditioner, pmax=pmax,
                 combined=object_combined)
-        stats = _step_stats(g, psi, scan, probe, eigen_probe,
-                            object_update_precond, lo, hi, op=op)
+        if packed:
+            bbeta_object, bbeta_probe = _packed_tail(
+                g, psi, scan, probe, eigen_probe, eigen_weights,
+                object_update_precond, lo, hi, comm, op=op,
+                num_batch=num_batch, recover_psi=recover_psi,
+                recover_probe=recover_probe,
+                norm=None if eigen_norms is None else
+                eigen_norms[batch_index:batch_index + 1],
+                steps_row=steps[batch_index],
+                probe_combined_update=probe_combined_update)
+        else:
+            stats = _step_stats(g, psi, scan, probe, eigen_probe,
+                                object_update_precond, lo, hi, op=op)
 
-        if recover_probe and eigen_weights is not None:
-            eigen_probe, eigen_weights = _update_nearplane(
-                g, stats, probe, eigen_probe, eigen_weights, lo, hi, comm,
-                num_batch=num_batch)
+            if recover_probe and eigen_weights is not None:
+                eigen_probe, eigen_weights = _update_nearplane(
+                    g, stats, probe, eigen_probe, eigen_weights, lo, hi, comm,
+                    num_batch=num_batch)
 
-        bbeta_object, bbeta_probe, _ = _solve_steps(
-            stats, g["costs"], g["count"], comm, pw=probe.shape[-1],
-            recover_psi=recover_psi, recover_probe=recover_probe,
-            out=steps[batch_index])
+            bbeta_object, bbeta_probe, _ = _solve_steps(
+                stats, g["costs"], g["count"], comm, pw=probe.shape[-1],
+                recover_psi=recover_psi, recover_probe=recover_probe,
+                out=steps[batch_index])
 
         if recover_psi:
             if not compact:
@@ -204,13 +231,15 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
             beta_object.append(bbeta_object)
 
         if recover_probe:
-            # probe += beta * mpu; combined += beta * mpu / num_batch
-            check(
-                lib.tike_probe_update(A.ptr(probe), A.ptr(probe_combined_update),
-                                      A.ptr(g["m_probe_update"]),
-                                      A.ptr(bbeta_probe), 1.0 / num_batch,
-                                      probe.numel(), A.stream_ptr()),
-                "probe update")
+            if not packed:  # (the packed tail's last launch does it)
+                # probe += beta * mpu; combined += beta * mpu / num_batch
+                check(
+                    lib.tike_probe_update(A.ptr(probe),
+                                          A.ptr(probe_combined_update),
+                                          A.ptr(g["m_probe_update"]),
+                                          A.ptr(bbeta_probe), 1.0 / num_batch,
+                                          probe.numel(), A.stream_ptr()),
+                    "probe update")
             beta_probe.append(bbeta_probe)
 
     batch_cost = steps[:, 4]
@@ -277,6 +306,17 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
     parameters.eigen_weights = eigen_weights
     parameters.eigen_probe = eigen_probe
     return parameters
+
+
+PACKED_TAIL = True
+"""Tests set this to False to run the staged tail (one entry per step of the
+reference's _update_nearplane / _precondition_nearplane_gradients)."""
+
+
+def _lo_hi(batch):
+    """[lo, hi) of a contiguous minibatch index range."""
+    lo = int(batch[0]) if len(batch) else 0
+    return lo, lo + len(batch)
 
 
 def _eigen_args(eigen_probe, weights):
@@ -669,6 +709,92 @@ def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
             A.ptr(eigen0), A.ptr(eproj), A.stream_ptr()),
         "step-size statistics")
     return stats[:B]
+
+
+def _packed_tail(g, psi, scan, probe, eigen_probe, eigen_weights,
+                 object_update_precond, lo, hi, comm, *, op, num_batch,
+                 recover_psi, recover_probe, norm, steps_row,
+                 probe_combined_update):
+    """Everything between the gradients of a minibatch and the next forward
+    pass (lstsq.py:136-205: step statistics, `_update_nearplane` with at most
+    one eigen probe, the 2x2 step lengths, `probe += beta * m_probe_update`)
+    in five launches (six kernels) and, when ranks share the minibatch, two small
+    all-reduces: { sum A1, sum A4, sum cost ; eigen update } and { sum step_o,
+    sum step_p, eigen weight denominator }.  Returns (beta_object,
+    beta_probe) as 0-d device tensors; eigen probe and weights are updated in
+    place; steps_row (5,) receives tike_lstsq_tail_finish's `steps`."""
+    B = hi - lo
+    dev = psi.device
+    st = A.stream_ptr()
+    S, pw = probe.shape[-3], probe.shape[-1]
+    P = pw * pw
+    count = float(g["count"])
+    ws = _workspace(op)
+    eig = recover_probe and eigen_weights is not None
+    C = Sm = 0
+    if eig and eigen_probe is not None:
+        C, Sm = eigen_probe.shape[-4], eigen_probe.shape[-3]
+        assert eigen_weights.shape[-2] == C + 1 and C == 1
+    mpu = g["m_probe_update"]
+    one = (eig and C == 1 and Sm >= 1 and g["patches"] is not None
+           and mpu is not None and norm is not None)
+    # one zeroed buffer: [sums3 (3), -, update (2 P) | nacc (3), - | tail3 (3), -]
+    small = ws.get("tail_small", (4 + 2 * P + 8,), torch.float32, dev)
+    small.zero_()
+    sums3 = small[:3]
+    update = small[4:4 + 2 * P]
+    nacc = small[4 + 2 * P:4 + 2 * P + 4]
+    tail3 = small[4 + 2 * P + 4:4 + 2 * P + 7]
+    stats = _step_stats(g, psi, scan, probe, eigen_probe,
+                        object_update_precond, lo, hi, op=op)
+    eps_total = float(np.float32(np.float32(1e-9) / P) * P)
+    E = w_rows = sums5 = None
+    row = 0
+    if eig:
+        w_rows = eigen_weights[lo:hi]  # (B, C+1, S) rows of this minibatch
+        row = w_rows.shape[-2] * w_rows.shape[-1]
+    if one:
+        E = eigen_probe[0, 0, 0]  # (pw, pw) view, contiguous
+        check(
+            lib.tike_eigen_pixel_update1(
+                A.ptr(g["patches"]), A.ptr(g["chi0"]), A.ptr(mpu[0, 0, 0]),
+                A.ptr(E), A.ptr(g["eigen_proj"]), w_rows[:, 1, 0].data_ptr(),
+                row, A.ptr(norm), A.ptr(update), B, pw, g["chi_modes"],
+                A.ptr(stats), A.ptr(g["costs"]), eps_total, A.ptr(sums3), st),
+            "eigen pixel update")
+    else:
+        check(
+            lib.tike_lstsq_step_sums(A.ptr(stats), A.ptr(g["costs"]), B,
+                                     eps_total, A.ptr(sums3), st),
+            "step-size sums")
+    if comm.collective:
+        comm.Allreduce(small[:4 + 2 * P] if one else small[:4])
+    beta_eigen = min(0.1, 1.0 / num_batch)
+    check(
+        lib.tike_lstsq_tail_mid(A.ptr(E), A.ptr(update), P, A.ptr(nacc),
+                                beta_eigen, A.ptr(stats), B, eps_total,
+                                A.ptr(sums3), count, int(recover_psi),
+                                int(recover_probe), A.ptr(tail3), st),
+        "step solve")
+    if one:
+        sums5 = ws.get("eigen_sums5", (max(B, 1), 5), torch.float32, dev)
+        check(
+            lib.tike_eigen_position_sums1(
+                A.ptr(g["patches"]), A.ptr(g["chi0"]), A.ptr(mpu[0, 0, 0]),
+                A.ptr(E), A.ptr(sums5), tail3[2:].data_ptr(), B, pw,
+                g["chi_modes"], st), "eigen position sums")
+    if comm.collective:
+        comm.Allreduce(tail3)
+    check(
+        lib.tike_lstsq_tail_finish(
+            A.ptr(tail3), A.ptr(sums3), count, A.ptr(steps_row),
+            A.ptr(probe) if recover_probe else None,
+            A.ptr(probe_combined_update) if recover_probe else None,
+            A.ptr(mpu), 1.0 / num_batch, probe.numel(),
+            None if w_rows is None else w_rows.data_ptr(), row, S, 0,
+            A.ptr(stats), A.ptr(sums5), B, P, st), "minibatch tail")
+    return (steps_row[2] if recover_psi else None,
+            steps_row[3] if recover_probe else None)
 
 
 def _solve_steps(stats, costs, count, comm, *, pw, recover_psi, recover_probe,
