@@ -71,7 +71,10 @@ def is_small_integer(dtype):
 
 def data_to_device(x, order=None, device=None):
     """The diffraction patterns in HBM, rows permuted by `order`: uint16 when
-    they arrived as <= 16-bit integers, float32 otherwise."""
+    they arrived as <= 16-bit integers, float32 otherwise.  (Detector counts
+    are non-negative: negative int8 / int16 values are clipped to 0 on the way
+    to uint16, and float16 is widened to float32 -- the reference keeps any
+    `itemsize <= 2` array as it is, ptycho.py:383-390.)"""
     if device is None:
         device = current_device()
     small = is_small_integer(x.dtype)

@@ -30,6 +30,10 @@ class Comm:
         # buffers of every minibatch) go through the library's own RCCL entry
         # (tike_comm_allreduce_sum, include/tike_amd.h) instead of
         # torch.distributed; the process group only hands out the unique id.
+        # Both issue on the caller's current stream and this class never uses
+        # torch's async_op collectives, so the two RCCL communicators of the
+        # process are ordered by that stream; do not mix `cabi` with
+        # asynchronous torch collectives on other streams.
         self._cabi = None
         if self.collective and os.environ.get("TIKE_COMM_BACKEND") == "cabi":
             self._cabi = self._create_cabi()
@@ -65,17 +69,29 @@ class Comm:
         return self
 
     def __exit__(self, type, value, traceback):
+        self.close()
+
+    def close(self):
+        """Destroy the library's own RCCL communicator (if any)."""
         if self._cabi is not None:
             from .. import _lib
+            handle, self._cabi = self._cabi, None
             torch.cuda.synchronize()
-            _lib.check(_lib.lib.tike_comm_destroy(self._cabi),
-                       "tike_comm_destroy")
-            self._cabi = None
+            _lib.check(_lib.lib.tike_comm_destroy(handle), "tike_comm_destroy")
+
+    def __del__(self):
+        # a Comm used without `with`: do not leak the ncclComm
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: nothing left to report to
+            pass
 
     def Allreduce(self, *tensors):
         """Sum the tensors across ranks IN PLACE; complex tensors are reduced
-        as interleaved float32.  Several tensors are packed into one flat
-        buffer so that a minibatch costs one collective."""
+        as interleaved float32.  Several float32 / complex64 tensors are
+        packed into one flat buffer so that they cost one collective; tensors
+        of any other dtype (float64 sums) are reduced on their own, in their
+        own precision."""
         if not self.collective:
             return tensors if len(tensors) != 1 else tensors[0]
         views = [
@@ -87,13 +103,21 @@ class Comm:
         elif len(views) == 1 and views[0].is_contiguous():
             dist.all_reduce(views[0], op=dist.ReduceOp.SUM, group=self.group)
         else:
-            flat = torch.cat([v.reshape(-1).to(torch.float32) for v in views])
-            self._allreduce_f32(flat)
-            off = 0
+            f32 = [v for v in views if v.dtype == torch.float32]
             for v in views:
-                n = v.numel()
-                v.copy_(flat[off:off + n].reshape(v.shape))
-                off += n
+                if v.dtype != torch.float32:  # never downcast
+                    w = v.contiguous()
+                    dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group)
+                    if w is not v:
+                        v.copy_(w)
+            if f32:
+                flat = torch.cat([v.reshape(-1) for v in f32])
+                self._allreduce_f32(flat)
+                off = 0
+                for v in f32:
+                    n = v.numel()
+                    v.copy_(flat[off:off + n].reshape(v.shape))
+                    off += n
         return tensors if len(tensors) != 1 else tensors[0]
 
     def Allreduce_scalars(self, values, device):
@@ -146,7 +170,9 @@ class Comm:
 
     def sync_random(self):
         """Give every rank the generator states of rank 0 (``np.random`` and
-        ``tike_amd.random.randomizer_np``).  The multi-rank solver relies on
+        ``tike_amd.random.randomizer_np``) -- this OVERWRITES the
+        process-global ``np.random`` state of the other ranks, on purpose.
+        The multi-rank solver relies on
         every rank drawing the same clustering seeds, minibatch permutation
         and RANSAC subsets; ranks started with different seeds (or with
         OS-seeded generators) would otherwise split the job differently."""

@@ -42,7 +42,7 @@ class PinnedData:
         self._slots = [None, None]
         self._free = [None, None]  # event after which a slot may be overwritten
         self._ready = None  # (lo, hi, slot, event) of the prefetched chunk
-        self._last = None  # (lo, hi, slot) handed out last
+        self._last = None  # (lo, hi, slot, copy-done event, stream) handed out last
         self.copies = 0  # host-to-device copies issued
         self.hits = 0  # chunks that were already on their way when asked for
 
@@ -82,10 +82,12 @@ class PinnedData:
         if n == 0:
             return torch.empty((0, *self.shape[1:]), dtype=self.dtype,
                                device=self.device)
+        cur = torch.cuda.current_stream(self.device)
         if self._last is not None and self._last[:2] == (lo, hi):
             s = self._last[2]  # asked for twice in one chunk iteration
+            if self._last[3] is not None and cur != self._last[4]:
+                cur.wait_event(self._last[3])  # a consumer on another stream
             return self._view(s, n)
-        cur = torch.cuda.current_stream(self.device)
         if self._ready is not None and self._ready[:2] == (lo, hi):
             _, _, s, done = self._ready
             self.hits += 1
@@ -101,8 +103,13 @@ class PinnedData:
         free = torch.cuda.Event()
         free.record(cur)
         self._free[other] = free
-        self._last = (lo, hi, s)
+        self._last = (lo, hi, s, done, cur)
         # the solvers walk a minibatch chunk by chunk: fetch the next one now
+        # (the guess `hi + n` misses on a shorter last chunk: copied on demand).
+        # cgrad re-walks the chunks of a minibatch for every line-search probe:
+        # with data_on_host and several chunks per minibatch the minibatch
+        # crosses PCIe once per probe -- size the chunks (or the minibatches)
+        # so that a minibatch is one chunk when that matters.
         nlo, nhi = hi, min(self.shape[0], hi + n)
         if nhi > nlo:
             self._ready = (nlo, nhi, other, self._issue(nlo, nhi, other))

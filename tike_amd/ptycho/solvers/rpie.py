@@ -245,21 +245,23 @@ def _gradients_multislice(data, psi, scan, probe, eigen_probe, eigen_weights,
         # diff = propagation.adj(farplane)[..., pad:end, pad:end]; a
         # multislice object has pad = 0
         diff = op.propagation.adj(far, overwrite=True)[:, 0].contiguous()
-        for tt in range(D - 1, -1, -1):
-            if recover_psi:
-                # psi numerator: sum_s conj(probe_tt) diff scattered (1/S below)
-                check(
-                    lib.tike_conv_adj(A.ptr(diff), A.ptr(sc),
-                                      A.ptr(probes[tt].contiguous()), 1,
-                                      A.ptr(acc[tt]), n, S, pw, pw, H, W, st),
-                    "object numerator")
-                # probe numerator: sum_n conj(patch_n(psi_tt)) diff
-                check(
-                    lib.tike_probe_grad(
-                        A.ptr(diff), A.ptr(sc), A.ptr(psi[tt]),
-                        A.ptr(patches0[blo:blo + n]) if tt == 0 else None,
-                        A.ptr(pacc[tt]), n, S, pw, H, W, st),
-                    "probe numerator")
+        # (rpie.py:444-472: the walk back through the slices happens only
+        # when the object is recovered; otherwise `diff` stays the exit-wave
+        # update of the LAST slice, and that is what the eigen weights see)
+        for tt in range(D - 1, -1, -1) if recover_psi else ():
+            # psi numerator: sum_s conj(probe_tt) diff scattered (1/S below)
+            check(
+                lib.tike_conv_adj(A.ptr(diff), A.ptr(sc),
+                                  A.ptr(probes[tt].contiguous()), 1,
+                                  A.ptr(acc[tt]), n, S, pw, pw, H, W, st),
+                "object numerator")
+            # probe numerator: sum_n conj(patch_n(psi_tt)) diff
+            check(
+                lib.tike_probe_grad(
+                    A.ptr(diff), A.ptr(sc), A.ptr(psi[tt]),
+                    A.ptr(patches0[blo:blo + n]) if tt == 0 else None,
+                    A.ptr(pacc[tt]), n, S, pw, H, W, st),
+                "probe numerator")
             if tt == 0:
                 break
             diff = op.diffraction.propagation.adj(diff)

@@ -1,6 +1,14 @@
 #!/bin/bash
 # SQ stall counters of an arbitrary command (run on the GPU box):
 #   bash tools/pmc_cmd.sh <kernel-substring> python3 bench.py --workload fwd128x1 ...
+# The command after the kernel substring must be the interpreter or binary ITSELF
+# on ONE GPU (python3 script.py ..., ./probe): with --pmc the profiler's preload
+# initialises the GPU before the program starts, so any hop that re-executes
+# (env, bash -c, taskset, numactl, a "#!/usr/bin/env" script, bench.py --gpus N
+# spawning torchrun) is an exec of a GPU-initialised process -- fatal on this pool.
+case "$2" in
+  env|bash|sh|taskset|numactl|torchrun) echo "pmc_cmd.sh: '$2' re-executes; give the program itself" >&2; exit 2;;
+esac
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 pat=$1; shift
