@@ -504,7 +504,9 @@ struct TkModeProbe {  // probe of one (position, mode): uniform values
   int nE;             // eigen probes to add on the fly (0 when `base` is final)
 };
 
-template <int N, int MW, int MPW, bool HAVE_PROJ>
+// EIG: eigen probes are applied on the fly (their loops cost the 512^2
+// instantiation 19 spilled registers when compiled in and never taken).
+template <int N, int MW, int MPW, bool HAVE_PROJ, bool EIG = true>
 __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
     const cf* __restrict__ mid, const cf* __restrict__ patches, const TkProbe probe,
     cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, float mpu_scale,
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
   // per-lane byte offset inside a row segment
   const long slice0 = (long)ya * N + (cb * CW + cw) * 64;
   const unsigned lb = (unsigned)lane * (unsigned)sizeof(cf);
-  if (HAVE_PROJ && probe.weights != nullptr && probe.eigen != nullptr) {
+  if (EIG && HAVE_PROJ && probe.weights != nullptr && probe.eigen != nullptr) {
     const int total = probe.C * probe.Sm * RB * 64 * CW;
     for (int i = threadIdx.x; i < total; i += 256) {
       const int x = i % (64 * CW), yb = (i / (64 * CW)) % RB, cs = i / (64 * CW * RB);
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
   // eigen probes vary the probe of the first Sm modes per position
   // (probe.py:272-303); only the waves that own those modes meet them
   const bool vary = HAVE_PROJ && probe.weights != nullptr;
-  const int nE = (vary && probe.eigen != nullptr) ? probe.C : 0;
+  const int nE = (EIG && vary && probe.eigen != nullptr) ? probe.C : 0;
   for (int n = b0; n < b1; ++n) {
     // keep the per-lane offset out of the loop's induction variables: bases
     // stay in scalar registers, one 32-bit VGPR offset serves every access
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
         }
         if (HAVE_PROJ) {
           const cf* __restrict__ Ps = probe.probe + (long)s * P + slice0;
-          const bool eig = nE > 0 && s < probe.Sm;  // wave-uniform, rare
+          const bool eig = EIG && nE > 0 && s < probe.Sm;  // wave-uniform, rare
 #pragma unroll
           for (int g = 0; g < RB; g += 8) {
             cf pc[8];
@@ -753,9 +755,15 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
   if (eig_lds > 32 * 1024) return TK_ERR_UNSUPPORTED;
 #define TK_P2G(N, MW_, MPW_)                                                                 \
   do {                                                                                       \
-    if (objproj)                                                                             \
+    if (objproj && eig_lds > 0)                                                              \
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true>), grid, block,    \
                          eig_lds,                                                            \
+                         stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
+                         (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
+                         chunk);                                                             \
+    else if (objproj)                                                                        \
+      hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true, false>), grid,    \
+                         block, 0,                                                           \
                          stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
                          (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
                          chunk);                                                             \

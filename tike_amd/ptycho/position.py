@@ -138,18 +138,26 @@ def estimate_global_transformation(positions0, positions1, weights=None,
     return result, np.linalg.norm(result(positions0) - positions1)
 
 
+def ransac_subsets(n, min_sample=4, max_iter=20):
+    """The random subsets of one RANSAC fit over n positions
+    (position.py:296-300), from the library's generator."""
+    return trandom.randomizer_np.choice(a=n, size=(max_iter, min_sample),
+                                        replace=True)
+
+
 def estimate_global_transformation_ransac(positions0, positions1, weights=None,
                                           transform=None, min_sample=4,
                                           max_error=32, min_consensus=0.75,
-                                          max_iter=20):
+                                          max_iter=20, subsets=None):
     """RANSAC estimate of the global affine transformation
     (position.py:273-327); the subsets come from ``tike_amd.random.
-    randomizer_np`` exactly as the reference draws them."""
+    randomizer_np`` exactly as the reference draws them (`subsets`: drawn
+    earlier by `ransac_subsets`, for a fit that is carried out later)."""
     transform = AffineTransform() if transform is None else transform
     best_fitness = np.inf
-    for subset in trandom.randomizer_np.choice(a=len(positions0),
-                                               size=(max_iter, min_sample),
-                                               replace=True):
+    if subsets is None:
+        subsets = ransac_subsets(len(positions0), min_sample, max_iter)
+    for subset in subsets:
         candidate, _ = estimate_global_transformation(
             positions0[subset], positions1[subset], weights, transform)
         error = np.linalg.norm(candidate(positions0) - positions1, axis=-1)

@@ -31,7 +31,8 @@ from . import solvers
 from .object import (positivity_constraint, remove_object_ambiguity,
                      smoothness_constraint)
 from .position import (affine_position_regularization,
-                       check_allowed_positions)
+                       check_allowed_positions,
+                       estimate_global_transformation_ransac, ransac_subsets)
 from .probe import (apply_median_filter_abs_probe, constrain_center_peak,
                     constrain_probe_sparsity, constrain_variable_probe,
                     finite_probe_support, get_varying_probe, orthogonalize_eig,
@@ -246,6 +247,8 @@ class Reconstruction():
                 1e-9),
         )
         self.comm = Comm()
+        self._pending_fits = []  # deferred affine fits of the positions
+        self._initial_scan_host = None
 
     # ------------------------------------------------------------- set-up
     def _shard(self, n_total):
@@ -368,18 +371,56 @@ class Reconstruction():
         """Affine regularisation of the updated positions (ptycho.py:521-524,
         854-866).  The fit sees ALL positions of the job (every rank runs the
         same host fit with its synchronised generator), so the result does
-        not depend on the number of ranks."""
+        not depend on the number of ranks.
+
+        With `use_position_regularization` off the fit changes nothing on the
+        device (it only updates `position_options.transform`), so it does not
+        hold up the next epoch: the positions are copied to pinned host memory
+        asynchronously, the random subsets are drawn NOW (the generator is
+        consumed in the reference's order) and the fit itself runs once the
+        copy has landed -- at a later epoch's end or when results are asked
+        for."""
         p = self.parameters
-        if p.position_options is None:
+        po = p.position_options
+        if po is None:
             return
+        local_fit = not self.comm.collective or self._presharded
+        if not po.use_position_regularization and local_fit:
+            snap = torch.empty(tuple(p.scan.shape), dtype=p.scan.dtype,
+                               pin_memory=True)
+            snap.copy_(p.scan, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            self._pending_fits.append(
+                (snap, done, ransac_subsets(p.scan.shape[0])))
+            self._resolve_fits(block=False)
+            return
+        self._resolve_fits(block=True)
         pos0 = pos1 = None
-        if self.comm.collective and not self._presharded:
-            pos0 = self._gather_positions(
-                p.position_options.initial_scan)[self.order]
+        if not local_fit:
+            pos0 = self._gather_positions(po.initial_scan)[self.order]
             pos1 = self._gather_positions(p.scan)[self.order]
         p.scan, p.position_options = affine_position_regularization(
-            updated=p.scan, position_options=p.position_options,
+            updated=p.scan, position_options=po,
             positions0=pos0, positions1=pos1)
+
+    def _resolve_fits(self, block=True):
+        """Carry out the deferred affine fits, oldest first (block=False: only
+        those whose positions have already reached the host)."""
+        po = self.parameters.position_options
+        while self._pending_fits:
+            snap, done, subsets = self._pending_fits[0]
+            if not block and not done.query():
+                return
+            done.synchronize()
+            if self._initial_scan_host is None:
+                self._initial_scan_host = A.to_host(po.initial_scan)
+            origin = A.to_host(po.origin)
+            po.transform, _ = estimate_global_transformation_ransac(
+                positions0=self._initial_scan_host - origin,
+                positions1=snap.numpy() - origin, transform=po.transform,
+                max_error=32, subsets=subsets)
+            self._pending_fits.pop(0)
 
     # ------------------------------------------------------------- results
     def _gather_positions(self, local):
@@ -408,6 +449,8 @@ class Reconstruction():
 
     def get_result(self):
         """Current parameter estimates on the host (ptycho.py:573-597)."""
+        if self.parameters.position_options is not None:
+            self._resolve_fits(block=True)
         p = self.parameters.copy_to_host()
         p.scan = self._gather_positions(self.parameters.scan)
         p.eigen_weights = self._gather_positions(self.parameters.eigen_weights)
@@ -436,6 +479,9 @@ class Reconstruction():
             "Adding data on-the-fly is disabled until further notice.")
 
     def __exit__(self, type, value, traceback):
+        if (type is None and getattr(self, "parameters", None) is not None
+                and self.parameters.position_options is not None):
+            self._resolve_fits(block=True)
         self.comm.__exit__(type, value, traceback)
         self.operator.__exit__(type, value, traceback)
         self.data = None
