@@ -443,6 +443,30 @@ int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, doub
                        float* weights_c, long weights_row, void* coefs_c, int coef_stride,
                        const float* esum, void* stream);
 
+/* ---- backtracking line search decided on the device (the conjugate-gradient
+ * solver; reference opt.py:216-278 `line_search` over the gaussian cost
+ * `Ptycho.cost`, ptycho.py:193-204, as solvers/cgrad.py composes them).
+ * Tries x + step d, x + step/2 d, ... for at most nslots step lengths; every
+ * trial is a cost-only forward pass (tike_fwd_pass1 + tike_fwd_gradient_scale
+ * over the minibatch in chunks of `chunk` positions), all enqueued at once: a
+ * trial whose predecessor was accepted returns immediately, so the host reads
+ * nothing back between trials.  det in {256, 512}, probe window = detector,
+ * every pixel measured.
+ *   variable  0: x, d, xs are the object (H,W); other = probe (S,det,det)
+ *             1: x, d, xs are the probe (S,det,det); other = object (H,W)
+ *   state     device double[4] = { fx, step, done, trials }: on entry the mean
+ *             cost at x and the first step length; on return, accepted: the
+ *             mean cost and step length accepted, done = 1 (xs = the new
+ *             iterate); not accepted: done = 0, step = the next length to try
+ *   count     positions over all ranks (the mean's denominator x det^2 is the
+ *             kernels'); skip: one device int of scratch; costs (nscan) f32 and
+ *             scratch (chunk,S,det,det) c64 workspaces. */
+int tike_cgrad_line_search(int variable, const void* x, const void* d, void* xs,
+                           const void* other, const float* scan, const void* data,
+                           int data_u16, void* scratch, float* costs, int nscan, int chunk,
+                           int S, int det, int H, int W, float fwd_scale, double count,
+                           double* state, int* skip, int nslots, void* stream);
+
 /* ---- the packed minibatch tail: the arithmetic of tike_lstsq_step_sums / _solve,
  * tike_probe_update and the tike_eigen_* entries above for the common case of ONE
  * eigen probe (or none), in four launches after the step statistics and with two

@@ -363,6 +363,62 @@ def test_cgrad_vs_oracle(tp, det, pw, S, N):
                  what="probe")
 
 
+@pytest.mark.parametrize("det,S,N,slots", [(256, 1, 12, (8, 4)),
+                                           (256, 2, 7, (1, 1)),
+                                           (512, 2, 4, (8, 4))])
+def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
+                                                          S, N, slots):
+    """The line search decided on the device (tike_cgrad_line_search: trials
+    enqueued ahead, skipped once one is accepted) follows opt.line_search
+    (opt.py:216-278) trial for trial: same accepted step lengths, therefore
+    the same iterates as the host-side search that reads every cost back.
+    slots = (1, 1): most searches run out of slots, which sends the call to
+    the host-side search -- the fallback must give the same result too."""
+    import importlib
+    C = importlib.import_module("tike_amd.ptycho.solvers.cgrad")
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=det + 3 * S, eigen=False)
+    results = []
+    for on_device in (True, False):
+        monkeypatch.setattr(C, "DEVICE_LINE_SEARCH", on_device)
+        monkeypatch.setattr(C, "LINE_SEARCH_SLOTS", slots)
+        calls = []
+        real = C._cg_device
+
+        def spy(*a, **k):
+            r = real(*a, **k)
+            calls.append(r is not None)
+            return r
+
+        monkeypatch.setattr(C, "_cg_device", spy)
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+            scan=scan.copy(),
+            algorithm_options=tp.CgradOptions(num_batch=2, cg_iter=3,
+                                              num_iter=2,
+                                              batch_method="compact"),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions())
+        with tp.Reconstruction(data, params, order=np.arange(N),
+                               batches=np.array_split(np.arange(N), 2)) as ctx:
+            ctx.iterate(2)
+            results.append(ctx.get_result())
+        monkeypatch.setattr(C, "_cg_device", real)
+        if on_device:
+            assert len(calls) == 8  # 2 epochs x 2 minibatches x (object, probe)
+            if slots == (8, 4):
+                assert all(calls)  # every search found its step in its slots
+            else:
+                assert not all(calls)  # the fallback ran
+        else:
+            assert not calls
+    a, b = results
+    np.testing.assert_allclose(np.array(a.algorithm_options.costs),
+                               np.array(b.algorithm_options.costs), rtol=1e-5)
+    assert_close(a.psi, b.psi, normwise=1e-5, maxabs=1e-4, what="psi")
+    assert_close(a.probe, b.probe, normwise=1e-5, maxabs=1e-4, what="probe")
+
+
 def test_lstsq_converges_and_resumes(tp):
     """Cost decreases monotonically on a clean synthetic problem and state
     round-trips through PtychoParameters (larger, pow-2 sizes)."""

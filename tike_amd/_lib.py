@@ -115,6 +115,8 @@ _PROTOTYPES = {
     "tike_lstsq_chunk_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i,
                                    _f, _l, _p, _p, _p, _p, _p, _p, _p, _p, _f,
                                    _p, _i, _i, _i, _i, _i, _f, _f, _p],
+    "tike_cgrad_line_search": [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i,
+                               _i, _i, _i, _i, _f, _d, _p, _p, _i, _p],
     "tike_comm_unique_id": [_p],
     "tike_comm_create": [_p, _i, _i, ctypes.POINTER(_p)],
     "tike_comm_destroy": [_p],

@@ -521,9 +521,11 @@ template <int N, bool FULL>
 __global__ __launch_bounds__(N, N == 256 ? 3 : 2) void fwd_pass1_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ scratch, cf* __restrict__ patches, int nscan, int S, int pw, int H, int W,
-    const cf* __restrict__ twtab) {
+    const cf* __restrict__ twtab, const int* __restrict__ skip) {
   using G2 = Fft2Geom<N>;
   constexpr unsigned EB = G2::T * sizeof(cf);  // bytes between a thread's elements
+  // a speculative launch (device-side line search) whose result is not needed
+  if (skip != nullptr && *skip != 0) return;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
   cf* twl = lds + G2::LDS_ELEMS;
   FftTwLds<N>::fill(twl, twtab);
@@ -692,13 +694,11 @@ __global__ __launch_bounds__(N, N == 256 ? 3 : 2) void fwd_pass1_kernel(
 
 // unique_probe: the varying probe of the first eigen_modes modes from
 // tike_varying_probe, or NULL with eigen_probe given: formed on the fly.
-extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* probe,
-                              int probe_per_scan, const void* unique_probe,
-                              const void* eigen_probe, const float* eigen_weights,
-                              int num_eigen, int eigen_modes, void* scratch, void* patches,
-                              int nscan, int S, int pw, int det, int H, int W, void* stream_) {
-  TK_ENTER();
-  hipStream_t stream = (hipStream_t)stream_;
+static int tk_fwd_pass1(const void* psi, const float* scan, const void* probe,
+                        int probe_per_scan, const void* unique_probe, const void* eigen_probe,
+                        const float* eigen_weights, int num_eigen, int eigen_modes, void* scratch,
+                        void* patches, int nscan, int S, int pw, int det, int H, int W,
+                        hipStream_t stream, const int* skip) {
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
   TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
   if (nscan == 0) return TK_OK;
@@ -713,7 +713,7 @@ extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* pr
   hipLaunchKernelGGL((fwd_pass1_kernel<N, FULL>),                                              \
                      dim3(tk_grid((long)nscan * (N / 16), N == 256 ? 8 : 1)),                  \
                      dim3(N), 0, stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches,   \
-                     nscan, S, pw, H, W, tw)
+                     nscan, S, pw, H, W, tw, skip)
   if (det == 256 && pw == det)
     TK_F1(256, true);
   else if (det == 256)
@@ -725,6 +725,17 @@ extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* pr
 #undef TK_F1
   TK_LAUNCH_CHECK();
   return TK_OK;
+}
+
+extern "C" int tike_fwd_pass1(const void* psi, const float* scan, const void* probe,
+                              int probe_per_scan, const void* unique_probe,
+                              const void* eigen_probe, const float* eigen_weights,
+                              int num_eigen, int eigen_modes, void* scratch, void* patches,
+                              int nscan, int S, int pw, int det, int H, int W, void* stream_) {
+  TK_ENTER();
+  return tk_fwd_pass1(psi, scan, probe, probe_per_scan, unique_probe, eigen_probe, eigen_weights,
+                      num_eigen, eigen_modes, scratch, patches, nscan, S, pw, det, H, W,
+                      (hipStream_t)stream_, nullptr);
 }
 
 // Counts and mask bits of the RB pixels (k1 + 16 k2, t) of position n of an
@@ -801,10 +812,12 @@ __global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kern
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, float* __restrict__ gscale,
     float* __restrict__ intensity, float* __restrict__ costs, cf* __restrict__ farplane,
-    long nitem, int S, float scale, float unmeasured_scaling, float inv_nmeasured) {
+    long nitem, int S, float scale, float unmeasured_scaling, float inv_nmeasured,
+    const int* __restrict__ skip) {
   constexpr int RB = N / 16;    // radix of the column pass
   constexpr int NH = N / 256;   // 256-column blocks per row
   __shared__ float red[4];
+  if (skip != nullptr && *skip != 0) return;  // speculative launch, not needed
   const float s2 = scale * scale;
   for (long v = blockIdx.x; v < nitem; v += gridDim.x) {
     // item = (position, k1, column block)
@@ -881,14 +894,11 @@ __global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kern
 // scratch: from tike_fwd_pass1 (UNSCALED column-pass input; `scale` is the
 // forward FFT normalisation applied here).  intensity / costs may be NULL, and
 // so may gscale when only the costs are wanted (a line-search probe).
-extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
-                                       const unsigned char* measured, float* gscale,
-                                       float* intensity, float* costs, void* farplane, int nscan,
-                                       int S, int det, float scale, int model,
-                                       float unmeasured_scaling, long num_measured,
-                                       void* stream_) {
-  TK_ENTER();
-  hipStream_t stream = (hipStream_t)stream_;
+static int tk_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
+                                 const unsigned char* measured, float* gscale, float* intensity,
+                                 float* costs, void* farplane, int nscan, int S, int det,
+                                 float scale, int model, float unmeasured_scaling,
+                                 long num_measured, hipStream_t stream, const int* skip) {
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1 && (model == 0 || model == 1) &&
                num_measured > 0);
   if (nscan == 0) return TK_OK;
@@ -904,7 +914,7 @@ extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, in
 #define TK_FGS(N, M, DT)                                                                     \
   hipLaunchKernelGGL((fwd_gradient_scale_kernel<N, M, DT>), grid, block, 0, stream,             \
                      (const cf*)scratch, (const DT*)data, measured, gscale, intensity, costs,   \
-                     (cf*)farplane, nitem, S, scale, unmeasured_scaling, inv)
+                     (cf*)farplane, nitem, S, scale, unmeasured_scaling, inv, skip)
 #define TK_FGS_N(N)                     \
   do {                                  \
     if (model == 0 && data_u16)         \
@@ -922,6 +932,114 @@ extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, in
     TK_FGS_N(512);
 #undef TK_FGS_N
 #undef TK_FGS
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
+                                       const unsigned char* measured, float* gscale,
+                                       float* intensity, float* costs, void* farplane, int nscan,
+                                       int S, int det, float scale, int model,
+                                       float unmeasured_scaling, long num_measured,
+                                       void* stream_) {
+  TK_ENTER();
+  return tk_fwd_gradient_scale(scratch, data, data_u16, measured, gscale, intensity, costs,
+                               farplane, nscan, S, det, scale, model, unmeasured_scaling,
+                               num_measured, (hipStream_t)stream_, nullptr);
+}
+
+// ------------------------------------------- line search decided on the device
+// Backtracking line search of the conjugate-gradient solver (reference
+// opt.py:216-278 line_search, as composed by solvers/cgrad.py): try
+// x + step d, x + step/2 d, ... until the gaussian cost of the minibatch is no
+// larger than at x.  Every trial is a cost-only forward pass; its launches are
+// enqueued for `nslots` step lengths AHEAD of the decisions, and a trial whose
+// predecessor was accepted returns at once (the `skip` word the kernels read):
+// no host round trip per trial.
+// state (device, double[4]): { fx = mean cost at x, step, done, trials }.
+//   in : fx, step (first step length to try)
+//   out: accepted -> fx = mean cost there, step = that step length, done = 1
+//        otherwise  step = the next step length to try (step / 2^nslots), done = 0
+// xs receives x + step d of the LAST trial made (accepted: the new iterate).
+__global__ __launch_bounds__(256) void ls_trial_kernel(const cf* __restrict__ x,
+                                                       const cf* __restrict__ d,
+                                                       cf* __restrict__ xs, long n,
+                                                       const double* __restrict__ state,
+                                                       float shrink,
+                                                       const int* __restrict__ skip) {
+  if (*skip != 0) return;
+  const float a = (float)state[1] * shrink;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const cf v = d[i];
+    xs[i] = mk(x[i].x + a * v.x, x[i].y + a * v.y);
+  }
+}
+
+// One workgroup: mean cost of the trial; accept if it is no larger than fx.
+__global__ __launch_bounds__(256) void ls_decide_kernel(const float* __restrict__ costs, int n,
+                                                        double inv_count, float shrink,
+                                                        int last, double* __restrict__ state,
+                                                        int* __restrict__ skip) {
+  if (*skip != 0) return;
+  __shared__ double red[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += (double)costs[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double f = red[0] * inv_count;
+    state[3] += 1.0;
+    if (f <= state[0]) {
+      state[0] = f;
+      state[1] = (double)((float)state[1] * shrink);
+      state[2] = 1.0;
+      *skip = 1;
+    } else if (last) {
+      state[1] = (double)((float)state[1] * shrink * 0.5f);
+    }
+  }
+}
+
+extern "C" int tike_cgrad_line_search(int variable, const void* x, const void* d, void* xs,
+                                      const void* other, const float* scan, const void* data,
+                                      int data_u16, void* scratch, float* costs, int nscan,
+                                      int chunk, int S, int det, int H, int W, float fwd_scale,
+                                      double count, double* state, int* skip, int nslots,
+                                      void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 1 && chunk >= 1 && S >= 1 && H >= 1 && W >= 1 && nslots >= 1 &&
+               nslots <= 30 && count > 0 && (variable == 0 || variable == 1));
+  TK_CHECK_ARG(x && d && xs && other && scan && data && scratch && costs && state && skip);
+  if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
+  const long n = variable == 0 ? (long)H * W : (long)S * det * det;
+  hipError_t e = hipMemsetAsync(skip, 0, sizeof(int), stream);
+  if (e == hipSuccess) e = hipMemsetAsync(state + 2, 0, sizeof(double), stream);  // done = 0
+  if (e != hipSuccess) return (int)e;
+  const size_t dsz = data_u16 ? 2 : 4;
+  float shrink = 1.0f;
+  for (int k = 0; k < nslots; ++k, shrink *= 0.5f) {
+    hipLaunchKernelGGL(ls_trial_kernel, dim3(tk_grid((n + 255) / 256, 8)), dim3(256), 0, stream,
+                       (const cf*)x, (const cf*)d, (cf*)xs, n, state, shrink, skip);
+    const void* psi = variable == 0 ? xs : other;
+    const void* probe = variable == 0 ? other : xs;
+    for (int lo = 0; lo < nscan; lo += chunk) {
+      const int m = nscan - lo < chunk ? nscan - lo : chunk;
+      int rc = tk_fwd_pass1(psi, scan + 2L * lo, probe, 0, nullptr, nullptr, nullptr, 0, 0,
+                            scratch, nullptr, m, S, det, det, H, W, stream, skip);
+      if (rc) return rc;
+      rc = tk_fwd_gradient_scale(scratch, (const char*)data + dsz * (size_t)lo * det * det,
+                                 data_u16, nullptr, nullptr, nullptr, costs + lo, nullptr, m, S,
+                                 det, fwd_scale, 0, 1.0f, (long)det * det, stream, skip);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(ls_decide_kernel, dim3(1), dim3(256), 0, stream, costs, nscan,
+                       1.0 / count, shrink, k + 1 == nslots, state, skip);
+  }
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -15,6 +15,7 @@ signatures.  Execution model (MI355X-first, differs from the reference):
 """
 import copy
 import logging
+import threading
 import time
 import typing
 import warnings
@@ -247,7 +248,10 @@ class Reconstruction():
                 1e-9),
         )
         self.comm = Comm()
-        self._pending_fits = []  # deferred affine fits of the positions
+        self._pending_fits = []  # futures of deferred affine position fits
+        self._free_snaps = []  # pinned host buffers of finished fits
+        self._fit_pool = None
+        self._fit_lock = threading.Lock()
         self._initial_scan_host = None
 
     # ------------------------------------------------------------- set-up
@@ -374,28 +378,36 @@ class Reconstruction():
         not depend on the number of ranks.
 
         With `use_position_regularization` off the fit changes nothing on the
-        device (it only updates `position_options.transform`), so it does not
-        hold up the next epoch: the positions are copied to pinned host memory
-        asynchronously, the random subsets are drawn NOW (the generator is
-        consumed in the reference's order) and the fit itself runs once the
-        copy has landed -- at a later epoch's end or when results are asked
-        for."""
+        device (it only updates `position_options.transform`), and its ~5 ms of
+        host work per epoch would leave the GPU idle: the positions are copied
+        to pinned host memory asynchronously, the random subsets are drawn NOW
+        (the generator is consumed in the reference's order) and the fit runs
+        on a worker thread, in order, while the next epoch's kernels are being
+        enqueued; results are joined when they are asked for."""
         p = self.parameters
         po = p.position_options
         if po is None:
             return
         local_fit = not self.comm.collective or self._presharded
         if not po.use_position_regularization and local_fit:
-            snap = torch.empty(tuple(p.scan.shape), dtype=p.scan.dtype,
-                               pin_memory=True)
+            # (pinned allocations cost milliseconds: the buffers are reused)
+            with self._fit_lock:
+                snap = self._free_snaps.pop() if self._free_snaps else None
+            if snap is None:
+                snap = torch.empty(tuple(p.scan.shape), dtype=p.scan.dtype,
+                                   pin_memory=True)
             snap.copy_(p.scan, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
-            self._pending_fits.append(
-                (snap, done, ransac_subsets(p.scan.shape[0])))
-            self._resolve_fits(block=False)
+            if self._fit_pool is None:
+                import concurrent.futures
+                self._fit_pool = concurrent.futures.ThreadPoolExecutor(1)
+                self._initial_scan_host = A.to_host(po.initial_scan)
+            self._pending_fits.append(self._fit_pool.submit(
+                self._fit_job, po, snap, done,
+                ransac_subsets(p.scan.shape[0])))
             return
-        self._resolve_fits(block=True)
+        self._resolve_fits()
         pos0 = pos1 = None
         if not local_fit:
             pos0 = self._gather_positions(po.initial_scan)[self.order]
@@ -404,23 +416,22 @@ class Reconstruction():
             updated=p.scan, position_options=po,
             positions0=pos0, positions1=pos1)
 
-    def _resolve_fits(self, block=True):
-        """Carry out the deferred affine fits, oldest first (block=False: only
-        those whose positions have already reached the host)."""
-        po = self.parameters.position_options
+    def _fit_job(self, po, snap, done, subsets):
+        """One deferred affine fit (worker thread; jobs run one at a time, in
+        the order they were submitted)."""
+        done.synchronize()
+        origin = A.to_host(po.origin)
+        po.transform, _ = estimate_global_transformation_ransac(
+            positions0=self._initial_scan_host - origin,
+            positions1=snap.numpy() - origin, transform=po.transform,
+            max_error=32, subsets=subsets)
+        with self._fit_lock:
+            self._free_snaps.append(snap)
+
+    def _resolve_fits(self):
+        """Join the deferred affine fits."""
         while self._pending_fits:
-            snap, done, subsets = self._pending_fits[0]
-            if not block and not done.query():
-                return
-            done.synchronize()
-            if self._initial_scan_host is None:
-                self._initial_scan_host = A.to_host(po.initial_scan)
-            origin = A.to_host(po.origin)
-            po.transform, _ = estimate_global_transformation_ransac(
-                positions0=self._initial_scan_host - origin,
-                positions1=snap.numpy() - origin, transform=po.transform,
-                max_error=32, subsets=subsets)
-            self._pending_fits.pop(0)
+            self._pending_fits.pop(0).result()
 
     # ------------------------------------------------------------- results
     def _gather_positions(self, local):
@@ -450,7 +461,7 @@ class Reconstruction():
     def get_result(self):
         """Current parameter estimates on the host (ptycho.py:573-597)."""
         if self.parameters.position_options is not None:
-            self._resolve_fits(block=True)
+            self._resolve_fits()
         p = self.parameters.copy_to_host()
         p.scan = self._gather_positions(self.parameters.scan)
         p.eigen_weights = self._gather_positions(self.parameters.eigen_weights)
@@ -481,7 +492,10 @@ class Reconstruction():
     def __exit__(self, type, value, traceback):
         if (type is None and getattr(self, "parameters", None) is not None
                 and self.parameters.position_options is not None):
-            self._resolve_fits(block=True)
+            self._resolve_fits()
+        if self._fit_pool is not None:
+            self._fit_pool.shutdown(wait=True)
+            self._fit_pool = None
         self.comm.__exit__(type, value, traceback)
         self.operator.__exit__(type, value, traceback)
         self.data = None

@@ -183,6 +183,70 @@ def _finish_cost(total, comm, op, lo, hi):
     return float(total.item()) / global_count(comm, op, lo, hi)
 
 
+DEVICE_LINE_SEARCH = True
+"""Tests set this to False to run opt.conjugate_gradient with the host-side
+line search (one read-back per trial) everywhere."""
+
+LINE_SEARCH_SLOTS = (8, 4)
+"""Step lengths enqueued ahead per line search: first CG iteration of a call
+(it starts from `step_length`), later iterations (they start from the length
+accepted last)."""
+
+
+def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
+               count, data, scan, lo, hi):
+    """opt.conjugate_gradient (opt.py:312-380: Dai-Yuan directions,
+    backtracking line search) for the object (variable 0) or the probe
+    (variable 1) with every line search decided on the device
+    (tike_cgrad_line_search): the gradient pass, the direction and up to
+    LINE_SEARCH_SLOTS cost-only trials of an iteration are enqueued without a
+    host round trip; ONE read-back per call says whether every search found
+    its step inside its slots.  Returns (x, mean cost as a 0-d device tensor),
+    or None when a search ran out of slots -- the caller then repeats the call
+    with the host-side search, which has no such limit."""
+    dev = psi.device
+    x = psi if variable == 0 else probe
+    other = probe if variable == 0 else psi
+    S, pw, det, H, W = plan.dims
+    N = hi - lo
+    state = torch.zeros((num_iter, 4), dtype=torch.float64, device=dev)
+    skip = torch.zeros(1, dtype=torch.int32, device=dev)
+    bufs = [torch.empty_like(x), torch.empty_like(x)]
+    scan_ptr = scan[lo:hi].data_ptr()
+    data_ptr = data[lo:hi].data_ptr()
+    st_ptr = A.stream_ptr()
+    grad0 = dir_ = None
+    for i in range(num_iter):
+        a, b = (x, other) if variable == 0 else (other, x)  # psi, probe
+        costs, acc, mpu = plan.gradients(op, comm, a, b, variable == 0,
+                                         variable == 1)
+        g = -torch.complex(acc[0], acc[1])[None] if variable == 0 else -mpu
+        grad1 = [g]
+        dir_ = (opt.direction_dy(torch, grad1) if i == 0 else
+                opt.direction_dy(torch, grad1, grad0, dir_))
+        grad0 = grad1
+        d = dir_[0].contiguous()
+        if i == 0:
+            # the cost at x comes out of the gradient pass (opt.py:246)
+            state[0, 0] = costs.sum(dtype=torch.float64) / count
+            state[0, 1] = float(step_length)
+        else:
+            state[i, :2] = state[i - 1, :2]
+        xs = bufs[i % 2]
+        check(
+            lib.tike_cgrad_line_search(
+                variable, A.ptr(x), A.ptr(d), A.ptr(xs), A.ptr(other),
+                scan_ptr, data_ptr, plan.u16, A.ptr(plan.far),
+                A.ptr(plan.costs), N, plan.far.shape[0], S, det, H, W,
+                plan.fwd_scale, count, state[i].data_ptr(), A.ptr(skip),
+                LINE_SEARCH_SLOTS[0 if i == 0 else 1], st_ptr),
+            "cgrad line search")
+        x = xs
+    if not bool((state[:, 2] == 1).all().item()):
+        return None
+    return x, state[-1, 0]
+
+
 class _Evaluator:
     """cost / gradient callbacks of one conjugate-gradient call.  The gradient
     pass forms the cost of its argument as well: it is kept ON THE DEVICE and
@@ -225,7 +289,20 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
         finish = lambda total: _finish_cost(total, comm, op, lo, hi)
         plan = _CostPlan(op, d, s, lo, hi, probe.shape[-3], probe.shape[-1],
                          psi.shape[-2], psi.shape[-1], psi.device)
-        if recover_psi:
+        # line searches decided on the device: one rank, HBM-resident data,
+        # the far-plane-free sizes
+        on_device = (DEVICE_LINE_SEARCH and not comm.collective and hi > lo
+                     and isinstance(d, torch.Tensor)
+                     and plan.supports_gradients())
+        count = global_count(comm, op, lo, hi)
+        done_psi = done_probe = False
+        if recover_psi and on_device:
+            r = _cg_device(plan, op, comm, psi, probe, 0, o.cg_iter,
+                           o.step_length, count, d, s, lo, hi)
+            if r is not None:
+                psi, cost = r
+                done_psi = True
+        if recover_psi and not done_psi:
             def run(x, want_grad):
                 r = _cost_and_grad(op, comm, d, x, s, probe, lo, hi,
                                    want_psi=True, want_probe=False,
@@ -237,7 +314,13 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
                 torch, x=psi, cost_function=ev.cost, grad=ev.grad,
                 dir_multi=lambda x: x[0], num_iter=o.cg_iter,
                 step_length=o.step_length)
-        if recover_probe:
+        if recover_probe and on_device:
+            r = _cg_device(plan, op, comm, psi, probe, 1, o.cg_iter,
+                           o.step_length, count, d, s, lo, hi)
+            if r is not None:
+                probe, cost = r
+                done_probe = True
+        if recover_probe and not done_probe:
             def run(x, want_grad):
                 r = _cost_and_grad(op, comm, d, psi, s, x, lo, hi,
                                    want_psi=False, want_probe=True,
@@ -253,6 +336,13 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
             cost = _cost_and_grad(op, comm, d, psi, s, probe, lo, hi, want_psi=False,
                                   want_probe=False, want_grad=False)[0]
         batch_cost.append(cost)
+    if any(isinstance(c, torch.Tensor) for c in batch_cost):
+        # device-side searches leave the cost on the device: one read-back
+        batch_cost = torch.stack([
+            c.to(torch.float64) if isinstance(c, torch.Tensor) else
+            torch.tensor(float(c), dtype=torch.float64, device=psi.device)
+            for c in batch_cost
+        ]).cpu().numpy()
     o.costs.append([float(np.mean(batch_cost))])
     parameters.psi, parameters.probe = psi, probe
     return parameters
