@@ -454,10 +454,11 @@ int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, doub
  * every pixel measured.
  *   variable  0: x, d, xs are the object (H,W); other = probe (S,det,det)
  *             1: x, d, xs are the probe (S,det,det); other = object (H,W)
- *   state     device double[4] = { fx, step, done, trials }: on entry the mean
- *             cost at x and the first step length; on return, accepted: the
- *             mean cost and step length accepted, done = 1 (xs = the new
- *             iterate); not accepted: done = 0, step = the next length to try
+ *   state     device double[5] = { fx, step, done, trials, failures }: on entry
+ *             the mean cost at x and the first step length; on return,
+ *             accepted: the mean cost and step length accepted, done = 1 (xs =
+ *             the new iterate); not accepted: done = 0, step = the next length
+ *             to try, failures += 1; trials counts the cost evaluations made
  *   count     positions over all ranks (the mean's denominator x det^2 is the
  *             kernels'); skip: one device int of scratch; costs (nscan) f32 and
  *             scratch (chunk,S,det,det) c64 workspaces. */

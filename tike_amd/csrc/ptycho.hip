@@ -956,10 +956,11 @@ extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, in
 // enqueued for `nslots` step lengths AHEAD of the decisions, and a trial whose
 // predecessor was accepted returns at once (the `skip` word the kernels read):
 // no host round trip per trial.
-// state (device, double[4]): { fx = mean cost at x, step, done, trials }.
+// state (device, double[5]): { fx = mean cost at x, step, done, trials, failures }.
 //   in : fx, step (first step length to try)
 //   out: accepted -> fx = mean cost there, step = that step length, done = 1
-//        otherwise  step = the next step length to try (step / 2^nslots), done = 0
+//        otherwise  step = the next step length to try (step / 2^nslots), done = 0,
+//        failures += 1 (a caller that chains searches reads it once at the end)
 // xs receives x + step d of the LAST trial made (accepted: the new iterate).
 __global__ __launch_bounds__(256) void ls_trial_kernel(const cf* __restrict__ x,
                                                        const cf* __restrict__ d,
@@ -1000,6 +1001,7 @@ __global__ __launch_bounds__(256) void ls_decide_kernel(const float* __restrict_
       *skip = 1;
     } else if (last) {
       state[1] = (double)((float)state[1] * shrink * 0.5f);
+      state[4] += 1.0;
     }
   }
 }

@@ -201,15 +201,18 @@ def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
     (tike_cgrad_line_search): the gradient pass, the direction and up to
     LINE_SEARCH_SLOTS cost-only trials of an iteration are enqueued without a
     host round trip; ONE read-back per call says whether every search found
-    its step inside its slots.  Returns (x, mean cost as a 0-d device tensor),
-    or None when a search ran out of slots -- the caller then repeats the call
+    its step inside its slots.  Returns (x, mean cost), or None when a search ran out of slots -- the caller then repeats the call
     with the host-side search, which has no such limit."""
     dev = psi.device
     x = psi if variable == 0 else probe
     other = probe if variable == 0 else psi
     S, pw, det, H, W = plan.dims
     N = hi - lo
-    state = torch.zeros((num_iter, 4), dtype=torch.float64, device=dev)
+    # { fx, step, done, trials, failures }: carried from search to search on
+    # the device (the step accepted last is the first one tried next,
+    # opt.py:366-371); one upload, one read-back per call
+    state = torch.from_numpy(
+        np.array([0.0, float(step_length), 0.0, 0.0, 0.0])).to(dev)
     skip = torch.zeros(1, dtype=torch.int32, device=dev)
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     scan_ptr = scan[lo:hi].data_ptr()
@@ -228,23 +231,21 @@ def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
         d = dir_[0].contiguous()
         if i == 0:
             # the cost at x comes out of the gradient pass (opt.py:246)
-            state[0, 0] = costs.sum(dtype=torch.float64) / count
-            state[0, 1] = float(step_length)
-        else:
-            state[i, :2] = state[i - 1, :2]
+            state[0] = costs.sum(dtype=torch.float64) / count
         xs = bufs[i % 2]
         check(
             lib.tike_cgrad_line_search(
                 variable, A.ptr(x), A.ptr(d), A.ptr(xs), A.ptr(other),
                 scan_ptr, data_ptr, plan.u16, A.ptr(plan.far),
                 A.ptr(plan.costs), N, plan.far.shape[0], S, det, H, W,
-                plan.fwd_scale, count, state[i].data_ptr(), A.ptr(skip),
+                plan.fwd_scale, count, A.ptr(state), A.ptr(skip),
                 LINE_SEARCH_SLOTS[0 if i == 0 else 1], st_ptr),
             "cgrad line search")
         x = xs
-    if not bool((state[:, 2] == 1).all().item()):
+    final = state.cpu()
+    if float(final[4]) != 0:  # a search ran out of slots
         return None
-    return x, state[-1, 0]
+    return x, float(final[0])
 
 
 class _Evaluator:

@@ -18,7 +18,7 @@ def main():
     S = [int(r["Start_Timestamp"]) for r in rows]
     E = [int(r["End_Timestamp"]) for r in rows]
     idx = [i for i, n in enumerate(names) if marker in n]
-    per_epoch = 10
+    per_epoch = int(sys.argv[4]) if len(sys.argv) > 4 else 10
     a, b = idx[-per_epoch * epochs - 1], idx[-1]
     busy = sum(E[i] - S[i] for i in range(a, b))
     span = S[b] - S[a]
