@@ -490,6 +490,11 @@ int tike_cgrad_line_search(int variable, const void* x, const void* d, void* xs,
  *   minibatch's weights_c^2); eigen0 (pw,pw) c64: that eigen probe.  With sums3 not
  *   NULL one extra workgroup also leaves sums3[0..2] = tike_lstsq_step_sums(stats,
  *   costs, nscan, eps): the two share one all-reduce.
+ *   Both eigen entries take psi (H,W) c64 and scan (nscan,2), or NULL: given, the
+ *   object patches O_n of interior positions are recomputed from psi (the taps and
+ *   arithmetic of tike_fwd_pass1 -- psi must still be the array the stored patches
+ *   were gathered from) instead of being streamed from `patches`: half the HBM
+ *   bytes of the pass.
  * tike_lstsq_tail_mid: the 2x2 solves of the B local positions with sums3 and
  *   count over all ranks: tail3[0..1] = { sum 0.9 max(0, Re x1), sum 0.9 max(0, Re
  *   x2) }; and, eigen0 not NULL, nacc[0..2] += { sum |update|^2, sum |eigen0|^2,
@@ -509,14 +514,16 @@ int tike_eigen_pixel_update1(const void* patches, const void* chi0, const void* 
                              const void* eigen0, const float* eigen_proj,
                              const float* weights_c, long weights_row, const float* norm,
                              void* update, int nscan, int pw, int chi_modes, const float* stats,
-                             const float* costs, float eps, float* sums3, void* stream);
+                             const float* costs, float eps, float* sums3, const void* psi,
+                             const float* scan, int H, int W, void* stream);
 int tike_lstsq_tail_mid(void* eigen0, const void* update, int npix, float* nacc,
                         float beta_eigen, const float* stats, int B, float eps,
                         const float* sums3, double count, int recover_psi, int recover_probe,
                         float* tail3, void* stream);
 int tike_eigen_position_sums1(const void* patches, const void* chi0, const void* mpu0,
                               const void* eigen0, float* sums5, float* dsum, int nscan, int pw,
-                              int chi_modes, void* stream);
+                              int chi_modes, const void* psi, const float* scan, int H, int W,
+                              void* stream);
 int tike_lstsq_tail_finish(const float* tail3, const float* sums3, double count, float* steps,
                            void* probe, void* combined, const void* mpu, float inv_num_batch,
                            long nprobe, float* weights, long weights_row, int S, int m,

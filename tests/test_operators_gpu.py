@@ -721,8 +721,9 @@ def test_abi_edge_cases():
     assert lib.tike_lstsq_step_stats(z, z, z, z, z, z, z, 0, 0, z, z, z, z, 0,
                                      1, 1, 64, 100, 100, z, z, st) == 0
     assert lib.tike_eigen_pixel_update1(z, z, z, z, z, z, 2, z, z, 0, 64, 1,
-                                        z, z, 0.0, z, st) == 0
-    assert lib.tike_eigen_position_sums1(z, z, z, z, z, z, 0, 64, 1, st) == 0
+                                        z, z, 0.0, z, z, z, 100, 100, st) == 0
+    assert lib.tike_eigen_position_sums1(z, z, z, z, z, z, 0, 64, 1, z, z, 100,
+                                         100, st) == 0
     # specialised entries refuse sizes they do not implement
     x = torch.zeros(4 * 128 * 128, dtype=torch.complex64, device="cuda")
     f = torch.zeros(128 * 128, dtype=torch.float32, device="cuda")

@@ -106,10 +106,11 @@ _PROTOTYPES = {
     "tike_lstsq_step_stats": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p,
                               _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "tike_eigen_pixel_update1": [_p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _i, _i,
-                                 _p, _p, _f, _p, _p],
+                                 _p, _p, _f, _p, _p, _p, _i, _i, _p],
     "tike_lstsq_tail_mid": [_p, _p, _i, _p, _f, _p, _i, _f, _p, _d, _i, _i, _p,
                             _p],
-    "tike_eigen_position_sums1": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "tike_eigen_position_sums1": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p,
+                                  _i, _i, _p],
     "tike_lstsq_tail_finish": [_p, _p, _d, _p, _p, _p, _p, _f, _l, _p, _l, _i,
                                _i, _p, _p, _i, _i, _p],
     "tike_lstsq_chunk_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i,

@@ -1124,6 +1124,30 @@ __global__ __launch_bounds__(256) void eigen_pixel_update_kernel(const TkResidua
   unsafeAtomicAdd(&update[2 * p + 1], acc.y);
 }
 
+// O_n = patch_n(psi) at one pixel of an INTERIOR position, recomputed from the
+// object (L2-resident: neighbouring positions share most of their footprint)
+// exactly as forward pass 1 formed the stored patch -- same taps, same order
+// of operations -- instead of streaming the stored patch from HBM.
+// off: byte offset of the pixel's upper-left tap inside psi.
+__device__ __forceinline__ cf tk_patch_pixel(const cf* __restrict__ psi, unsigned off,
+                                             unsigned row_bytes, const TkCorner& c) {
+  typedef float tk_v4f __attribute__((ext_vector_type(4)));
+  tk_v4f u, l;
+  __builtin_memcpy(&u, reinterpret_cast<const char*>(psi) + off, sizeof(u));
+  __builtin_memcpy(&l, reinterpret_cast<const char*>(psi) + off + row_bytes, sizeof(l));
+  cf o = mk(u.x * c.w00, u.y * c.w00);
+  o.x += u.z * c.w01;
+  o.y += u.w * c.w01;
+  o.x += l.x * c.w10;
+  o.y += l.y * c.w10;
+  o.x += l.z * c.w11;
+  o.y += l.w * c.w11;
+  return o;
+}
+__device__ __forceinline__ bool tk_interior(const TkCorner& c, int pw, int H, int W) {
+  return c.sy >= 0 && c.sx >= 0 && c.sy + pw < H && c.sx + pw < W && (long)H * W < (1L << 28);
+}
+
 // The packed tail (one eigen probe per mode, c = 0): the per-position factor
 // pm[n] = (eproj[n] / P + w[n]) / norm (probe.py:429-433) is formed on the fly
 // from the projection the step statistics left and the batch norm.
@@ -1135,7 +1159,8 @@ __global__ __launch_bounds__(256) void eigen_pixel_update1_kernel(
     const TkResidual R, const float* __restrict__ eproj, const float* __restrict__ weights_c,
     long row, const float* __restrict__ norm, float inv_P, float* __restrict__ update, int nscan,
     int chunk, const float* __restrict__ stats, const float* __restrict__ costs, float eps,
-    float* __restrict__ sums3) {
+    float* __restrict__ sums3, const cf* __restrict__ psi, const float* __restrict__ scan, int pw,
+    int H, int W) {
   if (blockIdx.x + 1 == gridDim.x) {
     if (blockIdx.y != 0 || sums3 == nullptr) return;
     __shared__ float red[4];
@@ -1161,12 +1186,36 @@ __global__ __launch_bounds__(256) void eigen_pixel_update1_kernel(
   const int b1 = min(nscan, b0 + chunk);
   const float inv_norm = 1.0f / norm[0];
   cf acc = mk(0.f, 0.f);
+  // O_n recomputed from the object when every position of the chunk is
+  // interior (decided once: no load sits behind a per-position branch)
+  bool gather = psi != nullptr;
+  if (gather) {
+    for (int n = b0; n < b1; ++n) gather = gather && tk_interior(tk_corner(scan, n), pw, H, W);
+  }
+  if (gather) {
+    const int py = (int)(p / pw), px = (int)(p % pw);
+    const unsigned row_bytes = (unsigned)W * (unsigned)sizeof(cf);
+    const unsigned lane_off = (unsigned)py * row_bytes + (unsigned)px * (unsigned)sizeof(cf);
+    const cf m0 = R.mpu0[p];
 #pragma unroll 4
-  for (int n = b0; n < b1; ++n) {
-    const cf r = R.at<true>(n, p);
-    const float w = (eproj[n] * inv_P + weights_c[n * row]) * inv_norm;
-    acc.x += r.x * w;
-    acc.y += r.y * w;
+    for (int n = b0; n < b1; ++n) {
+      const TkCorner c = tk_corner(scan, n);  // uniform
+      const cf x = R.chi0[n * R.XS + p];
+      const cf o = tk_patch_pixel(
+          psi, (unsigned)(c.sy * W + c.sx) * (unsigned)sizeof(cf) + lane_off, row_bytes, c);
+      const cf r = conjf(o) * x - m0;
+      const float w = (eproj[n] * inv_P + weights_c[n * row]) * inv_norm;
+      acc.x += r.x * w;
+      acc.y += r.y * w;
+    }
+  } else {
+#pragma unroll 4
+    for (int n = b0; n < b1; ++n) {
+      const cf r = R.at<true>(n, p);
+      const float w = (eproj[n] * inv_P + weights_c[n * row]) * inv_norm;
+      acc.x += r.x * w;
+      acc.y += r.y * w;
+    }
   }
   unsafeAtomicAdd(&update[2 * p], acc.x);
   unsafeAtomicAdd(&update[2 * p + 1], acc.y);
@@ -1174,26 +1223,53 @@ __global__ __launch_bounds__(256) void eigen_pixel_update1_kernel(
 
 // Position sums against the (already updated) first eigen probe, plus
 // dsum[0] += sum_n sums[n][2] / P (the denominator mean, probe.py:463-469).
-__global__ __launch_bounds__(256) void eigen_position_sums1_kernel(const TkResidual R,
-                                                                   float* __restrict__ sums,
-                                                                   float* __restrict__ dsum,
-                                                                   int nscan) {
+__global__ __launch_bounds__(256) void eigen_position_sums1_kernel(
+    const TkResidual R, float* __restrict__ sums, float* __restrict__ dsum, int nscan,
+    const cf* __restrict__ psi, const float* __restrict__ scan, int pw, int H, int W) {
   __shared__ float red[4];
   const cf* __restrict__ E = R.eigen;
+  const unsigned row_bytes = (unsigned)W * (unsigned)sizeof(cf);
+  const int qstep = (int)blockDim.x / pw, rstep = (int)blockDim.x % pw;
   for (int n = blockIdx.x; n < nscan; n += gridDim.x) {
     float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long p = threadIdx.x; p < R.P; p += blockDim.x) {
-      const cf e = E[p];
-      const cf r = R.at<true>(n, p);
-      const cf phi = R.patches[n * R.P + p] * e;
-      const cf x = R.chi0[n * R.XS + p];
-      a[0] += r.x * e.x + r.y * e.y;
-      a[1] += x.x * phi.x + x.y * phi.y;
-      a[2] += norm2(phi);
-      const cf re = r * conjf(e);
-      a[3] += re.x;
-      a[4] += re.y;
-    }
+    TkCorner c = {0, 0, 0.f, 0.f, 0.f, 0.f};
+    if (psi != nullptr) c = tk_corner(scan, n);  // uniform
+    const bool gather = psi != nullptr && tk_interior(c, pw, H, W);
+    const unsigned off0 = gather ? (unsigned)(c.sy * W + c.sx) * (unsigned)sizeof(cf) : 0u;
+    // (the choice is settled outside the pixel loop: a load behind a run-time
+    // condition would wait for the loads in front of the branch)
+    auto body = [&](auto g_tag) {
+      constexpr bool G = decltype(g_tag)::value;
+      int py = (int)threadIdx.x / pw, px = (int)threadIdx.x % pw;
+      for (long p = threadIdx.x; p < R.P; p += blockDim.x) {
+        const cf e = E[p];
+        const cf x = R.chi0[n * R.XS + p];
+        const cf m0 = R.mpu0[p];
+        cf o;
+        if constexpr (G)
+          o = tk_patch_pixel(psi, off0 + (unsigned)py * row_bytes + (unsigned)px * 8u, row_bytes, c);
+        else
+          o = R.patches[n * R.P + p];
+        const cf r = conjf(o) * x - m0;
+        const cf phi = o * e;
+        py += qstep;
+        px += rstep;
+        if (px >= pw) {
+          px -= pw;
+          ++py;
+        }
+        a[0] += r.x * e.x + r.y * e.y;
+        a[1] += x.x * phi.x + x.y * phi.y;
+        a[2] += norm2(phi);
+        const cf re = r * conjf(e);
+        a[3] += re.x;
+        a[4] += re.y;
+      }
+    };
+    if (gather)
+      body(std::true_type{});
+    else
+      body(std::false_type{});
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
       const float v = tk_block_sum256(a[k], red);
@@ -1274,10 +1350,12 @@ extern "C" int tike_eigen_pixel_update1(const void* patches, const void* chi0,
                                         long weights_row, const float* norm, void* update,
                                         int nscan, int pw, int chi_modes, const float* stats,
                                         const float* costs, float eps, float* sums3,
+                                        const void* psi, const float* scan, int H, int W,
                                         void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && chi_modes >= 1 && weights_row >= 1);
   TK_CHECK_ARG(!sums3 || (stats && costs));
+  TK_CHECK_ARG(!psi || (scan && H >= 1 && W >= 1));
   if (nscan == 0) {
     if (sums3) return (int)hipMemsetAsync(sums3, 0, 3 * sizeof(float), (hipStream_t)stream);
     return TK_OK;
@@ -1289,7 +1367,7 @@ extern "C" int tike_eigen_pixel_update1(const void* patches, const void* chi0,
   const TkResidual R = make_residual(patches, chi0, mpu0, eigen0, nullptr, 1, 1, 0, pw, chi_modes);
   hipLaunchKernelGGL(eigen_pixel_update1_kernel, grid, dim3(256), 0, (hipStream_t)stream, R,
                      eigen_proj, weights_c, weights_row, norm, 1.0f / (float)P, (float*)update,
-                     nscan, chunk, stats, costs, eps, sums3);
+                     nscan, chunk, stats, costs, eps, sums3, (const cf*)psi, scan, pw, H, W);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -1297,14 +1375,16 @@ extern "C" int tike_eigen_pixel_update1(const void* patches, const void* chi0,
 extern "C" int tike_eigen_position_sums1(const void* patches, const void* chi0,
                                          const void* mpu0, const void* eigen0, float* sums,
                                          float* dsum, int nscan, int pw, int chi_modes,
+                                         const void* psi, const float* scan, int H, int W,
                                          void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && chi_modes >= 1);
+  TK_CHECK_ARG(!psi || (scan && H >= 1 && W >= 1));
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen0 && sums && dsum);
   const TkResidual R = make_residual(patches, chi0, mpu0, eigen0, nullptr, 1, 1, 0, pw, chi_modes);
   hipLaunchKernelGGL(eigen_position_sums1_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
-                     (hipStream_t)stream, R, sums, dsum, nscan);
+                     (hipStream_t)stream, R, sums, dsum, nscan, (const cf*)psi, scan, pw, H, W);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
