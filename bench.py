@@ -36,6 +36,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: vector FP32 peak
+READ_CEILING_GBS = 6450.0  # tools/probe/bw_probe.hip: best pure read stream
 
 
 def parse():
@@ -335,6 +336,8 @@ def measured_traffic(workload, launch_n):
             continue
         per = {k: v.get("hbm_bytes_per_launch")
                for k, v in doc.get("kernels", {}).items()}
+        per.update({k: v.get("hbm_bytes_per_launch")
+                    for k, v in doc.get("composite", {}).items()})
         return per, doc.get("hbm_bytes_per_step"), os.path.basename(f)
     return {}, None, None
 
@@ -606,6 +609,16 @@ def main():
                       "step after the warm-up, every launch bracketed"
             if profile is not None else "timed steps: every launch bracketed",
         }
+        if roofline["frac"] > READ_CEILING_GBS / HBM_PEAK_GBS and (
+                roofline["traffic"] is None):
+            # a rate above what a pure read stream reaches on this chip can only
+            # come from cache hits inside the launch: not stated without the
+            # counters that show them
+            roofline["frac_withheld"] = (
+                f"algorithmic bytes / time = {achieved:.0f} GB/s exceeds the "
+                f"measured read-stream ceiling ({READ_CEILING_GBS:.0f} GB/s) and "
+                "no PMC traffic figure is committed for this kernel")
+            roofline["achieved"] = roofline["frac"] = None
         if not a.workload.startswith("fwd"):
             # the whole iteration against SURVEY 8(d)'s compulsory bytes and
             # flops (report both fractions)

@@ -24,6 +24,13 @@ KERNELS = {
     "void fwd_colpass_inplace_kernel": "tike_ptycho_fwd",
     "void fwd_gradient_scale_kernel": "tike_fwd_gradient_scale",
     "void fwd_grad_ifft2_pass1_kernel": "tike_fwd_grad_ifft2_pass1",
+    "void fwd_grad_ifft2_pass1_single_kernel": "tike_fwd_grad_ifft2_pass1",
+    "void fwd128_lds_kernel": "tike_ptycho_fwd",
+    "void farplane_gradient_kernel": "tike_farplane_gradient",
+    "eigen_pixel_update1_kernel": "tike_eigen_pixel_update1",
+    "eigen_position_sums1_kernel": "tike_eigen_position_sums1",
+    "ls_trial_kernel": "tike_cgrad_line_search:trial",
+    "ls_decide_kernel": "tike_cgrad_line_search:decide",
     "void fwd_grad_ifft2_pass1_resident_kernel": "tike_fwd_grad_ifft2_pass1",
     "void grad_ifft2_pass1_512_kernel": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 1, false>": "tike_grad_ifft2_pass1",
@@ -54,21 +61,34 @@ SOLVER_ONLY = ("psi_precond_kernel", "void fwd_gradient_scale_kernel",
                "void fwd_grad_ifft2_pass1_kernel",
                "void fwd_grad_ifft2_pass1_resident_kernel",
                "void step_stats_kernel", "void probe_grad_kernel",
-               "void gradient_scale_kernel", "void farplane_gradient_kernel")
+               "void gradient_scale_kernel", "void farplane_gradient_kernel",
+               "void fwd_grad_ifft2_pass1_single_kernel", "ls_trial_kernel")
 
 
-def collect(d, counter):
+def collect(d, counter, cgrad=False):
     rows = collections.defaultdict(list)  # entry -> [(grid, value)]
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         table = list(csv.DictReader(open(f)))
         starts = [int(r["Dispatch_Id"]) for r in table
                   if r["Kernel_Name"].startswith(SOLVER_ONLY)]
         first = min(starts) if starts else 0
+        # cgrad: the forward kernels run both in the gradient pass (followed by
+        # the gradient kernels) and in cost-only line-search trials (followed by
+        # the cost kernel and the decision): told apart by what comes next
+        order = sorted({(int(r["Dispatch_Id"]), r["Kernel_Name"])
+                        for r in table if "fillBuffer" not in r["Kernel_Name"]})
+        nxt = {order[i][0]: order[i + 1][1] for i in range(len(order) - 1)}
         for r in table:
             if r["Counter_Name"] != counter or int(r["Dispatch_Id"]) < first:
                 continue
             for prefix, entry in KERNELS.items():
                 if r["Kernel_Name"].startswith(prefix):  # first match wins
+                    if cgrad and entry == "tike_fwd_pass1" and nxt.get(
+                            int(r["Dispatch_Id"]), "").startswith(
+                                "void fwd_gradient_scale_kernel"):
+                        entry += ":cost_only"
+                    if cgrad and entry == "tike_fwd_gradient_scale":
+                        entry += ":cost_only"
                     rows[entry].append((int(r["Grid_Size"]),
                                         float(r["Counter_Value"])))
                     break
@@ -82,8 +102,9 @@ def collect(d, counter):
 
 def main():
     fetch_dir, write_dir, workload, n, out = sys.argv[1:6]
-    fetch = collect(fetch_dir, "FETCH_SIZE")
-    write = collect(write_dir, "WRITE_SIZE")
+    cgrad = workload in ("c1", "c2")
+    fetch = collect(fetch_dir, "FETCH_SIZE", cgrad)
+    write = collect(write_dir, "WRITE_SIZE", cgrad)
     doc = {
         "workload": workload,
         "positions_per_launch": int(n),
@@ -111,6 +132,15 @@ def main():
     setup = {"c3": ("tike_ptycho_fwd_intensity",),
              "c2": ("tike_ptycho_fwd_intensity",),
              "c5": ("tike_ptycho_fwd_intensity",)}.get(workload, ())
+    if workload == "c2":
+        # the gradient of a chunk is ONE C-ABI call made of four launches
+        parts = ("tike_fwd_pass1", "tike_fwd_grad_ifft2_pass1",
+                 "tike_ifft2_pass2_gradients", "tike_scatter_patches")
+        if all(k in doc["kernels"] for k in parts):
+            doc["composite"] = {"tike_lstsq_chunk_gradients": {
+                "parts": list(parts),
+                "hbm_bytes_per_launch": sum(
+                    doc["kernels"][k]["hbm_bytes_per_launch"] for k in parts)}}
     doc["setup_kernels_excluded_from_step"] = list(setup)
     doc["hbm_bytes_per_step"] = sum(
         k["hbm_bytes_per_launch"] * k["launches"]
