@@ -88,7 +88,11 @@ class ProbeOptions:
         return self._copy(_to_dev)
 
     def copy_to_host(self) -> "ProbeOptions":
-        return self._copy(lambda x: None if x is None else A.to_host(x))
+        o = self._copy(lambda x: None if x is None else A.to_host(x))
+        # the per-epoch mode powers are appended as device tensors (no host
+        # round trip per epoch); they become host arrays here
+        o.power = [A.to_host(p) if A.is_device(p) else p for p in self.power]
+        return o
 
 
 def get_varying_probe(shared_probe, eigen_probe=None, weights=None):

@@ -533,7 +533,7 @@ def _apply_probe_constraints(parameters, *, epoch):
             parameters.probe = parameters.probe.contiguous()
         else:
             pwr = probe_power(parameters.probe)
-        po.power.append(A.to_host(pwr))
+        po.power.append(pwr)  # device tensor; host array in copy_to_host()
     o = parameters.algorithm_options
     if (o.rescale_method == "constant_probe_photons"
             and len(o.costs) % o.rescale_period == 0):
