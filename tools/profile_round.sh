@@ -35,4 +35,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $o/${tag}_pmc_$c -- python3 bench.py --no-cpu-baseline --no-secondary --steps 1 --warmup 0 > /dev/null 2>&1
 done
 python3 tools/pmc_traffic.py $o/${tag}_pmc_FETCH_SIZE $o/${tag}_pmc_WRITE_SIZE c3 1000 $o/profiles_$tag/${tag}_pmc_traffic_c3.json
+# 4. the other workloads' traffic (so that every bench line's roofline has counters behind it)
+bash tools/pmc_workload.sh c2 1000 $tag > /dev/null 2>&1
+bash tools/pmc_workload.sh c1 256 $tag > /dev/null 2>&1
+bash tools/pmc_workload.sh c5 400 $tag > /dev/null 2>&1
+# 5. dynamic instruction mix of the c3 kernels (two SQ_INSTS_* passes)
+bash tools/inst_mix_pmc.sh $tag > /dev/null 2>&1
+cp $o/${tag}_inst_mix.md $o/profiles_$tag/${tag}_inst_mix_dynamic.md
+# 6. SQ stall counters of the 128^2 forward kernel (north_star's 60 % target)
+bash tools/pmc_cmd.sh fwd128_lds_kernel python3 bench.py --workload fwd128x1 --no-cpu-baseline --steps 5 --warmup 1 > $o/profiles_$tag/${tag}_pmc_sq_fwd128.txt 2>&1
+# 7. the re-benched default line last (the box is warm)
+python3 bench.py > $o/profiles_$tag/${tag}_bench_c3.json 2> $o/${tag}_bench_c3.err
 cat $o/profiles_$tag/${tag}_bench_c3.json
