@@ -221,6 +221,19 @@ def test_affine_transform_roundtrip_and_fit():
     ofit, _ = opos.estimate_global_transformation_ransac(
         p0, p1, opos.IDENTITY, np.random.default_rng(5))
     np.testing.assert_allclose(rfit.astuple(), ofit, atol=1e-6)
+    # a fit carried out later with subsets drawn earlier (the deferred fit of
+    # Reconstruction._apply_position_constraints) consumes the generator exactly
+    # as the immediate fit does, and gives the same transformation
+    trandom.randomizer_np = np.random.default_rng(5)
+    subsets = pos.ransac_subsets(len(p0))
+    state_after = trandom.randomizer_np.bit_generator.state
+    later, _ = pos.estimate_global_transformation_ransac(p0, p1,
+                                                         subsets=subsets)
+    assert trandom.randomizer_np.bit_generator.state == state_after
+    np.testing.assert_allclose(later.astuple(), rfit.astuple(), atol=0)
+    trandom.randomizer_np = np.random.default_rng(5)
+    pos.estimate_global_transformation_ransac(p0, p1)
+    assert trandom.randomizer_np.bit_generator.state == state_after
 
 
 def test_position_options_split_join():

@@ -65,8 +65,12 @@ SPLIT_FORWARD_SIZES = (256, 512)
 (tike_ptycho_fwd_intensity) and the gradient-scaled inverse."""
 
 
-CHUNK_POSITIONS_OVERRIDE = None
-"""Tests set this to force small kernel chunks (several per minibatch)."""
+import os as _os
+
+CHUNK_POSITIONS_OVERRIDE = (int(_os.environ["TIKE_CHUNK_POSITIONS"])
+                            if _os.environ.get("TIKE_CHUNK_POSITIONS") else None)
+"""Tests set this to force small kernel chunks (several per minibatch);
+TIKE_CHUNK_POSITIONS does the same for A/B runs of the bench."""
 
 
 def fused_gradients(S, pw, det):
