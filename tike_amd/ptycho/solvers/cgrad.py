@@ -201,8 +201,9 @@ def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
     (tike_cgrad_line_search): the gradient pass, the direction and up to
     LINE_SEARCH_SLOTS cost-only trials of an iteration are enqueued without a
     host round trip; ONE read-back per call says whether every search found
-    its step inside its slots.  Returns (x, mean cost), or None when a search ran out of slots -- the caller then repeats the call
-    with the host-side search, which has no such limit."""
+    its step inside its slots.  Returns (x, mean cost), or None when a search
+    ran out of slots -- the caller then repeats the call with the host-side
+    search, which has no such limit."""
     dev = psi.device
     x = psi if variable == 0 else probe
     other = probe if variable == 0 else psi

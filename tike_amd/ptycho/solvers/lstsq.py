@@ -748,6 +748,9 @@ def _packed_tail(g, psi, scan, probe, eigen_probe, eigen_weights,
     mpu = g["m_probe_update"]
     one = (eig and C == 1 and Sm >= 1 and g["patches"] is not None
            and mpu is not None and norm is not None)
+    # (an eigen probe that this tail cannot update must never be skipped
+    # silently: lstsq_grad sends such configurations to the staged entries)
+    assert one or C == 0, "packed tail: eigen probe without its operands"
     # one zeroed buffer: [sums3 (3), -, update (2 P) | nacc (3), - | tail3 (3), -]
     small = ws.get("tail_small", (4 + 2 * P + 8,), torch.float32, dev)
     small.zero_()
