@@ -450,8 +450,9 @@ int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, doub
  * trial is a cost-only forward pass (tike_fwd_pass1 + tike_fwd_gradient_scale
  * over the minibatch in chunks of `chunk` positions), all enqueued at once: a
  * trial whose predecessor was accepted returns immediately, so the host reads
- * nothing back between trials.  det in {256, 512}, probe window = detector,
- * every pixel measured.
+ * nothing back between trials.  det in {128, 256, 512} (128: float32 data; the
+ * trial is tike_ptycho_fwd + the cost of tike_farplane_gradient), probe window =
+ * detector, every pixel measured.
  *   variable  0: x, d, xs are the object (H,W); other = probe (S,det,det)
  *             1: x, d, xs are the probe (S,det,det); other = object (H,W)
  *   state     device double[5] = { fx, step, done, trials, failures }: on entry
@@ -547,7 +548,11 @@ int tike_lstsq_tail_finish(const float* tail3, const float* sums3, double count,
  * objproj (nscan,det,det) c64 (overwritten); object_acc / objproj may both be
  * NULL (probe gradient only), m_probe_update and chi0 may be NULL.
  * Probe window = detector; det = 256 with S <= 8, or det = 512 with S <= 4;
- * model 0 gaussian / 1 poisson (without per-mode step lengths):
+ * model 0 gaussian / 1 poisson (without per-mode step lengths).
+ * det = 128 with S <= 8 (float32 data, no eigen probes) runs the pipeline that
+ * keeps the far plane at that size (tike_ptycho_fwd_intensity ->
+ * tike_gradient_scale -> tike_ifft2_pass1_scaled -> tike_ifft2_pass2_gradients ->
+ * tike_scatter_patches); gscale must then hold 2 x (nscan,det,det) f32.
  * TIKE_ERR_UNSUPPORTED otherwise -- compose the stages yourself. */
 int tike_lstsq_chunk_gradients(const void* psi, const float* scan, const void* probe,
                                const void* eigen_probe, const float* eigen_weights,

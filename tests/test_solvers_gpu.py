@@ -365,7 +365,9 @@ def test_cgrad_vs_oracle(tp, det, pw, S, N):
 
 @pytest.mark.parametrize("det,S,N,slots", [(256, 1, 12, (8, 4)),
                                            (256, 2, 7, (1, 1)),
-                                           (512, 2, 4, (8, 4))])
+                                           (512, 2, 4, (8, 4)),
+                                           (128, 1, 10, (8, 4)),  # configs[0] size
+                                           (128, 2, 6, (8, 4))])
 def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
                                                           S, N, slots):
     """The line search decided on the device (tike_cgrad_line_search: trials

@@ -412,7 +412,11 @@ static int launch_fwd_pos(const cf* psi, const float* scan, const TkProbe& probe
 #endif
 static int launch_fwd128_lds(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                              float* intensity, int nscan, int S, int H, int W, float scale,
-                             hipStream_t stream, cf* patches);
+                             hipStream_t stream, cf* patches, const int* skip = nullptr);
+static int tk_farplane_gradient(void* farplane, const float* data, const unsigned char* measured,
+                                float* intensity, float* costs, int nscan, int S, int det,
+                                int model, int apply_gradient, float unmeasured_scaling,
+                                long num_measured, hipStream_t stream, const int* skip);
 
 extern "C" int tike_ptycho_fwd_intensity(const void* psi, const float* scan, const void* probe,
                                          int probe_per_scan, const void* unique_probe,
@@ -1017,7 +1021,8 @@ extern "C" int tike_cgrad_line_search(int variable, const void* x, const void* d
   TK_CHECK_ARG(nscan >= 1 && chunk >= 1 && S >= 1 && H >= 1 && W >= 1 && nslots >= 1 &&
                nslots <= 30 && count > 0 && (variable == 0 || variable == 1));
   TK_CHECK_ARG(x && d && xs && other && scan && data && scratch && costs && state && skip);
-  if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
+  if (det != 128 && det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
+  if (det == 128 && data_u16) return TK_ERR_UNSUPPORTED;  // the 128^2 cost kernel reads float32
   const long n = variable == 0 ? (long)H * W : (long)S * det * det;
   hipError_t e = hipMemsetAsync(skip, 0, sizeof(int), stream);
   if (e == hipSuccess) e = hipMemsetAsync(state + 2, 0, sizeof(double), stream);  // done = 0
@@ -1031,6 +1036,19 @@ extern "C" int tike_cgrad_line_search(int variable, const void* x, const void* d
     const void* probe = variable == 0 ? other : xs;
     for (int lo = 0; lo < nscan; lo += chunk) {
       const int m = nscan - lo < chunk ? nscan - lo : chunk;
+      if (det == 128) {
+        // whole-tile forward (far plane stored) + the cost of that far plane:
+        // the two launches of a host-side trial at this size
+        const TkProbe P = tk_make_probe(probe, 0, nullptr, nullptr, 0, 0, S, det);
+        int rc = launch_fwd128_lds((const cf*)psi, scan + 2L * lo, P, (cf*)scratch, nullptr, m, S,
+                                   H, W, fwd_scale, stream, nullptr, skip);
+        if (rc) return rc;
+        rc = tk_farplane_gradient(scratch, (const float*)data + (size_t)lo * det * det, nullptr,
+                                  nullptr, costs + lo, m, S, det, 0, 0, 1.0f, (long)det * det,
+                                  stream, skip);
+        if (rc) return rc;
+        continue;
+      }
       int rc = tk_fwd_pass1(psi, scan + 2L * lo, probe, 0, nullptr, nullptr, nullptr, 0, 0,
                             scratch, nullptr, m, S, det, det, H, W, stream, skip);
       if (rc) return rc;
@@ -1084,10 +1102,12 @@ template <bool WITH_I>
 __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ farplane, float* __restrict__ intensity, cf* __restrict__ patches, int nscan,
-    int S, int H, int W, float scale, const cf* __restrict__ twtab) {
+    int S, int H, int W, float scale, const cf* __restrict__ twtab,
+    const int* __restrict__ skip) {
   constexpr int N = 128, T = 8, LS = TK_L128_LS;
   static_assert(FftPlan<N>::E == 16 && LS >= N + N / 16, "row plan: 16 elements x 8 threads");
   __shared__ cf lds[N * LS + FftTwLds<N>::ELEMS];
+  if (skip != nullptr && *skip != 0) return;  // speculative launch, not needed
   cf* twl = lds + N * LS;
   FftTwLds<N>::fill(twl, twtab);
   __syncthreads();
@@ -1234,16 +1254,16 @@ __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
 
 static int launch_fwd128_lds(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                              float* intensity, int nscan, int S, int H, int W, float scale,
-                             hipStream_t stream, cf* patches) {
+                             hipStream_t stream, cf* patches, const int* skip) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   const dim3 grid(tk_grid(nscan, 1)), block(1024);
   if (intensity)
     hipLaunchKernelGGL((fwd128_lds_kernel<true>), grid, block, 0, stream, psi, scan, probe,
-                       farplane, intensity, patches, nscan, S, H, W, scale, tw);
+                       farplane, intensity, patches, nscan, S, H, W, scale, tw, skip);
   else
     hipLaunchKernelGGL((fwd128_lds_kernel<false>), grid, block, 0, stream, psi, scan, probe,
-                       farplane, intensity, patches, nscan, S, H, W, scale, tw);
+                       farplane, intensity, patches, nscan, S, H, W, scale, tw, skip);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -1566,8 +1586,9 @@ __global__ __launch_bounds__(256) void farplane_gradient_kernel(
     cf* __restrict__ farplane, const float* __restrict__ data,
     const unsigned char* __restrict__ mask, float* __restrict__ intensity,
     float* __restrict__ costs, int nscan, int S, int det, float unmeasured_scaling,
-    float inv_nmeasured) {
+    float inv_nmeasured, const int* __restrict__ skip) {
   __shared__ float red[4];
+  if (skip != nullptr && *skip != 0) return;  // speculative launch, not needed
   const long npix = (long)det * det;
   const long n = blockIdx.y;
   cf* __restrict__ F = farplane + n * S * npix;
@@ -1605,13 +1626,10 @@ __global__ __launch_bounds__(256) void farplane_gradient_kernel(
   }
 }
 
-extern "C" int tike_farplane_gradient(void* farplane, const float* data,
-                                      const unsigned char* measured, float* intensity,
-                                      float* costs, int nscan, int S, int det, int model,
-                                      int apply_gradient, float unmeasured_scaling,
-                                      long num_measured, void* stream_) {
-  TK_ENTER();
-  hipStream_t stream = (hipStream_t)stream_;
+static int tk_farplane_gradient(void* farplane, const float* data, const unsigned char* measured,
+                                float* intensity, float* costs, int nscan, int S, int det,
+                                int model, int apply_gradient, float unmeasured_scaling,
+                                long num_measured, hipStream_t stream, const int* skip) {
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1);
   TK_CHECK_ARG(model == 0 || model == 1);
   TK_CHECK_ARG(num_measured > 0);
@@ -1626,7 +1644,8 @@ extern "C" int tike_farplane_gradient(void* farplane, const float* data,
   const dim3 grid((unsigned)((npix + TK_FG_PIX - 1) / TK_FG_PIX), (unsigned)nscan), block(256);
 #define TK_FG(M, G)                                                                          \
   hipLaunchKernelGGL((farplane_gradient_kernel<M, G>), grid, block, 0, stream, (cf*)farplane, \
-                     data, measured, intensity, costs, nscan, S, det, unmeasured_scaling, inv)
+                     data, measured, intensity, costs, nscan, S, det, unmeasured_scaling, inv,    \
+                     skip)
   if (model == 0 && apply_gradient) TK_FG(0, true);
   if (model == 0 && !apply_gradient) TK_FG(0, false);
   if (model == 1 && apply_gradient) TK_FG(1, true);
@@ -1634,6 +1653,17 @@ extern "C" int tike_farplane_gradient(void* farplane, const float* data,
 #undef TK_FG
   TK_LAUNCH_CHECK();
   return TK_OK;
+}
+
+extern "C" int tike_farplane_gradient(void* farplane, const float* data,
+                                      const unsigned char* measured, float* intensity,
+                                      float* costs, int nscan, int S, int det, int model,
+                                      int apply_gradient, float unmeasured_scaling,
+                                      long num_measured, void* stream_) {
+  TK_ENTER();
+  return tk_farplane_gradient(farplane, data, measured, intensity, costs, nscan, S, det, model,
+                              apply_gradient, unmeasured_scaling, num_measured,
+                              (hipStream_t)stream_, nullptr);
 }
 
 // ------------------------------------------------ gradient scale from intensity

@@ -535,8 +535,33 @@ extern "C" int tike_lstsq_chunk_gradients(
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(psi && scan && probe && data && scratch && work && patches);
   TK_CHECK_ARG(scratch != work && (object_acc == nullptr) == (objproj == nullptr));
-  if (!((det == 256 && S <= 8) || (det == 512 && S <= 4))) return TK_ERR_UNSUPPORTED;
+  if (!((det == 128 && S <= 8) || (det == 256 && S <= 8) || (det == 512 && S <= 4)))
+    return TK_ERR_UNSUPPORTED;
   TK_CHECK_ARG(gscale || det == 256);  // 256^2: the factor stays in registers
+  if (det == 128) {
+    // the far plane is kept at this size (whole tile in LDS): forward +
+    // intensity -> gradient factor + costs -> scaled inverse pass 1 -> pass 2 +
+    // gradients -> scatter.  gscale holds TWO (nscan,det,det) tables here: the
+    // factor, then the intensity.  float32 data only.
+    if (data_u16 || (eigen_weights && eigen_modes > 0)) return TK_ERR_UNSUPPORTED;
+    float* inten = gscale + (size_t)nscan * det * det;
+    int rc = tike_ptycho_fwd_intensity(psi, scan, probe, 0, nullptr, eigen_weights, num_eigen,
+                                       eigen_modes, scratch, inten, patches, nscan, S, det, det,
+                                       H, W, fwd_scale, stream);
+    if (rc) return rc;
+    rc = tike_gradient_scale(inten, (const float*)data, measured, gscale, costs, nscan, det,
+                             model, unmeasured_scaling, num_measured, stream);
+    if (rc) return rc;
+    rc = tike_ifft2_pass1_scaled(scratch, gscale, nullptr, nullptr, S, work, (long)nscan * S, det,
+                                 stream);
+    if (rc) return rc;
+    rc = tike_ifft2_pass2_gradients(work, patches, probe, eigen_probe, eigen_weights, num_eigen,
+                                    eigen_modes, objproj, chi0, m_probe_update, mpu_scale, nscan,
+                                    S, det, inv_scale, stream);
+    if (rc) return rc;
+    if (object_acc) rc = tike_scatter_patches(objproj, scan, object_acc, nscan, det, H, W, stream);
+    return rc;
+  }
   int rc = tike_fwd_pass1(psi, scan, probe, 0, nullptr, eigen_probe, eigen_weights, num_eigen,
                           eigen_modes, scratch, patches, nscan, S, det, det, H, W, stream);
   if (rc) return rc;

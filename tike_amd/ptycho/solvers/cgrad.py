@@ -91,10 +91,12 @@ class _CostPlan:
         return self.costs
 
     def supports_gradients(self):
-        """The far-plane-free sizes, probe window = detector: the gradient of a
-        chunk is ONE C-ABI call (tike_lstsq_chunk_gradients)."""
+        """The far-plane-free sizes and 128^2 (float32 data), probe window =
+        detector: the gradient of a chunk is ONE C-ABI call
+        (tike_lstsq_chunk_gradients)."""
         S, pw, det, _, _ = self.dims
-        return (self.split and pw == det and fused_gradients(S, pw, det)
+        return ((self.split or (det == 128 and not self.u16)) and pw == det
+                and fused_gradients(S, pw, det)
                 and all(c[3] is not None for c in self.chunks))
 
     def gradients(self, op, comm, psi, probe, want_psi, want_probe):
@@ -106,7 +108,9 @@ class _CostPlan:
         ws = _workspace(op)
         n_max = self.far.shape[0]
         mid = ws.get("mid", tuple(self.far.shape), torch.complex64, dev)
-        gscale = ws.get("gscale", (n_max, det, det), torch.float32, dev)
+        # (128^2 keeps the far plane: factor table + intensity table)
+        gscale = ws.get("gscale", ((2 if det == 128 else 1) * n_max, det, det),
+                        torch.float32, dev)
         N = self.costs.shape[0]
         patches = ws.get("patches", (max(N, 1), pw, pw), torch.complex64, dev)
         objproj = ws.get("objproj", (n_max, pw, pw), torch.complex64, dev)
@@ -292,7 +296,7 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
         plan = _CostPlan(op, d, s, lo, hi, probe.shape[-3], probe.shape[-1],
                          psi.shape[-2], psi.shape[-1], psi.device)
         # line searches decided on the device: one rank, HBM-resident data,
-        # the far-plane-free sizes
+        # the far-plane-free sizes and 128^2
         on_device = (DEVICE_LINE_SEARCH and not comm.collective and hi > lo
                      and isinstance(d, torch.Tensor)
                      and plan.supports_gradients())
