@@ -32,6 +32,17 @@ extern "C" {
 #define TIKE_ERR_COMM 2000000 /* + ncclResult_t of a failed RCCL call */
 #define TIKE_COMM_ID_BYTES 128
 
+/* Version of THIS header.  Bumped whenever an entry point is added, removed or
+ * changes its argument list (entries take up to 31 positional arguments, so a
+ * binding built against another header would pass garbage without noticing).
+ * A binding compares tike_abi_version() of the loaded library with the
+ * TIKE_ABI_VERSION it was written against before its first call
+ * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
+#define TIKE_ABI_VERSION 4
+
+/* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
+int tike_abi_version(void);
+
 /* Create the per-device constant tables (FFT twiddles).  Allocates; call once
  * per device before capturing graphs.  Every other call does it lazily. */
 int tike_init(void);

@@ -67,3 +67,40 @@ def test_comm_entries_reject_bad_arguments_without_a_gpu():
     assert lib.tike_comm_allreduce_sum(None, None, 4, 0, None) == L.ERR_ARG
     assert lib.tike_comm_broadcast(None, None, 4, 0, None) == L.ERR_ARG
     assert lib.tike_comm_destroy(None) == 0
+
+
+def test_abi_version_of_header_library_and_binding_agree():
+    """`tike_abi_version()` lets a binding detect a library built from another
+    header before it passes 31 positional arguments to the wrong entry."""
+    text = open(L.HEADER_PATH).read()
+    m = re.search(r"^#define\s+TIKE_ABI_VERSION\s+(\d+)", text, flags=re.M)
+    assert m, "include/tike_amd.h must define TIKE_ABI_VERSION"
+    lib = ctypes.CDLL(L.LIB_PATH)
+    lib.tike_abi_version.restype = ctypes.c_int
+    assert lib.tike_abi_version() == int(m.group(1)) == L.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
+    monkeypatch.setattr(L, "ABI_VERSION", L.ABI_VERSION + 1)
+    import pytest
+    with pytest.raises(ImportError, match="ABI version"):
+        L._check_abi_version()
+
+
+def test_fft_radix_host_unit_test_builds_and_passes(tmp_path):
+    """csrc/fft_radix.h says "host-unit-tested": this is the harness that runs
+    tests/csrc/test_fft_radix.cpp (plain g++, no GPU)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        import pytest
+        pytest.skip("no g++")
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "csrc", "test_fft_radix.cpp")
+    exe = str(tmp_path / "test_fft_radix")
+    cmd = ["g++", "-O2", "-std=c++17", "-I",
+           os.path.join(os.path.dirname(here), "tike_amd", "csrc"), src, "-o",
+           exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr

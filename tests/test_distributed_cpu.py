@@ -161,3 +161,49 @@ def test_single_rank_comm_is_identity():
     np.testing.assert_allclose(
         comm.Allreduce_scalars([1.5, torch.tensor(2.0)], "cpu").numpy(),
         [1.5, 2.0])
+
+
+def _resolve_in_group(rank, world):
+    from tike_amd.ptycho import _spawn
+    out = [_spawn.resolve(None), _spawn.resolve(world), _spawn.resolve((0, 1))]
+    try:
+        _spawn.resolve(1)
+    except ValueError as e:
+        out.append(str(e))
+    return out
+
+
+def test_num_gpu_is_honoured_or_refused(monkeypatch):
+    """`num_gpu` (reference ptycho.py:182-187): left out = this process / this
+    job; N from a plain process = N spawned ranks; anything that contradicts
+    the running process group raises."""
+    from tike_amd.ptycho import _spawn
+    assert _spawn.requested_devices(None) is None
+    assert _spawn.requested_devices(3) == (0, 1, 2)
+    assert _spawn.requested_devices((4, 2)) == (4, 2)
+    with pytest.raises(ValueError):
+        _spawn.requested_devices(0)
+    with pytest.raises(ValueError):
+        _spawn.requested_devices((0, -1))
+    # plain process
+    assert _spawn.resolve(None) == ("here", None)
+    assert _spawn.resolve(1) == ("here", None)
+    assert _spawn.resolve((3,)) == ("here", 3)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert _spawn.resolve(4) == ("spawn", (0, 1, 2, 3))
+    assert _spawn.resolve((6, 7)) == ("spawn", (6, 7))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    with pytest.warns(UserWarning, match="only 2 GPU"):
+        assert _spawn.resolve(4) == ("spawn", (0, 1))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.warns(UserWarning):
+        assert _spawn.resolve(4) == ("here", 0)
+    monkeypatch.setenv("TIKE_AMD_OVERSUBSCRIBE", "1")
+    assert _spawn.resolve(2) == ("spawn", (0, 0))
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 0)
+    with pytest.raises(RuntimeError, match="GPU"):
+        _spawn.resolve(2)
+    # inside a two-rank job
+    for out in _run(_resolve_in_group):
+        assert out[:3] == [("here", None)] * 3
+        assert "world" in out[3] or "job of 2" in out[3]

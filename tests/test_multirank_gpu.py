@@ -176,3 +176,56 @@ def test_rccl_collectives_single_rank(backend):
     assert_close(psi, single.psi, normwise=1e-4, maxabs=1e-3, what="psi")
     assert_close(probe, single.probe, normwise=1e-4, maxabs=1e-3, what="probe")
     np.testing.assert_allclose(scan, single.scan, atol=1e-3)
+
+
+def test_reconstruct_num_gpu_starts_the_ranks_itself(monkeypatch):
+    """The reference's one-call contract (ptycho.py:182-187,371-381):
+    ``reconstruct(data, parameters, num_gpu=2)`` from a plain process uses two
+    ranks -- here two spawned children that share the test box's GPU over
+    gloo (TIKE_AMD_OVERSUBSCRIBE) -- and returns the one-rank iterates."""
+    import tike_amd.ptycho as tp
+    import tike_amd.random
+    single = _reconstruct(True, "wobbly_center", positions=True)
+    data, scan, probe, psi0, ep, ew = _problem(True)
+    np.random.seed(1)
+    tike_amd.random.randomizer_np = np.random.default_rng(2)
+    params = tp.PtychoParameters(
+        probe=probe.copy(), psi=psi0.copy(), scan=scan.copy(), eigen_probe=ep,
+        eigen_weights=ew,
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=3,
+                                          batch_method="wobbly_center"),
+        probe_options=tp.ProbeOptions(force_orthogonality=True),
+        object_options=tp.ObjectOptions(),
+        position_options=tp.PositionOptions(
+            scan.copy(), use_adaptive_moment=True,
+            use_position_regularization=True, update_magnitude_limit=2))
+    monkeypatch.setenv("TIKE_AMD_OVERSUBSCRIBE", "1")
+    r = tp.reconstruct(data, params, num_gpu=2)
+    np.testing.assert_allclose(np.array(r.algorithm_options.costs),
+                               np.array(single.algorithm_options.costs),
+                               rtol=1e-3)
+    assert_close(r.psi, single.psi, normwise=1e-3, maxabs=1e-2, what="psi")
+    assert_close(r.probe, single.probe, normwise=1e-3, maxabs=1e-2,
+                 what="probe")
+    np.testing.assert_allclose(r.scan, single.scan, atol=5e-3)
+    assert r.eigen_weights.shape == single.eigen_weights.shape
+    # the caller's generators advanced as in an in-process call
+    after = tike_amd.random.randomizer_np.bit_generator.state
+    assert after != np.random.default_rng(2).bit_generator.state
+
+
+def test_reconstruction_context_refuses_num_gpu_it_cannot_honour(monkeypatch):
+    import tike_amd.ptycho as tp
+    data, scan, probe, psi0, _, _ = _problem(False)
+    params = tp.PtychoParameters(
+        probe=probe, psi=psi0, scan=scan,
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=1),
+        probe_options=tp.ProbeOptions(), object_options=tp.ObjectOptions())
+    monkeypatch.setenv("TIKE_AMD_OVERSUBSCRIBE", "1")
+    with pytest.raises(ValueError, match="num_gpu"):
+        tp.Reconstruction(data, params, num_gpu=2)
+    monkeypatch.delenv("TIKE_AMD_OVERSUBSCRIBE")
+    # fewer GPUs than requested: the reference's rule -- warn, use what is there
+    with pytest.warns(UserWarning, match="GPU"):
+        r = tp.reconstruct(data, params, num_gpu=64)
+    assert len(r.algorithm_options.costs) == 1

@@ -20,6 +20,8 @@ LIB_PATH = os.environ.get("TIKE_AMD_LIB") or os.path.join(
     _HERE, "csrc", "libtike_amd.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
+# the header version this binding's prototypes were written against
+ABI_VERSION = 4
 ERR_ARG = 1000001
 ERR_UNSUPPORTED = 1000002
 ERR_COMM = 2000000
@@ -40,6 +42,7 @@ _f = ctypes.c_float
 _d = ctypes.c_double
 
 _PROTOTYPES = {
+    "tike_abi_version": [],
     "tike_init": [],
     "tike_patch_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "tike_patch_adj": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -134,9 +137,30 @@ def declared_symbols():
 
 
 for _name, _args in _PROTOTYPES.items():
-    _fn = getattr(lib, _name)
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError as e:
+        raise ImportError(
+            f"{LIB_PATH} does not export {_name}: it was built from another "
+            "include/tike_amd.h; rebuild it (`make -C tike_amd/csrc`).") from e
     _fn.argtypes = _args
     _fn.restype = ctypes.c_int
+
+
+def _check_abi_version():
+    """Refuse a library built from another header: its entries would take
+    this binding's positional arguments for something else."""
+    got = lib.tike_abi_version()
+    m = re.search(r"^#define\s+TIKE_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read(),
+                  flags=re.M) if os.path.isfile(HEADER_PATH) else None
+    if got != ABI_VERSION or (m and int(m.group(1)) != ABI_VERSION):
+        raise ImportError(
+            f"{LIB_PATH} reports ABI version {got}, include/tike_amd.h "
+            f"{m.group(1) if m else '?'}, this binding expects {ABI_VERSION}: "
+            "rebuild the library (`make -C tike_amd/csrc`).")
+
+
+_check_abi_version()
 
 
 def check(rc, what=""):

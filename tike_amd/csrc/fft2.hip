@@ -33,6 +33,8 @@ const cf* tk_twiddles() {
   return d;
 }
 
+extern "C" int tike_abi_version(void) { return TIKE_ABI_VERSION; }
+
 extern "C" int tike_init(void) { return tk_twiddles() ? TK_OK : (int)hipErrorNotInitialized; }
 
 // ------------------------------------------------------------ pow2 kernel

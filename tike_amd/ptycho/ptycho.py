@@ -4,8 +4,10 @@
 ``reconstruct`` / ``Reconstruction`` / ``simulate`` keep the reference's
 signatures.  Execution model (MI355X-first, differs from the reference):
 
-* one process per GPU.  ``num_gpu`` is accepted for compatibility; the number
-  of GPUs is the ``torch.distributed`` world size (launch with ``torchrun``);
+* one process per GPU.  ``reconstruct(..., num_gpu=N)`` called from a plain
+  process starts N child ranks itself (``_spawn.py``) and returns their
+  result; inside a ``torch.distributed`` job (torchrun) the world size is the
+  number of GPUs and a ``num_gpu`` that disagrees with it is an error;
 * the whole dataset is HBM-resident (no pinned-host chunk streaming,
   reference communicators/stream.py:285-404);
 * scan positions -- not object stripes -- are sharded across ranks and the
@@ -28,7 +30,7 @@ from .. import cluster
 from .. import precision
 from ..communicators import Comm
 from ..operators import Ptycho
-from . import solvers
+from . import _spawn, solvers
 from .object import (positivity_constraint, remove_object_ambiguity,
                      smoothness_constraint)
 from .position import (affine_position_regularization,
@@ -97,22 +99,37 @@ def simulate(detector_shape, probe, scan, psi, fly=1, eigen_probe=None,
         return operator.asnumpy(out)
 
 
-def reconstruct(data, parameters, num_gpu=1, use_mpi=False, **kwargs):
+def reconstruct(data, parameters, num_gpu=None, use_mpi=False, **kwargs):
     """Solve the ptychography problem (ptycho.py:182-262).
 
     data (FRAME, WIDE, HIGH): measured intensities, FFT-shifted so that the
     diffraction peak is at the corners.  Returns the updated
     ``PtychoParameters`` (host arrays), which can be passed back in to resume.
     Extra keyword arguments go to `Reconstruction` (e.g. ``data_on_host``).
+
+    num_gpu: an int N or a tuple of device numbers, as in the reference.
+    Left out, the call uses this process's GPU -- or, inside a
+    ``torch.distributed`` job, all of the job's ranks.  N > 1 from a plain
+    process starts N child processes (one rank per GPU, RCCL) that shard the
+    positions, and returns their result; a value that contradicts a running
+    process group raises ValueError (`_spawn.resolve`).
     """
-    with Reconstruction(data, parameters, num_gpu, use_mpi,
-                        **kwargs) as context:
+    if use_mpi:
+        raise NotImplementedError(
+            "multi-node MPI is out of scope; launch one process per GPU "
+            "with torchrun instead")
+    how, where = _spawn.resolve(num_gpu)
+    if how == "spawn":
+        return _spawn.reconstruct_spawned(data, parameters, where, **kwargs)
+    with Reconstruction(data, parameters,
+                        num_gpu if where is None else (where,),
+                        use_mpi, **kwargs) as context:
         context.iterate(parameters.algorithm_options.num_iter)
         result = context.get_result()
     return result
 
 
-def reconstruct_multigrid(data, parameters, num_gpu=1, use_mpi=False,
+def reconstruct_multigrid(data, parameters, num_gpu=None, use_mpi=False,
                           num_levels=3, interp=None):
     """Coarse-to-fine reconstruction (ptycho.py:975-1047): the real-space
     parameters are downsampled by 2^(num_levels-1) and the diffraction
@@ -126,13 +143,10 @@ def reconstruct_multigrid(data, parameters, num_gpu=1, use_mpi=False,
                       " may be visible.")
     resampled = parameters.resample(0.5**(num_levels - 1), interp)
     for level in range(num_levels - 1, -1, -1):
-        with Reconstruction(
-                data=data if level == 0 else solvers.crop_fourier_space(
-                    data, data.shape[-1] // (2**level)),
-                parameters=resampled, num_gpu=num_gpu,
-                use_mpi=use_mpi) as context:
-            context.iterate(resampled.algorithm_options.num_iter)
-            result = context.get_result()
+        result = reconstruct(
+            data=data if level == 0 else solvers.crop_fourier_space(
+                data, data.shape[-1] // (2**level)),
+            parameters=resampled, num_gpu=num_gpu, use_mpi=use_mpi)
         if level == 0:
             return result
         resampled = result.resample(2.0, interp)
@@ -182,9 +196,23 @@ class Reconstruction():
         of holding them in HBM.  Results are identical.
     """
 
-    def __init__(self, data, parameters, num_gpu=1, use_mpi=False, *,
+    def __init__(self, data, parameters, num_gpu=None, use_mpi=False, *,
                  presharded=False, order=None, batches=None,
                  spatial_sort=True, data_on_host=False):
+        # a context lives in ONE process with ONE GPU: `num_gpu` must agree
+        # with the process group it runs in (`reconstruct` is the entry that
+        # starts ranks by itself)
+        how, device = _spawn.resolve(num_gpu)
+        if how == "spawn":
+            raise ValueError(
+                f"Reconstruction(num_gpu={num_gpu!r}): a Reconstruction "
+                "context drives the GPU of its own process.  Call "
+                f"tike_amd.ptycho.reconstruct(..., num_gpu={num_gpu!r}), "
+                "which starts one rank per GPU itself, or launch the script "
+                "with `python -m torch.distributed.run --nproc-per-node "
+                f"{len(_spawn.requested_devices(num_gpu))}`")
+        if device is not None:
+            torch.cuda.set_device(device)  # ptycho.py:344-345
         if (np.any(np.asarray(data.shape) < 1) or data.ndim != 3
                 or data.shape[-2] != data.shape[-1]):
             raise ValueError(
