@@ -6,109 +6,155 @@ Once-per-run host code, out of the accelerated scope; restated so that
 import numpy as np
 
 
-def wobbly_center(population, num_cluster):
-    """Maximally heterogeneous equal-size clusters (cluster.py:302-377)."""
-    population = np.asarray(population)
+def _check_cluster_count(num_cluster):
     if not 0 < num_cluster < 0xFFFF:
         raise ValueError(
             f"The number of clusters must be 0 < {num_cluster} < 65536.")
-    if (num_cluster == 1) or (num_cluster >= len(population)):
-        return np.array_split(np.arange(population.shape[0]), num_cluster)
-    start = np.argpartition(
-        np.linalg.norm(population - np.mean(population, axis=0, keepdims=True),
-                       axis=1), num_cluster, axis=0)[:num_cluster]
-    UNASSIGNED = 0xFFFF
-    labels = np.full(len(population), UNASSIGNED, dtype="uint16")
-    labels[start] = range(num_cluster)
-    for c in range(len(population) - len(start)):
-        c = c % num_cluster
-        free = labels == UNASSIGNED
-        furthest = np.argmax(
-            np.linalg.norm(population[free] - np.mean(
-                population[labels == c], axis=0, keepdims=True), axis=1))
-        i = np.argmax(np.cumsum(free) == (furthest + 1))
-        labels[i] = c
-    return [np.flatnonzero(labels == c) for c in range(num_cluster)]
+
+
+def wobbly_center(population, num_cluster):
+    """Equal-size clusters that each span the whole population
+    (maximal-heterogeneity clustering, Mishra et al. arXiv:1709.01423; the
+    reference's `cluster.wobbly_center`, cluster.py:302-377, whose labels this
+    reproduces: the `num_cluster` points nearest the global centroid seed the
+    clusters, then the clusters take turns, each claiming the free point
+    farthest from its own current mean)."""
+    points = np.asarray(population)
+    _check_cluster_count(num_cluster)
+    count = len(points)
+    if num_cluster == 1 or num_cluster >= count:
+        return contiguous(points, num_cluster)
+    owner = np.full(count, -1, dtype=np.int64)
+    spread = np.linalg.norm(points - points.mean(axis=0, keepdims=True), axis=1)
+    owner[np.argpartition(spread, num_cluster, axis=0)[:num_cluster]] = (
+        np.arange(num_cluster))
+    for turn in range(count - num_cluster):
+        cluster = turn % num_cluster
+        centre = points[owner == cluster].mean(axis=0, keepdims=True)
+        reach = np.linalg.norm(points - centre, axis=1)
+        reach[owner >= 0] = -1.0  # claimed points are out of the race
+        owner[np.argmax(reach)] = cluster  # first of the farthest free points
+    return [np.flatnonzero(owner == c) for c in range(num_cluster)]
+
+
+class _EqualSizeKMeans:
+    """Equal-size k-means ("compact" batches): k-means++ seeds, a capacity-
+    limited greedy assignment, then pairwise swaps that lower the summed
+    distance to the centroids.  Restates the procedure of the reference's
+    `cluster.compact` (cluster.py:465-637) -- same draws from the legacy
+    NumPy generator, same tie-breaking -- as three vectorised steps."""
+
+    def __init__(self, points, num_cluster):
+        self.x = points
+        self.k = num_cluster
+        self.n = len(points)
+        self.rows = np.arange(self.n)
+        self.capacity = np.full(num_cluster, self.n // num_cluster)
+        self.capacity[:self.n % num_cluster] += 1
+        self.label = np.full(self.n, -1, dtype=np.int64)
+        self.dist = np.empty((self.n, num_cluster))
+
+    def _distances(self, centroids):
+        for c in range(self.k):
+            self.dist[:, c] = np.linalg.norm(centroids[c] - self.x, axis=1)
+
+    def seed(self):
+        """k-means++: the first seed uniform, every further one with
+        probability proportional to the squared distance to the nearest seed
+        (inverse-CDF sampling of one legacy-generator uniform per seed: the
+        draws `RandomState.choice` makes)."""
+        seeds = np.empty(self.k, dtype=np.int64)
+        seeds[0] = np.random.randint(0, self.n, size=1)[0]
+        nearest = np.inf
+        for c in range(1, self.k):
+            gap = np.linalg.norm(self.x - self.x[seeds[c - 1]], axis=1)**2
+            nearest = np.minimum(nearest, gap)
+            cdf = np.cumsum((nearest / nearest.sum()).astype(np.float64))
+            cdf /= cdf[-1]
+            seeds[c] = cdf.searchsorted(np.random.random_sample(1),
+                                        side="right")[0]
+        self.centroids = self.x[seeds]
+        self._distances(self.centroids)
+        self.label[seeds] = np.arange(self.k)
+        return seeds
+
+    def fill(self):
+        """Hand the free points to their nearest cluster that still has room,
+        most decisive point first (smallest nearest-minus-farthest distance);
+        whenever a cluster becomes full the preferences are re-evaluated over
+        the clusters that remain."""
+        room = self.capacity - np.bincount(self.label[self.label >= 0],
+                                           minlength=self.k)
+        while True:
+            open_ = np.flatnonzero(room > 0)
+            free = np.flatnonzero(self.label < 0)
+            if not len(open_) or not len(free):
+                break
+            d = self.dist[:, open_]
+            near = open_[np.argmin(d, axis=1)]
+            far = open_[np.argmax(d, axis=1)]
+            urgency = self.dist[self.rows, near] - self.dist[self.rows, far]
+            queue = free[np.argsort(urgency[free])]
+            target = near[queue]
+            # the cluster whose last free place is taken first ends the round
+            stop = len(queue) - 1
+            for c in np.unique(target):
+                where = np.flatnonzero(target == c)
+                if len(where) >= room[c]:
+                    stop = min(stop, where[room[c] - 1])
+            taken = queue[:stop + 1]
+            self.label[taken] = target[:stop + 1]
+            room -= np.bincount(target[:stop + 1], minlength=self.k)
+
+    def refine(self, max_iter):
+        """Swap pairs of points between clusters while that lowers the sum of
+        the two points' distances to their centroids, unhappiest point first;
+        centroids move after every sweep that swapped something."""
+        for _ in range(max_iter):
+            self._distances(self.centroids)
+            best = np.argmin(self.dist, axis=1)
+            regret = self.dist[self.rows, best] - self.dist[self.rows,
+                                                            self.label]
+            moved = False
+            for p in np.argsort(regret):
+                if not regret[p] < 0:
+                    continue
+                home = self.label[p]
+                # gain of exchanging p with every other point q:
+                # d(p, home) + d(q, own(q)) - d(p, own(q)) - d(q, home)
+                gain = self.dist[p, home] + self.dist[self.rows, self.label]
+                gain -= self.dist[p, self.label]
+                gain -= self.dist[:, home]
+                gain[(self.label == home) | ~(gain > 0)] = -np.inf
+                q = int(np.argmax(gain))
+                if gain[q] == -np.inf:
+                    continue
+                moved = True
+                self.label[q], self.label[p] = home, self.label[q]
+                for i in (q, p):
+                    regret[i] = self.dist[i, best[i]] - self.dist[i,
+                                                                  self.label[i]]
+            if not moved:
+                break
+            for c in range(self.k):
+                self.centroids[c] = self.x[self.label == c].mean(axis=0)
+        return self.label
 
 
 def compact(population, num_cluster, max_iter=500):
-    """Equal-size k-means-like clusters (cluster.py:465-637), same greedy
-    fill and swap refinement; seeds with legacy ``np.random.choice``."""
-    population = np.asarray(population)
-    if not 0 < num_cluster < 0xFFFF:
-        raise ValueError(
-            f"The number of clusters must be 0 < {num_cluster} < 65536.")
-    if (num_cluster == 1) or (num_cluster >= len(population)):
-        return np.array_split(np.arange(population.shape[0]), num_cluster)
-    n = len(population)
-    _all = np.arange(n)
-    size = np.zeros(num_cluster, dtype="int")
-    max_size = np.full(num_cluster, n // num_cluster)
-    max_size[:n % num_cluster] += 1
-    start = np.zeros(num_cluster, dtype="int")
-    start[0] = np.random.choice(_all, size=1, p=None)[0]
-    distances = np.inf
-    for c in range(1, num_cluster):
-        distances = np.minimum(
-            distances,
-            np.linalg.norm(population - population[start[c - 1]], axis=1)**2)
-        start[c] = np.random.choice(_all, size=1,
-                                    p=distances / distances.sum())[0]
-    centroids = population[start].astype(float)
-    UNASSIGNED = 0xFFFF
-    labels = np.full(n, UNASSIGNED, dtype="uint16")
-    distances = np.empty((n, num_cluster))
-    unfilled = list(range(num_cluster))
-    unassigned = list(range(n))
-    for c in unfilled:
-        distances[:, c] = np.linalg.norm(centroids[c] - population, axis=1)
-        p = start[c]
-        labels[p] = c
-        unassigned.remove(p)
-        size[c] += 1
-    for c in range(num_cluster):
-        if size[c] >= max_size[c]:
-            unfilled.remove(c)
-    while unfilled:
-        nearest = np.array(unfilled)[np.argmin(distances[:, unfilled], axis=1)]
-        farthest = np.array(unfilled)[np.argmax(distances[:, unfilled],
-                                                axis=1)]
-        priority = np.array(unassigned)[np.argsort(
-            (distances[_all, nearest] - distances[_all, farthest])[unassigned])]
-        for p in priority:
-            labels[p] = nearest[p]
-            unassigned.remove(p)
-            size[nearest[p]] += 1
-            if size[nearest[p]] >= max_size[nearest[p]]:
-                unfilled.remove(nearest[p])
-                break
-    for _ in range(max_iter):
-        swapped = False
-        for c in range(num_cluster):
-            distances[:, c] = np.linalg.norm(centroids[c] - population, axis=1)
-        wanted = np.argmin(distances, axis=1)
-        happiness = distances[_all, wanted] - distances[_all, labels]
-        for p in np.argsort(happiness):
-            if happiness[p] < 0:
-                net = (distances[p, labels[p]] + distances[_all, labels] -
-                       distances[p, labels] - distances[_all, labels[p]])
-                good = np.flatnonzero(
-                    np.logical_and(net > 0, labels != labels[p]))
-                if good.size > 0:
-                    swapped = True
-                    o = good[np.argmax(net[good])]
-                    labels[o], labels[p] = labels[p], labels[o]
-                    happiness[o] = distances[o, wanted[o]] - distances[
-                        o, labels[o]]
-                    happiness[p] = distances[p, wanted[p]] - distances[
-                        p, labels[p]]
-        if not swapped:
-            break
-        for c in range(num_cluster):
-            centroids[c] = np.mean(population[labels == c], axis=0)
-    indices = [np.flatnonzero(labels == c) for c in range(num_cluster)]
-    indices.sort(key=len, reverse=True)
-    return indices
+    """Equal-size, spatially compact clusters, largest first (the reference's
+    `cluster.compact`, cluster.py:465-637; see `_EqualSizeKMeans`).  Seeds with
+    the legacy ``np.random`` generator, as the reference does."""
+    points = np.asarray(population)
+    _check_cluster_count(num_cluster)
+    if num_cluster == 1 or num_cluster >= len(points):
+        return contiguous(points, num_cluster)
+    model = _EqualSizeKMeans(points, num_cluster)
+    model.seed()
+    model.fill()
+    labels = model.refine(max_iter)
+    groups = [np.flatnonzero(labels == c) for c in range(num_cluster)]
+    return sorted(groups, key=len, reverse=True)
 
 
 def contiguous(population, num_cluster):

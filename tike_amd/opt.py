@@ -11,79 +11,103 @@ import torch
 logger = logging.getLogger(__name__)
 
 
+def _recent_cost_slope(history, window):
+    """Slope of the least-squares line through the last `window` epoch costs
+    (an epoch's minibatch costs are averaged first)."""
+    per_epoch = np.asarray(history[-window:], dtype=float).reshape(
+        window, -1).mean(axis=1)
+    return np.polyfit(np.arange(window), per_epoch, 1)[0]
+
+
 def is_converged(algorithm_options):
-    """True if the cost slope over the window is non-negative (opt.py:21-45)."""
+    """Has the cost stopped falling?  Every half window the slope of the
+    recent costs is examined; a slope that is not negative means converged
+    (the criterion of the reference's opt.is_converged, opt.py:21-45)."""
     window = algorithm_options.convergence_window
-    if (window >= 2 and len(algorithm_options.costs) >= window
-            and len(algorithm_options.costs) % window // 2 == 0):
-        m = np.array(algorithm_options.costs[-window:])
-        m = np.mean(np.reshape(m, (len(m), -1)), axis=1)
-        p = np.polyfit(x=range(window), y=m, deg=1, full=False, cov=False)
-        if p[0] >= 0:
-            return True
-    return False
+    epochs = len(algorithm_options.costs)
+    if window < 2 or epochs < window or epochs % window >= 2:
+        return False
+    flat = _recent_cost_slope(algorithm_options.costs, window) >= 0
+    if flat:
+        logger.info("cost has not decreased over the last %d epochs", window)
+    return bool(flat)
 
 
 def momentum(g, v, m, vdecay=None, mdecay=0.9):
-    """m = mdecay*m + (1-mdecay)*g (opt.py:67-82)."""
-    m = 0 if m is None else m
-    m = mdecay * m + (1 - mdecay) * g
-    return m, None, m
+    """Exponential moving average of the search direction: returns
+    (direction, None, average) like `adam` (opt.py:67-82)."""
+    average = (1 - mdecay) * g if m is None else mdecay * m + (1 - mdecay) * g
+    return average, None, average
 
 
 def adam(g, v=None, m=None, vdecay=0.999, mdecay=0.9, eps=1e-8):
-    """ADAM direction (opt.py:165-213)."""
-    is_t = isinstance(g, torch.Tensor)
-    zeros = torch.zeros_like if is_t else np.zeros_like
-    sqrt = torch.sqrt if is_t else np.sqrt
-    v = zeros(g.real) if v is None else v
-    m = zeros(g) if m is None else m
-    m = mdecay * m + (1 - mdecay) * g
-    v = vdecay * v + (1 - vdecay) * (g * g.conj()).real
-    m_ = m / (1 - mdecay)
-    v_ = sqrt(v / (1 - vdecay))
-    return m_ / (v_ + eps), v, m
+    """Adaptive-moment direction (Kingma & Ba, arXiv:1412.6980) in the variant
+    the reference uses (opt.py:165-213): both moving averages are divided by
+    their single-step weights (1 - decay), not by 1 - decay**t.  Returns
+    (direction, second moment, first moment)."""
+    root = torch.sqrt if isinstance(g, torch.Tensor) else np.sqrt
+    power = (g * g.conj()).real
+    first = (1 - mdecay) * g
+    second = (1 - vdecay) * power
+    if m is not None:
+        first = mdecay * m + first
+    if v is not None:
+        second = vdecay * v + second
+    direction = (first / (1 - mdecay)) / (root(second / (1 - vdecay)) + eps)
+    return direction, second, first
 
 
 def fit_line_least_squares(y, x):
-    """(slope, intercept) of the least-squares line (opt.py:383-400)."""
+    """(slope, intercept) of the least-squares line y = slope * x + intercept
+    (opt.py:383-400), from the centred moments."""
     x = np.asarray(x, dtype=float)
     y = np.asarray(y, dtype=float)
-    assert len(x) == len(y)
-    count = len(x)
-    sum_x, sum_y = np.sum(x), np.sum(y)
-    slope = (count * np.sum(x * y) - sum_x * sum_y) / (count * np.sum(x * x) -
-                                                       sum_x * sum_x)
-    return slope, (sum_y - slope * sum_x) / count
+    if len(x) != len(y) or not len(x):
+        raise AssertionError("x and y must be equally long and not empty")
+    dx = x - x.mean()
+    slope = np.dot(dx, y - y.mean()) / np.dot(dx, dx)
+    return slope, y.mean() - slope * x.mean()
+
+
+def _shrinking_steps(first, factor, floor=1e-32):
+    """first, first * factor, first * factor**2, ... while >= floor (the first
+    one always)."""
+    step = first
+    while True:
+        yield step
+        step *= factor
+        if step < floor:
+            return
 
 
 def line_search(f, x, d, update_multi, step_length=1, step_shrink=0.5,
                 cost=None):
-    """Backtracking line search (opt.py:216-278)."""
+    """Backtracking line search (opt.py:216-278): the first of the step
+    lengths step_length * step_shrink**k (>= 1e-32) whose cost does not exceed
+    f(x).  Returns (step, cost at the accepted point, accepted point); when no
+    step is accepted, (0, f(x), x) with a warning."""
     assert 0 < step_shrink < 1
-    fx = f(x) if cost is None else cost
-    while True:
-        xsd = update_multi(x, step_length, d)
-        fxsd = f(xsd)
-        if fxsd <= fx:
-            break
-        step_length *= step_shrink
-        if step_length < 1e-32:
-            warnings.warn("Line search failed for conjugate gradient.")
-            step_length, fxsd, xsd = 0, fx, x
-            break
-    return step_length, fxsd, xsd
+    start_cost = f(x) if cost is None else cost
+    for step in _shrinking_steps(step_length, step_shrink):
+        candidate = update_multi(x, step, d)
+        candidate_cost = f(candidate)
+        if candidate_cost <= start_cost:
+            return step, candidate_cost, candidate
+    warnings.warn("Line search failed for conjugate gradient.")
+    return 0, start_cost, x
 
 
 def direction_dy(xp, grad1, grad0=None, dir_=None):
-    """Dai-Yuan search direction (opt.py:281-301); lists of one array per
-    device as in the reference."""
-    if dir_ is None:
-        return [-grad1[0]]
+    """Dai-Yuan conjugate direction -g1 + beta * d with
+    beta = |g1|^2 / <d, g1 - g0> (opt.py:281-301).  Arguments and result are
+    one-element lists (one array per device in the reference)."""
     g1 = grad1[0]
-    norm2 = (g1 * g1.conj()).real.sum()
-    den = (dir_[0].conj() * (g1 - grad0[0])).sum() + 1e-32
-    return [-g1 + dir_[0] * norm2 / den]
+    if dir_ is None:
+        return [-g1]
+    d = dir_[0]
+    beta = (g1 * g1.conj()).real.sum() / ((d.conj() *
+                                           (g1 - grad0[0])).sum() + 1e-32)
+    return [d * beta - g1]
 
 
 def update_single(x, step_length, d):
@@ -94,27 +118,36 @@ def dir_single(x):
     return x
 
 
+class _ConjugateDirections:
+    """The part of nonlinear CG that remembers: turns each new gradient into
+    the next search direction with the given rule (Dai-Yuan by default)."""
+
+    def __init__(self, array_module, rule, spread):
+        self.xp, self.rule, self.spread = array_module, rule, spread
+        self.previous = ()  # (gradient, direction) of the last iteration
+
+    def __call__(self, gradient):
+        direction = self.rule(self.xp, gradient, *self.previous)
+        self.previous = (gradient, direction)
+        return self.spread(direction)
+
+
 def conjugate_gradient(array_module, x, cost_function, grad,
                        direction_dy=direction_dy, dir_multi=dir_single,
                        update_multi=update_single, num_iter=1, step_length=1,
                        num_search=None, cost=None):
-    """Nonlinear conjugate gradient with backtracking (opt.py:312-380)."""
-    num_search = num_iter if num_search is None else num_search
-    grad0 = dir_ = None
-    for i in range(num_iter):
-        grad1 = grad(x)
-        if i == 0:
-            dir_ = direction_dy(array_module, grad1)
-        else:
-            dir_ = direction_dy(array_module, grad1, grad0, dir_)
-        grad0 = grad1
-        dir_list = dir_multi(dir_)
-        if i < num_search:
-            step_length, cost, x = line_search(
-                f=cost_function, x=x, d=dir_list, update_multi=update_multi,
-                step_length=step_length, cost=cost)
-        else:
-            x = update_multi(x, step_length, dir_list)
-    if num_search < num_iter:
-        cost = cost_function(x)
-    return x, cost
+    """Nonlinear conjugate gradient (opt.py:312-380): `num_iter` Dai-Yuan
+    directions; the first `num_search` of them (default: all) are followed by
+    a backtracking line search that starts from the step length the previous
+    search accepted, the others reuse that step length.  Returns (x, cost)."""
+    searched = min(num_iter, num_iter if num_search is None else num_search)
+    next_move = _ConjugateDirections(array_module, direction_dy, dir_multi)
+    for _ in range(searched):
+        step_length, cost, x = line_search(cost_function, x,
+                                           next_move(grad(x)), update_multi,
+                                           step_length, cost=cost)
+    if searched == num_iter:
+        return x, cost
+    for _ in range(searched, num_iter):  # the rest reuse the last step length
+        x = update_multi(x, step_length, next_move(grad(x)))
+    return x, cost_function(x)

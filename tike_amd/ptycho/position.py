@@ -19,24 +19,19 @@ from .. import random as trandom
 
 
 def check_allowed_positions(scan, psi, probe_shape):
-    """Raise ValueError unless 1 <= floor(scan) <= psi.shape - probe - 1
-    (position.py:600-628)."""
-    scan = A.to_host(scan)
-    int_scan = scan // 1
-    min_corner = np.min(int_scan, axis=-2)
-    max_corner = np.max(int_scan, axis=-2)
-    valid_min_corner = (1, 1)
-    valid_max_corner = (psi.shape[-2] - probe_shape[-2] - 1,
-                        psi.shape[-1] - probe_shape[-1] - 1)
-    if (min_corner[0] < valid_min_corner[0]
-            or min_corner[1] < valid_min_corner[1]
-            or max_corner[0] > valid_max_corner[0]
-            or max_corner[1] > valid_max_corner[1]):
+    """Raise ValueError unless every patch lies inside the object with one
+    pixel to spare: 1 <= floor(scan) <= psi.shape - probe_shape - 1 on both
+    axes (the kernels read the pixel after a patch's last one; the rule and
+    the message of the reference, position.py:600-628)."""
+    corner = np.floor(A.to_host(scan))
+    lowest, highest = corner.min(axis=-2), corner.max(axis=-2)
+    room = np.subtract(psi.shape[-2:], probe_shape[-2:]) - 1
+    if np.any(lowest[:2] < 1) or np.any(highest[:2] > room):
         raise ValueError(
             "Scan positions must be >= 1 and "
             "scan positions + 1 + probe.shape must be <= psi.shape. "
             "psi may be too small or the scan positions may be scaled wrong. "
-            f"The span of scan is {min_corner} to {max_corner}, and "
+            f"The span of scan is {lowest} to {highest}, and "
             f"the shape of psi is {psi.shape}.")
 
 
@@ -66,35 +61,36 @@ class AffineTransform:
 
     @classmethod
     def fromarray(cls, T) -> "AffineTransform":
-        """Decompose a 2x2 (or 3x2) matrix, Graphics Gems 2 section 7.1
-        (position.py:166-193)."""
-        T = np.asarray(T)
-        R = T[:2, :2].copy()
-        scale0 = np.linalg.norm(R[0])
-        if scale0 <= 0:
-            return AffineTransform()
-        R[0] /= scale0
-        shear1 = R[0] @ R[1]
-        R[1] -= shear1 * R[0]
-        scale1 = np.linalg.norm(R[1])
-        if scale1 <= 0:
-            return AffineTransform()
-        R[1] /= scale1
-        shear1 /= scale1
-        angle = np.arccos(R[0, 0])
-        return AffineTransform(
-            scale0=float(scale0), scale1=float(scale1), shear1=float(shear1),
-            angle=float(angle),
-            t0=float(T[2, 0] if T.shape[0] > 2 else 0),
-            t1=float(T[2, 1] if T.shape[0] > 2 else 0))
+        """The transform whose `asarray()` (and, for a 3 x 2 input,
+        translation) is T.  The rows of the 2 x 2 part are orthogonalised in
+        order (a QR factorisation of its transpose with a positive diagonal:
+        the decomposition of Graphics Gems II 7.1 that the reference uses,
+        position.py:166-193): the diagonal holds the scales, the off-diagonal
+        term over scale1 the shear, and the angle is arccos of the first
+        component of the first unit row.  A rank-deficient matrix gives the
+        identity transform."""
+        T = np.asarray(T, dtype=np.float64)
+        basis, factor = np.linalg.qr(T[:2, :2].T)
+        flip = np.where(np.diag(factor) < 0, -1.0, 1.0)
+        basis, factor = basis * flip, factor * flip[:, None]
+        tiny = 1e-12 * np.abs(factor).max()  # rows on one line: no rotation
+        if not (factor[0, 0] > tiny and factor[1, 1] > tiny):
+            return cls()
+        shift = T[2] if len(T) > 2 else (0.0, 0.0)
+        return cls(scale0=float(factor[0, 0]), scale1=float(factor[1, 1]),
+                   shear1=float(factor[0, 1] / factor[1, 1]),
+                   angle=float(np.arccos(np.clip(basis[0, 0], -1.0, 1.0))),
+                   t0=float(shift[0]), t1=float(shift[1]))
 
     def asarray(self, xp=np) -> np.ndarray:
-        """2x2 matrix scale @ shear @ rotate (position.py:195-220)."""
-        cosx, sinx = np.cos(self.angle), np.sin(self.angle)
-        f = precision.floating
-        return (np.array([[self.scale0, 0.0], [0.0, self.scale1]], dtype=f)
-                @ np.array([[1.0, 0.0], [self.shear1, 1.0]], dtype=f)
-                @ np.array([[+cosx, -sinx], [+sinx, +cosx]], dtype=f))
+        """The 2 x 2 matrix diag(scale0, scale1) @ [[1, 0], [shear1, 1]] @
+        rotation(angle), multiplied out (position.py:195-220); row vectors
+        are transformed as x @ matrix."""
+        c, s = np.cos(self.angle), np.sin(self.angle)
+        sheared = (self.shear1 * c + s, c - self.shear1 * s)
+        return np.array([[self.scale0 * c, -self.scale0 * s],
+                         [self.scale1 * sheared[0], self.scale1 * sheared[1]]],
+                        dtype=precision.floating)
 
     def asarray3(self, xp=np) -> np.ndarray:
         T = np.empty((3, 2), dtype=precision.floating)
@@ -122,20 +118,24 @@ class AffineTransform:
 
 def estimate_global_transformation(positions0, positions1, weights=None,
                                    transform=None):
-    """Weighted least squares for the global affine transformation
-    (position.py:252-270); host arrays."""
-    a = np.pad(positions0, ((0, 0), (0, 1)), constant_values=1)
-    b = positions1
+    """The affine transformation that maps positions0 onto positions1 in the
+    (weighted) least-squares sense, and the residual norm over these
+    positions (position.py:252-270).  Solves the normal equations of
+    [positions0, 1] @ X = positions1; positions on one line make them
+    singular, which yields the identity transform.  Host arrays."""
+    design = np.concatenate(
+        [positions0, np.ones_like(positions0[..., :1])], axis=-1)
+    target = positions1
+    if weights is not None:
+        root = np.sqrt(weights)[..., None]
+        design, target = design * root, target * root
+    gram = design.conj().swapaxes(-1, -2)
     try:
-        if weights is not None:
-            w = np.sqrt(weights[..., None])
-            a, b = a * w, b * w
-        aT = a.conj().swapaxes(-1, -2)
-        result = AffineTransform.fromarray(np.linalg.inv(aT @ a) @ aT @ b)
+        fitted = AffineTransform.fromarray(
+            np.linalg.solve(gram @ design, gram @ target))
     except np.linalg.LinAlgError:
-        # singular when the positions are colinear
-        result = AffineTransform()
-    return result, np.linalg.norm(result(positions0) - positions1)
+        fitted = AffineTransform()
+    return fitted, np.linalg.norm(fitted(positions0) - positions1)
 
 
 def ransac_subsets(n, min_sample=4, max_iter=20):
@@ -145,30 +145,40 @@ def ransac_subsets(n, min_sample=4, max_iter=20):
                                         replace=True)
 
 
+def _consensus_fits(positions0, positions1, weights, subsets, max_error,
+                    min_consensus):
+    """(fitness, model) of every random subset whose rough fit explains at
+    least `min_consensus` of all positions to within `max_error` pixels; the
+    model is refitted on those inliers."""
+    for rows in subsets:
+        rough, _ = estimate_global_transformation(positions0[rows],
+                                                  positions1[rows], weights)
+        miss = np.linalg.norm(rough(positions0) - positions1, axis=-1)
+        inliers = miss <= max_error
+        if inliers.mean() >= min_consensus:
+            model, fitness = estimate_global_transformation(
+                positions0[inliers], positions1[inliers], weights)
+            yield fitness, model
+
+
 def estimate_global_transformation_ransac(positions0, positions1, weights=None,
                                           transform=None, min_sample=4,
                                           max_error=32, min_consensus=0.75,
                                           max_iter=20, subsets=None):
     """RANSAC estimate of the global affine transformation
-    (position.py:273-327); the subsets come from ``tike_amd.random.
+    (position.py:273-327): the consensus fit with the smallest residual (the
+    first of equals), or `transform` unchanged with fitness inf when no
+    subset reaches consensus.  The subsets come from ``tike_amd.random.
     randomizer_np`` exactly as the reference draws them (`subsets`: drawn
     earlier by `ransac_subsets`, for a fit that is carried out later)."""
-    transform = AffineTransform() if transform is None else transform
-    best_fitness = np.inf
     if subsets is None:
         subsets = ransac_subsets(len(positions0), min_sample, max_iter)
-    for subset in subsets:
-        candidate, _ = estimate_global_transformation(
-            positions0[subset], positions1[subset], weights, transform)
-        error = np.linalg.norm(candidate(positions0) - positions1, axis=-1)
-        inliers = error <= max_error
-        if np.sum(inliers) / len(inliers) >= min_consensus:
-            candidate, fitness = estimate_global_transformation(
-                positions0[inliers], positions1[inliers], weights, candidate)
-            if fitness < best_fitness:
-                best_fitness = fitness
-                transform = candidate
-    return transform, best_fitness
+    best = (np.inf, AffineTransform() if transform is None else transform)
+    for fitness, model in _consensus_fits(positions0, positions1, weights,
+                                          subsets, max_error, min_consensus):
+        if fitness < best[0]:
+            best = (fitness, model)
+    return best[1], best[0]
 
 
 def gaussian_derivative_taps(sigma=0.333, truncate=6.0):
@@ -222,51 +232,51 @@ class PositionOptions:
     _momentum: np.ndarray = dataclasses.field(init=False, default=None)
 
     def __post_init__(self):
-        if A.is_device(self.initial_scan):
-            self.initial_scan = self.initial_scan.to(torch.float32)
-            n = tuple(self.initial_scan.shape)
-            if self.confidence is None:
-                self.confidence = torch.ones_like(self.initial_scan)
-            if self.use_adaptive_moment:
-                self._momentum = torch.zeros((*n[:-1], 4), dtype=torch.float32,
-                                             device=self.initial_scan.device)
-            return
-        self.initial_scan = np.asarray(self.initial_scan).astype(
-            precision.floating)
+        """float32 positions; unit confidence and zero ADAM moments unless
+        given.  Host (NumPy) and device (torch) arrays alike."""
+        scan = self.initial_scan
+        on_device = A.is_device(scan)
+        if on_device:
+            scan = scan.to(torch.float32)
+            fill = lambda value, *shape: torch.full(  # noqa: E731
+                shape, value, dtype=torch.float32, device=scan.device)
+        else:
+            scan = np.asarray(scan).astype(precision.floating)
+            fill = lambda value, *shape: np.full(  # noqa: E731
+                shape, value, dtype=precision.floating)
+        self.initial_scan = scan
         if self.confidence is None:
-            self.confidence = np.ones(self.initial_scan.shape,
-                                      dtype=precision.floating)
+            self.confidence = fill(1.0, *scan.shape)
         if self.use_adaptive_moment:
-            self._momentum = np.zeros((*self.initial_scan.shape[:-1], 4),
-                                      dtype=precision.floating)
+            self._momentum = fill(0.0, *scan.shape[:-1], 4)
 
-    def _like(self, initial_scan, confidence, momentum):
-        new = PositionOptions(
-            initial_scan, use_adaptive_moment=self.use_adaptive_moment,
-            vdecay=self.vdecay, mdecay=self.mdecay,
-            use_position_regularization=self.use_position_regularization,
-            update_magnitude_limit=self.update_magnitude_limit,
-            transform=self.transform, origin=self.origin,
-            confidence=confidence, update_start=self.update_start)
-        if self.use_adaptive_moment:
+    def _like(self, initial_scan, confidence, momentum=None, **changes):
+        """A copy of the settings around other per-position arrays
+        (momentum None: start from zero moments)."""
+        settings = {
+            f.name: getattr(self, f.name)
+            for f in dataclasses.fields(self)
+            if f.init and f.name not in ("initial_scan", "confidence")
+        }
+        settings.update(changes)
+        new = PositionOptions(initial_scan, confidence=confidence, **settings)
+        if self.use_adaptive_moment and momentum is not None:
             new._momentum = momentum
         return new
 
     def split(self, indices) -> "PositionOptions":
-        """Keep only the positions in `indices` (position.py:432-447)."""
-        return self._like(
-            self.initial_scan[..., indices, :],
-            None if self.confidence is None else
-            self.confidence[..., indices, :],
-            None if self._momentum is None else
-            self._momentum[..., indices, :])
+        """The options of the positions `indices` only (position.py:432-447)."""
+        rows = lambda v: None if v is None else v[..., indices, :]  # noqa: E731
+        return self._like(rows(self.initial_scan), rows(self.confidence),
+                          rows(self._momentum))
 
     def insert(self, other, indices):
-        self.initial_scan[..., indices, :] = other.initial_scan
-        if self.confidence is not None:
-            self.confidence[..., indices, :] = other.confidence
-        if self.use_adaptive_moment:
-            self._momentum[..., indices, :] = other._momentum
+        """Write `other`'s per-position arrays into rows `indices` of this
+        one's (the inverse of `split`, position.py:449-456)."""
+        for name in ("initial_scan", "confidence", "_momentum"):
+            mine, theirs = getattr(self, name), getattr(other, name)
+            if mine is not None and theirs is not None:
+                mine[..., indices, :] = theirs
         return self
 
     @staticmethod
@@ -293,16 +303,11 @@ class PositionOptions:
                           h(self._momentum))
 
     def resample(self, factor: float) -> "PositionOptions":
-        new = PositionOptions(
-            self.initial_scan * factor,
-            use_adaptive_moment=self.use_adaptive_moment, vdecay=self.vdecay,
-            mdecay=self.mdecay,
-            use_position_regularization=self.use_position_regularization,
-            update_magnitude_limit=self.update_magnitude_limit,
-            transform=self.transform.resample(factor),
-            confidence=self.confidence, update_start=self.update_start,
-            origin=self.origin * factor)
-        return new  # momentum restarts at zero when the grid changes
+        """The options on a grid `factor` times finer: lengths scale, the
+        ADAM moments restart from zero (position.py:534-553)."""
+        return self._like(self.initial_scan * factor, self.confidence,
+                          transform=self.transform.resample(factor),
+                          origin=self.origin * factor)
 
     # second (v) and first (m) moments of ADAM, packed as the reference does
     @property
@@ -325,27 +330,28 @@ class PositionOptions:
 def affine_position_regularization(updated, position_options, max_error=32,
                                    *, positions0=None, positions1=None,
                                    relax=0.9):
-    """Fit the global affine transformation between the initial and the
-    updated positions and, if asked, pull the positions towards it
-    (position.py:716-776).
+    """Refresh `position_options.transform` -- the global affine map from the
+    initial to the updated positions (RANSAC, about `origin`) -- and, when
+    `use_position_regularization` is set, move every updated position the
+    fraction `relax` of the way to where that map puts its initial position
+    (translation excluded) (position.py:716-776).
 
     `updated` / `position_options.initial_scan` are this rank's positions;
     `positions0` / `positions1` are the host arrays the fit uses (all
     positions of the job; default: this rank's own).
     """
-    origin = A.to_host(position_options.origin)
     if positions0 is None:
         positions0 = A.to_host(position_options.initial_scan)
         positions1 = A.to_host(updated)
-    new_transform, _ = estimate_global_transformation_ransac(
-        positions0=positions0 - origin, positions1=positions1 - origin,
-        transform=position_options.transform, max_error=max_error)
-    position_options.transform = new_transform
-    if position_options.use_position_regularization:
-        predicted = new_transform(position_options.initial_scan, shift=False)
-        updated = updated * (1 - relax) + relax * predicted
-        if A.is_device(updated):
-            updated = updated.to(torch.float32)
-        else:
-            updated = updated.astype(precision.floating)
-    return updated, position_options
+    origin = A.to_host(position_options.origin)
+    position_options.transform = estimate_global_transformation_ransac(
+        positions0 - origin, positions1 - origin,
+        transform=position_options.transform, max_error=max_error)[0]
+    if not position_options.use_position_regularization:
+        return updated, position_options
+    target = position_options.transform(position_options.initial_scan,
+                                        shift=False)
+    pulled = updated * (1 - relax) + relax * target
+    pulled = (pulled.to(torch.float32) if A.is_device(pulled) else
+              pulled.astype(precision.floating))
+    return pulled, position_options

@@ -96,53 +96,62 @@ class ProbeOptions:
 
 
 def get_varying_probe(shared_probe, eigen_probe=None, weights=None):
-    """weights[0]*probe + sum_c weights[c+1]*eigen[c] (probe.py:272-303).
+    """The probe of every position: weights[:, 0] * shared probe plus, for the
+    modes that own eigen probes, sum_c weights[:, c + 1] * eigen_probe[c]
+    (probe.py:272-303).  shared_probe (..., 1, 1, S, H, W); eigen_probe
+    (..., 1, C, S', H, W) with S' <= S; weights (..., N, C + 1, S) ->
+    (..., N, 1, S, H, W).  Without weights: a copy of the shared probe.
 
     The solver never materialises this (the HIP kernels synthesise it on the
     fly); kept for the API and for tests.
     """
-    sp, was = _t(shared_probe)
+    shared, was = _t(shared_probe)
     if weights is None:
-        return _back(sp.clone(), was)
-    w, _ = _t(weights)
-    unique = w[..., [0], :, None, None] * sp
+        return _back(shared.clone(), was)
+    w = _t(weights)[0][..., None, None]  # (..., N, C + 1, S, 1, 1)
+    unique = w[..., :1, :, :, :] * shared
     if eigen_probe is not None:
-        ep, _ = _t(eigen_probe)
-        m = ep.shape[-3]
-        for c in range(ep.shape[-4]):
-            unique[..., :m, :, :] += (w[..., [c + 1], :m, None, None] *
-                                      ep[..., [c], :m, :, :])
+        eigen = _t(eigen_probe)[0]
+        varying = eigen.shape[-3]
+        unique[..., :varying, :, :] += torch.sum(
+            w[..., 1:, :varying, :, :] * eigen, dim=-4, keepdim=True)
     return _back(unique, was)
 
 
+def _clip_outliers(weights, percentile=0.95, slack=1.5):
+    """Limit |weights| to `slack` times their `percentile` over the positions
+    (axis -3; linear interpolation between order statistics, what
+    np.percentile / cp.percentile compute), keeping the signs.  A sort, not
+    torch.quantile, which is two orders of magnitude slower on ROCm here."""
+    magnitude = weights.abs()
+    ranked = torch.sort(magnitude, dim=-3).values
+    at = percentile * (magnitude.shape[-3] - 1)
+    below = int(np.floor(at))
+    above = min(below + 1, magnitude.shape[-3] - 1)
+    blend = float(at - below)
+    limit = slack * torch.lerp(ranked[..., below:below + 1, :, :],
+                               ranked[..., above:above + 1, :, :], blend)
+    return torch.minimum(magnitude, limit) * torch.sign(weights)
+
+
 def constrain_variable_probe(variable_probe, weights):
-    """Normalise, orthogonalise and sort the eigen probes; clip weight
-    outliers at 1.5x the 95th percentile (probe.py:306-359)."""
-    vp, was = _t(variable_probe)
+    """Keep the eigen-probe decomposition well posed (probe.py:306-359): unit
+    mean-square eigen probes (their scale moves into the weights),
+    Gram-Schmidt orthogonal across the eigen index, ordered by the power of
+    their weights, and weight outliers clipped (`_clip_outliers`)."""
+    eigen, was = _t(variable_probe)
     w, _ = _t(weights)
-    vnorm = linalg.mnorm(vp, axis=(-2, -1), keepdims=True)
-    vp = vp / vnorm
-    pwm = vp.shape[-3]
-    w[..., 1:, :pwm] *= vnorm[..., 0, 0]
-    vp = linalg.orthogonalize_gs(vp, axis=(-2, -1), N=-4)
-    power = linalg.norm(w[..., 1:, :pwm], keepdims=True, axis=-3)**2
-    for i in range(pwm):
-        order = torch.argsort(-power[..., i].flatten())
-        w[..., 1:, i] = w[..., 1 + order, i]
-        vp[..., :, i, :, :] = vp[..., order, i, :, :]
-    aevol = w.abs()
-    # 95th percentile over positions with linear interpolation (what
-    # cp.percentile / np.percentile compute); a sort, not torch.quantile,
-    # which is two orders of magnitude slower on ROCm for this shape.
-    srt = torch.sort(aevol, dim=-3).values
-    npos = aevol.shape[-3]
-    pos = 0.95 * (npos - 1)
-    lo, hi = int(np.floor(pos)), int(np.ceil(pos))
-    frac = float(pos - lo)
-    limit = 1.5 * (srt[..., lo:lo + 1, :, :] * (1.0 - frac) +
-                   srt[..., hi:hi + 1, :, :] * frac)
-    w = torch.minimum(aevol, limit) * torch.sign(w)
-    return _back(vp, was), _back(w, was)
+    varying = eigen.shape[-3]
+    scale = linalg.mnorm(eigen, axis=(-2, -1), keepdims=True)
+    w[..., 1:, :varying] *= scale[..., 0, 0]
+    eigen = linalg.orthogonalize_gs(eigen / scale, axis=(-2, -1), N=-4)
+    strength = torch.square(w[..., 1:, :varying]).sum(dim=-3)  # (..., C, S')
+    for mode in range(varying):
+        ranking = torch.argsort(strength[..., mode].flatten(),
+                                descending=True)
+        w[..., 1:, mode] = w[..., 1 + ranking, mode]
+        eigen[..., :, mode, :, :] = eigen[..., ranking, mode, :, :]
+    return _back(eigen, was), _back(_clip_outliers(w), was)
 
 
 def orthogonalize_eig(x):
@@ -176,93 +185,108 @@ def power(probe):
 
 
 def gaussian(size, rin=0.8, rout=1.0):
-    """Flat-top radial probe amplitude (probe.py:784-814)."""
-    r, c = np.mgrid[:size, :size] + 0.5
-    rs = np.sqrt((r - size / 2)**2 + (c - size / 2)**2)
-    rmax = np.sqrt(2) * 0.5 * rout * rs.max() + 1.0
-    rmin = np.sqrt(2) * 0.5 * rin * rs.max()
-    img = np.zeros((size, size), dtype=precision.floating)
-    img[rs < rmin] = 1.0
-    img[rs > rmax] = 0.0
-    zone = np.logical_and(rs > rmin, rs < rmax)
-    img[zone] = np.divide(rmax - rs[zone], rmax - rmin)
-    return img
+    """Flat-top probe amplitude on a size x size grid (probe.py:784-814): 1
+    inside the radius rin, 0 outside rout, a linear ramp between them; radii
+    are measured from the grid centre to pixel centres, in units of the
+    half-diagonal scaled by sqrt(2)/2 (rout is one pixel wider)."""
+    offset = (np.arange(size) + 0.5) - size / 2
+    radius = np.sqrt(np.add.outer(offset**2, offset**2))
+    reach = np.sqrt(2) * 0.5 * radius.max()
+    inner, outer = rin * reach, rout * reach + 1.0
+    ramp = (outer - radius) / (outer - inner)
+    return np.select([radius < inner, (radius > inner) & (radius < outer)],
+                     [1.0, ramp], 0.0).astype(precision.floating)
 
 
 def adjust_probe_power(probe, power=None):
-    """Rescale modes to relative power 1/N by default (probe.py:479-497)."""
-    if power is None:
-        power = 1.0 / np.arange(1, probe.shape[-3] + 1)
-    power = power[..., None, None]
-    norm = np.sqrt(np.sum(np.abs(probe)**2, axis=(-2, -1), keepdims=True))
-    probe *= power * norm[..., 0:1, :, :] / norm
+    """Give the modes the relative powers `power` (default 1, 1/2, ... 1/M) in
+    units of the first mode's norm; rescales `probe` in place and returns it
+    (probe.py:479-497)."""
+    modes = probe.shape[-3]
+    share = 1.0 / np.arange(1, modes + 1) if power is None else power
+    amplitude = np.sqrt(np.sum(np.abs(probe)**2, axis=(-2, -1), keepdims=True))
+    gain = share[..., None, None] * amplitude[..., :1, :, :]
+    np.multiply(probe, gain / amplitude, out=probe)
     return probe
 
 
 def add_modes_random_phase(probe, nmodes):
-    """Extra modes = first mode times random linear phase ramps
-    (probe.py:500-531)."""
-    all_modes = np.empty((*probe.shape[:-3], nmodes, *probe.shape[-2:]),
-                         dtype=probe.dtype)
-    pw = probe.shape[-1]
-    for m in range(nmodes):
-        if m < probe.shape[-3]:
-            all_modes[..., m, :, :] = probe[..., m, :, :]
-        else:
-            shift = np.exp(-2j * np.pi * (np.random.rand(2, 1) - 0.5) *
-                           ((np.arange(0, pw) + 0.5) / pw - 0.5))
-            all_modes[..., m, :, :] = (probe[..., 0, :, :] * shift[0][None] *
-                                       shift[1][:, None])
-    return all_modes
+    """A probe of `nmodes` modes: the given ones, then copies of mode 0 under
+    random linear phase ramps -- tilts of up to half a period across the
+    window in x and y, two legacy-generator draws per new mode (Odstrcil et
+    al., Opt. Express 24, 8360; probe.py:500-531)."""
+    given = probe.shape[-3]
+    width = probe.shape[-1]
+    coordinate = (np.arange(width) + 0.5) / width - 0.5
+    modes = [probe[..., m, :, :] for m in range(min(given, nmodes))]
+    for _ in range(nmodes - given):
+        tilt_x, tilt_y = np.random.rand(2) - 0.5
+        ramp_x = np.exp(-2j * np.pi * tilt_x * coordinate)
+        ramp_y = np.exp(-2j * np.pi * tilt_y * coordinate)
+        modes.append(probe[..., 0, :, :] * ramp_x * ramp_y[:, None])
+    return np.stack(modes, axis=-3).astype(probe.dtype, copy=False)
+
+
+def _jittered_weights(shape, varying):
+    """Eigen-probe weights before anything is known: 1 for the shared probe
+    (index 0 of axis -2), a zero-mean 1e-6 jitter over the positions (axis -3)
+    for the eigen probes of the first `varying` modes, 0 for the rest.  The
+    whole block is drawn from the legacy generator, used or not."""
+    jitter = 1e-6 * np.random.rand(*shape).astype(precision.floating)
+    jitter -= jitter.mean(axis=-3, keepdims=True)
+    weights = np.zeros_like(jitter)
+    weights[..., 1:, :varying] = jitter[..., 1:, :varying]
+    weights[..., 0, :] = 1.0
+    return weights
 
 
 def init_varying_probe(scan, shared_probe, num_eigen_probes,
                        probes_with_modes=1):
-    """Initial eigen probes and weights (probe.py:660-723)."""
-    probes_with_modes = max(probes_with_modes, 0)
-    if probes_with_modes > shared_probe.shape[-3]:
-        raise ValueError(
-            f"probes_with_modes ({probes_with_modes}) cannot be more than "
-            f"the number of probes ({shared_probe.shape[-3]})!")
+    """(eigen_probe, weights) to start an orthogonal-probe-relaxation run
+    (probe.py:660-723).  weights (..., N, num_eigen_probes, S) float32, see
+    `_jittered_weights`; eigen_probe (..., 1, num_eigen_probes - 1,
+    probes_with_modes, H, W): unit-mean-square complex noise from
+    `tike_amd.random.randomizer_np`, drawn after the weights (None when there
+    is nothing besides the shared probe)."""
+    *lead, _, modes, height, width = shared_probe.shape
+    varying = max(probes_with_modes, 0)
+    if varying > modes:
+        raise ValueError(f"probes_with_modes ({varying}) cannot be more than "
+                         f"the number of probes ({modes})!")
     if num_eigen_probes < 1:
         return None, None
-    weights = 1e-6 * np.random.rand(
-        *scan.shape[:-1], num_eigen_probes,
-        shared_probe.shape[-3]).astype(precision.floating)
-    weights -= np.mean(weights, axis=-3, keepdims=True)
-    weights[..., 0, :] = 1.0
-    weights[..., 1:, probes_with_modes:] = 0
+    weights = _jittered_weights((*scan.shape[:-1], num_eigen_probes, modes),
+                                varying)
     if num_eigen_probes == 1:
         return None, weights
-    eigen_probe = trandom.numpy_complex(*shared_probe.shape[:-4],
-                                        num_eigen_probes - 1,
-                                        probes_with_modes,
-                                        *shared_probe.shape[-2:])
-    eigen_probe /= linalg.mnorm(eigen_probe, axis=(-2, -1), keepdims=True)
-    return eigen_probe, weights
+    noise = trandom.numpy_complex(*lead, num_eigen_probes - 1, varying, height,
+                                  width)
+    return noise / linalg.mnorm(noise, axis=(-2, -1), keepdims=True), weights
 
 
 def finite_probe_support(probe, *, radius=0.5, degree=5.0, p=1.0):
-    """Supergaussian penalty mask (probe.py:919-964)."""
+    """Penalty p * (1 - exp(-(r / radius)^(2 degree))) on the probe grid, r
+    measured in window widths from the centre (probe.py:919-964): 0 in the
+    middle, p far outside `radius`.  0.0 when p <= 0."""
     if p <= 0:
         return 0.0
-    N = probe.shape[-1]
-    centers = torch.linspace(-0.5, 0.5, N + 1, device=probe.device)[:-1] + 0.5 / N
-    i, j = torch.meshgrid(centers, centers, indexing="xy")
-    mask = 1 - torch.exp(-(torch.square(i / radius) +
-                           torch.square(j / radius))**degree)
-    return (p * mask).to(torch.float32)
+    width = probe.shape[-1]
+    axis = (torch.arange(width, device=probe.device, dtype=torch.float32) +
+            0.5) / width - 0.5
+    r2 = (torch.square(axis)[:, None] + torch.square(axis)[None, :]) / (
+        radius * radius)
+    return (p * -torch.expm1(-r2**degree)).to(torch.float32)
 
 
 def rescale_probe_using_fixed_intensity_photons(probe, Nphotons,
                                                 probe_power_fraction=None):
-    """Rescale shared modes so their total intensity is Nphotons
-    (probe.py:967-993)."""
-    photons = torch.sum(probe.abs()**2, (-1, -2))
-    if probe_power_fraction is None:
-        probe_power_fraction = photons / torch.sum(photons)
-    return probe * torch.sqrt(probe_power_fraction * Nphotons /
-                              photons)[..., None, None]
+    """Scale every shared mode so that the modes hold Nphotons in total, split
+    as `probe_power_fraction` (default: as they are) (probe.py:967-993)."""
+    energy = probe.abs().square().sum(dim=(-2, -1), keepdim=True)
+    share = (energy / energy.sum() if probe_power_fraction is None else
+             torch.as_tensor(probe_power_fraction,
+                             device=probe.device)[..., None, None])
+    return probe * torch.sqrt(share * Nphotons / energy)
 
 
 # ---------------------------------------------------------- probe constraints
@@ -400,10 +424,11 @@ def add_modes_cartesian_hermite(probe, nmodes):
 
 
 def simulate_varying_weights(scan, eigen_probe):
-    """Random sinusoidal eigen-probe weights along the scan: amplitude 1,
-    random phase, period at most one scan (probe.py:647-657)."""
-    N = scan.shape[1]
-    x = np.arange(N)[..., :, None, None]
-    period = N * np.random.rand(*eigen_probe.shape[:-2])
-    phase = 2 * np.pi * np.random.rand(*eigen_probe.shape[:-2])
-    return np.sin(2 * np.pi / period * x - phase)
+    """Sinusoidal eigen-probe weights along the scan, for simulations: unit
+    amplitude, a random period of at most one scan length and a random phase
+    per eigen probe and mode (probe.py:647-657; legacy generator, the periods
+    drawn before the phases)."""
+    count = scan.shape[1]
+    period, phase = np.random.rand(2, *eigen_probe.shape[:-2])
+    index = np.arange(count).reshape(count, 1, 1)
+    return np.sin(2 * np.pi / (count * period) * index - 2 * np.pi * phase)
