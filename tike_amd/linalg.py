@@ -68,39 +68,46 @@ def hermitian(x):
 
 
 def lstsq(a, b, weights=None):
-    """Batched least squares a @ x = b (linalg.py:33-61)."""
-    assert a.shape[:-1] == b.shape[:-1]
+    """Least-squares solution x of a @ x = b for stacks of matrices, a
+    (..., M, N), b (..., M, K) -> x (..., N, K), through the normal equations
+    (a^H a) x = a^H b; rows optionally weighted by `weights` (..., M)
+    (linalg.py:33-61)."""
+    if tuple(a.shape[:-1]) != tuple(b.shape[:-1]):
+        raise AssertionError(f"Leading dims of a {tuple(a.shape)} and b "
+                             f"{tuple(b.shape)} must be same!")
     if weights is not None:
-        assert weights.shape == a.shape[:-1]
-        w = _sqrt(weights[..., None])
-        a, b = a * w, b * w
-    aT = hermitian(a)
-    inv = torch.linalg.inv if _is_t(a) else np.linalg.inv
-    return inv(aT @ a) @ aT @ b
+        if tuple(weights.shape) != tuple(a.shape[:-1]):
+            raise AssertionError("one weight per row of a")
+        row_scale = _sqrt(weights)[..., None]
+        a, b = a * row_scale, b * row_scale
+    solve = torch.linalg.solve if _is_t(a) else np.linalg.solve
+    adjoint = hermitian(a)
+    return solve(adjoint @ a, adjoint @ b)
 
 
 def orthogonalize_gs(x, axis=-1, N=None):
-    """Gram-Schmidt orthogonalisation (linalg.py:64-105)."""
-    try:
-        axis = tuple(a % x.ndim for a in axis)
-    except TypeError:
-        axis = (axis % x.ndim,)
+    """Gram-Schmidt for complex arrays (linalg.py:64-105): the vectors live
+    on `axis` (one or several dimensions) and are counted along dimension N
+    (default: the last dimension outside `axis`); all other dimensions
+    broadcast.  Vector k + 1 onwards lose their component along the already
+    orthogonal vector k, for k = 0, 1, ..."""
+    dims = x.ndim
+    along = tuple(d % dims for d in (axis if isinstance(axis, (tuple, list))
+                                     else (axis,)))
     if N is None:
-        N = x.ndim - 1
-        while N in axis:
-            N -= 1
-    N = N % x.ndim
-    if N in axis:
+        N = max((d for d in range(dims) if d not in along), default=-1)
+    N %= dims
+    if N in along:
         raise ValueError("Cannot orthogonalize a single vector.")
-    if _is_t(x):
-        x = torch.movedim(x, N, 0)
-        u = x.clone()
-    else:
-        x = np.moveaxis(x, N, 0)
-        u = x.copy()
-    for i in range(1, len(x)):
-        u[i:] -= projection(x[i:], u[i - 1:i], axis=axis)
-    return torch.movedim(u, 0, N) if _is_t(u) else np.moveaxis(u, 0, N)
+    move = torch.movedim if _is_t(x) else np.moveaxis
+    original = move(x, N, 0)
+    basis = original.clone() if _is_t(x) else original.copy()
+    for k in range(len(original) - 1):
+        pivot = basis[k:k + 1]
+        overlap = inner(original[k + 1:], pivot, axis=along, keepdims=True)
+        basis[k + 1:] -= pivot * (overlap /
+                                  inner(pivot, pivot, axis=along, keepdims=True))
+    return move(basis, 0, N)
 
 
 def cov(x):

@@ -18,14 +18,11 @@ class Convolution(Operator):
 
     def __init__(self, probe_shape, nz, n, ntheta=None, detector_shape=None,
                  **kwargs):
-        self.probe_shape = probe_shape
-        self.nz = nz
-        self.n = n
-        self.detector_shape = (probe_shape if detector_shape is None else
-                               detector_shape)
-        self.pad = (self.detector_shape - self.probe_shape) // 2
-        self.end = self.probe_shape + self.pad
-        self.patch = Patch()
+        det = probe_shape if detector_shape is None else detector_shape
+        margin = (det - probe_shape) // 2  # probe window centred in detector
+        vars(self).update(probe_shape=probe_shape, detector_shape=det, nz=nz,
+                          n=n, pad=margin, end=margin + probe_shape,
+                          patch=Patch())
 
     @staticmethod
     def _flat(x, keep):

@@ -30,12 +30,10 @@ class FresnelSpectProp(Operator):
 
     def __init__(self, norm="ortho", pixel_size=1e-7, probe_FOV=(1e-6, 1e-6),
                  distance=1e-6, wavelength=1e-9, **kwargs):
-        self.norm = norm
-        self.pixel_size = pixel_size
-        self.probe_FOV = probe_FOV
-        self.distance = distance
-        self.wavelength = wavelength
-        self._cache = {}
+        vars(self).update(norm=norm, pixel_size=pixel_size,
+                          probe_FOV=probe_FOV, distance=distance,
+                          wavelength=wavelength)
+        self._cache = {}  # propagator per (shape, device)
 
     def _propagator(self, shape, device):
         key = (tuple(shape), str(device))

@@ -26,20 +26,18 @@ class Multislice(Operator):
                  multislice_propagation_distance=1e-9,
                  propagation=FresnelSpectProp, diffraction=Convolution,
                  norm="ortho", **kwargs):
-        self.diffraction = diffraction(probe_shape=probe_shape,
-                                       detector_shape=detector_shape, nz=nz,
-                                       n=n, **kwargs)
+        geometry = dict(probe_shape=probe_shape, detector_shape=detector_shape,
+                        nz=nz, n=n)
+        optics = dict(
+            probe_wavelength=probe_wavelength,
+            probe_FOV_lengths=probe_FOV_lengths,
+            multislice_propagation_distance=multislice_propagation_distance)
+        vars(self).update(geometry, **optics)  # the reference's attributes
+        self.diffraction = diffraction(**geometry, **kwargs)
         self.propagation = propagation(
-            norm=norm, probe_shape=probe_shape, wavelength=probe_wavelength,
-            probe_FOV=probe_FOV_lengths,
+            norm=norm, probe_shape=probe_shape, probe_FOV=probe_FOV_lengths,
+            wavelength=probe_wavelength,
             distance=multislice_propagation_distance, **kwargs)
-        self.probe_shape = probe_shape
-        self.detector_shape = detector_shape
-        self.nz = nz
-        self.n = n
-        self.probe_wavelength = probe_wavelength
-        self.probe_FOV_lengths = probe_FOV_lengths
-        self.multislice_propagation_distance = multislice_propagation_distance
 
     def __enter__(self):
         self.propagation.__enter__()
@@ -65,14 +63,22 @@ class Multislice(Operator):
                 "a multislice object needs detector_shape == probe_shape "
                 "(the propagated exit wave is the next slice's probe)")
 
+    def _incident_probes(self, probe, scan, psi):
+        """The probe that falls on slice 0, 1, ...: the exit wave of a slice,
+        carried on by `propagation`, is the next slice's probe
+        (multislice.py:86-91)."""
+        beam = probe
+        for depth, layer in enumerate(psi):
+            yield beam
+            if depth + 1 < len(psi):
+                beam = self.propagation.fwd(
+                    self.diffraction.fwd(psi=layer, scan=scan, probe=beam))
+
     def fwd(self, probe, scan, psi, **kwargs):
-        """multislice.py:69-92."""
+        """Exit wave behind the last slice (multislice.py:69-92)."""
         self._check_slices(psi)
-        exitwave = self.diffraction.fwd(psi=psi[0], scan=scan, probe=probe)
-        for s in range(1, len(psi)):
-            exitwave = self.diffraction.fwd(
-                psi=psi[s], scan=scan, probe=self.propagation.fwd(exitwave))
-        return exitwave
+        *_, last = self._incident_probes(probe, scan, psi)
+        return self.diffraction.fwd(psi=psi[-1], scan=scan, probe=last)
 
     def fwd_return_intermediate_probes(self, probe, scan, psi, **kwargs):
         """Exit wave plus the probe incident on every slice, (D, N, S, pw, pw)
@@ -82,50 +88,39 @@ class Multislice(Operator):
         psi = A.to_device(psi, np.complex64)
         scan = A.to_device(scan, np.float32)
         probe = A.to_device(probe, np.complex64)
-        N = scan.shape[-2]
-        probes = torch.zeros((psi.shape[0], N, *probe.shape[-3:]),
-                             dtype=torch.complex64, device=psi.device)
-        probes[0] = probe[..., 0, :, :, :] if probe.ndim == 5 else probe
-        exitwave = None
-        for t in range(len(psi)):
-            exitwave = self.diffraction.fwd(psi=psi[t], scan=scan,
-                                            probe=probes[t])
-            if t == len(psi) - 1:
-                break
-            probes[t + 1] = self.propagation.fwd(nearplane=exitwave)
-        return A.like_input(exitwave, kind), A.like_input(probes, kind)
+        first = probe[..., 0, :, :, :] if probe.ndim == 5 else probe
+        beams = list(self._incident_probes(first, scan, psi))
+        exitwave = self.diffraction.fwd(psi=psi[-1], scan=scan,
+                                        probe=beams[-1])
+        every = (scan.shape[-2], *probe.shape[-3:])
+        stacked = torch.stack([b.expand(every) for b in beams]).contiguous()
+        return A.like_input(exitwave, kind), A.like_input(stacked, kind)
 
     def adj(self, nearplane, probe, scan, psi, overwrite=False, **kwargs):
-        """multislice.py:144-194 (including the division of psi_adj by the
-        number of slices)."""
+        """Adjoint of `fwd` with respect to the object slices and the probe
+        (multislice.py:144-194): the incident probes are recomputed front to
+        back, then the wave is taken back slice by slice -- each slice yields
+        its object gradient from (wave, incident probe) and hands
+        conj(object) x wave, back-propagated, to the slice in front.  The
+        object gradient is divided by the number of slices, as the reference
+        does."""
         self._check_slices(psi)
         kind = nearplane
         psi = A.to_device(psi, np.complex64)
         scan = A.to_device(scan, np.float32)
         probe = A.to_device(probe, np.complex64)
-        nearplane = A.to_device(nearplane, np.complex64)
-        nslices = len(psi)
-        probes = [None] * nslices
-        probes[0] = probe
-        for s in range(1, nslices):
-            probes[s] = self.propagation.fwd(
-                self.diffraction.fwd(psi=psi[s - 1], scan=scan,
-                                     probe=probes[s - 1]))
-        psi_adj = torch.zeros_like(psi)
-        psi_adj[nslices - 1] = self.diffraction.adj(
-            nearplane=nearplane, probe=probes[nslices - 1], scan=scan,
-            overwrite=False)
-        probe_adj = self.diffraction.adj_probe(nearplane=nearplane, scan=scan,
-                                               psi=psi[nslices - 1])
-        for s in range(nslices - 2, -1, -1):
-            probe_adj = self.propagation.adj(probe_adj)
-            psi_adj[s] = self.diffraction.adj(nearplane=probe_adj,
-                                              probe=probes[s], scan=scan,
-                                              overwrite=False)
-            probe_adj = self.diffraction.adj_probe(nearplane=probe_adj,
-                                                   scan=scan, psi=psi[s])
-        return (A.like_input(psi_adj / nslices, kind),
-                A.like_input(probe_adj, kind))
+        wave = A.to_device(nearplane, np.complex64)
+        beams = list(self._incident_probes(probe, scan, psi))
+        psi_adj = torch.empty_like(psi)
+        for depth in reversed(range(len(psi))):
+            if depth < len(psi) - 1:
+                wave = self.propagation.adj(wave)
+            psi_adj[depth] = self.diffraction.adj(
+                nearplane=wave, probe=beams[depth], scan=scan, overwrite=False)
+            wave = self.diffraction.adj_probe(nearplane=wave, scan=scan,
+                                              psi=psi[depth])
+        return (A.like_input(psi_adj / len(psi), kind),
+                A.like_input(wave, kind))
 
     @property
     def patch(self):
@@ -146,14 +141,11 @@ class SingleSlice(Multislice):
     def __init__(self, detector_shape, probe_shape, nz, n,
                  propagation=ZeroPropagation, diffraction=Convolution,
                  norm="ortho", **kwargs):
-        self.diffraction = diffraction(probe_shape=probe_shape,
-                                       detector_shape=detector_shape, nz=nz,
-                                       n=n, **kwargs)
+        geometry = dict(probe_shape=probe_shape, detector_shape=detector_shape,
+                        nz=nz, n=n)
+        vars(self).update(geometry)
+        self.diffraction = diffraction(**geometry, **kwargs)
         self.propagation = propagation(detector_shape=detector_shape)
-        self.probe_shape = probe_shape
-        self.detector_shape = detector_shape
-        self.nz = nz
-        self.n = n
 
     def fwd(self, probe, scan, psi, **kwargs):
         assert psi.shape[0] == 1 and psi.ndim == 3
@@ -162,8 +154,6 @@ class SingleSlice(Multislice):
     def adj(self, nearplane, probe, scan, psi=None, overwrite=False,
             **kwargs):
         assert psi is None or (psi.shape[0] == 1 and psi.ndim == 3)
-        psi_adj = self.diffraction.adj(nearplane=nearplane, probe=probe,
-                                       scan=scan, overwrite=False)[None, ...]
-        probe_adj = self.diffraction.adj_probe(nearplane=nearplane, scan=scan,
-                                               psi=psi[0], overwrite=False)
-        return psi_adj, probe_adj
+        common = dict(nearplane=nearplane, scan=scan, overwrite=False)
+        return (self.diffraction.adj(probe=probe, **common)[None, ...],
+                self.diffraction.adj_probe(psi=psi[0], **common))

@@ -19,68 +19,76 @@ class Patch(Operator):
     (..., K, width+, width+) with (N * nrepeat) % K == 0 for the adjoint.
     """
 
+    @staticmethod
+    def _geometry(positions, patches, image_stack, patch_width):
+        """Shape rules common to `fwd` and `adj` (the reference's asserts,
+        patch.py:96-101,143-157): returns (stack dims, number of images, N)."""
+        stack = tuple(positions.shape[:-2])
+        assert positions.shape[-1] == 2, positions.shape
+        assert patch_width <= patches.shape[-1]
+        assert tuple(image_stack) == stack
+        assert tuple(patches.shape[:-3]) == stack, (positions.shape,
+                                                    patches.shape)
+        return stack, int(np.prod(stack, dtype=np.int64)), positions.shape[-2]
+
+    @staticmethod
+    def _result(device_array, given, kind):
+        """The caller's own array when one was given (filled in place, as the
+        reference does), else a new array of the caller's kind."""
+        if given is not None and A.is_device(given):
+            if device_array.data_ptr() != given.data_ptr():
+                given.copy_(device_array)
+            return given
+        return A.like_input(device_array, kind)
+
     def fwd(self, images, positions, patches=None, patch_width=0, height=0,
             width=0, nrepeat=1):
+        """patches[..., n * nrepeat + r] = the window of `images` at
+        positions[..., n] (bilinear), written into the centre of the (possibly
+        wider) patch array; allocates zeros when `patches` is None."""
         kind = images
-        patch_width = patches.shape[-1] if patch_width == 0 else patch_width
+        window = patches.shape[-1] if patch_width == 0 else patch_width
         images = A.to_device(images, np.complex64)
         positions = A.to_device(positions, np.float32)
-        lead = tuple(positions.shape[:-2])
         if patches is None:
-            patches_t = torch.zeros(
-                (*lead, positions.shape[-2] * nrepeat, patch_width,
-                 patch_width), dtype=torch.complex64, device=images.device)
+            out = torch.zeros((*positions.shape[:-2],
+                               positions.shape[-2] * nrepeat, window, window),
+                              dtype=torch.complex64, device=images.device)
         else:
-            patches_t = A.to_device(patches, np.complex64)
-        assert patch_width <= patches_t.shape[-1]
-        assert tuple(images.shape[:-2]) == lead
-        assert tuple(patches_t.shape[:-3]) == lead, (positions.shape,
-                                                     patches_t.shape)
-        assert positions.shape[-2] * nrepeat == patches_t.shape[-3]
-        assert positions.shape[-1] == 2, positions.shape
-        nimage = int(np.prod(lead)) if lead else 1
+            out = A.to_device(patches, np.complex64)
+        _, nimage, count = self._geometry(positions, out, images.shape[:-2],
+                                          window)
+        assert count * nrepeat == out.shape[-3]
         check(
-            lib.tike_patch_fwd(A.ptr(images), A.ptr(patches_t),
-                               A.ptr(positions), nimage, images.shape[-2],
-                               images.shape[-1], positions.shape[-2], nrepeat,
-                               patch_width, patches_t.shape[-1],
+            lib.tike_patch_fwd(A.ptr(images), A.ptr(out), A.ptr(positions),
+                               nimage, images.shape[-2], images.shape[-1],
+                               count, nrepeat, window, out.shape[-1],
                                A.stream_ptr()), "Patch.fwd")
-        if patches is not None and A.is_device(patches) and \
-                patches_t.data_ptr() != patches.data_ptr():
-            patches.copy_(patches_t)
-            return patches
-        return A.like_input(patches_t, kind)
+        return self._result(out, patches, kind)
 
     def adj(self, positions, patches, images=None, patch_width=0, height=0,
             width=0, nrepeat=1):
+        """images += the patches scattered back with the same bilinear
+        weights; K = patches.shape[-3] patches are cycled over the
+        N * nrepeat windows (K = 1: one patch added everywhere); allocates a
+        zero (height, width) image stack when `images` is None."""
         kind = patches
         patches = A.to_device(patches, np.complex64)
         positions = A.to_device(positions, np.float32)
-        patch_width = patches.shape[-1] if patch_width == 0 else patch_width
-        assert patch_width <= patches.shape[-1]
-        lead = tuple(positions.shape[:-2])
+        window = patches.shape[-1] if patch_width == 0 else patch_width
         if images is None:
-            images_t = torch.zeros((*lead, height, width),
-                                   dtype=torch.complex64,
-                                   device=patches.device)
+            out = torch.zeros((*positions.shape[:-2], height, width),
+                              dtype=torch.complex64, device=patches.device)
         else:
-            images_t = A.to_device(images, np.complex64)
-        height, width = images_t.shape[-2:]
-        assert tuple(images_t.shape[:-2]) == lead
-        N = positions.shape[-2]
-        assert positions.shape[-1] == 2
-        assert tuple(patches.shape[:-3]) == lead
-        K = patches.shape[-3]
-        assert (N * nrepeat) % K == 0 and K >= nrepeat
+            out = A.to_device(images, np.complex64)
+        _, nimage, count = self._geometry(positions, patches, out.shape[:-2],
+                                          window)
+        given = patches.shape[-3]
+        assert (count * nrepeat) % given == 0 and given >= nrepeat
         assert patches.shape[-1] == patches.shape[-2]
-        nimage = int(np.prod(lead)) if lead else 1
         check(
-            lib.tike_patch_adj(A.ptr(images_t), A.ptr(patches),
-                               A.ptr(positions), nimage, height, width, N,
-                               nrepeat, patch_width, patches.shape[-1], K,
+            lib.tike_patch_adj(A.ptr(out), A.ptr(patches), A.ptr(positions),
+                               nimage, out.shape[-2], out.shape[-1], count,
+                               nrepeat, window, patches.shape[-1], given,
                                A.stream_ptr()), "Patch.adj")
-        if images is not None and A.is_device(images) and \
-                images_t.data_ptr() != images.data_ptr():
-            images.copy_(images_t)
-            return images
-        return A.like_input(images_t, kind)
+        return self._result(out, images, kind)

@@ -36,22 +36,16 @@ class Ptycho(Operator):
                  **kwargs):
         if nz is None or n is None:
             raise TypeError("Ptycho requires nz and n (object height, width)")
+        shapes = dict(probe_shape=probe_shape, detector_shape=detector_shape,
+                      nz=nz, n=n)
+        optics = dict(
+            probe_wavelength=probe_wavelength,
+            probe_FOV_lengths=probe_FOV_lengths,
+            multislice_propagation_distance=multislice_propagation_distance)
+        vars(self).update(shapes, norm=norm, **optics)
+        self.diffraction = diffraction(**shapes, **optics, **kwargs)
         self.propagation = propagation(detector_shape=detector_shape,
                                        norm=norm, **kwargs)
-        self.diffraction = diffraction(
-            probe_shape=probe_shape, probe_wavelength=probe_wavelength,
-            probe_FOV_lengths=probe_FOV_lengths, detector_shape=detector_shape,
-            nz=nz, n=n,
-            multislice_propagation_distance=multislice_propagation_distance,
-            **kwargs)
-        self.probe_shape = probe_shape
-        self.detector_shape = detector_shape
-        self.nz = nz
-        self.n = n
-        self.norm = norm
-        self.probe_wavelength = probe_wavelength
-        self.probe_FOV_lengths = probe_FOV_lengths
-        self.multislice_propagation_distance = multislice_propagation_distance
 
     def __enter__(self):
         self.propagation.__enter__()
@@ -113,15 +107,14 @@ class Ptycho(Operator):
 
     def fwd_return_intermediate_probes(self, probe, scan, psi, **kwargs):
         """(farplane, probes incident on every slice) -- ptycho.py:131-146."""
-        kind = psi
-        psi = A.to_device(psi, np.complex64)
-        scan = A.to_device(scan, np.float32)
-        probe = A.to_device(probe, np.complex64)
-        exitwave, probes = self.diffraction.fwd_return_intermediate_probes(
-            psi=psi, scan=scan, probe=probe)
-        far = self.propagation.fwd(nearplane=exitwave,
-                                   overwrite=True)[..., None, :, :, :]
-        return A.like_input(far, kind), A.like_input(probes, kind)
+        on_device = (A.to_device(psi, np.complex64),
+                     A.to_device(scan, np.float32),
+                     A.to_device(probe, np.complex64))
+        exitwave, beams = self.diffraction.fwd_return_intermediate_probes(
+            psi=on_device[0], scan=on_device[1], probe=on_device[2])
+        far = self.propagation.fwd(nearplane=exitwave, overwrite=True)
+        return (A.like_input(far.unsqueeze(-4), psi),
+                A.like_input(beams, psi))
 
     def adj(self, farplane, probe, scan, psi, overwrite=False, **kwargs):
         kind = farplane

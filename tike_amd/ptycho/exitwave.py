@@ -56,24 +56,26 @@ class ExitWaveOptions:
                                      dtype=bool))
 
 
+def _low_frequencies(n: int, w: int):
+    """Where the w lowest frequencies sit on a corner-centred (unshifted FFT)
+    axis of length n: the first w - w // 2 and the last w // 2 samples."""
+    upper = w // 2
+    return np.r_[0:w - upper, n - upper:n]
+
+
 def crop_fourier_space(x, w: int):
-    """Crop the last two axes of x to w x w keeping the low frequencies of a
-    corner-centred spectrum (exitwave.py:237-249, options.py:366-377)."""
+    """The w x w lowest frequencies of the last two (corner-centred) axes
+    (exitwave.py:237-249, options.py:366-377)."""
     assert x.shape[-2] == x.shape[-1], "Only works on square arrays right now."
-    half1 = w // 2
-    half0 = w - half1
-    keep = np.r_[0:half0, (x.shape[-1] - half1):x.shape[-1]]
-    return x[..., keep][..., keep, :]
+    keep = _low_frequencies(x.shape[-1], w)
+    return x[..., keep[:, None], keep[None, :]]
 
 
 def pad_fourier_space(x, w: int):
-    """Inverse of crop_fourier_space: zero-pad the high frequencies
-    (options.py:380-388)."""
+    """Inverse of crop_fourier_space: the spectrum embedded in a w x w one
+    whose higher frequencies are zero (options.py:380-388)."""
     assert x.shape[-2] == x.shape[-1], "Only works on square arrays right now."
-    half1 = x.shape[-1] // 2
-    half0 = x.shape[-1] - half1
-    new_x = np.zeros((*x.shape[:-2], w, w), dtype=x.dtype)
-    cols = np.r_[0:half0, (w - half1):w]
-    new_x[..., 0:half0, cols] = x[..., 0:half0, :]
-    new_x[..., w - half1:w, cols] = x[..., x.shape[-2] - half1:, :]
-    return new_x
+    slots = _low_frequencies(w, x.shape[-1])
+    wide = np.zeros((*x.shape[:-2], w, w), dtype=x.dtype)
+    wide[..., slots[:, None], slots[None, :]] = x
+    return wide

@@ -96,25 +96,30 @@ def _gaussian_spectrum(lambda0, bandwidth, energy):
         [wavelengths, np.exp(-(wavelengths - lambda0)**2 / sigma**2)], axis=1)
 
 
+def _spectral_lines(lambda0, bandwidth, energy, spectrum):
+    """`energy` (wavelength, weight) rows, brightest first: an even sub-sample
+    of the supplied spectrum (ascending wavelengths), or a Gaussian line."""
+    if spectrum is None:
+        lines = _gaussian_spectrum(lambda0, bandwidth, energy)
+    else:
+        table = np.asarray(spectrum)
+        lines = table[::len(table) // energy][:energy]
+    brightest_first = np.argsort(-lines[:, 1])
+    return lines[brightest_first][:energy]
+
+
 def MW_probe(probe_shape, lambda0, dx, dis_defocus, zone_plate_params,
              energy=1, bandwidth=0.01, spectrum=None):
     """Multi-wavelength probes (1, 1, energy, W, W), brightest line first, each
     scaled by the square root of its spectral weight (fresnel.py:68-157).  All
     wavelengths are propagated to the plane that is `dis_defocus` behind the
     focus of the brightest one."""
-    if spectrum is None:
-        spectrum = _gaussian_spectrum(lambda0, bandwidth, energy)
-    else:
-        spectrum = np.asarray(spectrum)
-        spectrum = spectrum[::spectrum.shape[0] // energy, :][:energy, :]
-    spectrum = spectrum[np.argsort(-spectrum[:, 1])]
-    _, _, focal0 = _zone_plate(spectrum[0, 0], dis_defocus, probe_shape, dx,
-                               zone_plate_params)
+    lines = _spectral_lines(lambda0, bandwidth, energy, spectrum)
+    optics = (dis_defocus, probe_shape, dx, zone_plate_params)
+    plane = _zone_plate(lines[0, 0], *optics)[2] + dis_defocus
     modes = []
-    for wavelength, weight in spectrum[:energy]:
-        plate, pitch, _ = _zone_plate(wavelength, dis_defocus, probe_shape, dx,
-                                      zone_plate_params)
-        field = _fresnel_transform(plate, pitch, focal0 + dis_defocus,
-                                   wavelength)
-        modes.append(_unit_power(field) * np.sqrt(weight))
-    return np.stack(modes, axis=0)[None, None].astype(np.complex64)
+    for wavelength, weight in lines:
+        plate, pitch, _ = _zone_plate(wavelength, *optics)
+        field = _fresnel_transform(plate, pitch, plane, wavelength)
+        modes.append(np.sqrt(weight) * _unit_power(field))
+    return np.stack(modes)[None, None].astype(np.complex64)

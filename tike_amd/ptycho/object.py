@@ -71,13 +71,12 @@ class ObjectOptions:
 
 
 def positivity_constraint(x, r):
-    """r*|x| + (1-r)*x (object.py:207-223)."""
-    if r > 0:
-        if r > 1:
-            raise ValueError(
-                f"Positivity constraint must be in the range [0, 1] not {r}.")
-        return r * x.abs() + (1 - r) * x
-    return x
+    """Move the object the fraction r of the way to its own magnitude (which
+    drains the phase: a "positive" object), r in [0, 1] (object.py:207-223)."""
+    if r > 1:
+        raise ValueError(
+            f"Positivity constraint must be in the range [0, 1] not {r}.")
+    return x if r <= 0 else torch.lerp(x, x.abs().to(x.dtype), float(r))
 
 
 def smoothness_constraint(x, a):
@@ -98,13 +97,15 @@ def smoothness_constraint(x, a):
 
 
 def get_padded_object(scan, probe, extra: int = 0):
-    """Ones-initialised (0.5+0j) object and shifted scan (object.py:256-274)."""
-    int_scan = scan // 1
-    min_corner = np.min(int_scan, axis=-2)
-    max_corner = np.max(int_scan, axis=-2)
-    span = max_corner - min_corner + probe.shape[-1] + 2 + 2 * extra
-    return np.full(span.astype(precision.integer), 0.5 + 0j,
-                   dtype=precision.cfloating), scan + 1 - min_corner + extra
+    """(psi, scan): the smallest object of 0.5 + 0j that holds every patch
+    with a one-pixel border plus `extra`, and the positions moved into it
+    (object.py:256-274)."""
+    corner = np.floor(scan)
+    first = corner.min(axis=-2)
+    pixels = corner.max(axis=-2) - first + (probe.shape[-1] + 2 + 2 * extra)
+    psi = np.full(pixels.astype(precision.integer), 0.5 + 0j,
+                  dtype=precision.cfloating)
+    return psi, scan + (1 + extra) - first
 
 
 def remove_object_ambiguity(psi, probe, preconditioner):

@@ -75,28 +75,25 @@ def simulate(detector_shape, probe, scan, psi, fly=1, eigen_probe=None,
     """Real-valued detector counts of simulated ptychography data
     (ptycho.py:128-179).  Returns (FRAME, det, det) float32 on the host."""
     check_allowed_positions(scan, psi, probe.shape)
-    with Ptycho(probe_shape=probe.shape[-1],
-                detector_shape=int(detector_shape), nz=psi.shape[-2],
-                n=psi.shape[-1], **kwargs) as operator:
-        scan = operator.asarray(scan, dtype=precision.floating)
-        psi = operator.asarray(psi, dtype=precision.cfloating)
-        probe = operator.asarray(probe, dtype=precision.cfloating)
-        if eigen_weights is not None:
-            eigen_weights = operator.asarray(eigen_weights,
-                                             dtype=precision.floating)
-        if eigen_probe is not None:
-            eigen_probe = operator.asarray(eigen_probe,
-                                           dtype=precision.cfloating)
-        N = scan.shape[0]
-        out = torch.empty((N, operator.detector_shape,
-                           operator.detector_shape), dtype=torch.float32,
-                          device=psi.device)
-        for lo, hi, inten in _intensity_chunks(operator, psi, scan, probe,
-                                               eigen_probe, eigen_weights):
-            out[lo:hi] = inten
-        if fly > 1:
-            out = out.reshape(N // fly, fly, *out.shape[-2:]).sum(dim=1)
-        return operator.asnumpy(out)
+    det = int(detector_shape)
+    with Ptycho(det, probe.shape[-1], nz=psi.shape[-2], n=psi.shape[-1],
+                **kwargs) as operator:
+
+        def on_device(array, dtype):
+            return None if array is None else operator.asarray(array,
+                                                               dtype=dtype)
+
+        real, cplx = precision.floating, precision.cfloating
+        frames = [
+            inten for _, _, inten in _intensity_chunks(
+                operator, on_device(psi, cplx), on_device(scan, real),
+                on_device(probe, cplx), on_device(eigen_probe, cplx),
+                on_device(eigen_weights, real))
+        ]
+        counts = torch.cat(frames)
+        if fly > 1:  # `fly` consecutive positions expose one frame
+            counts = counts.reshape(-1, fly, det, det).sum(dim=1)
+        return operator.asnumpy(counts)
 
 
 def reconstruct(data, parameters, num_gpu=None, use_mpi=False, **kwargs):
@@ -137,20 +134,20 @@ def reconstruct_multigrid(data, parameters, num_gpu=None, use_mpi=False,
     `algorithm_options.num_iter` epochs and hands its upsampled result to the
     next."""
     data = A.to_host(data)
-    if (data.shape[-1] * 0.5**(num_levels - 1)) < 64:
+    coarsest = 2**(num_levels - 1)
+    if data.shape[-1] / coarsest < 64:
         warnings.warn("Cropping diffraction patterns to less than 64 pixels "
                       "wide is not recommended because the full doughnut"
                       " may be visible.")
-    resampled = parameters.resample(0.5**(num_levels - 1), interp)
-    for level in range(num_levels - 1, -1, -1):
-        result = reconstruct(
-            data=data if level == 0 else solvers.crop_fourier_space(
-                data, data.shape[-1] // (2**level)),
-            parameters=resampled, num_gpu=num_gpu, use_mpi=use_mpi)
-        if level == 0:
-            return result
-        resampled = result.resample(2.0, interp)
-    raise RuntimeError("This should not happen.")
+    current = parameters.resample(1.0 / coarsest, interp)
+    for shrink in (2**k for k in range(num_levels - 1, -1, -1)):
+        patterns = (data if shrink == 1 else solvers.crop_fourier_space(
+            data, data.shape[-1] // shrink))
+        result = reconstruct(patterns, current, num_gpu=num_gpu,
+                             use_mpi=use_mpi)
+        if shrink > 1:
+            current = result.resample(2.0, interp)
+    return result
 
 
 def _check_batches(order, batches, n_total):
@@ -530,69 +527,85 @@ class Reconstruction():
         torch.cuda.empty_cache()
 
 
+def _penalised(probe, mask):
+    """probe - mask * conj(mask * probe): the reference's support penalties
+    (ptycho.py:733-752)."""
+    return probe - mask * torch.conj(mask * probe)
+
+
+def _probe_steps(options, probe):
+    """(enabled, transform) for every probe constraint, in the order the
+    reference applies them (ptycho.py:731-778)."""
+    yield options.probe_support > 0, lambda p: _penalised(
+        p, finite_probe_support(p, p=options.probe_support,
+                                radius=options.probe_support_radius,
+                                degree=options.probe_support_degree))
+    ramp = torch.linspace(0, 1, probe.shape[-3], dtype=torch.float32,
+                          device=probe.device)[..., None, None]
+    yield options.additional_probe_penalty > 0, lambda p: _penalised(
+        p, options.additional_probe_penalty * ramp)
+    yield options.median_filter_abs_probe, lambda p: (
+        apply_median_filter_abs_probe(
+            p, med_filt_px=options.median_filter_abs_probe_px))
+    yield options.force_centered_intensity, constrain_center_peak
+    yield options.force_sparsity < 1, lambda p: constrain_probe_sparsity(
+        p, f=options.force_sparsity)
+
+
 def _apply_probe_constraints(parameters, *, epoch):
-    """ptycho.py:723-808."""
+    """End-of-epoch treatment of the probe (ptycho.py:723-808): the enabled
+    constraints of `_probe_steps`, orthogonalisation (or just the mode
+    powers), the periodic photon rescale, and the eigen-probe constraint."""
     po = parameters.probe_options
     if po is None:
         return parameters
-    if po.recover_probe(epoch):
-        if po.probe_support > 0:
-            b0 = finite_probe_support(parameters.probe, p=po.probe_support,
-                                      radius=po.probe_support_radius,
-                                      degree=po.probe_support_degree)
-            parameters.probe = parameters.probe - b0 * torch.conj(
-                b0 * parameters.probe)
-        if po.additional_probe_penalty > 0:
-            b1 = po.additional_probe_penalty * torch.linspace(
-                0, 1, parameters.probe.shape[-3], dtype=torch.float32,
-                device=parameters.probe.device)[..., None, None]
-            parameters.probe = parameters.probe - b1 * torch.conj(
-                b1 * parameters.probe)
-        if po.median_filter_abs_probe:
-            parameters.probe = apply_median_filter_abs_probe(
-                parameters.probe, med_filt_px=po.median_filter_abs_probe_px)
-        if po.force_centered_intensity:
-            parameters.probe = constrain_center_peak(parameters.probe)
-        if po.force_sparsity < 1:
-            parameters.probe = constrain_probe_sparsity(parameters.probe,
-                                                        f=po.force_sparsity)
+    updating = po.recover_probe(epoch)
+    if updating:
+        probe = parameters.probe
+        for enabled, transform in _probe_steps(po, probe):
+            if enabled:
+                probe = transform(probe)
         if po.force_orthogonality:
-            parameters.probe, pwr = orthogonalize_eig(parameters.probe)
-            parameters.probe = parameters.probe.contiguous()
+            probe, mode_power = orthogonalize_eig(probe)
+            probe = probe.contiguous()
         else:
-            pwr = probe_power(parameters.probe)
-        po.power.append(pwr)  # device tensor; host array in copy_to_host()
+            mode_power = probe_power(probe)
+        parameters.probe = probe
+        po.power.append(mode_power)  # device tensor; host in copy_to_host()
     o = parameters.algorithm_options
     if (o.rescale_method == "constant_probe_photons"
             and len(o.costs) % o.rescale_period == 0):
         parameters.probe = rescale_probe_using_fixed_intensity_photons(
             parameters.probe, Nphotons=po.probe_photons,
             probe_power_fraction=None)
-    if parameters.eigen_probe is not None and po.recover_probe(epoch):
-        eigen_probe, eigen_weights = constrain_variable_probe(
-            parameters.eigen_probe, parameters.eigen_weights)
-        parameters.eigen_probe = eigen_probe.contiguous()
-        parameters.eigen_weights = eigen_weights.contiguous()
+    if updating and parameters.eigen_probe is not None:
+        parameters.eigen_probe, parameters.eigen_weights = (
+            x.contiguous() for x in constrain_variable_probe(
+                parameters.eigen_probe, parameters.eigen_weights))
     return parameters
 
 
 def _apply_object_constraints(parameters):
-    """ptycho.py:811-854."""
+    """End-of-epoch treatment of the object (ptycho.py:811-854): positivity,
+    smoothness, unit magnitude clip -- each only when its option is set --
+    and the periodic removal of the object / probe scale ambiguity."""
     oo = parameters.object_options
     if oo is None:
         return parameters
-    if oo.positivity_constraint:
-        parameters.psi = positivity_constraint(parameters.psi,
-                                               r=oo.positivity_constraint)
-    if oo.smoothness_constraint:
-        parameters.psi = smoothness_constraint(parameters.psi,
-                                               a=oo.smoothness_constraint)
-    if oo.clip_magnitude:
-        parameters.psi = _clip_magnitude(parameters.psi, a_max=1.0)
+    steps = (
+        (oo.positivity_constraint,
+         lambda x: positivity_constraint(x, r=oo.positivity_constraint)),
+        (oo.smoothness_constraint,
+         lambda x: smoothness_constraint(x, a=oo.smoothness_constraint)),
+        (oo.clip_magnitude, lambda x: _clip_magnitude(x, a_max=1.0)),
+    )
+    for enabled, transform in steps:
+        if enabled:
+            parameters.psi = transform(parameters.psi)
     o = parameters.algorithm_options
-    if (o.name != "dm" and o.rescale_method == "mean_of_abs_object"
-            and oo.preconditioner is not None
-            and len(o.costs) % o.rescale_period == 0):
+    due = len(o.costs) % o.rescale_period == 0
+    if (due and o.name != "dm" and o.rescale_method == "mean_of_abs_object"
+            and oo.preconditioner is not None):
         parameters.psi, parameters.probe = remove_object_ambiguity(
             parameters.psi, parameters.probe, oo.preconditioner)
     return parameters

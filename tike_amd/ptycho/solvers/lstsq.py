@@ -934,48 +934,63 @@ def _update_nearplane(g, stats, probe, eigen_probe, eigen_weights, lo, hi,
     return eigen_probe, eigen_weights
 
 
+def _trimmed_mean(rows, proportion=0.05):
+    """Column means without the `proportion` smallest and largest entries of
+    each column (scipy.stats.trim_mean)."""
+    count = rows.shape[0]
+    cut = int(proportion * count)
+    return torch.sort(rows, dim=0).values[cut:count - cut].mean(dim=0)
+
+
 def _update_position(scan, position_options, numerator, denominator, comm,
                      *, alpha=0.05, epoch=0):
-    """Shift every position against its least-squares estimate
-    (lstsq.py:764-806).  The damping maximum and the trimmed mean run over
-    the positions of ALL ranks."""
-    if epoch < position_options.update_start:
+    """Move every position by its damped least-squares shift estimate
+    numerator / ((1 - alpha) denominator + alpha max(denominator)), clipped to
+    `update_magnitude_limit`, with the common drift (5 % trimmed mean)
+    removed and, if asked, passed through ADAM (lstsq.py:764-806).  The
+    damping maximum and the trimmed mean run over the positions of ALL
+    ranks."""
+    po = position_options
+    if epoch < po.update_start:
         return scan
-    dmax = comm.Allreduce_max(denominator.max())
-    step = numerator / ((1 - alpha) * denominator +
-                        alpha * torch.clamp(dmax, min=1e-6))
-    limit = position_options.update_magnitude_limit
-    if limit > 0:
-        step = torch.clamp(step, -limit, limit)
-    # remove outliers and subtract the mean (scipy.stats.trim_mean, 5 %)
-    every = comm.Allgather_rows(step)
-    n = every.shape[0]
-    cut = int(0.05 * n)
-    trimmed = torch.sort(every, dim=0).values[cut:n - cut].mean(dim=0)
-    step = step - trimmed
-    if position_options.use_adaptive_moment:
-        step, position_options.v, position_options.m = opt.adam(
-            step, position_options.v, position_options.m,
-            vdecay=position_options.vdecay, mdecay=position_options.mdecay)
-    return scan - step
+    ceiling = torch.clamp(comm.Allreduce_max(denominator.max()), min=1e-6)
+    shift = numerator / ((1 - alpha) * denominator + alpha * ceiling)
+    if po.update_magnitude_limit > 0:
+        shift = shift.clamp(-po.update_magnitude_limit,
+                            po.update_magnitude_limit)
+    shift = shift - _trimmed_mean(comm.Allgather_rows(shift))
+    if po.use_adaptive_moment:
+        shift, po.v, po.m = opt.adam(shift, po.v, po.m, vdecay=po.vdecay,
+                                     mdecay=po.mdecay)
+    return scan - shift
+
+
+def _cost_is_falling(errors):
+    """The smaller of the last two epoch costs lies below the larger of the
+    two before the last one."""
+    return len(errors) >= 3 and max(errors[-3:-1]) > min(errors[-2:])
 
 
 def _momentum_checked(g, v, m, mdecay, errors, beta=1.0, memory_length=3):
-    """Momentum only while the cost trends downward and the recent update
-    directions agree (lstsq.py:809-858)."""
-    m = torch.zeros_like(g) if m is None else m
-    previous_g = (torch.zeros((memory_length, *g.shape), dtype=g.dtype,
-                              device=g.device) if v is None else v)
-    previous_g = torch.roll(previous_g, shifts=-1, dims=0)
-    previous_g[-1] = g / linalg.norm(g) * beta
-    if (len(errors) > 2
-            and max(errors[-3], errors[-2]) > min(errors[-2], errors[-1])):
-        corr = linalg.inner(previous_g[:-1], previous_g[-1],
-                            axis=(-2, -1)).real.flatten().cpu().numpy()
-        if np.all(corr > 0):
-            friction, _ = opt.fit_line_least_squares(
-                x=np.arange(len(corr) + 1), y=[0] + np.log(corr).tolist())
-            friction = 0.5 * max(-friction, 0)
-            m = (1 - friction) * m + g
-            return mdecay * m, previous_g, m
-    return torch.zeros_like(g), previous_g, m / 2
+    """Momentum that has to be earned (lstsq.py:809-858).  `v` keeps the last
+    `memory_length` update directions, unit length times `beta`, newest last;
+    `m` is the running sum.  Momentum is granted only if the cost trends
+    downwards (`_cost_is_falling`) AND the newest direction has a positive
+    overlap with every remembered one; the running sum is then damped by half
+    the rate at which the log-overlap falls off into the past (a line fit
+    through it, anchored at 0 for the newest) before `g` joins it.  Otherwise
+    the step is zero and the sum is halved.  Returns (step, v, m)."""
+    memory = (g.new_zeros((memory_length, *g.shape)) if v is None else v)
+    memory = torch.cat((memory[1:], (g / linalg.norm(g) * beta)[None]))
+    total = torch.zeros_like(g) if m is None else m
+    overlap = None
+    if _cost_is_falling(errors):
+        overlap = (memory[:-1] * memory[-1].conj()).real.sum(
+            dim=(-2, -1)).flatten().cpu().numpy()
+    if overlap is None or not (overlap > 0).all():
+        return torch.zeros_like(g), memory, total / 2
+    slope, _ = opt.fit_line_least_squares(
+        x=np.arange(overlap.size + 1),
+        y=np.concatenate(([0.0], np.log(overlap))))
+    total = (1 - 0.5 * max(-slope, 0)) * total + g
+    return mdecay * total, memory, total

@@ -80,28 +80,30 @@ class PtychoParameters():
     position_options: typing.Union[PositionOptions, None] = None
 
     def __post_init__(self):
-        if (self.scan.ndim != 2 or self.scan.shape[1] != 2
-                or np.any(np.asarray(self.scan.shape) < 1)):
+        """Shape rules of the forward model (options.py:141-168): scan (N, 2);
+        probe (1, 1, S, W, W); psi (D, H', W') larger than the probe window;
+        every patch inside psi.  All pixels count as measured unless
+        `exitwave_options` says otherwise."""
+        scan, probe, psi = (tuple(int(n) for n in x.shape)
+                            for x in (self.scan, self.probe, self.psi))
+        if len(scan) != 2 or scan[1] != 2 or scan[0] < 1:
             raise ValueError(f"scan shape {self.scan.shape} is incorrect. "
                              "It should be (N, 2) "
                              "where N >= 1 is the number of scan positions.")
-        if (self.probe.ndim != 5 or tuple(self.probe.shape[:2]) != (1, 1)
-                or np.any(np.asarray(self.probe.shape) < 1)
-                or self.probe.shape[-2] != self.probe.shape[-1]):
+        if (len(probe) != 5 or probe[:2] != (1, 1) or min(probe) < 1
+                or probe[3] != probe[4]):
             raise ValueError(f"probe shape {self.probe.shape} is incorrect. "
                              "It should be (1, 1, S, W, H) "
                              "where S >=1 is the number of probes, and "
                              "W, H >= 1 are the square probe grid dimensions.")
-        if (self.psi.ndim != 3 or np.any(
-                np.asarray(self.psi.shape[-2:]) <= np.asarray(
-                    self.probe.shape[-2:]))):
+        if len(psi) != 3 or psi[1] <= probe[3] or psi[2] <= probe[4]:
             raise ValueError(
                 f"psi shape {self.psi.shape} is incorrect. "
                 "It should be (D, W, H) where W, H > probe.shape[-2:].")
         check_allowed_positions(self.scan, self.psi, self.probe.shape)
         if self.exitwave_options is None:
-            self.exitwave_options = ExitWaveOptions(measured_pixels=np.ones(
-                tuple(self.probe.shape[-2:]), dtype=np.bool_))
+            self.exitwave_options = ExitWaveOptions(
+                measured_pixels=np.ones(probe[3:], dtype=np.bool_))
 
     def _map(self, f, fo):
         return PtychoParameters(
@@ -122,27 +124,30 @@ class PtychoParameters():
     def resample(self, factor: float, interp=None) -> "PtychoParameters":
         """Host copy of the parameters on a grid rescaled by `factor`
         (options.py:170-196): probes by `interp` (Fourier interpolation by
-        default), the object by a cubic spline, positions scaled."""
+        default), the object by a cubic spline, positions scaled; the option
+        objects rescale themselves."""
         interp = _resize_fft if interp is None else interp
-        h = A.to_host
-        return PtychoParameters(
-            probe=interp(h(self.probe), factor),
-            psi=_resize_spline(h(self.psi), factor),
-            scan=h(self.scan) * factor,
-            eigen_probe=interp(h(self.eigen_probe), factor)
-            if self.eigen_probe is not None else None,
-            eigen_weights=None if self.eigen_weights is None else h(
-                self.eigen_weights),
-            algorithm_options=self.algorithm_options,
-            probe_options=self.probe_options.resample(factor, interp)
-            if self.probe_options is not None else None,
-            object_options=self.object_options.resample(factor, interp)
-            if self.object_options is not None else None,
-            position_options=self.position_options.copy_to_host().resample(
-                factor) if self.position_options is not None else None,
-            exitwave_options=self.exitwave_options.resample(factor)
-            if self.exitwave_options is not None else None,
-        )
+
+        def each(value, change):
+            return None if value is None else change(value)
+
+        return dataclasses.replace(
+            self,
+            probe=interp(A.to_host(self.probe), factor),
+            psi=_resize_spline(A.to_host(self.psi), factor),
+            scan=A.to_host(self.scan) * factor,
+            eigen_probe=each(self.eigen_probe,
+                             lambda e: interp(A.to_host(e), factor)),
+            eigen_weights=each(self.eigen_weights, A.to_host),
+            probe_options=each(self.probe_options,
+                               lambda o: o.resample(factor, interp)),
+            object_options=each(self.object_options,
+                                lambda o: o.resample(factor, interp)),
+            position_options=each(
+                self.position_options,
+                lambda o: o.copy_to_host().resample(factor)),
+            exitwave_options=each(self.exitwave_options,
+                                  lambda o: o.resample(factor)))
 
     def copy_to_device(self) -> "PtychoParameters":
         return self._map(
@@ -156,23 +161,27 @@ class PtychoParameters():
 
     @staticmethod
     def split(indices, *, x: "PtychoParameters") -> "PtychoParameters":
-        """Host copy keeping only the positions in `indices`
+        """Host copy of `x` that keeps only the positions `indices`: the
+        per-position arrays (scan, eigen weights, position options) are
+        sliced, the shared ones cast to the working precision
         (options.py:266-290)."""
-        return PtychoParameters(
-            probe=np.asarray(x.probe).astype(precision.cfloating),
-            psi=np.asarray(x.psi).astype(precision.cfloating),
-            scan=np.asarray(x.scan)[indices].astype(precision.floating),
-            eigen_probe=np.asarray(x.eigen_probe).astype(precision.cfloating)
-            if x.eigen_probe is not None else None,
-            eigen_weights=np.asarray(x.eigen_weights)[indices].astype(
-                precision.floating) if x.eigen_weights is not None else None,
+
+        def cast(array, dtype, rows=slice(None)):
+            if array is None:
+                return None
+            return np.asarray(array)[rows].astype(dtype)
+
+        positions = x.position_options
+        return dataclasses.replace(
+            x,
+            probe=cast(x.probe, precision.cfloating),
+            psi=cast(x.psi, precision.cfloating),
+            eigen_probe=cast(x.eigen_probe, precision.cfloating),
+            scan=cast(x.scan, precision.floating, indices),
+            eigen_weights=cast(x.eigen_weights, precision.floating, indices),
             algorithm_options=copy.deepcopy(x.algorithm_options),
-            exitwave_options=x.exitwave_options,
-            probe_options=x.probe_options,
-            object_options=x.object_options,
-            position_options=x.position_options.split(indices)
-            if x.position_options is not None else None,
-        )
+            position_options=(None if positions is None else
+                              positions.split(indices)))
 
 
 def _resize_spline(x, f: float):
@@ -183,10 +192,12 @@ def _resize_spline(x, f: float):
 
 
 def _resize_fft(x, f: float):
-    """Fourier interpolation of the last two axes (options.py:391-409)."""
+    """Fourier interpolation of the last two axes to int(width * f) samples:
+    the spectrum cropped (f < 1) or zero-padded (f > 1) (options.py:391-409)."""
     if f == 1:
         return x
-    crop_or_pad = crop_fourier_space if f < 1 else pad_fourier_space
-    return np.fft.ifft2(
-        crop_or_pad(np.fft.fft2(x, norm="ortho", axes=(-2, -1)),
-                    w=int(x.shape[-1] * f)), norm="ortho", axes=(-2, -1))
+    width = int(x.shape[-1] * f)
+    spectrum = np.fft.fft2(x, norm="ortho")
+    spectrum = (crop_fourier_space(spectrum, width) if f < 1 else
+                pad_fourier_space(spectrum, width))
+    return np.fft.ifft2(spectrum, norm="ortho")

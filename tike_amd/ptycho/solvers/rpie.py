@@ -90,47 +90,46 @@ def rpie(parameters, data, batches, comm, *, op, epoch):
     return parameters
 
 
+def _second_step(direction, options, errors):
+    """The accelerated part of an update: checked momentum once epoch costs
+    exist, ADAM before that.  Keeps the moments in `options`."""
+    if errors:
+        step, options.v, options.m = L._momentum_checked(
+            g=direction, v=options.v, m=options.m, mdecay=options.mdecay,
+            errors=errors, memory_length=3)
+    else:
+        step, options.v, options.m = opt.adam(
+            g=direction, v=options.v, m=options.m, vdecay=options.vdecay,
+            mdecay=options.mdecay)
+    return step
+
+
+def _peak(weight):
+    return torch.amax(weight.real, dim=(-2, -1), keepdim=True)
+
+
 def _update(psi, probe, psi_num, probe_num, object_options, probe_options,
             recover_probe, o, errors=None):
-    """rpie.py:217-307."""
+    """Apply the accumulated rPIE numerators (rpie.py:217-307).  Object:
+    numerator over the alpha-regularised preconditioner
+    (1 - alpha) P + alpha max P; probe: numerator of the first slice over
+    alpha max P only, as the reference does.  With
+    `use_adaptive_moment` the accelerated direction is applied as a second
+    step on top (probe: main mode only, the other modes step twice)."""
     if object_options:
-        P = object_options.preconditioner
-        deno = ((1 - o.alpha) * P + o.alpha *
-                torch.amax(P.real, dim=(-2, -1), keepdim=True))
-        dpsi = psi_num
-        psi = psi + dpsi / deno
+        weight = object_options.preconditioner
+        damping = (1 - o.alpha) * weight + o.alpha * _peak(weight)
+        psi = psi + psi_num / damping
         if object_options.use_adaptive_moment:
-            if errors:
-                dpsi, object_options.v, object_options.m = L._momentum_checked(
-                    g=dpsi, v=object_options.v, m=object_options.m,
-                    mdecay=object_options.mdecay, errors=errors,
-                    memory_length=3)
-            else:
-                dpsi, object_options.v, object_options.m = opt.adam(
-                    g=dpsi, v=object_options.v, m=object_options.m,
-                    vdecay=object_options.vdecay,
-                    mdecay=object_options.mdecay)
-            psi = psi + dpsi / deno
+            psi = psi + _second_step(psi_num, object_options,
+                                     errors) / damping
     if recover_probe:
-        dprobe = probe_num[0]  # (1, 1, S, pw, pw) of the first slice
-        deno = o.alpha * torch.amax(probe_options.preconditioner[0].real,
-                                    dim=(-2, -1), keepdim=True)
-        probe = probe + dprobe / deno
+        step = probe_num[0]  # (1, 1, S, pw, pw): the first slice's probe
+        damping = o.alpha * _peak(probe_options.preconditioner[0])
+        probe = probe + step / damping
         if probe_options.use_adaptive_moment:
-            mode = 0  # ptychoshelves only applies momentum to the main probe
-            if errors:
-                (dprobe[0, 0, mode], probe_options.v,
-                 probe_options.m) = L._momentum_checked(
-                     g=dprobe[0, 0, mode], v=probe_options.v,
-                     m=probe_options.m, mdecay=probe_options.mdecay,
-                     errors=errors, memory_length=3)
-            else:
-                (dprobe[0, 0, mode], probe_options.v,
-                 probe_options.m) = opt.adam(
-                     g=dprobe[0, 0, mode], v=probe_options.v,
-                     m=probe_options.m, vdecay=probe_options.vdecay,
-                     mdecay=probe_options.mdecay)
-            probe = probe + dprobe / deno
+            step[0, 0, 0] = _second_step(step[0, 0, 0], probe_options, errors)
+            probe = probe + step / damping
     return psi, probe.contiguous()
 
 
