@@ -79,11 +79,14 @@ def launch_ranks(a):
 
 # ------------------------------------------------------------ synthetic input
 def synthetic(N_total, S, det, lo, hi, seed=1234):
-    """SURVEY 8(d) generator.  Raster at 8 px pitch + U[0,1) jitter, shuffled
-    once; pw = det; psi amplitude 0.75+0.25U, phase pi(U-0.5); probe = radial
-    flat-top amplitude x random phase, mode m scaled 1/(m+1).  Every rank
-    builds the same global problem and keeps positions [lo, hi) of the
-    shuffled order."""
+    """SURVEY 8(d) generator (the build's own code).  Raster at 8 px pitch +
+    U[0,1) jitter, shuffled once; pw = det; psi amplitude 0.75+0.25U, phase
+    pi(U-0.5); probe mode 0 = flat-top radial amplitude (rin 0.8, rout 1.0)
+    x exp(i pi U) with U smoothed by a 5x5 box; mode m > 0 = mode 0 x a
+    random linear phase ramp (tilts of up to half a period across the
+    window), scaled 1/(m+1).  Every rank builds the same global problem and
+    keeps positions [lo, hi) of the shuffled order."""
+    import scipy.ndimage
     rng = np.random.default_rng(seed)
     pw = det
     side = int(np.ceil(np.sqrt(N_total)))
@@ -95,12 +98,23 @@ def synthetic(N_total, S, det, lo, hi, seed=1234):
     amp = 0.75 + 0.25 * rng.random((1, HW, HW), dtype=np.float32)
     ph = np.pi * (rng.random((1, HW, HW), dtype=np.float32) - 0.5)
     psi = (amp * np.exp(1j * ph)).astype(np.complex64)
-    r = (np.arange(pw) + 0.5 - pw / 2) / (pw / 2)
-    a = np.clip(1.25 - np.sqrt(r[:, None]**2 + r[None, :]**2), 0, 1)
-    probe = np.stack([
-        a * np.exp(1j * np.pi * rng.random((pw, pw))) / (m + 1)
-        for m in range(S)
-    ])[None, None].astype(np.complex64)
+    # flat top of radius 0.8, linear ramp to zero one pixel beyond radius 1.0
+    # (in units of the half width), pixel-centre radii
+    r = np.hypot(*np.meshgrid(np.arange(pw) + 0.5 - pw / 2,
+                              np.arange(pw) + 0.5 - pw / 2, indexing="ij"))
+    reach = (pw - 1) / 2  # sqrt(2)/2 x the pixel-centre half diagonal
+    inner, outer = 0.8 * reach, 1.0 * reach + 1.0
+    window = np.clip((outer - r) / (outer - inner), 0.0, 1.0)
+    phase = scipy.ndimage.uniform_filter(rng.random((pw, pw)), size=5,
+                                         mode="wrap")
+    mode0 = window * np.exp(1j * np.pi * phase)
+    t = (np.arange(pw) + 0.5) / pw - 0.5
+    modes = [mode0]
+    for m in range(1, S):
+        tilt = rng.random(2) - 0.5
+        ramp = np.exp(-2j * np.pi * (tilt[0] * t[None, :] + tilt[1] * t[:, None]))
+        modes.append(mode0 * ramp / (m + 1))
+    probe = np.stack(modes)[None, None].astype(np.complex64)
     return dict(scan=scan[lo:hi], psi=psi, probe=probe, HW=HW, pw=pw, det=det)
 
 
@@ -342,6 +356,96 @@ def measured_traffic(workload, launch_n):
     return {}, None, None
 
 
+EPOCH_DEFAULTS = {
+    # workload: (detector, modes, positions per GPU, minibatches)
+    "c1": (128, 1, 256, 1),
+    "c2": (256, 1, 10000, 10),
+    "c3": (256, 8, 10000, 10),
+    # c5 = 80 000 positions over 8 GPUs
+    "c5": (512, 4, 10000, 10),
+}
+
+
+def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
+    """Synthetic problem + Reconstruction context of one epoch workload.
+    c1 = BASELINE configs[0] (256 positions, 128x128, 1 mode, cgrad, one
+    minibatch); c2: 1 mode, cgrad; c3 (= one GPU's share of c4): 8 modes +
+    eigen probes, lstsq_grad; c5: 512x512, 4 modes, lstsq_grad with position
+    correction.  Global problem: N * world positions; this rank holds its
+    share of every global minibatch, concatenated
+    (Reconstruction(presharded=True))."""
+    det, S, N, num_batch = EPOCH_DEFAULTS[workload]
+    N = positions or N
+    Ng = N * world
+    per = Ng // num_batch
+    share = per // world
+    idx = np.concatenate([
+        np.arange(b * per + rank * share, b * per + (rank + 1) * share)
+        for b in range(num_batch)
+    ])
+    full = synthetic(Ng, S, det, 0, Ng)
+    p = dict(full, scan=full["scan"][idx])
+    N = len(idx)
+    np.random.seed(1234 + rank)
+    eigen_probe = eigen_weights = None
+    C = 0
+    if workload == "c3":
+        import tike_amd.random
+        tike_amd.random.randomizer_np = np.random.default_rng(4321)
+        eigen_probe, eigen_weights = tp.init_varying_probe(
+            p["scan"], p["probe"], num_eigen_probes=2, probes_with_modes=1)
+        C = eigen_probe.shape[-4]
+    data = tp.simulate(det, p["probe"], p["scan"], p["psi"])
+    params = tp.PtychoParameters(
+        probe=p["probe"].copy(),
+        psi=np.full_like(p["psi"], 0.5 + 0j), scan=p["scan"],
+        eigen_probe=eigen_probe, eigen_weights=eigen_weights,
+        # BASELINE configs[0] / [1] name the conjugate-gradient solver
+        algorithm_options=(tp.CgradOptions(num_batch=num_batch, cg_iter=4)
+                           if workload in ("c1", "c2") else
+                           tp.LstsqOptions(num_batch=num_batch,
+                                           batch_method="compact")),
+        probe_options=tp.ProbeOptions(force_orthogonality=True),
+        object_options=tp.ObjectOptions(),
+        position_options=tp.PositionOptions(
+            p["scan"].copy(), use_adaptive_moment=True,
+            update_magnitude_limit=1.0) if workload == "c5" else None)
+    ctx = tp.Reconstruction(
+        data if data_on_host else A.to_device(data, np.float32), params,
+        presharded=True, order=np.arange(N),
+        batches=np.array_split(np.arange(N), num_batch),
+        data_on_host=data_on_host)
+    ctx.__enter__()
+    return dict(ctx=ctx, p=p, data=data, det=det, S=S, N=N, C=C,
+                num_batch=num_batch)
+
+
+def epoch_leg(workload, tp, A, torch, positions=0, epochs=2):
+    """One short leg of another BASELINE configuration: one warm-up epoch,
+    then `epochs` timed ones (wall clock around synchronised epochs)."""
+    built = epoch_problem(workload, positions, 1, 0, tp, A)
+    ctx = built["ctx"]
+    try:
+        ctx.iterate(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.iterate(epochs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        ctx.__exit__(None, None, None)
+    det, S, N = built["det"], built["S"], built["N"]
+    b_iter, f_iter = iteration_bounds(S, det, det)
+    rate = N * epochs / dt
+    return dict(workload=workload, positions=N, modes=S, detector=det,
+                solver="cgrad (cg_iter=4)" if workload in ("c1", "c2") else
+                "lstsq_grad", num_batch=built["num_batch"],
+                position_correction=workload == "c5", epochs=epochs,
+                ms_per_epoch=dt / epochs * 1e3, value=rate, unit="patterns/s",
+                iteration_hbm_frac=b_iter * rate / 1e9 / HBM_PEAK_GBS,
+                iteration_fp32_frac=f_iter * rate / 1e12 / FP32_PEAK_TFLOPS)
+
+
 def forward_leg(ops, A, torch, det, S, N, iters=10):
     """One short leg of the forward operator alone (hip-event timed)."""
     p = synthetic(N, S, det, 0, N)
@@ -428,52 +532,11 @@ def main():
         # probes; c5: 512x512, 4 modes, position correction on
         # c1 = BASELINE configs[0], the reference's CPU-runnable case: 256
         # positions, 128x128, 1 mode, cgrad (one minibatch)
-        det = {"c1": 128, "c5": 512}.get(a.workload, 256)
-        S = {"c1": 1, "c2": 1, "c3": 8, "c5": 4}[a.workload]
-        N = a.positions or {"c1": 256, "c5": 4000}.get(a.workload, 10000)
-        num_batch = 1 if a.workload == "c1" else 10
-        # global problem: N*world positions; this rank's share of every
-        # global minibatch, concatenated (see Reconstruction(presharded=True))
-        Ng = N * world
-        per = Ng // num_batch
-        share = per // world
-        idx = np.concatenate([
-            np.arange(b * per + rank * share, b * per + (rank + 1) * share)
-            for b in range(num_batch)
-        ])
-        full = synthetic(Ng, S, det, 0, Ng)
-        p = dict(full, scan=full["scan"][idx])
-        N = len(idx)
-        np.random.seed(1234 + rank)
-        eigen_probe = eigen_weights = None
-        if a.workload == "c3":
-            import tike_amd.random
-            tike_amd.random.randomizer_np = np.random.default_rng(4321)
-            eigen_probe, eigen_weights = tp.init_varying_probe(
-                p["scan"], p["probe"], num_eigen_probes=2, probes_with_modes=1)
-            C = eigen_probe.shape[-4]
-        data = tp.simulate(det, p["probe"], p["scan"], p["psi"])
-        data_dev = A.to_device(data, np.float32)
-        params = tp.PtychoParameters(
-            probe=p["probe"].copy(),
-            psi=np.full_like(p["psi"], 0.5 + 0j), scan=p["scan"],
-            eigen_probe=eigen_probe, eigen_weights=eigen_weights,
-            # BASELINE configs[1] names the conjugate-gradient solver
-            algorithm_options=(tp.CgradOptions(num_batch=num_batch, cg_iter=4)
-                               if a.workload in ("c1", "c2") else
-                               tp.LstsqOptions(num_batch=num_batch,
-                                               batch_method="compact")),
-            probe_options=tp.ProbeOptions(force_orthogonality=True),
-            object_options=tp.ObjectOptions(),
-            position_options=tp.PositionOptions(
-                p["scan"].copy(), use_adaptive_moment=True,
-                update_magnitude_limit=1.0) if a.workload == "c5" else None)
-        ctx = tp.Reconstruction(data if a.data_on_host else data_dev, params,
-                                presharded=True, order=np.arange(N),
-                                batches=np.array_split(np.arange(N),
-                                                       num_batch),
-                                data_on_host=a.data_on_host)
-        ctx.__enter__()
+        built = epoch_problem(a.workload, a.positions, world, rank, tp, A,
+                              data_on_host=a.data_on_host)
+        ctx, p, data = built["ctx"], built["p"], built["data"]
+        det, S, N, C = built["det"], built["S"], built["N"], built["C"]
+        num_batch = built["num_batch"]
         # every all-reduce, timed like a kernel
         timers.wrap_method(ctx.comm, "Allreduce", "allreduce")
         # ... and counted apart where it is issued once per epoch
@@ -572,6 +635,10 @@ def main():
         secondary = [forward_leg(ops, A, torch, 256, 1, 4096),
                      forward_leg(ops, A, torch, 128, 1, 16384),
                      forward_leg(ops, A, torch, 256, 8, 512)]
+        # ... and the other BASELINE configurations, one short leg each
+        del data, p
+        torch.cuda.empty_cache()
+        secondary += [epoch_leg(w, tp, A, torch) for w in ("c1", "c2", "c5")]
 
     if rank == 0:
         summ = timers.summary()  # the timed steps

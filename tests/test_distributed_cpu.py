@@ -50,6 +50,13 @@ def _allreduce(rank, world):
     mx = comm.Allreduce_max(torch.tensor(3.0 - rank))
     rows = comm.Allgather_rows(
         torch.full((2 + rank, 2), float(rank), dtype=torch.float32))
+    # a collective started early and waited for later, then a plain one
+    early = torch.arange(6, dtype=torch.float32) * (rank + 1)
+    handle = comm.Allreduce_start(early[2:])
+    late = comm.Allreduce(torch.ones(3) * (rank + 1))
+    handle.wait()
+    assert torch.equal(early, torch.tensor([0., rank + 1, 6, 9, 12, 15]))
+    assert torch.equal(late, torch.full((3,), 3.0))
     return (a.numpy(), b.numpy(), s.numpy(), single.numpy(), comm.size,
             comm.rank, float(mx), rows.numpy())
 

@@ -82,11 +82,27 @@ def _worker(rank, world, port, eigen, method, ret, positions=False,
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # every float32 sum the solver issues, in order: ("start" | "sum", numel)
+    from tike_amd.communicators import Comm
+    log = []
+    plain, early = Comm.Allreduce, Comm.Allreduce_start
+
+    def logged_sum(self, *tensors):
+        log.append(("sum", sum(t.numel() * (2 if t.is_complex() else 1)
+                               for t in tensors)))
+        return plain(self, *tensors)
+
+    def logged_start(self, flat):
+        log.append(("start", flat.numel()))
+        return early(self, flat)
+
+    Comm.Allreduce, Comm.Allreduce_start = logged_sum, logged_start
     try:
         r = _reconstruct(eigen, method, positions, rank=rank, shape=shape,
                          num_iter=num_iter)
         ret[rank] = (r.psi, r.probe, r.eigen_weights, r.scan,
-                     np.array(r.algorithm_options.costs))
+                     np.array(r.algorithm_options.costs), log,
+                     r.psi.shape[-2] * r.psi.shape[-1], r.probe.size)
     finally:
         dist.destroy_process_group()
 
@@ -117,7 +133,22 @@ def test_two_ranks_match_one_rank(eigen, method, positions, shape):
         p.join(600)
         assert p.exitcode == 0
     for rank in range(2):
-        psi, probe, ew, scan, costs = ret[rank]
+        psi, probe, ew, scan, costs, log, npix, nprobe = ret[rank]
+        # the same collectives in the same order on both ranks, and per
+        # minibatch: the probe-gradient slice started early (it travels
+        # during the object scatter), then the object slice, then the two
+        # small packed sums of the tail
+        assert log == ret[0][5]
+        starts = [i for i, (kind, n) in enumerate(log)
+                  if kind == "start" and n == 2 * nprobe]
+        assert len(starts) == 2 * num_iter  # two minibatches per epoch
+        for i in starts:
+            assert log[i + 1] == ("sum", 2 * npix), log[i:i + 4]
+        if shape is C3:  # packed tail: exactly two more sums per minibatch
+            for a, b in zip(starts, starts[1:] + [len(log)]):
+                tail = [x for x in log[a + 2:b] if x[0] == "sum"]
+                small = [x for x in tail if x[1] <= 2 * 256 * 256 + 4]
+                assert len(small) >= 2, log[a:b]
         np.testing.assert_allclose(
             costs, np.array(single.algorithm_options.costs), rtol=1e-3)
         assert_close(psi, single.psi, normwise=1e-3, maxabs=1e-2,

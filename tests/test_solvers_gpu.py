@@ -818,6 +818,72 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
                          what="eigen_weights (packed tail)")
 
 
+@pytest.mark.parametrize("u16_and_mask", [False, True])
+def test_resident_gradient_kernel_vs_oracle_beyond_one_wave(tp, u16_and_mask):
+    """The kernel of record (`fwd_grad_ifft2_pass1_resident_kernel`, what
+    `tike_fwd_grad_ifft2_pass1` runs at 256^2 with 8 modes) against the ORACLE
+    at a size where its rotated prefetch is live: 64 positions = 1024 work
+    items for 256 resident workgroups, so every workgroup requests the rows of
+    its next item while it finishes the current one.  (The smaller oracle
+    cases launch fewer work items than workgroups; the bench-sized cases
+    compare with the two-launch path, not with the oracle.)  Variant: uint16
+    counts + a mask with unmeasured pixels that hold garbage."""
+    import tike_amd._arrays as A
+    from tike_amd.communicators import Comm
+    from tike_amd.operators import Ptycho
+    from tike_amd.ptycho.solvers import lstsq as L
+    from oracle import solvers as osol
+    det, S, N = 256, 8, 64
+    scan, psi_true, probe0, ep, ew, data = _headline_problem(
+        tp, det, S, N, seed=77, eigen=True)
+    rng = np.random.default_rng(9)
+    psi0 = (psi_true * (1 + 0.1 * rng.standard_normal(psi_true.shape))
+            ).astype(np.complex64)
+    mask = np.ones((det, det), dtype=bool)
+    data_in = data
+    if u16_and_mask:
+        mask = rng.random((det, det)) > 0.1
+        data = np.round(data * (20000.0 / data.max())).astype(np.uint16)
+        data_in = data.copy()
+        data_in[:, ~mask] = 65535  # never read: the mask selects
+    o = osol.get_nearplane_gradients(
+        data.astype(np.float32), psi0, scan, probe0, ep, ew, 0, N,
+        num_batch=1, detector_shape=det, measured_pixels=mask)
+    calls = []
+    entry = L.lib.tike_fwd_grad_ifft2_pass1
+
+    def counted(*args):
+        calls.append(args[6])  # positions in this launch
+        return entry(*args)
+
+    L.lib.tike_fwd_grad_ifft2_pass1 = counted
+    try:
+        HW = psi0.shape[-1]
+        with Ptycho(probe_shape=det, detector_shape=det, nz=HW, n=HW) as op:
+            out = L._get_nearplane_gradients(
+                A.data_to_device(data_in), A.to_device(psi0),
+                A.to_device(scan), A.to_device(probe0), A.to_device(ep),
+                A.to_device(ew), 0, N, Comm(), num_batch=1,
+                exitwave_options=tp.ExitWaveOptions(measured_pixels=mask),
+                op=op, recover_psi=True, recover_probe=True)
+    finally:
+        L.lib.tike_fwd_grad_ifft2_pass1 = entry
+    assert calls == [N], calls  # one resident launch over all 64 positions
+    np.testing.assert_allclose(out["costs"].cpu().numpy(),
+                               np.ravel(o["costs"]), rtol=COST_RTOL)
+    assert_close(L.object_upd_sum(out).cpu().numpy(), o["object_upd_sum"],
+                 normwise=2e-5, what="object_upd_sum")
+    assert_close(out["m_probe_update"].cpu().numpy(), o["m_probe_update"],
+                 normwise=2e-5, what="m_probe_update")
+    chi0 = out["chi0"]
+    if out["chi_modes"] > 1:
+        chi0 = chi0[:N, 0, 0]
+    assert_close(chi0.cpu().numpy(), o["chi"][:, 0, 0], normwise=2e-5,
+                 what="chi mode 0")
+    assert_close(out["patches"].cpu().numpy(), o["patches"][:, 0, 0],
+                 what="patches")
+
+
 def test_bench_launcher_refuses_more_gpus_than_visible():
     """`python bench.py --gpus N` with fewer than N GPUs must fail loudly
     (never a silent 1-GPU number), before touching the GPU."""

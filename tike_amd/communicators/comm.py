@@ -14,6 +14,13 @@ import torch
 import torch.distributed as dist
 
 
+class _Done:
+    """Handle of a collective that needs no waiting."""
+
+    def wait(self):
+        return True
+
+
 class Comm:
     """All-reduce helper bound to a process group (or to a single rank)."""
 
@@ -80,11 +87,15 @@ class Comm:
             _lib.check(_lib.lib.tike_comm_destroy(handle), "tike_comm_destroy")
 
     def __del__(self):
-        # a Comm used without `with`: do not leak the ncclComm
-        try:
-            self.close()
-        except Exception:  # interpreter shutdown: nothing left to report to
-            pass
+        # Never tear a communicator down from the garbage collector: that can
+        # run mid-epoch on another thread, at interpreter shutdown, or while
+        # other ranks are still inside a collective.  Use `with Comm() as c:`
+        # or call close(); a leaked handle is reported, not destroyed.
+        if getattr(self, "_cabi", None) is not None:
+            import warnings
+            warnings.warn("Comm was not closed: its RCCL communicator is "
+                          "leaked (use it as a context manager)",
+                          ResourceWarning, stacklevel=2)
 
     def Allreduce(self, *tensors):
         """Sum the tensors across ranks IN PLACE; complex tensors are reduced
@@ -119,6 +130,25 @@ class Comm:
                     v.copy_(flat[off:off + n].reshape(v.shape))
                     off += n
         return tensors if len(tensors) != 1 else tensors[0]
+
+    def Allreduce_start(self, flat):
+        """Begin the in-place sum of a contiguous float32 tensor across ranks
+        and return a handle whose ``wait()`` makes the caller's stream wait
+        for it.  The collective runs on the process group's own stream behind
+        everything enqueued so far, so kernels launched between this call and
+        ``wait()`` overlap it (the probe-gradient slice travels while the
+        object scatter runs).  Collectives started here and plain `Allreduce`
+        calls execute in issue order on every rank.  With the library's own
+        communicator (TIKE_COMM_BACKEND=cabi), which lives on the caller's
+        stream, the sum is carried out at once."""
+        if not self.collective:
+            return _Done()
+        assert flat.dtype == torch.float32 and flat.is_contiguous()
+        if self._cabi is not None and flat.is_cuda:
+            self._allreduce_f32(flat)
+            return _Done()
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group,
+                               async_op=True)
 
     def Allreduce_scalars(self, values, device):
         """Sum a short list of 0-d DEVICE tensors across ranks -> float64

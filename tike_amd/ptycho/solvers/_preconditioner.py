@@ -69,13 +69,20 @@ def _probe_preconditioner(parameters, operator):
 def update_preconditioners(comm, parameters, operator, *, psi=True,
                            probe=True):
     """Refresh both preconditioners once per epoch (:170-209).  `psi` /
-    `probe` = False skips one (cgrad reads neither while it iterates)."""
+    `probe` = False skips one (cgrad reads neither while it iterates).  With
+    several ranks the probe preconditioner's sum travels while the object
+    preconditioner's kernel runs."""
+    probe_sum = probe_pre = None
+    if parameters.probe_options and probe:
+        probe_pre = _probe_preconditioner(parameters, operator)
+        probe_sum = comm.Allreduce_start(
+            torch.view_as_real(probe_pre).reshape(-1))
     if parameters.object_options and psi:
         # accumulated as float32 (real-valued), stored complex64 like the
         # reference's array (object.py:69-72)
         parameters.object_options.preconditioner = comm.Allreduce(
             _psi_preconditioner(parameters, operator)).to(torch.complex64)
-    if parameters.probe_options and probe:
-        parameters.probe_options.preconditioner = comm.Allreduce(
-            _probe_preconditioner(parameters, operator))
+    if probe_pre is not None:
+        probe_sum.wait()
+        parameters.probe_options.preconditioner = probe_pre
     return parameters

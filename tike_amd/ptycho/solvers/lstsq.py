@@ -374,6 +374,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     obj_acc = grads[:n_obj].view(2, H, W) if recover_psi else None
     m_probe_update = (torch.view_as_complex(
         grads[n_obj:].view(*probe.shape, 2)) if recover_probe else None)
+    probe_sum = None  # handle of the early all-reduce of the probe gradient
     chi0 = None  # allocated below unless chi itself can be handed on
     patches = None
     pos_major = det in POSITION_MAJOR_SIZES
@@ -644,6 +645,11 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     A.ptr(position_terms[0][clo:chi_hi]),
                     A.ptr(position_terms[1][clo:chi_hi]), n, S, pw, st),
                 "position shift sums")
+        if (chi_hi == hi and comm.collective and recover_psi
+                and recover_probe):
+            # the probe gradient is complete: its slice of the flat buffer
+            # travels while the last object scatter runs
+            probe_sum = comm.Allreduce_start(grads[n_obj:])
         if recover_psi:
             check(
                 lib.tike_scatter_patches(A.ptr(objproj),
@@ -655,7 +661,11 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
 
     # complete the sums over positions across ranks
     if comm.collective and grads.numel():
-        comm.Allreduce(grads)
+        if probe_sum is None:
+            comm.Allreduce(grads)
+        else:
+            comm.Allreduce(grads[:n_obj])
+            probe_sum.wait()
     count = global_count(comm, op, lo, hi)
     if recover_probe and not fused:
         m_probe_update = m_probe_update / num_batch  # (fused: in the kernel)
