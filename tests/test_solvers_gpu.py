@@ -363,19 +363,23 @@ def test_cgrad_vs_oracle(tp, det, pw, S, N):
                  what="probe")
 
 
-@pytest.mark.parametrize("det,S,N,slots", [(256, 1, 12, (8, 4)),
-                                           (256, 2, 7, (1, 1)),
-                                           (512, 2, 4, (8, 4)),
-                                           (128, 1, 10, (8, 4)),  # configs[0] size
-                                           (128, 2, 6, (8, 4))])
+@pytest.mark.parametrize("det,S,N,slots,most", [
+    (256, 1, 12, (8, 4), 30),
+    (256, 2, 7, (1, 1), 30),  # out of slots -> repeated with more slots
+    (256, 2, 7, (1, 1), 1),  # ... no more to be had -> host-side search
+    (512, 2, 4, (8, 4), 30),
+    (128, 1, 10, (8, 4), 30),  # configs[0] size
+    (128, 2, 6, (8, 4), 30)])
 def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
-                                                          S, N, slots):
+                                                          S, N, slots, most):
     """The line search decided on the device (tike_cgrad_line_search: trials
     enqueued ahead, skipped once one is accepted) follows opt.line_search
     (opt.py:216-278) trial for trial: same accepted step lengths, therefore
     the same iterates as the host-side search that reads every cost back.
-    slots = (1, 1): most searches run out of slots, which sends the call to
-    the host-side search -- the fallback must give the same result too."""
+    slots = (1, 1): most searches run out of slots; the call is then repeated
+    with every slot the entry allows (and the reconstruction remembers what
+    its searches needed), or -- `most` = 1: there are no more -- handed to the
+    host-side search.  Every route must give the same result."""
     import importlib
     C = importlib.import_module("tike_amd.ptycho.solvers.cgrad")
     scan, psi_true, probe0, _, _, data = _headline_problem(
@@ -384,6 +388,7 @@ def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
     for on_device in (True, False):
         monkeypatch.setattr(C, "DEVICE_LINE_SEARCH", on_device)
         monkeypatch.setattr(C, "LINE_SEARCH_SLOTS", slots)
+        monkeypatch.setattr(C, "MAX_SLOTS", most)
         calls = []
         real = C._cg_device
 
@@ -407,11 +412,17 @@ def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
             results.append(ctx.get_result())
         monkeypatch.setattr(C, "_cg_device", real)
         if on_device:
-            assert len(calls) == 8  # 2 epochs x 2 minibatches x (object, probe)
+            # 2 epochs x 2 minibatches x (object, probe) = 8 CG calls
             if slots == (8, 4):
-                assert all(calls)  # every search found its step in its slots
+                assert calls == [True] * 8  # every step found in its slots
+            elif most == 1:
+                assert len(calls) == 8 and not all(calls)  # host fallback ran
             else:
-                assert not all(calls)  # the fallback ran
+                # a call that ran out was repeated with more slots and then
+                # succeeded; what it needed is remembered, so that the last
+                # calls succeed at once
+                assert calls.count(True) == 8 and not all(calls)
+                assert calls[-2:] == [True, True]
         else:
             assert not calls
     a, b = results

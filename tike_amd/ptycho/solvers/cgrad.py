@@ -192,22 +192,62 @@ DEVICE_LINE_SEARCH = True
 line search (one read-back per trial) everywhere."""
 
 LINE_SEARCH_SLOTS = (8, 4)
-"""Step lengths enqueued ahead per line search: first CG iteration of a call
-(it starts from `step_length`), later iterations (they start from the length
-accepted last)."""
+"""Step lengths enqueued ahead per line search to begin with: first CG
+iteration of a call (it starts from `step_length`), later iterations (they
+start from the length accepted last).  A reconstruction then learns what its
+searches need (`_SlotPolicy`)."""
+
+MAX_SLOTS = 30  # tike_cgrad_line_search's limit: step_length / 2^29
+
+
+class _SlotPolicy:
+    """How many trial step lengths to enqueue ahead, per variable (object,
+    probe) and kind of search (first of a call, later ones), learnt from the
+    trials the previous calls of this reconstruction needed: one more than the
+    largest number seen lately, decaying by one per call.  A skipped slot costs
+    about 20 us, a search that runs out of slots costs the whole CG call again
+    -- so a problem whose steps shrink below step_length / 2^7 pays for that
+    once, not in every call of every epoch (round-3 advisor finding)."""
+
+    def __init__(self):
+        self.slots = {v: list(LINE_SEARCH_SLOTS) for v in (0, 1)}
+
+    def get(self, variable):
+        return tuple(self.slots[variable])
+
+    def learn(self, variable, trials_per_search):
+        """trials_per_search: trials each search of a successful call made."""
+        seen = (trials_per_search[0], max(trials_per_search[1:], default=1))
+        for kind in (0, 1):
+            want = min(MAX_SLOTS, int(seen[kind]) + 1)
+            floor = LINE_SEARCH_SLOTS[kind]
+            self.slots[variable][kind] = max(want, floor,
+                                             self.slots[variable][kind] - 1)
+
+    def widen(self, variable):
+        """After a search ran out of slots: every slot the entry allows."""
+        self.slots[variable] = [MAX_SLOTS, MAX_SLOTS]
+
+
+def _slot_policy(op):
+    policy = getattr(op, "_cgrad_slot_policy", None)
+    if policy is None:
+        policy = op._cgrad_slot_policy = _SlotPolicy()
+    return policy
 
 
 def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
-               count, data, scan, lo, hi):
+               count, data, scan, lo, hi, slots=LINE_SEARCH_SLOTS):
     """opt.conjugate_gradient (opt.py:312-380: Dai-Yuan directions,
     backtracking line search) for the object (variable 0) or the probe
     (variable 1) with every line search decided on the device
     (tike_cgrad_line_search): the gradient pass, the direction and up to
     LINE_SEARCH_SLOTS cost-only trials of an iteration are enqueued without a
     host round trip; ONE read-back per call says whether every search found
-    its step inside its slots.  Returns (x, mean cost), or None when a search
-    ran out of slots -- the caller then repeats the call with the host-side
-    search, which has no such limit."""
+    its step inside its `slots` (first search, later searches).  Returns
+    (x, mean cost, trials made by every search), or None when a search ran out
+    of slots -- the caller then repeats the call with more slots or with the
+    host-side search, which has no limit."""
     dev = psi.device
     x = psi if variable == 0 else probe
     other = probe if variable == 0 else psi
@@ -219,6 +259,8 @@ def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
     state = torch.from_numpy(
         np.array([0.0, float(step_length), 0.0, 0.0, 0.0])).to(dev)
     skip = torch.zeros(1, dtype=torch.int32, device=dev)
+    # running total of trials after every search (read back with the state)
+    trial_log = torch.zeros(num_iter, dtype=torch.float64, device=dev)
     bufs = [torch.empty_like(x), torch.empty_like(x)]
     scan_ptr = scan[lo:hi].data_ptr()
     data_ptr = data[lo:hi].data_ptr()
@@ -244,13 +286,34 @@ def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
                 scan_ptr, data_ptr, plan.u16, A.ptr(plan.far),
                 A.ptr(plan.costs), N, plan.far.shape[0], S, det, H, W,
                 plan.fwd_scale, count, A.ptr(state), A.ptr(skip),
-                LINE_SEARCH_SLOTS[0 if i == 0 else 1], st_ptr),
+                slots[0 if i == 0 else 1], st_ptr),
             "cgrad line search")
+        trial_log[i].copy_(state[3])
         x = xs
-    final = state.cpu()
-    if float(final[4]) != 0:  # a search ran out of slots
+    final = torch.cat((state, trial_log)).cpu().numpy()
+    if final[4] != 0:  # a search ran out of slots
         return None
-    return x, float(final[0])
+    return x, float(final[0]), np.diff(final[5:], prepend=0.0)
+
+
+def _cg_on_device(plan, op, comm, psi, probe, variable, o, count, data, scan,
+                  lo, hi):
+    """`_cg_device` with the slot counts this reconstruction has learnt; a
+    call whose search runs out of slots is repeated once with every slot the
+    entry allows before the host-side search takes over.  Returns (x, cost)
+    or None."""
+    policy = _slot_policy(op)
+    for attempt in range(2):
+        r = _cg_device(plan, op, comm, psi, probe, variable, o.cg_iter,
+                       o.step_length, count, data, scan, lo, hi,
+                       slots=policy.get(variable))
+        if r is not None:
+            policy.learn(variable, r[2])
+            return r[0], r[1]
+        if policy.get(variable) == (MAX_SLOTS, MAX_SLOTS):
+            break
+        policy.widen(variable)
+    return None
 
 
 class _Evaluator:
@@ -303,8 +366,8 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
         count = global_count(comm, op, lo, hi)
         done_psi = done_probe = False
         if recover_psi and on_device:
-            r = _cg_device(plan, op, comm, psi, probe, 0, o.cg_iter,
-                           o.step_length, count, d, s, lo, hi)
+            r = _cg_on_device(plan, op, comm, psi, probe, 0, o, count, d, s,
+                              lo, hi)
             if r is not None:
                 psi, cost = r
                 done_psi = True
@@ -321,8 +384,8 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
                 dir_multi=lambda x: x[0], num_iter=o.cg_iter,
                 step_length=o.step_length)
         if recover_probe and on_device:
-            r = _cg_device(plan, op, comm, psi, probe, 1, o.cg_iter,
-                           o.step_length, count, d, s, lo, hi)
+            r = _cg_on_device(plan, op, comm, psi, probe, 1, o, count, d, s,
+                              lo, hi)
             if r is not None:
                 probe, cost = r
                 done_probe = True

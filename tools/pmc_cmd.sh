@@ -6,9 +6,26 @@
 # initialises the GPU before the program starts, so any hop that re-executes
 # (env, bash -c, taskset, numactl, a "#!/usr/bin/env" script, bench.py --gpus N
 # spawning torchrun) is an exec of a GPU-initialised process -- fatal on this pool.
-case "$2" in
-  env|bash|sh|taskset|numactl|torchrun) echo "pmc_cmd.sh: '$2' re-executes; give the program itself" >&2; exit 2;;
+prog=$(basename -- "$2")
+case "$prog" in
+  env|bash|sh|dash|taskset|numactl|torchrun|nohup|timeout|stdbuf) echo "pmc_cmd.sh: '$2' re-executes; give the program itself" >&2; exit 2;;
 esac
+case "$prog" in
+  python|python3|python3.*) ;;
+  *) # anything else must be a native executable: a script's "#!" line is an exec too
+     if [ "$(head -c 4 -- "$(command -v -- "$2" || echo "$2")" 2>/dev/null | tail -c 3)" != "ELF" ]; then
+       echo "pmc_cmd.sh: '$2' is neither python3 nor an ELF binary (a script would re-exec its interpreter)" >&2; exit 2
+     fi;;
+esac
+prev=""
+for a in "$@"; do
+  case "$a" in
+    torch.distributed.run|torch.distributed.launch) echo "pmc_cmd.sh: a launcher re-executes the ranks" >&2; exit 2;;
+    --gpus=*) [ "${a#--gpus=}" -gt 1 ] 2>/dev/null && { echo "pmc_cmd.sh: --gpus > 1 spawns ranks" >&2; exit 2; };;
+  esac
+  if [ "$prev" = "--gpus" ] && [ "$a" -gt 1 ] 2>/dev/null; then echo "pmc_cmd.sh: --gpus > 1 spawns ranks" >&2; exit 2; fi
+  prev=$a
+done
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 pat=$1; shift

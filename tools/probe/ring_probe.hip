@@ -30,7 +30,12 @@
 
 typedef float2 cf;
 constexpr int N = 256;            // tile edge
-constexpr long TILE = (long)N * N;  // elements of a mode tile
+// Row pitch (elements) and mode-tile pitch of both hand-offs: 256 / 65536 in the
+// product; padded values take the rows {16 r + k1} off the 32 KiB stride.
+__constant__ int c_pitch = 256;
+__constant__ long c_tile = 65536;
+#define PITCH c_pitch
+#define TILE c_tile
 constexpr int LINE = 16;          // unsigneds per counter (64 B)
 
 struct Ctl {
@@ -126,9 +131,9 @@ __global__ __launch_bounds__(256) void kernA(cf* __restrict__ h1, int R1, int S,
   }
   cf* slot = h1 + (long)(pos % R1) * S * TILE;
   for (int s = 0; s < S; ++s) {
-    cf* tile = slot + (long)s * TILE + (long)rg * 16 * N;
+    cf* tile = slot + (long)s * TILE + (long)rg * 16 * PITCH;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st<SK>(tile + r * N + t, work(mkv(pos, s, rg * 16 + r, t), K, a));
+    for (int r = 0; r < 16; ++r) st<SK>(tile + r * PITCH + t, work(mkv(pos, s, rg * 16 + r, t), K, a));
   }
   if (SYNC) publish<SK>(ready1 + (long)pos * LINE);
 }
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(512) void kernB(const cf* __restrict__ h1, cf* __re
   for (int m = 0; m < MH; ++m) {
     const cf* tile = slot + (long)(h * MH + m) * TILE;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[m][r] = ld<LK>(tile + (long)(16 * r + k1) * N + t);
+    for (int r = 0; r < 16; ++r) v[m][r] = ld<LK>(tile + (long)(16 * r + k1) * PITCH + t);
   }
   // the measured counts of this (position, k1) row set: D-sized read, as the product's kernel
   float d = 0.f;
@@ -183,9 +188,9 @@ __global__ __launch_bounds__(512) void kernB(const cf* __restrict__ h1, cf* __re
   cf* oslot = h2 + (long)(pos % R2) * S * TILE;
 #pragma unroll
   for (int m = 0; m < MH; ++m) {
-    cf* tile = oslot + (long)(h * MH + m) * TILE + (long)k1 * 16 * N;
+    cf* tile = oslot + (long)(h * MH + m) * TILE + (long)k1 * 16 * PITCH;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st<SK>(tile + r * N + t, v[m][r]);
+    for (int r = 0; r < 16; ++r) st<SK>(tile + r * PITCH + t, v[m][r]);
   }
   if (d == 123.456f) sink[0] = d;
   if (SYNC) publish<SK>(ready2 + (long)pos * LINE);
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void kernC(const cf* __restrict__ h2, int R2, 
     for (int m = 0; m < 2; ++m) {
       const cf* tile = slot + (long)(2 * w + m) * TILE + cg * 64 + lane;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[m][r] = ld<LK>(tile + (long)(ya + 16 * r) * N);
+      for (int r = 0; r < 16; ++r) v[m][r] = ld<LK>(tile + (long)(ya + 16 * r) * PITCH);
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -259,6 +264,7 @@ int main(int argc, char** argv) {
   int npos = 1000, R1 = 16, R2 = 16, nA = 64, nB = 112, nC = 80, KA = 28, KB = 38, KC = 20, J = 3;
   int sk = ST_PLAIN, lk = LD_ACQ, check = 1, reps = 3;
   std::string mode = "all";
+  int pitch = 256; long tilepad = 0;
   for (int i = 1; i < argc; ++i) {
     auto eq = [&](const char* k) { return !strncmp(argv[i], k, strlen(k)) ? argv[i] + strlen(k) : nullptr; };
     const char* v;
@@ -273,18 +279,24 @@ int main(int argc, char** argv) {
     else if ((v = eq("--check="))) check = atoi(v);
     else if ((v = eq("--reps="))) reps = atoi(v);
     else if ((v = eq("--mode="))) mode = v;
+    else if ((v = eq("--pitch="))) pitch = atoi(v);
+    else if ((v = eq("--tilepad="))) tilepad = atol(v);
     else { printf("unknown argument %s\n", argv[i]); return 2; }
   }
   constexpr int S = 8;
-  const long slot = (long)S * TILE * sizeof(cf);
+  const long tile_elems = (long)pitch * N + tilepad;
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(c_pitch), &pitch, sizeof(int)));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(c_tile), &tile_elems, sizeof(long)));
+  printf("row pitch %d elements, tile pitch %ld elements\n", pitch, tile_elems);
+  const long slot = (long)S * tile_elems * sizeof(cf);
   printf("npos %d  slot %.1f MiB  rings %d / %d slots (%.0f + %.0f MiB)  CUs %d/%d/%d  K %d/%d/%d  J %d  store %d load %d check %d\n",
          npos, slot / 1048576.0, R1, R2, R1 * slot / 1048576.0, R2 * slot / 1048576.0, nA, nB, nC, KA, KB, KC, J, sk, lk, check);
 
   cf *h1, *h2; float *data, *sink; unsigned* ctr; Ctl* ctl;
   const long full = (long)npos * slot;
   CK(hipMalloc(&h1, full)); CK(hipMalloc(&h2, full));
-  CK(hipMalloc(&data, (long)npos * TILE * 4)); CK(hipMalloc(&sink, 64));
-  CK(hipMemset(data, 0, (long)npos * TILE * 4));
+  CK(hipMalloc(&data, (long)npos * 65536L * 4)); CK(hipMalloc(&sink, 64));
+  CK(hipMemset(data, 0, (long)npos * 65536L * 4));
   CK(hipMalloc(&ctr, (long)4 * npos * LINE * 4)); CK(hipMalloc(&ctl, sizeof(Ctl)));
   unsigned *ready1 = ctr, *done1 = ctr + (long)npos * LINE, *ready2 = ctr + (long)2 * npos * LINE, *done2 = ctr + (long)3 * npos * LINE;
 
@@ -292,7 +304,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1, ea, eb, ec;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb)); CK(hipEventCreate(&ec));
   const float a = 1.0f;
-  const double hb = 4.0 * full;  // hand-off bytes: written once and read once, twice
+  const double hb = 4.0 * npos * S * 65536.0 * sizeof(cf);  // hand-off bytes: written once and read once, twice
 
   auto reset = [&]() {
     CK(hipMemsetAsync(ctr, 0, (long)4 * npos * LINE * 4, s0));
