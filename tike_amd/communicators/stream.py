@@ -40,7 +40,9 @@ class PinnedData:
         self.ndim = self._host.ndim
         self._copy = torch.cuda.Stream(self.device)
         self._slots = [None, None]
-        self._free = [None, None]  # event after which a slot may be overwritten
+        # events (one per stream that read it) after which a slot may be rewritten
+        self._free = [None, None]
+        self._readers = [set(), set()]  # streams handed each slot's chunk
         self._ready = None  # (lo, hi, slot, event) of the prefetched chunk
         self._last = None  # (lo, hi, slot, copy-done event, stream) handed out last
         self.copies = 0  # host-to-device copies issued
@@ -64,8 +66,8 @@ class PinnedData:
     def _issue(self, lo, hi, s):
         """Start copying rows [lo, hi) into slot s on the copy stream."""
         buf = self._slot(s, hi - lo)
-        if self._free[s] is not None:
-            self._copy.wait_event(self._free[s])
+        for event in self._free[s] or ():  # every stream that read this slot
+            self._copy.wait_event(event)
         with torch.cuda.stream(self._copy):
             buf[:hi - lo].copy_(self._host[lo:hi], non_blocking=True)
             done = torch.cuda.Event()
@@ -87,6 +89,7 @@ class PinnedData:
             s = self._last[2]  # asked for twice in one chunk iteration
             if self._last[3] is not None and cur != self._last[4]:
                 cur.wait_event(self._last[3])  # a consumer on another stream
+                self._readers[s].add(cur)  # ... whose reads the slot outlives
             return self._view(s, n)
         if self._ready is not None and self._ready[:2] == (lo, hi):
             _, _, s, done = self._ready
@@ -100,9 +103,14 @@ class PinnedData:
         cur.wait_event(done)
         # everything queued so far has finished with the other slot
         other = 1 - s
-        free = torch.cuda.Event()
-        free.record(cur)
-        self._free[other] = free
+        released = []
+        for stream in self._readers[other] | {cur}:
+            event = torch.cuda.Event()
+            event.record(stream)
+            released.append(event)
+        self._free[other] = released
+        self._readers[other] = set()
+        self._readers[s] = {cur}
         self._last = (lo, hi, s, done, cur)
         # the solvers walk a minibatch chunk by chunk: fetch the next one now
         # (the guess `hi + n` misses on a shorter last chunk: copied on demand).

@@ -521,7 +521,11 @@ extern "C" int tike_ptycho_fwd_gradient_scale(
 // waves: 13 % slower).
 // FULL: probe window = detector (pw == N, no padding): every probe / patch
 // access of a thread is `uniform base + one 32-bit lane offset + 8 T i` bytes.
-template <int N, bool FULL>
+// KEEP: plain stores of the hand-off instead of non-temporal ones -- they stay
+// in the Infinity Cache for a consumer that follows within ~256 MiB (the
+// forward operator's sub-batched column pass); the solver's minibatch-sized
+// hand-off does not fit and keeps the non-temporal stores.
+template <int N, bool FULL, bool KEEP = false>
 __global__ __launch_bounds__(N, N == 256 ? 3 : 2) void fwd_pass1_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ scratch, cf* __restrict__ patches, int nscan, int S, int pw, int H, int W,
@@ -689,7 +693,10 @@ __global__ __launch_bounds__(N, N == 256 ? 3 : 2) void fwd_pass1_kernel(
         for (int k1 = 0; k1 < 16; ++k1) {
           cf o = v[k1];
           if (k1 > 0) o = mul_tw<false>(o, twtab[N + r * k1]);  // uniform -> scalar load
-          tk_st_stream(mid + k1 * N, o);
+          if (KEEP)
+            mid[k1 * N] = o;
+          else
+            tk_st_stream(mid + k1 * N, o);
         }
       }
     }
@@ -702,7 +709,7 @@ static int tk_fwd_pass1(const void* psi, const float* scan, const void* probe,
                         int probe_per_scan, const void* unique_probe, const void* eigen_probe,
                         const float* eigen_weights, int num_eigen, int eigen_modes, void* scratch,
                         void* patches, int nscan, int S, int pw, int det, int H, int W,
-                        hipStream_t stream, const int* skip) {
+                        hipStream_t stream, const int* skip, bool keep = false) {
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
   TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
   if (nscan == 0) return TK_OK;
@@ -713,11 +720,18 @@ static int tk_fwd_pass1(const void* psi, const float* scan, const void* probe,
   if (!tw) return (int)hipErrorNotInitialized;
   const TkProbe P = tk_make_probe(probe, probe_per_scan, unique_probe ? nullptr : eigen_probe,
                                   eigen_weights, num_eigen, eigen_modes, S, pw, unique_probe);
-#define TK_F1(N, FULL)                                                                          \
-  hipLaunchKernelGGL((fwd_pass1_kernel<N, FULL>),                                              \
+#define TK_F1K(N, FULL, KEEP)                                                                   \
+  hipLaunchKernelGGL((fwd_pass1_kernel<N, FULL, KEEP>),                                        \
                      dim3(tk_grid((long)nscan * (N / 16), N == 256 ? 8 : 1)),                  \
                      dim3(N), 0, stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches,   \
                      nscan, S, pw, H, W, tw, skip)
+#define TK_F1(N, FULL)      \
+  do {                      \
+    if (keep)               \
+      TK_F1K(N, FULL, true);  \
+    else                    \
+      TK_F1K(N, FULL, false); \
+  } while (0)
   if (det == 256 && pw == det)
     TK_F1(256, true);
   else if (det == 256)
@@ -727,6 +741,7 @@ static int tk_fwd_pass1(const void* psi, const float* scan, const void* probe,
   else
     TK_F1(512, false);
 #undef TK_F1
+#undef TK_F1K
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -1340,17 +1355,38 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
     // column pass in place -- two streaming kernels; faster than one workgroup
     // per tile / per position (below) for every mode count: 256^2 x 1 mode
     // 2.57 -> 2.75 M tiles/s, x 3 modes +22 %, 512^2 +47 %
-    int rc = tike_fwd_pass1(psi, scan, probe, probe_per_scan, nullptr, eigen_probe, eigen_weights,
-                            num_eigen, eigen_modes, farplane, nullptr, nscan, S, pw, det, H, W,
-                            stream_);
-    if (rc) return rc;
-    const long nitem = ntile * 16 * (det / 256);
-    if (det == 256)
-      hipLaunchKernelGGL((fwd_colpass_inplace_kernel<256>), dim3(tk_grid(nitem, 32)), dim3(256),
-                         0, stream, far, ntile, scale);
-    else
-      hipLaunchKernelGGL((fwd_colpass_inplace_kernel<512>), dim3(tk_grid(nitem, 32)), dim3(256),
-                         0, stream, far, ntile, scale);
+    // ... in sub-batches of about 256 MiB of far plane: pass 1 keeps its
+    // hand-off in the Infinity Cache (plain stores), the column pass that
+    // follows reads it from there and overwrites it in place, so HBM sees the
+    // far plane once (256^2 x 1 mode: 2.83 -> 2.95 M patterns/s; smaller
+    // sub-batches lose more to their launches than the cache returns,
+    // profiles/r04_experiments.md).  TIKE_FWD_SUB_MIB overrides the size.
+    static const long sub_mib =
+        getenv("TIKE_FWD_SUB_MIB") ? atol(getenv("TIKE_FWD_SUB_MIB")) : 256;
+    const size_t tile_bytes = sizeof(cf) * (size_t)det * det;
+    long sub = sub_mib > 0 ? (sub_mib << 20) / (long)(tile_bytes * S) : nscan;
+    if (sub < 16) sub = 16;
+    const bool keep = sub < nscan;
+    for (long lo = 0; lo < nscan; lo += sub) {
+      const int m = (int)(nscan - lo < sub ? nscan - lo : sub);
+      int rc = tk_fwd_pass1(psi, scan + 2 * lo,
+                            (const char*)probe +
+                                (probe_per_scan ? sizeof(cf) * (size_t)S * pw * pw * lo : 0),
+                            probe_per_scan, nullptr, eigen_probe,
+                            eigen_weights ? eigen_weights + lo * (num_eigen + 1) * S : nullptr,
+                            num_eigen, eigen_modes, (char*)farplane + tile_bytes * S * lo,
+                            nullptr, m, S, pw, det, H, W, stream, nullptr, keep);
+      if (rc) return rc;
+      const long mt = (long)m * S;
+      const long nitem = mt * 16 * (det / 256);
+      cf* fm = far + lo * S * det * det;
+      if (det == 256)
+        hipLaunchKernelGGL((fwd_colpass_inplace_kernel<256>), dim3(tk_grid(nitem, 32)),
+                           dim3(256), 0, stream, fm, mt, scale);
+      else
+        hipLaunchKernelGGL((fwd_colpass_inplace_kernel<512>), dim3(tk_grid(nitem, 32)),
+                           dim3(256), 0, stream, fm, mt, scale);
+    }
     TK_LAUNCH_CHECK();
     return TK_OK;
   }

@@ -408,7 +408,10 @@ class Reconstruction():
         to pinned host memory asynchronously, the random subsets are drawn NOW
         (the generator is consumed in the reference's order) and the fit runs
         on a worker thread, in order, while the next epoch's kernels are being
-        enqueued; results are joined when they are asked for."""
+        enqueued; results are joined when they are asked for (`get_result`,
+        `__exit__`, the next regularised fit).  Between `iterate` and
+        `get_result`, `parameters.position_options.transform` may therefore
+        still be the previous epoch's: read it from `get_result()`."""
         p = self.parameters
         po = p.position_options
         if po is None:
@@ -431,6 +434,11 @@ class Reconstruction():
             self._pending_fits.append(self._fit_pool.submit(
                 self._fit_job, po, snap, done,
                 ransac_subsets(p.scan.shape[0])))
+            # finished fits leave the queue as we go (their exceptions
+            # surface here); never more than two epochs' fits outstanding
+            while self._pending_fits and (self._pending_fits[0].done()
+                                          or len(self._pending_fits) > 2):
+                self._pending_fits.pop(0).result()
             return
         self._resolve_fits()
         pos0 = pos1 = None
@@ -515,9 +523,16 @@ class Reconstruction():
             "Adding data on-the-fly is disabled until further notice.")
 
     def __exit__(self, type, value, traceback):
-        if (type is None and getattr(self, "parameters", None) is not None
-                and self.parameters.position_options is not None):
-            self._resolve_fits()
+        # join the deferred fits on every path; on the error path their own
+        # failures are logged instead of masking the exception in flight
+        while self._pending_fits:
+            fit = self._pending_fits.pop(0)
+            try:
+                fit.result()
+            except Exception:  # noqa: BLE001
+                if type is None:
+                    raise
+                logger.exception("deferred affine position fit failed")
         if self._fit_pool is not None:
             self._fit_pool.shutdown(wait=True)
             self._fit_pool = None
