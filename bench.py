@@ -166,7 +166,9 @@ class KernelTimers:
         return e
 
     def wrap_method(self, obj, method, name):
-        """Time a Python-level call (the RCCL all-reduce) the same way."""
+        """Time a Python-level call (the RCCL all-reduce) the same way.  `name`
+        may be a function of the call's arguments (the object-gradient sum is
+        told apart from the small packed sums by its size)."""
         fn = getattr(obj, method)
 
         def wrapper(*args, **kw):
@@ -176,7 +178,8 @@ class KernelTimers:
             e0.record()
             out = fn(*args, **kw)
             e1.record()
-            self.events[name].append((e0, e1))
+            self.events[name(*args) if callable(name) else name].append(
+                (e0, e1))
             return out
 
         setattr(obj, method, wrapper)
@@ -538,7 +541,14 @@ def main():
         det, S, N, C = built["det"], built["S"], built["N"], built["C"]
         num_batch = built["num_batch"]
         # every all-reduce, timed like a kernel
-        timers.wrap_method(ctx.comm, "Allreduce", "allreduce")
+        n_object = 2 * p["HW"]**2  # float32 words of the object-gradient slice
+
+        def which(*tensors):
+            words = sum(t.numel() * (2 if t.is_complex() else 1)
+                        for t in tensors)
+            return "allreduce:object" if words >= n_object else "allreduce"
+
+        timers.wrap_method(ctx.comm, "Allreduce", which)
         # ... and counted apart where it is issued once per epoch
         # (preconditioners, eigen-weight norms: outside the minibatch loop)
         import tike_amd.ptycho.solvers.lstsq as _L
@@ -676,7 +686,13 @@ def main():
                       "step after the warm-up, every launch bracketed"
             if profile is not None else "timed steps: every launch bracketed",
         }
-        if roofline["frac"] > READ_CEILING_GBS / HBM_PEAK_GBS and (
+        if not nbytes:
+            # an entry that runs a data-dependent number of passes (the
+            # device-side line search): no byte model, no fraction
+            roofline["achieved"] = roofline["frac"] = None
+            roofline["note"] = ("no algorithmic-byte model for this entry "
+                                "(data-dependent number of trial passes)")
+        elif roofline["frac"] > READ_CEILING_GBS / HBM_PEAK_GBS and (
                 roofline["traffic"] is None):
             # a rate above what a pure read stream reaches on this chip can only
             # come from cache hits inside the launch: not stated without the
@@ -722,19 +738,37 @@ def main():
             "config": workload,
             "roofline": roofline,
         }
-        if "allreduce" in summ and (world > 1 or forced):
-            # every collective of the timed steps (HIP events around
-            # Comm.Allreduce): per minibatch the gradient buffer + two small
-            # packed buffers, per epoch the two preconditioners (+ the eigen
-            # weight norms)
-            ar = summ["allreduce"]
+        if (world > 1 or forced) and ("allreduce" in summ
+                                      or "allreduce:object" in summ):
+            # every blocking collective of the timed steps (HIP events around
+            # Comm.Allreduce): per minibatch the object-gradient slice + two
+            # small packed buffers (the probe-gradient slice is started early
+            # with Comm.Allreduce_start and hides behind the object scatter:
+            # not in these events), per epoch the object preconditioner (+
+            # the eigen weight norms)
+            small = summ.get("allreduce", dict(calls=0, total_ms=0.0,
+                                               avg_ms=0.0))
+            big = summ.get("allreduce:object")
             nb = workload.get("num_batch", 1)
             per_epoch = counts["epoch"] / max(counts["steps"], 1)
+            calls = small["calls"] + (big["calls"] if big else 0)
+            total = small["total_ms"] + (big["total_ms"] if big else 0.0)
             line["allreduce"] = dict(
-                calls_per_step=ar["calls"] / a.steps,
-                calls_per_minibatch=(ar["calls"] / a.steps - per_epoch) / nb,
-                avg_ms=ar["avg_ms"], ms_per_step=ar["total_ms"] / a.steps,
+                calls_per_step=calls / a.steps,
+                calls_per_minibatch=(calls / a.steps - per_epoch) / nb,
+                started_early_per_minibatch=1,
+                avg_ms=total / max(calls, 1), ms_per_step=total / a.steps,
                 gradient_bytes=8 * (p["HW"]**2 + S * pw * pw))
+            if big:
+                nbytes = 8 * p["HW"]**2
+                # ring all-reduce: every rank sends and receives
+                # 2 (n - 1) / n of the buffer
+                line["allreduce"]["object_slice"] = dict(
+                    bytes=nbytes, calls_per_step=big["calls"] / a.steps,
+                    avg_ms=big["avg_ms"],
+                    algbw_GBs=nbytes / (big["avg_ms"] * 1e-3) / 1e9,
+                    busbw_GBs=(2 * (world - 1) / max(world, 1)) * nbytes /
+                    (big["avg_ms"] * 1e-3) / 1e9)
         if secondary is not None:
             line["secondary"] = secondary
         if cpu is not None:

@@ -935,9 +935,13 @@ def test_bench_rccl_path_through_the_launcher():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
-    # per minibatch: the gradient buffer + two small packed buffers
+    # per minibatch: the object-gradient slice + two small packed buffers
+    # block the stream (the probe-gradient slice is started early)
     assert line["allreduce"]["calls_per_step"] >= 10
     assert line["allreduce"]["calls_per_minibatch"] <= 3
+    big = line["allreduce"]["object_slice"]
+    assert 10 <= big["calls_per_step"] <= 11 and big["bytes"] > 0
+    assert big["avg_ms"] > 0 and big["busbw_GBs"] == 0  # one rank: no traffic
     assert 0 < line["roofline"]["iteration_hbm_frac"] < 1
 
 
