@@ -38,7 +38,7 @@ extern "C" {
  * A binding compares tike_abi_version() of the loaded library with the
  * TIKE_ABI_VERSION it was written against before its first call
  * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
-#define TIKE_ABI_VERSION 4
+#define TIKE_ABI_VERSION 5
 
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
@@ -453,6 +453,25 @@ int tike_eigen_dsum(const float* sums, int B, long P, float* dsum, void* stream)
 int tike_eigen_weights(const float* sums, int B, long P, const float* dsum, double count,
                        float* weights_c, long weights_row, void* coefs_c, int coef_stride,
                        const float* esum, void* stream);
+
+/* ---- conjugate direction of the conjugate-gradient solver on the device
+ * (reference opt.py:281-301 `direction_dy`, Dai-Yuan, as solvers/cgrad.py
+ * composes it with the gradient buffers of tike_lstsq_chunk_gradients):
+ *   g1 = -update        update = the accumulated descent direction of the
+ *                       minibatch, either planar (2, n) float32 (the object
+ *                       accumulator) or n interleaved complex64 (the probe's
+ *                       m_probe_update) -- exactly one of the two is given
+ *   first != 0:  direction = -g1
+ *   otherwise:   direction = -g1 + direction |g1|^2 / (sum conj(direction)
+ *                (g1 - gradient) + 1e-32)     (gradient = g1 of the last call)
+ *   gradient <- g1
+ *   first != 0 and costs given: state[0] = sum(costs[0..ncost)) / count -- the
+ *                mean cost at x that tike_cgrad_line_search starts from.
+ * gradient, direction: n complex64, updated in place; sums: 4 doubles of
+ * scratch (zeroed by the call).  Two kernels, no host synchronisation. */
+int tike_cgrad_direction(const float* update_planar, const void* update_complex, void* gradient,
+                         void* direction, long n, int first, const float* costs, int ncost,
+                         double count, double* state, double* sums, void* stream);
 
 /* ---- backtracking line search decided on the device (the conjugate-gradient
  * solver; reference opt.py:216-278 `line_search` over the gaussian cost

@@ -432,6 +432,55 @@ def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
     assert_close(a.probe, b.probe, normwise=1e-5, maxabs=1e-4, what="probe")
 
 
+@pytest.mark.parametrize("planar", [True, False])
+def test_cgrad_direction_entry_equals_direction_dy(tp, planar):
+    """tike_cgrad_direction (negated update -> gradient, the Dai-Yuan sums and
+    the new direction in two kernels, + the mean cost on the first iteration)
+    against tike_amd.opt.direction_dy, which is pinned to the reference's
+    (tests/test_host_golden_cpu.py)."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd import opt
+    from tike_amd._lib import check, lib
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    n = 70 * 93
+    c64 = lambda: torch.randn(n, 2, generator=gen).to(dev)
+    ups = [c64() for _ in range(3)]  # accumulated updates of three iterations
+    costs = torch.rand(1000, generator=gen).to(dev)
+    count = 1000.0
+    gradient = torch.empty(n, dtype=torch.complex64, device=dev)
+    direction = torch.empty(n, dtype=torch.complex64, device=dev)
+    state = torch.zeros(5, dtype=torch.float64, device=dev)
+    sums = torch.empty(4, dtype=torch.float64, device=dev)
+    g0 = d0 = None
+    for i, up in enumerate(ups):
+        if planar:
+            buf = up.t().contiguous()  # (2, n): real plane, imaginary plane
+            args = (A.ptr(buf), None)
+        else:
+            buf = torch.view_as_complex(up.contiguous())
+            args = (None, A.ptr(buf))
+        check(lib.tike_cgrad_direction(*args, A.ptr(gradient), A.ptr(direction),
+                                       n, int(i == 0), A.ptr(costs), 1000,
+                                       count, A.ptr(state), A.ptr(sums),
+                                       A.stream_ptr()), "direction")
+        g1 = -torch.view_as_complex(up.contiguous())
+        want = (opt.direction_dy(torch, [g1]) if i == 0 else
+                opt.direction_dy(torch, [g1], [g0], [d0]))[0]
+        assert_close(gradient.cpu().numpy(), g1.cpu().numpy(), normwise=1e-7,
+                     what="gradient")
+        assert_close(direction.cpu().numpy(), want.cpu().numpy(),
+                     normwise=2e-6, maxabs=2e-5, what=f"direction {i}")
+        g0, d0 = g1, direction.clone()
+    assert float(state[0]) == pytest.approx(
+        float(costs.sum(dtype=torch.float64)) / count, rel=1e-12)
+    # exactly one form of the update must be given
+    assert lib.tike_cgrad_direction(None, None, A.ptr(gradient),
+                                    A.ptr(direction), n, 1, None, 0, 0.0, None,
+                                    A.ptr(sums), A.stream_ptr()) == 1000001
+
+
 def test_lstsq_converges_and_resumes(tp):
     """Cost decreases monotonically on a clean synthetic problem and state
     round-trips through PtychoParameters (larger, pow-2 sizes)."""

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("TIKE_AMD_LIB") or os.path.join(
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
 # the header version this binding's prototypes were written against
-ABI_VERSION = 4
+ABI_VERSION = 5
 ERR_ARG = 1000001
 ERR_UNSUPPORTED = 1000002
 ERR_COMM = 2000000
@@ -119,6 +119,7 @@ _PROTOTYPES = {
     "tike_lstsq_chunk_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i,
                                    _f, _l, _p, _p, _p, _p, _p, _p, _p, _p, _f,
                                    _p, _i, _i, _i, _i, _i, _f, _f, _p],
+    "tike_cgrad_direction": [_p, _p, _p, _p, _l, _i, _p, _i, _d, _p, _p, _p],
     "tike_cgrad_line_search": [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i,
                                _i, _i, _i, _i, _f, _d, _p, _p, _i, _p],
     "tike_comm_unique_id": [_p],

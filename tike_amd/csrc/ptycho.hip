@@ -1025,6 +1025,111 @@ __global__ __launch_bounds__(256) void ls_decide_kernel(const float* __restrict_
   }
 }
 
+// ------------------------------------------- conjugate direction on the device
+// Dai-Yuan direction of the conjugate-gradient solver (reference opt.py:281-301
+// direction_dy as solvers/cgrad.py composes it) in two kernels instead of a
+// dozen element-wise launches:
+//   g1 = -(accumulated update)            (object: planar (2, n) float32;
+//                                          probe: interleaved complex (n))
+//   first:  d = -g1
+//   else:   d = -g1 + d |g1|^2 / (sum conj(d) (g1 - g0) + 1e-32)
+//   g0 <- g1;  first: state[0] = sum(costs) / count   (the cost at x)
+// sums[0..3] (double, zeroed here): |g1|^2, Re / Im of the denominator, sum(costs)
+__global__ __launch_bounds__(256) void cg_sums_kernel(const float* __restrict__ planar,
+                                                      const cf* __restrict__ inter,
+                                                      const cf* __restrict__ g0,
+                                                      const cf* __restrict__ d, long n, int first,
+                                                      const float* __restrict__ costs, int ncost,
+                                                      double* __restrict__ sums) {
+  __shared__ float red[4];
+  __shared__ double redd[256];
+  float nn = 0.f, dr = 0.f, di = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const cf a = planar ? mk(planar[i], planar[n + i]) : inter[i];
+    const cf g1 = mk(-a.x, -a.y);
+    nn += norm2(g1);
+    if (!first) {
+      const cf y = mk(g1.x - g0[i].x, g1.y - g0[i].y);
+      const cf t = conjf(d[i]) * y;
+      dr += t.x;
+      di += t.y;
+    }
+  }
+  nn = tk_block_sum256(nn, red);
+  dr = tk_block_sum256(dr, red);
+  di = tk_block_sum256(di, red);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(&sums[0], (double)nn);
+    if (!first) {
+      unsafeAtomicAdd(&sums[1], (double)dr);
+      unsafeAtomicAdd(&sums[2], (double)di);
+    }
+  }
+  if (first && costs != nullptr) {  // uniform: the mean cost, summed in double
+    double cs = 0.0;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < ncost; i += gridDim.x * 256L)
+      cs += (double)costs[i];
+    redd[threadIdx.x] = cs;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) redd[threadIdx.x] += redd[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0 && redd[0] != 0.0) unsafeAtomicAdd(&sums[3], redd[0]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cg_direction_kernel(const float* __restrict__ planar,
+                                                           const cf* __restrict__ inter,
+                                                           cf* __restrict__ g0, cf* __restrict__ d,
+                                                           long n, int first, int have_costs,
+                                                           double inv_count,
+                                                           const double* __restrict__ sums,
+                                                           double* __restrict__ state) {
+  cf beta = mk(0.f, 0.f);
+  if (!first) {
+    // |g1|^2 / (den + 1e-32), complex
+    const float nr = (float)sums[0];
+    const float er = (float)sums[1] + 1e-32f, ei = (float)sums[2];
+    const float m = er * er + ei * ei;
+    beta = mk(nr * er / m, -nr * ei / m);
+  }
+  if (first && have_costs && blockIdx.x == 0 && threadIdx.x == 0) state[0] = sums[3] * inv_count;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const cf a = planar ? mk(planar[i], planar[n + i]) : inter[i];
+    const cf g1 = mk(-a.x, -a.y);
+    cf nd = mk(-g1.x, -g1.y);
+    if (!first) {
+      const cf t = d[i] * beta;
+      nd = mk(t.x - g1.x, t.y - g1.y);
+    }
+    d[i] = nd;
+    g0[i] = g1;
+  }
+}
+
+extern "C" int tike_cgrad_direction(const float* update_planar, const void* update_complex,
+                                    void* gradient, void* direction, long n, int first,
+                                    const float* costs, int ncost, double count, double* state,
+                                    double* sums, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(n >= 1 && gradient && direction && sums);
+  TK_CHECK_ARG((update_planar != nullptr) != (update_complex != nullptr));
+  TK_CHECK_ARG(!(first && costs != nullptr) || (ncost >= 1 && count > 0 && state != nullptr));
+  hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(double), stream);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid(tk_grid((n + 255) / 256, 4)), block(256);
+  hipLaunchKernelGGL(cg_sums_kernel, grid, block, 0, stream, update_planar,
+                     (const cf*)update_complex, (const cf*)gradient, (const cf*)direction, n,
+                     first, first ? costs : nullptr, ncost, sums);
+  hipLaunchKernelGGL(cg_direction_kernel, grid, block, 0, stream, update_planar,
+                     (const cf*)update_complex, (cf*)gradient, (cf*)direction, n, first,
+                     (int)(first && costs != nullptr), count > 0 ? 1.0 / count : 0.0, sums, state);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 extern "C" int tike_cgrad_line_search(int variable, const void* x, const void* d, void* xs,
                                       const void* other, const float* scan, const void* data,
                                       int data_u16, void* scratch, float* costs, int nscan,

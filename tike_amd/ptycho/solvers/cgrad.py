@@ -265,20 +265,22 @@ def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
     scan_ptr = scan[lo:hi].data_ptr()
     data_ptr = data[lo:hi].data_ptr()
     st_ptr = A.stream_ptr()
-    grad0 = dir_ = None
+    # gradient and direction of the previous iteration, and the four sums of
+    # tike_cgrad_direction: one entry per iteration instead of a dozen torch
+    # launches (negation, two reductions, the Dai-Yuan update, the cost at x)
+    gradient, d = torch.empty_like(x), torch.empty_like(x)
+    sums = torch.empty(4, dtype=torch.float64, device=dev)
     for i in range(num_iter):
         a, b = (x, other) if variable == 0 else (other, x)  # psi, probe
         costs, acc, mpu = plan.gradients(op, comm, a, b, variable == 0,
                                          variable == 1)
-        g = -torch.complex(acc[0], acc[1])[None] if variable == 0 else -mpu
-        grad1 = [g]
-        dir_ = (opt.direction_dy(torch, grad1) if i == 0 else
-                opt.direction_dy(torch, grad1, grad0, dir_))
-        grad0 = grad1
-        d = dir_[0].contiguous()
-        if i == 0:
-            # the cost at x comes out of the gradient pass (opt.py:246)
-            state[0] = costs.sum(dtype=torch.float64) / count
+        check(
+            lib.tike_cgrad_direction(
+                A.ptr(acc) if variable == 0 else None,
+                None if variable == 0 else A.ptr(mpu), A.ptr(gradient),
+                A.ptr(d), x.numel(), int(i == 0), A.ptr(costs),
+                costs.numel(), count, A.ptr(state), A.ptr(sums), st_ptr),
+            "cgrad direction")
         xs = bufs[i % 2]
         check(
             lib.tike_cgrad_line_search(
