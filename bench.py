@@ -142,6 +142,9 @@ class KernelTimers:
                 if not self.enabled or (self.only is not None
                                         and _name not in self.only):
                     return _fn(*args)
+                import torch
+                if torch.cuda.is_current_stream_capturing():
+                    return _fn(*args)  # a graph capture: nothing to time
                 e0, e1 = self.pair()
                 e0.record()
                 rc = _fn(*args)
@@ -424,12 +427,13 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
 
 
 def epoch_leg(workload, tp, A, torch, positions=0, epochs=2):
-    """One short leg of another BASELINE configuration: one warm-up epoch,
+    """One short leg of another BASELINE configuration: one warm-up epoch
+    (cgrad: two -- the second occurrence of a CG call captures its graph),
     then `epochs` timed ones (wall clock around synchronised epochs)."""
     built = epoch_problem(workload, positions, 1, 0, tp, A)
     ctx = built["ctx"]
     try:
-        ctx.iterate(1)
+        ctx.iterate(2 if workload in ("c1", "c2") else 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ctx.iterate(epochs)
@@ -599,6 +603,15 @@ def main():
     profile = None
     for _ in range(a.warmup):
         step()
+    # cgrad replays its CG calls from captured graphs: launches inside a
+    # replay cannot be bracketed, so the per-kernel shares (and the dominant
+    # kernel's launch time) come from steps launched one by one, the timed
+    # steps run as users run them (graphs on, no events)
+    import importlib
+    _cg = importlib.import_module("tike_amd.ptycho.solvers.cgrad")
+    graphs_on = _cg.USE_GRAPHS and a.workload in ("c1", "c2")
+    if graphs_on:
+        _cg.USE_GRAPHS = False
     if a.warmup > 0:
         # twice: torch creates the HIP event behind a pooled Event object at
         # its first record(), which the first bracketed step pays for
@@ -618,6 +631,12 @@ def main():
             ks = {k: v for k, v in profile[0].items() if k.startswith("tike_")}
             dominant = max(ks, key=lambda k: ks[k]["total_ms"])
         timers.only = {dominant.split(":")[0]}
+    if graphs_on:
+        _cg.USE_GRAPHS = True
+        if profile is not None:
+            timers.only = set()
+            step()  # the occurrence that captures
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -659,7 +678,7 @@ def main():
         if dominant is None:
             dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
         pw = det
-        k = summ[dominant]
+        k = summ.get(dominant) or full[dominant]
         nbytes = algorithmic_bytes(dominant, launch_n, S, det, pw, C)
         achieved = nbytes / (k["avg_ms"] * 1e-3) / 1e9
         ktot = sum(v["total_ms"] for v in kernels.values())
@@ -686,6 +705,11 @@ def main():
                       "step after the warm-up, every launch bracketed"
             if profile is not None else "timed steps: every launch bracketed",
         }
+        if graphs_on:
+            roofline["events"] = (
+                "launch time and shares: an untimed step launched one by one "
+                "after the warm-up; the timed steps replay captured graphs "
+                "(no events inside a replay)")
         if not nbytes:
             # an entry that runs a data-dependent number of passes (the
             # device-side line search): no byte model, no fraction

@@ -389,6 +389,7 @@ def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
         monkeypatch.setattr(C, "DEVICE_LINE_SEARCH", on_device)
         monkeypatch.setattr(C, "LINE_SEARCH_SLOTS", slots)
         monkeypatch.setattr(C, "MAX_SLOTS", most)
+        monkeypatch.setattr(C, "USE_GRAPHS", False)  # every call through the spy
         calls = []
         real = C._cg_device
 
@@ -425,6 +426,49 @@ def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
                 assert calls[-2:] == [True, True]
         else:
             assert not calls
+    a, b = results
+    np.testing.assert_allclose(np.array(a.algorithm_options.costs),
+                               np.array(b.algorithm_options.costs), rtol=1e-5)
+    assert_close(a.psi, b.psi, normwise=1e-5, maxabs=1e-4, what="psi")
+    assert_close(a.probe, b.probe, normwise=1e-5, maxabs=1e-4, what="probe")
+
+
+@pytest.mark.parametrize("det,S,N", [(128, 1, 10), (256, 2, 7)])
+def test_cgrad_graph_replay_equals_eager_launches(tp, monkeypatch, det, S, N):
+    """From its second occurrence on a CG call is replayed from a captured HIP
+    graph (`_CgGraph`): four epochs with replay == four epochs launched one by
+    one, and the graphs were really used."""
+    import importlib
+    C = importlib.import_module("tike_amd.ptycho.solvers.cgrad")
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=det + 5 * S, eigen=False)
+    results, replays = [], []
+    for graphs in (True, False):
+        monkeypatch.setattr(C, "USE_GRAPHS", graphs)
+        count = [0]
+        real = C._CgGraph.__call__
+
+        def counted(self, x, other):
+            count[0] += 1
+            return real(self, x, other)
+
+        monkeypatch.setattr(C._CgGraph, "__call__", counted)
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+            scan=scan.copy(),
+            algorithm_options=tp.CgradOptions(num_batch=2, cg_iter=3,
+                                              batch_method="compact"),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions())
+        with tp.Reconstruction(data, params, order=np.arange(N),
+                               batches=np.array_split(np.arange(N), 2)) as ctx:
+            ctx.iterate(4)
+            results.append(ctx.get_result())
+        monkeypatch.setattr(C._CgGraph, "__call__", real)
+        replays.append(count[0])
+    # 4 epochs x 2 minibatches x (object, probe) = 16 calls; a call is eager
+    # the first time its (minibatch, variable, slot counts) occurs
+    assert replays[0] >= 6 and replays[1] == 0, replays
     a, b = results
     np.testing.assert_allclose(np.array(a.algorithm_options.costs),
                                np.array(b.algorithm_options.costs), rtol=1e-5)

@@ -8,6 +8,9 @@ and the gradient ``Ptycho.adj(gaussian_grad(...))`` (objective.py:31-44),
 following the multi-GPU pattern of lamino/solvers/cgrad.py:58-92: the cost and
 the gradient are summed over ranks, every rank then takes the same step.
 """
+import logging
+import os
+
 import numpy as np
 import torch
 
@@ -19,6 +22,8 @@ from ..exitwave import ExitWaveOptions
 from .lstsq import (SPLIT_FORWARD_SIZES, _get_nearplane_gradients, _workspace,
                     chunk_positions, fused_gradients, global_count)
 
+
+logger = logging.getLogger(__name__)
 
 _GAUSSIAN = {}
 
@@ -204,13 +209,16 @@ class _SlotPolicy:
     """How many trial step lengths to enqueue ahead, per variable (object,
     probe) and kind of search (first of a call, later ones), learnt from the
     trials the previous calls of this reconstruction needed: one more than the
-    largest number seen lately, decaying by one per call.  A skipped slot costs
-    about 20 us, a search that runs out of slots costs the whole CG call again
-    -- so a problem whose steps shrink below step_length / 2^7 pays for that
-    once, not in every call of every epoch (round-3 advisor finding)."""
+    largest number seen; a count that has been two or more too generous for
+    eight calls in a row shrinks by one.  A skipped slot costs about 20 us, a
+    search that runs out of slots costs the whole CG call again -- so a
+    problem whose steps shrink below step_length / 2^7 pays for that once,
+    not in every call of every epoch (round-3 advisor finding).  Counts change
+    rarely, which keeps the captured launch sequences (`_CgGraph`) valid."""
 
     def __init__(self):
         self.slots = {v: list(LINE_SEARCH_SLOTS) for v in (0, 1)}
+        self.generous = {v: [0, 0] for v in (0, 1)}
 
     def get(self, variable):
         return tuple(self.slots[variable])
@@ -219,14 +227,24 @@ class _SlotPolicy:
         """trials_per_search: trials each search of a successful call made."""
         seen = (trials_per_search[0], max(trials_per_search[1:], default=1))
         for kind in (0, 1):
-            want = min(MAX_SLOTS, int(seen[kind]) + 1)
-            floor = LINE_SEARCH_SLOTS[kind]
-            self.slots[variable][kind] = max(want, floor,
-                                             self.slots[variable][kind] - 1)
+            want = max(min(MAX_SLOTS, int(seen[kind]) + 1),
+                       LINE_SEARCH_SLOTS[kind])
+            have = self.slots[variable][kind]
+            if want > have:
+                self.slots[variable][kind] = want
+                self.generous[variable][kind] = 0
+            elif want <= have - 2:
+                self.generous[variable][kind] += 1
+                if self.generous[variable][kind] >= 8:
+                    self.slots[variable][kind] = have - 1
+                    self.generous[variable][kind] = 0
+            else:
+                self.generous[variable][kind] = 0
 
     def widen(self, variable):
         """After a search ran out of slots: every slot the entry allows."""
         self.slots[variable] = [MAX_SLOTS, MAX_SLOTS]
+        self.generous[variable] = [0, 0]
 
 
 def _slot_policy(op):
@@ -236,32 +254,27 @@ def _slot_policy(op):
     return policy
 
 
-def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
-               count, data, scan, lo, hi, slots=LINE_SEARCH_SLOTS):
-    """opt.conjugate_gradient (opt.py:312-380: Dai-Yuan directions,
-    backtracking line search) for the object (variable 0) or the probe
-    (variable 1) with every line search decided on the device
-    (tike_cgrad_line_search): the gradient pass, the direction and up to
-    LINE_SEARCH_SLOTS cost-only trials of an iteration are enqueued without a
-    host round trip; ONE read-back per call says whether every search found
-    its step inside its `slots` (first search, later searches).  Returns
-    (x, mean cost, trials made by every search), or None when a search ran out
-    of slots -- the caller then repeats the call with more slots or with the
-    host-side search, which has no limit."""
-    dev = psi.device
-    x = psi if variable == 0 else probe
-    other = probe if variable == 0 else psi
+def _cg_enqueue(plan, op, comm, x, other, variable, num_iter, step_init,
+                count, data, scan, lo, hi, slots, bufs):
+    """Enqueue one conjugate-gradient call -- opt.conjugate_gradient
+    (opt.py:312-380: Dai-Yuan directions, backtracking line search) for the
+    object (variable 0) or the probe (variable 1) with every line search
+    decided on the device (tike_cgrad_line_search): per iteration the gradient
+    pass, the direction (tike_cgrad_direction) and up to `slots` cost-only
+    trials, no host round trip, nothing but launches (so the whole call can be
+    captured as a graph).  step_init: device double[5] {0, step_length, 0, 0,
+    0}; bufs: two iterates' worth of scratch.  Returns (the last iterate,
+    device double[5 + num_iter]: the search state { fx, step, done, trials,
+    failures } followed by the running total of trials after every search)."""
+    dev = x.device
     S, pw, det, H, W = plan.dims
     N = hi - lo
-    # { fx, step, done, trials, failures }: carried from search to search on
-    # the device (the step accepted last is the first one tried next,
-    # opt.py:366-371); one upload, one read-back per call
-    state = torch.from_numpy(
-        np.array([0.0, float(step_length), 0.0, 0.0, 0.0])).to(dev)
+    # carried from search to search on the device (the step accepted last is
+    # the first one tried next, opt.py:366-371)
+    out = torch.zeros(5 + num_iter, dtype=torch.float64, device=dev)
+    state = out[:5]
+    state.copy_(step_init)
     skip = torch.zeros(1, dtype=torch.int32, device=dev)
-    # running total of trials after every search (read back with the state)
-    trial_log = torch.zeros(num_iter, dtype=torch.float64, device=dev)
-    bufs = [torch.empty_like(x), torch.empty_like(x)]
     scan_ptr = scan[lo:hi].data_ptr()
     data_ptr = data[lo:hi].data_ptr()
     st_ptr = A.stream_ptr()
@@ -290,29 +303,127 @@ def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
                 plan.fwd_scale, count, A.ptr(state), A.ptr(skip),
                 slots[0 if i == 0 else 1], st_ptr),
             "cgrad line search")
-        trial_log[i].copy_(state[3])
+        out[5 + i].copy_(state[3])
         x = xs
-    final = torch.cat((state, trial_log)).cpu().numpy()
-    if final[4] != 0:  # a search ran out of slots
+    return x, out
+
+
+def _cg_result(x, out):
+    """Read a call's state back (the ONE host synchronisation of a call):
+    (x, mean cost, trials made by every search), or None when a search ran
+    out of slots."""
+    final = out.cpu().numpy()
+    if final[4] != 0:
         return None
     return x, float(final[0]), np.diff(final[5:], prepend=0.0)
 
 
+def _step_init(step_length, dev):
+    return torch.from_numpy(
+        np.array([0.0, float(step_length), 0.0, 0.0, 0.0])).to(dev)
+
+
+def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
+               count, data, scan, lo, hi, slots=LINE_SEARCH_SLOTS):
+    """`_cg_enqueue` launched eagerly + its read-back.  Returns (x, mean
+    cost, trials made by every search), or None when a search ran out of its
+    slots -- the caller then repeats the call with more slots or with the
+    host-side search, which has no limit."""
+    x = psi if variable == 0 else probe
+    other = probe if variable == 0 else psi
+    bufs = [torch.empty_like(x), torch.empty_like(x)]
+    return _cg_result(*_cg_enqueue(
+        plan, op, comm, x, other, variable, num_iter,
+        _step_init(step_length, x.device), count, data, scan, lo, hi, slots,
+        bufs))
+
+
+USE_GRAPHS = os.environ.get("TIKE_CGRAD_GRAPHS", "0") == "1"
+"""A conjugate-gradient call is a fixed sequence of ~10 launches per trial
+slot whose only data-dependent control flow lives on the device (the `skip`
+word), so it can be captured once and replayed as a HIP graph from its second
+occurrence on (`_CgGraph`).  MEASURED SLOWER on ROCm 7.2 / gfx950 and therefore
+OFF unless TIKE_CGRAD_GRAPHS=1: BASELINE configs[0] (256 positions, every
+launch shorter than its own issue) 73.4 k patterns/s launched one by one,
+35.7 k replayed -- a replay of ~270 nodes costs ~6 us per node on the GPU
+side, more than eager launches that the host issues ahead; c2 67.8 k vs 66.6 k
+(profiles/r04_experiments.md).  Kept as an option and under test."""
+
+MAX_GRAPHS = 64
+
+
+class _CgGraph:
+    """The captured launch sequence of one `_cg_enqueue` call.  Inputs are
+    copied into static buffers, the graph is replayed, the result is cloned
+    out (the buffers belong to the graph)."""
+
+    def __init__(self, enqueue, x, other, step_length):
+        self.x = torch.empty_like(x)
+        self.other = torch.empty_like(other)
+        self.bufs = [torch.empty_like(x), torch.empty_like(x)]
+        self.init = _step_init(step_length, x.device)
+        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(self.graph):
+            self.result, self.out = enqueue(self.x, self.other, self.init,
+                                            self.bufs)
+
+    def __call__(self, x, other):
+        self.x.copy_(x)
+        self.other.copy_(other)
+        self.graph.replay()
+        return self.result.clone(), self.out
+
+
 def _cg_on_device(plan, op, comm, psi, probe, variable, o, count, data, scan,
                   lo, hi):
-    """`_cg_device` with the slot counts this reconstruction has learnt; a
+    """One CG call on the device with the slot counts this reconstruction has
+    learnt, replayed from a graph once the same call has been seen before; a
     call whose search runs out of slots is repeated once with every slot the
     entry allows before the host-side search takes over.  Returns (x, cost)
     or None."""
     policy = _slot_policy(op)
+    x = psi if variable == 0 else probe
+    other = probe if variable == 0 else psi
+    graphs = getattr(op, "_cgrad_graphs", None)
+    if graphs is None:
+        graphs = op._cgrad_graphs = {}
     for attempt in range(2):
-        r = _cg_device(plan, op, comm, psi, probe, variable, o.cg_iter,
-                       o.step_length, count, data, scan, lo, hi,
-                       slots=policy.get(variable))
+        slots = policy.get(variable)
+
+        def enqueue(x_, other_, init, bufs):
+            return _cg_enqueue(plan, op, comm, x_, other_, variable,
+                               o.cg_iter, init, count, data, scan, lo, hi,
+                               slots, bufs)
+
+        key = (variable, lo, hi, slots, tuple(x.shape), tuple(other.shape),
+               o.cg_iter, float(o.step_length), float(count),
+               plan.far.data_ptr(), plan.costs.data_ptr(), scan.data_ptr(),
+               data.data_ptr())
+        seen = graphs.get(key) if USE_GRAPHS else "eager"
+        if seen is False:  # second occurrence: capture
+            try:
+                seen = graphs[key] = _CgGraph(enqueue, x, other, o.step_length)
+            except Exception as e:  # noqa: BLE001 -- capture is an optimisation
+                logger.warning("cgrad: graph capture failed (%s); this call "
+                               "stays eager", e)
+                seen = graphs[key] = "eager"
+        if seen is None or seen == "eager":
+            # first occurrence: eager (it also warms every lazily created
+            # table and workspace a capture must not allocate)
+            if seen is None:
+                if len(graphs) >= MAX_GRAPHS:
+                    graphs.clear()
+                graphs[key] = False
+            r = _cg_device(plan, op, comm, psi, probe, variable, o.cg_iter,
+                           o.step_length, count, data, scan, lo, hi,
+                           slots=slots)
+        else:
+            r = _cg_result(*seen(x, other))
         if r is not None:
             policy.learn(variable, r[2])
             return r[0], r[1]
-        if policy.get(variable) == (MAX_SLOTS, MAX_SLOTS):
+        if slots == (MAX_SLOTS, MAX_SLOTS):
             break
         policy.widen(variable)
     return None
