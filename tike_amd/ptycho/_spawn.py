@@ -107,9 +107,12 @@ def _rank_main(rank, devices, port, backend, shared, view, blob, results):
     import torch.distributed as dist
     try:
         torch.cuda.set_device(devices[rank])
+        extra = {}
+        if backend == "nccl":  # bind the communicator to this rank's GPU
+            extra["device_id"] = torch.device("cuda", devices[rank])
         dist.init_process_group(backend,
                                 init_method=f"tcp://127.0.0.1:{port}",
-                                rank=rank, world_size=len(devices))
+                                rank=rank, world_size=len(devices), **extra)
         try:
             import tike_amd.random
             from tike_amd.ptycho.ptycho import Reconstruction
