@@ -209,6 +209,36 @@ def test_rccl_collectives_single_rank(backend):
     np.testing.assert_allclose(scan, single.scan, atol=1e-3)
 
 
+def test_reconstruct_num_gpu_hands_uint16_counts_through_shared_memory(
+        monkeypatch):
+    """16-bit detector counts reach the spawned ranks as they are (shared
+    memory, viewed back as uint16) and stay 16-bit in HBM there: the two-rank
+    result equals the one-rank result on the same counts."""
+    import tike_amd.ptycho as tp
+    data, scan, probe, psi0, _, _ = _problem(False)
+    counts = np.round(data * (20000.0 / data.max())).astype(np.uint16)
+
+    def run(num_gpu):
+        np.random.seed(3)
+        params = tp.PtychoParameters(
+            probe=probe.copy(), psi=psi0.copy(), scan=scan.copy(),
+            algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
+                                              batch_method="compact"),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions())
+        return tp.reconstruct(counts, params, num_gpu=num_gpu)
+
+    one = run(None)
+    monkeypatch.setenv("TIKE_AMD_OVERSUBSCRIBE", "1")
+    two = run(2)
+    np.testing.assert_allclose(np.array(two.algorithm_options.costs),
+                               np.array(one.algorithm_options.costs),
+                               rtol=1e-3)
+    assert_close(two.psi, one.psi, normwise=1e-3, maxabs=1e-2, what="psi")
+    assert_close(two.probe, one.probe, normwise=1e-3, maxabs=1e-2,
+                 what="probe")
+
+
 def test_reconstruct_num_gpu_starts_the_ranks_itself(monkeypatch):
     """The reference's one-call contract (ptycho.py:182-187,371-381):
     ``reconstruct(data, parameters, num_gpu=2)`` from a plain process uses two

@@ -988,6 +988,24 @@ def test_resident_gradient_kernel_vs_oracle_beyond_one_wave(tp, u16_and_mask):
                  what="patches")
 
 
+def test_example_script_runs_and_converges():
+    """examples/reconstruct_synthetic.py: the drop-in use shown to a tike user
+    (simulate + reconstruct through the public API) runs and lowers the cost."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run(
+        [sys.executable, os.path.join(root, "examples",
+                                      "reconstruct_synthetic.py"),
+         "--positions", "100", "--width", "64", "--epochs", "4"],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    assert "cost per epoch" in r.stdout
+
+
 def test_bench_launcher_refuses_more_gpus_than_visible():
     """`python bench.py --gpus N` with fewer than N GPUs must fail loudly
     (never a silent 1-GPU number), before touching the GPU."""
