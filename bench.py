@@ -661,13 +661,25 @@ def main():
         if ctx is not None:
             ctx.__exit__(None, None, None)
             ctx = None
-        secondary = [forward_leg(ops, A, torch, 256, 1, 4096),
-                     forward_leg(ops, A, torch, 128, 1, 16384),
-                     forward_leg(ops, A, torch, 256, 8, 512)]
+        def guarded(name, leg, *args):
+            # a secondary leg must never cost the headline line
+            try:
+                return leg(*args)
+            except Exception as e:  # noqa: BLE001
+                torch.cuda.empty_cache()
+                return dict(workload=name, error=f"{type(e).__name__}: {e}")
+
+        secondary = [guarded("fwd256x1", forward_leg, ops, A, torch, 256, 1,
+                             4096),
+                     guarded("fwd128x1", forward_leg, ops, A, torch, 128, 1,
+                             16384),
+                     guarded("fwd256x8", forward_leg, ops, A, torch, 256, 8,
+                             512)]
         # ... and the other BASELINE configurations, one short leg each
-        del data, p
+        del data
         torch.cuda.empty_cache()
-        secondary += [epoch_leg(w, tp, A, torch) for w in ("c1", "c2", "c5")]
+        secondary += [guarded(w, epoch_leg, w, tp, A, torch)
+                      for w in ("c1", "c2", "c5")]
 
     if rank == 0:
         summ = timers.summary()  # the timed steps
