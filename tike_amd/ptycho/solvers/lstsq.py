@@ -253,10 +253,7 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
                                 epoch=epoch)
 
     # one device->host scalar per epoch, as in the reference (lstsq.py:222)
-    if _os.environ.get("TIKE_X_NO_COST_SYNC") == "1":  # EXPERIMENT: timing only
-        algorithm_options.costs.append([0.0])
-    else:
-        algorithm_options.costs.append([float(batch_cost.mean().item())])
+    algorithm_options.costs.append([float(batch_cost.mean().item())])
     if (eigen_weights is not None and eigen_weights.shape[1] > 1
             and not np.isfinite(algorithm_options.costs[-1][0])):
         # probe.py:426-427 raises when a minibatch's eigen weights are all
