@@ -450,6 +450,22 @@ if ONLY == "rpie":
           batch_method="compact", epochs=2, algo="rpie", alpha=1.0, depth=2,
           rng=np.random.default_rng(97))
     sys.exit(0)
+if ONLY == "rpie2":
+    # round 4: the reference's other rpie test configurations
+    # (tests/ptycho/test_ptycho.py:490-543,670-700): the Poisson noise model
+    # with per-mode step lengths and a variable (eigen) probe, alpha = 1
+    recon("poisson", N=40, pw=24, det=32, S=2, eigen=0, num_batch=2,
+          batch_method="compact", epochs=3, orth=True, algo="rpie", alpha=1.0,
+          rng=np.random.default_rng(96), noise_model="poisson",
+          usemodes="dominant_mode")
+    recon("poisson_all", N=36, pw=16, det=16, S=3, eigen=0, num_batch=2,
+          batch_method="wobbly_center", epochs=3, orth=True, algo="rpie",
+          alpha=1.0, rng=np.random.default_rng(95), noise_model="poisson",
+          usemodes="all_modes", mask_frac=0.1, scaling=0.9)
+    recon("eigen", N=40, pw=24, det=24, S=2, eigen=2, num_batch=2,
+          batch_method="compact", epochs=3, orth=True, algo="rpie", alpha=1.0,
+          rng=np.random.default_rng(94))
+    sys.exit(0)
 
 recon("compact", N=48, pw=24, det=32, S=2, eigen=0, num_batch=2,
       batch_method="compact", epochs=3, adaptive=True, orth=True)

@@ -359,7 +359,8 @@ def test_multislice_vs_reference(golden):
     assert_close(qa, g["pt_probe_adj"], what="ptycho probe_adj (3 slices)")
 
 
-@pytest.mark.parametrize("tag", ["epie", "object", "twoslice"])
+@pytest.mark.parametrize("tag", ["epie", "object", "twoslice", "poisson",
+                                 "poisson_all", "eigen"])
 def test_rpie_reconstruction_vs_reference(golden, tag):
     """The oracle's rpie (solvers/rpie.py:26-612 as this snapshot has it)
     replays the reference's own runs: alpha = 1 (ePIE) with object and probe,

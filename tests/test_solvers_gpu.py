@@ -1056,12 +1056,17 @@ def test_bench_rccl_path_through_the_launcher():
     assert 0 < line["roofline"]["iteration_hbm_frac"] < 1
 
 
-@pytest.mark.parametrize("tag", ["epie", "object", "twoslice"])
+@pytest.mark.parametrize("tag", ["epie", "object", "twoslice", "poisson",
+                                 "poisson_all", "eigen"])
 def test_rpie_reconstruct_twice_vs_reference(tp, golden, tag):
     """rpie (solvers/rpie.py:26-612) against the reference's own runs:
     alpha = 1 (ePIE, object + probe, compact batches), the default alpha with
-    the object alone on NaN-masked data (wobbly_center batches), and a
-    two-slice object through Multislice / FresnelSpectProp."""
+    the object alone on NaN-masked data (wobbly_center batches), a two-slice
+    object through Multislice / FresnelSpectProp, and (round 4) the
+    reference's remaining rpie test configurations
+    (tests/ptycho/test_ptycho.py:490-543,670-700): the Poisson model with
+    dominant-mode and per-mode step lengths (NaN-masked data) and a variable
+    (eigen) probe."""
     import warnings
     g = golden(f"rpie_recon_{tag}.npz")
     with warnings.catch_warnings():
@@ -1082,6 +1087,15 @@ def test_rpie_reconstruct_twice_vs_reference(tp, golden, tag):
                  what="psi after call 2")
     assert_close(r2.probe, g["probe_2"], normwise=5e-3, maxabs=5e-2,
                  what="probe after call 2")
+    if "eigen_weights_1" in g:
+        # rpie.py:209-214 divides the weights by their rms over the positions:
+        # the columns of modes without eigen probes are 0 / 0 = NaN in the
+        # reference as well
+        want = g["eigen_weights_1"]
+        finite = np.isfinite(want)
+        assert np.array_equal(np.isfinite(r1.eigen_weights), finite)
+        np.testing.assert_allclose(r1.eigen_weights[finite], want[finite],
+                                   rtol=5e-3, atol=5e-3)
 
 
 @pytest.mark.parametrize("det,S,N,eigen", [(256, 8, 12, True), (128, 2, 10, False)])
