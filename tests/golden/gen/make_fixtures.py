@@ -450,6 +450,17 @@ if ONLY == "rpie":
           batch_method="compact", epochs=2, algo="rpie", alpha=1.0, depth=2,
           rng=np.random.default_rng(97))
     sys.exit(0)
+if ONLY == "lstsq2":
+    # round 4: the reference's "no probe" lstsq_grad test configurations
+    # (tests/ptycho/test_ptycho.py:390-407,433-452): object recovery alone,
+    # with momentum, random and compact minibatch order
+    recon("noprobe", N=40, pw=24, det=32, S=2, eigen=0, num_batch=3,
+          batch_method="wobbly_center", epochs=3, adaptive=True, no_probe=True,
+          rng=np.random.default_rng(93))
+    recon("compact_noprobe", N=36, pw=16, det=16, S=1, eigen=0, num_batch=2,
+          batch_method="compact", epochs=4, adaptive=True, no_probe=True,
+          rng=np.random.default_rng(92))
+    sys.exit(0)
 if ONLY == "rpie2":
     # round 4: the reference's other rpie test configurations
     # (tests/ptycho/test_ptycho.py:490-543,670-700): the Poisson noise model

@@ -227,6 +227,9 @@ def _replay(g, second=False, solver="lstsq_grad"):
               unmeasured_pixels_scaling=float(g["scaling"]))
     epochs = int(g["epochs"])
     rescale_kw = {}
+    if solver != "rpie" and "no_probe" in g and bool(g["no_probe"]):
+        # the reference's "no probe" runs: an update start that never comes
+        kw.update(probe_update_start=10**6, probe_adaptive_moment=False)
     if solver == "rpie":
         kw.update(solver="rpie", recover_probe=not bool(g["no_probe"]))
         kw.pop("object_adaptive_moment")
@@ -272,7 +275,8 @@ def _replay(g, second=False, solver="lstsq_grad"):
 
 
 @pytest.mark.parametrize("tag", ["compact", "wobbly_eigen", "poisson_all",
-                                 "poisson_dominant"])
+                                 "poisson_dominant", "noprobe",
+                                 "compact_noprobe"])
 def test_lstsq_reconstruction_vs_reference(golden, tag):
     g = golden(f"lstsq_recon_{tag}.npz")
     first, state, order = _replay(g, second=True)

@@ -154,8 +154,8 @@ def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
             batch_method=str(g["batch_method"]), num_iter=int(g["epochs"]))),
         probe_options=tp.ProbeOptions(
             force_orthogonality=orth, use_adaptive_moment=adaptive,
-            **(dict(update_start=10**6) if algo == "rpie" and bool(
-                g["no_probe"]) else {}),
+            **(dict(update_start=10**6)
+               if "no_probe" in g and bool(g["no_probe"]) else {}),
             **(dict(probe_wavelength=float(g["phys"][0]),
                     probe_FOV_lengths=(float(g["phys"][1]),
                                        float(g["phys"][2])))
@@ -194,7 +194,8 @@ def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
 
 
 @pytest.mark.parametrize("tag", ["compact", "wobbly_eigen", "poisson_all",
-                                 "poisson_dominant"])
+                                 "poisson_dominant", "noprobe",
+                                 "compact_noprobe"])
 def test_lstsq_reconstruct_twice_vs_reference(tp, golden, tag):
     """The reference's ReconstructTwice template (tests/ptycho/templates.py:
     115-129), asserted against the reference's own iterates."""
