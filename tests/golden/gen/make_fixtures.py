@@ -461,6 +461,16 @@ if ONLY == "lstsq2":
           batch_method="compact", epochs=4, adaptive=True, no_probe=True,
           rng=np.random.default_rng(92))
     sys.exit(0)
+if ONLY == "positions2":
+    # round 4: position correction on data with unmeasured detector regions
+    # (tests/ptycho/test_position.py:373-412): NaN-masked patterns
+    recon("positions_masked", N=36, pw=24, det=24, S=2, eigen=0, num_batch=2,
+          batch_method="compact", epochs=3, orth=True,
+          rng=np.random.default_rng(91),
+          positions=dict(use_adaptive_moment=True,
+                         update_magnitude_limit=5), position_error=0.8,
+          psi_true_start=True, mask_frac=0.1, scaling=0.9)
+    sys.exit(0)
 if ONLY == "rpie2":
     # round 4: the reference's other rpie test configurations
     # (tests/ptycho/test_ptycho.py:490-543,670-700): the Poisson noise model

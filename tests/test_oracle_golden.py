@@ -296,7 +296,8 @@ def test_lstsq_reconstruction_vs_reference(golden, tag):
                  what="psi after call 2")
 
 
-@pytest.mark.parametrize("tag", ["positions_adam", "positions_plain"])
+@pytest.mark.parametrize("tag", ["positions_adam", "positions_plain",
+                                 "positions_masked"])
 def test_position_correction_vs_reference(golden, tag):
     """lstsq_grad with position correction (gaussian-derivative shift
     estimate, trimmed mean, ADAM, affine regularisation with RANSAC draws from

@@ -243,7 +243,8 @@ def test_chunked_minibatches_vs_reference(tp, golden, tag, monkeypatch):
         np.testing.assert_allclose(r1.scan, g["scan_1"], atol=2e-3)
 
 
-@pytest.mark.parametrize("tag", ["positions_adam", "positions_plain"])
+@pytest.mark.parametrize("tag", ["positions_adam", "positions_plain",
+                                 "positions_masked"])
 def test_position_correction_vs_reference(tp, golden, tag):
     """lstsq_grad with position correction (lstsq.py:545-579,764-806; affine
     regularisation position.py:716-776) against the reference's own run:
