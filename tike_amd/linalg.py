@@ -70,7 +70,7 @@ def hermitian(x):
 def lstsq(a, b, weights=None):
     """Least-squares solution x of a @ x = b for stacks of matrices, a
     (..., M, N), b (..., M, K) -> x (..., N, K), through the normal equations
-    (a^H a) x = a^H b; rows optionally weighted by `weights` (..., M)
+    x = (a^H a)^-1 a^H b; rows optionally weighted by `weights` (..., M)
     (linalg.py:33-61)."""
     if tuple(a.shape[:-1]) != tuple(b.shape[:-1]):
         raise AssertionError(f"Leading dims of a {tuple(a.shape)} and b "
@@ -80,9 +80,15 @@ def lstsq(a, b, weights=None):
             raise AssertionError("one weight per row of a")
         row_scale = _sqrt(weights)[..., None]
         a, b = a * row_scale, b * row_scale
-    solve = torch.linalg.solve if _is_t(a) else np.linalg.solve
+    # Evaluated as (inverse(a^H a) a^H) b in the working precision, like the
+    # reference: with float32 pixel coordinates (the affine position fit) the
+    # normal equations are ill-conditioned enough (cond ~ 1e4-1e5) for a
+    # differently ordered solve to move the translation by tenths of a pixel
+    # -- the reference-run fixtures pin this order
+    # (lstsq_recon_positions_masked.npz).
+    inverse = torch.linalg.inv if _is_t(a) else np.linalg.inv
     adjoint = hermitian(a)
-    return solve(adjoint @ a, adjoint @ b)
+    return inverse(adjoint @ a) @ adjoint @ b
 
 
 def orthogonalize_gs(x, axis=-1, N=None):

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .. import _arrays as A
-from .. import precision
+from .. import linalg, precision
 from .. import random as trandom
 
 
@@ -92,6 +92,21 @@ class AffineTransform:
                          [self.scale1 * sheared[0], self.scale1 * sheared[1]]],
                         dtype=precision.floating)
 
+    @classmethod
+    def fit(cls, positions0, positions1, weights=None) -> "AffineTransform":
+        """Least-squares transform with positions0 -> positions1 (rows may be
+        weighted): the normal equations of [positions0, 1] @ X = positions1,
+        solved in the positions' own precision and the reference's evaluation
+        order (see `linalg.lstsq`).  Positions on one line make them singular:
+        the identity transform is returned."""
+        ones = np.ones_like(positions0[..., :1])
+        try:
+            return cls.fromarray(
+                linalg.lstsq(np.concatenate([positions0, ones], axis=-1),
+                             positions1, weights))
+        except np.linalg.LinAlgError:
+            return cls()
+
     def asarray3(self, xp=np) -> np.ndarray:
         T = np.empty((3, 2), dtype=precision.floating)
         T[2] = (self.t0, self.t1)
@@ -119,22 +134,9 @@ class AffineTransform:
 def estimate_global_transformation(positions0, positions1, weights=None,
                                    transform=None):
     """The affine transformation that maps positions0 onto positions1 in the
-    (weighted) least-squares sense, and the residual norm over these
-    positions (position.py:252-270).  Solves the normal equations of
-    [positions0, 1] @ X = positions1; positions on one line make them
-    singular, which yields the identity transform.  Host arrays."""
-    design = np.concatenate(
-        [positions0, np.ones_like(positions0[..., :1])], axis=-1)
-    target = positions1
-    if weights is not None:
-        root = np.sqrt(weights)[..., None]
-        design, target = design * root, target * root
-    gram = design.conj().swapaxes(-1, -2)
-    try:
-        fitted = AffineTransform.fromarray(
-            np.linalg.solve(gram @ design, gram @ target))
-    except np.linalg.LinAlgError:
-        fitted = AffineTransform()
+    (weighted) least-squares sense (`AffineTransform.fit`) and the residual
+    norm over these positions (position.py:252-270).  Host arrays."""
+    fitted = AffineTransform.fit(positions0, positions1, weights)
     return fitted, np.linalg.norm(fitted(positions0) - positions1)
 
 
