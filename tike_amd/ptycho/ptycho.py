@@ -298,6 +298,11 @@ class Reconstruction():
                 # one clustering for the whole job: rank 0's (the generators
                 # are synchronised too, see Comm.sync_random)
                 order, batches = self.comm.broadcast_object((order, batches))
+        # the arrangement the reference's clustering leaves the positions in
+        # (concatenated batches): the RANSAC subsets of the affine position
+        # fit are INDICES into it, and a fit whose rough 4-point models drop
+        # some positions depends on which positions an index names
+        self.cluster_order = np.array(order, copy=True)
         if self._spatial_sort:
             # neighbours in space become neighbours in memory inside every
             # minibatch (see cluster.spatial_order); batch membership and
@@ -430,7 +435,11 @@ class Reconstruction():
             if self._fit_pool is None:
                 import concurrent.futures
                 self._fit_pool = concurrent.futures.ThreadPoolExecutor(1)
-                self._initial_scan_host = A.to_host(po.initial_scan)
+                # rows of this rank's arrays in the reference's arrangement
+                self._fit_rows = np.argsort(self.local_order)[
+                    self.cluster_order] if not self._presharded else slice(None)
+                self._initial_scan_host = A.to_host(
+                    po.initial_scan)[self._fit_rows]
             self._pending_fits.append(self._fit_pool.submit(
                 self._fit_job, po, snap, done,
                 ransac_subsets(p.scan.shape[0])))
@@ -442,9 +451,10 @@ class Reconstruction():
             return
         self._resolve_fits()
         pos0 = pos1 = None
-        if not local_fit:
-            pos0 = self._gather_positions(po.initial_scan)[self.order]
-            pos1 = self._gather_positions(p.scan)[self.order]
+        if not self._presharded:
+            # all positions of the job, in the reference's arrangement
+            pos0 = self._gather_positions(po.initial_scan)[self.cluster_order]
+            pos1 = self._gather_positions(p.scan)[self.cluster_order]
         p.scan, p.position_options = affine_position_regularization(
             updated=p.scan, position_options=po,
             positions0=pos0, positions1=pos1)
@@ -456,7 +466,8 @@ class Reconstruction():
         origin = A.to_host(po.origin)
         po.transform, _ = estimate_global_transformation_ransac(
             positions0=self._initial_scan_host - origin,
-            positions1=snap.numpy() - origin, transform=po.transform,
+            positions1=snap.numpy()[self._fit_rows] - origin,
+            transform=po.transform,
             max_error=32, subsets=subsets)
         with self._fit_lock:
             self._free_snaps.append(snap)
