@@ -18,6 +18,7 @@ What it does
    (``tests/data/ptycho_setup.pickle.lzma``, ``ptycho_gaussian.pickle.lzma``,
    ``tests/ptycho/ortho-{in,out}.mat``) as ``.npz``.
 """
+import json
 import lzma
 import os
 import pickle
@@ -329,7 +330,8 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
           adaptive=False, orth=False, rng=None, noise_model="gaussian",
           usemodes="all_modes", mask_frac=0.0, scaling=1.0, positions=None,
           position_error=0.0, psi_true_start=False, algo="lstsq", alpha=None,
-          no_probe=False, depth=1):
+          no_probe=False, depth=1, probe_extra=None, object_extra=None,
+          algo_extra=None):
     rng = globals()["rng"] if rng is None else rng
     p = make_problem(rng, N, pw, det, S, eigen=eigen,
                      margin=8 if positions else 0,
@@ -364,14 +366,17 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
             num_batch=num_batch, batch_method=batch_method, num_iter=epochs,
             **({} if alpha is None else dict(alpha=alpha)))
                            if algo == "rpie" else tike.ptycho.LstsqOptions(
-            num_batch=num_batch, batch_method=batch_method, num_iter=epochs)),
+            num_batch=num_batch, batch_method=batch_method, num_iter=epochs,
+            **(algo_extra or {}))),
         # (the reference reads the wavelength from probe_options, so "no
         # probe recovery" is a start epoch that is never reached)
         probe_options=tike.ptycho.ProbeOptions(
             force_orthogonality=orth, use_adaptive_moment=adaptive,
-            update_start=10**6 if no_probe else 0, **PHYS_PROBE),
+            update_start=10**6 if no_probe else 0, **PHYS_PROBE,
+            **(probe_extra or {})),
         object_options=tike.ptycho.ObjectOptions(
-            use_adaptive_moment=adaptive, **PHYS_OBJECT),
+            use_adaptive_moment=adaptive, **PHYS_OBJECT,
+            **(object_extra or {})),
         exitwave_options=tike.ptycho.ExitWaveOptions(
             measured_pixels=measured, noise_model=noise_model,
             step_length_usemodes=usemodes,
@@ -420,6 +425,9 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
          adaptive=adaptive, orth=orth, measured=measured,
          noise_model=noise_model, usemodes=usemodes, scaling=scaling,
          alpha=-1.0 if alpha is None else alpha, no_probe=no_probe,
+         extras=np.array(json.dumps(dict(probe=probe_extra or {},
+                                         object=object_extra or {},
+                                         algorithm=algo_extra or {}))),
          phys=np.array([PHYS_PROBE.get("probe_wavelength", np.nan),
                         *PHYS_PROBE.get("probe_FOV_lengths", (np.nan, np.nan)),
                         PHYS_OBJECT.get("multislice_propagation_distance",
@@ -470,6 +478,33 @@ if ONLY == "positions2":
           positions=dict(use_adaptive_moment=True,
                          update_magnitude_limit=5), position_error=0.8,
           psi_true_start=True, mask_frac=0.1, scaling=0.9)
+    sys.exit(0)
+if ONLY == "constraints":
+    # round 4: every probe / object constraint of ptycho.py:723-854 switched
+    # on in one run (their order of application is part of the result)
+    import cupyx.scipy.ndimage as _cnd
+    import scipy.ndimage as _snd
+    cp.unravel_index = lambda indices, dims, order="C": np.unravel_index(
+        indices, dims, order=order)
+    _cnd.median_filter = lambda input, size, **kw: _snd.median_filter(
+        input, size=tuple(int(v) for v in size), **kw)
+    recon("constraints", N=40, pw=24, det=24, S=2, eigen=0, num_batch=2,
+          batch_method="compact", epochs=3, orth=True,
+          rng=np.random.default_rng(90),
+          probe_extra=dict(probe_support=0.3, additional_probe_penalty=0.05,
+                           median_filter_abs_probe=True,
+                           median_filter_abs_probe_px=(3.0, 3.0),
+                           force_centered_intensity=True, force_sparsity=0.1),
+          object_extra=dict(positivity_constraint=0.3,
+                            smoothness_constraint=0.05, clip_magnitude=True),
+          algo_extra=dict(rescale_period=2))
+    recon("constraints_photons", N=36, pw=16, det=16, S=2, eigen=0,
+          num_batch=2, batch_method="compact", epochs=3, orth=False,
+          rng=np.random.default_rng(89),
+          probe_extra=dict(probe_photons=5e3, probe_support=0.2),
+          object_extra=dict(clip_magnitude=True),
+          algo_extra=dict(rescale_method="constant_probe_photons",
+                          rescale_period=2))
     sys.exit(0)
 if ONLY == "rpie2":
     # round 4: the reference's other rpie test configurations

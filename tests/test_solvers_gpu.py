@@ -133,7 +133,13 @@ def test_lstsq_minibatch_kernels_vs_reference(tp, golden, tag):
 
 
 def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
+    import json
     import tike_amd.random
+    extras = (json.loads(str(g["extras"])) if "extras" in g else
+              dict(probe={}, object={}, algorithm={}))
+    for k in ("median_filter_abs_probe_px", "probe_FOV_lengths"):
+        if k in extras["probe"]:
+            extras["probe"][k] = tuple(extras["probe"][k])
     det = int(g["det"])
     sizes = g["batch_sizes"]
     ends = np.cumsum(sizes)
@@ -151,9 +157,11 @@ def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
             **({} if float(g["alpha"]) < 0 else dict(alpha=float(g["alpha"]))))
                            if algo == "rpie" else tp.LstsqOptions(
             num_batch=int(g["num_batch"]),
-            batch_method=str(g["batch_method"]), num_iter=int(g["epochs"]))),
+            batch_method=str(g["batch_method"]), num_iter=int(g["epochs"]),
+            **extras["algorithm"])),
         probe_options=tp.ProbeOptions(
             force_orthogonality=orth, use_adaptive_moment=adaptive,
+            **extras["probe"],
             **(dict(update_start=10**6)
                if "no_probe" in g and bool(g["no_probe"]) else {}),
             **(dict(probe_wavelength=float(g["phys"][0]),
@@ -161,7 +169,7 @@ def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
                                        float(g["phys"][2])))
                if algo == "rpie" and g["psi0"].shape[0] > 1 else {})),
         object_options=tp.ObjectOptions(
-            use_adaptive_moment=adaptive,
+            use_adaptive_moment=adaptive, **extras["object"],
             **(dict(multislice_propagation_distance=float(g["phys"][3]))
                if algo == "rpie" and g["psi0"].shape[0] > 1 else {})),
         exitwave_options=tp.ExitWaveOptions(
@@ -195,7 +203,8 @@ def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
 
 @pytest.mark.parametrize("tag", ["compact", "wobbly_eigen", "poisson_all",
                                  "poisson_dominant", "noprobe",
-                                 "compact_noprobe"])
+                                 "compact_noprobe", "constraints",
+                                 "constraints_photons"])
 def test_lstsq_reconstruct_twice_vs_reference(tp, golden, tag):
     """The reference's ReconstructTwice template (tests/ptycho/templates.py:
     115-129), asserted against the reference's own iterates."""
