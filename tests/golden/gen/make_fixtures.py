@@ -24,6 +24,8 @@ import os
 import pickle
 import subprocess
 import sys
+
+sys.dont_write_bytecode = True  # never write into /root/reference
 import tempfile
 
 import numpy as np

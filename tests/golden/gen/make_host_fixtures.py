@@ -13,6 +13,8 @@ replays the same inputs (and the same generator seeds) through tike_amd.
 import os
 import sys
 
+sys.dont_write_bytecode = True  # never write into /root/reference
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

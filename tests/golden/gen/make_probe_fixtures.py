@@ -18,6 +18,8 @@
 import os
 import sys
 
+sys.dont_write_bytecode = True  # never write into /root/reference
+
 import numpy as np
 import scipy.io
 
