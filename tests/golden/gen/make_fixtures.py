@@ -164,7 +164,7 @@ for tag, (nscan, pw, det, S, HW, shared) in {
 
 # ---- synthetic ptychography problem ---------------------------------------
 def make_problem(rng, N, pw, det, S, pitch=3.0, eigen=0, margin=0,
-                 position_error=0.0):
+                 position_error=0.0, eigen_modes=1):
     side = int(np.ceil(np.sqrt(N)))
     ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
                               indexing="ij"), -1).reshape(-1, 2)[:N]
@@ -193,7 +193,8 @@ def make_problem(rng, N, pw, det, S, pitch=3.0, eigen=0, margin=0,
         tike.random.randomizer_np = np.random.default_rng(
             int(rng.integers(1 << 30)))
         eigen_probe, eigen_weights = tike.ptycho.probe.init_varying_probe(
-            scan, probe0, num_eigen_probes=eigen + 1, probes_with_modes=1)
+            scan, probe0, num_eigen_probes=eigen + 1,
+            probes_with_modes=eigen_modes)
     return dict(scan=scan, scan_true=scan_true, psi_true=psi_true,
                 probe_true=probe, data=data,
                 psi0=psi0, probe0=probe0, eigen_probe=eigen_probe,
@@ -333,11 +334,11 @@ def recon(tag, N, pw, det, S, eigen, num_batch, batch_method, epochs,
           usemodes="all_modes", mask_frac=0.0, scaling=1.0, positions=None,
           position_error=0.0, psi_true_start=False, algo="lstsq", alpha=None,
           no_probe=False, depth=1, probe_extra=None, object_extra=None,
-          algo_extra=None):
+          algo_extra=None, eigen_modes=1):
     rng = globals()["rng"] if rng is None else rng
     p = make_problem(rng, N, pw, det, S, eigen=eigen,
                      margin=8 if positions else 0,
-                     position_error=position_error)
+                     position_error=position_error, eigen_modes=eigen_modes)
     if depth > 1:
         # multislice object: every slice starts from the same guess, slightly
         # perturbed so that the slices are distinguishable
@@ -507,6 +508,17 @@ if ONLY == "constraints":
           object_extra=dict(clip_magnitude=True),
           algo_extra=dict(rescale_method="constant_probe_photons",
                           rescale_period=2))
+    sys.exit(0)
+if ONLY == "eigen2":
+    # round 4: eigen probes on two of three modes (probes_with_modes = 2):
+    # the forward model varies both, the update touches mode 0 only
+    # (lstsq.py:169,297-364); one and two eigen probes
+    recon("eigen_modes2", N=40, pw=24, det=24, S=3, eigen=1, num_batch=2,
+          batch_method="compact", epochs=3, orth=True, eigen_modes=2,
+          rng=np.random.default_rng(88))
+    recon("eigen2_modes2", N=36, pw=16, det=32, S=2, eigen=2, num_batch=2,
+          batch_method="wobbly_center", epochs=3, orth=True, eigen_modes=2,
+          rng=np.random.default_rng(87))
     sys.exit(0)
 if ONLY == "rpie2":
     # round 4: the reference's other rpie test configurations

@@ -204,7 +204,8 @@ def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
 @pytest.mark.parametrize("tag", ["compact", "wobbly_eigen", "poisson_all",
                                  "poisson_dominant", "noprobe",
                                  "compact_noprobe", "constraints",
-                                 "constraints_photons"])
+                                 "constraints_photons", "eigen_modes2",
+                                 "eigen2_modes2"])
 def test_lstsq_reconstruct_twice_vs_reference(tp, golden, tag):
     """The reference's ReconstructTwice template (tests/ptycho/templates.py:
     115-129), asserted against the reference's own iterates."""
