@@ -520,6 +520,62 @@ if ONLY == "eigen2":
           batch_method="wobbly_center", epochs=3, orth=True, eigen_modes=2,
           rng=np.random.default_rng(87))
     sys.exit(0)
+if ONLY == "cgrad2":
+    # round 4: the cgrad composition with the PROBE step and two minibatches:
+    # per minibatch, tike.opt.conjugate_gradient on psi (cost = Ptycho.cost,
+    # gradient = Ptycho.adj(gaussian_grad)[0]) then on the probe (gradient =
+    # sum over the positions of Ptycho.adj(...)[1]), as
+    # lamino/solvers/cgrad.py:58-92 alternates its variables
+    rng_c = np.random.default_rng(86)
+    p = make_problem(rng_c, 40, 24, 24, 2)
+    HW = p["psi0"].shape[-1]
+    halves = np.array_split(np.arange(40), 2)
+    with tike.operators.Ptycho(probe_shape=24, detector_shape=24, nz=HW, n=HW,
+                               **PHYS) as op:
+        psi, probe = A(p["psi0"]), A(p["probe0"])
+        scan_all, data_all = A(p["scan"]), A(p["data"])
+        epoch_costs, psis, probes = [], [], []
+        for _ in range(3):
+            batch_cost = []
+            for b in halves:
+                scan, data = scan_all[b], data_all[b]
+
+                def far_gradient(psi_, probe_):
+                    inten, far = op._compute_intensity(data, psi_, scan, probe_)
+                    return tike.operators.gaussian_grad(data, far, inten)
+
+                def wide(probe_):
+                    return cp.asarray(np.broadcast_to(
+                        probe_, (len(scan), *probe_.shape[1:])).copy())
+
+                psi, c = tike.opt.conjugate_gradient(
+                    cp, x=psi,
+                    cost_function=lambda x: float(op.cost(
+                        data, x, scan, probe, model="gaussian")),
+                    grad=lambda x: [op.adj(farplane=far_gradient(x, probe),
+                                           probe=wide(probe), scan=scan,
+                                           psi=x)[0]],
+                    dir_multi=lambda d: d[0], num_iter=3, step_length=1.0)
+                psi = cp.asarray(psi, dtype=np.complex64)
+                probe, c = tike.opt.conjugate_gradient(
+                    cp, x=probe,
+                    cost_function=lambda q: float(op.cost(
+                        data, psi, scan, q, model="gaussian")),
+                    grad=lambda q: [cp.sum(op.adj(
+                        farplane=far_gradient(psi, q), probe=wide(q),
+                        scan=scan, psi=psi)[1], axis=0, keepdims=True)],
+                    dir_multi=lambda d: d[0], num_iter=3, step_length=1.0)
+                probe = cp.asarray(probe, dtype=np.complex64)
+                batch_cost.append(float(c))
+            epoch_costs.append(float(np.mean(batch_cost)))
+            psis.append(np.asarray(psi).copy())
+            probes.append(np.asarray(probe).copy())
+    save("cgrad_probe.npz", data=p["data"], psi0=p["psi0"],
+         probe0=p["probe0"], scan=p["scan"], det=24, cg_iter=3,
+         costs=np.array(epoch_costs), psis=np.stack(psis),
+         probes=np.stack(probes))
+    print("cgrad_probe costs", epoch_costs)
+    sys.exit(0)
 if ONLY == "rpie2":
     # round 4: the reference's other rpie test configurations
     # (tests/ptycho/test_ptycho.py:490-543,670-700): the Poisson noise model

@@ -335,6 +335,23 @@ def test_cgrad_vs_reference_composition(golden):
         assert relerr(state["psi"], g["psis"][i]) < 2e-3
 
 
+def test_cgrad_with_probe_vs_reference_composition(golden):
+    """The oracle's cgrad with the probe step and two minibatches replays the
+    same composition of the reference's own pieces."""
+    g = golden("cgrad_probe.npz")
+    det, N = int(g["det"]), len(g["scan"])
+    state = dict(psi=g["psi0"].copy(), probe=g["probe0"].copy(),
+                 scan=g["scan"].copy(), costs=[])
+    batches = np.array_split(np.arange(N), 2)
+    for i in range(3):
+        state = sol.cgrad(state, g["data"], batches, detector_shape=det,
+                          cg_iter=int(g["cg_iter"]), recover_probe=True)
+        np.testing.assert_allclose(state["costs"][-1][0], g["costs"][i],
+                                   rtol=2e-3)
+        assert relerr(state["psi"], g["psis"][i]) < 2e-3
+        assert relerr(state["probe"], g["probes"][i]) < 2e-3
+
+
 def test_multislice_vs_reference(golden):
     """FresnelSpectProp, Multislice (3 slices) and Ptycho over it, against
     the reference's own outputs (operators/cupy/multislice.py:69-194,

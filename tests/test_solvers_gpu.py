@@ -328,6 +328,33 @@ def test_cgrad_vs_reference_composition(tp, golden):
         assert relerr(params.psi, g["psis"][i]) < 2e-3
 
 
+def test_cgrad_with_probe_vs_reference_composition(tp, golden):
+    """Two minibatches, object then probe per minibatch (3 CG iterations
+    each), three epochs, against the same composition of the reference's own
+    pieces (tike.opt.conjugate_gradient over Ptycho.cost / Ptycho.adj, the
+    probe gradient summed over the positions)."""
+    g = golden("cgrad_probe.npz")
+    det, N = int(g["det"]), len(g["scan"])
+    params = tp.PtychoParameters(
+        probe=g["probe0"].copy(), psi=g["psi0"].copy(), scan=g["scan"].copy(),
+        algorithm_options=tp.CgradOptions(num_batch=2, cg_iter=int(g["cg_iter"]),
+                                          batch_method="contiguous"),
+        probe_options=tp.ProbeOptions(init_rescale_from_measurements=False),
+        object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    with tp.Reconstruction(g["data"], params, order=np.arange(N),
+                           batches=np.array_split(np.arange(N), 2),
+                           spatial_sort=False) as ctx:
+        for i in range(3):
+            ctx.iterate(1)
+            r = ctx.get_result()
+            np.testing.assert_allclose(r.algorithm_options.costs[-1][0],
+                                       g["costs"][i], rtol=5e-3)
+            assert relerr(r.psi, g["psis"][i]) < 3e-3
+            assert relerr(r.probe, g["probes"][i]) < 3e-3
+
+
 @pytest.mark.parametrize("det,pw,S,N", [(256, 256, 1, 6), (256, 192, 2, 5),
                                         (128, 128, 1, 8), (512, 512, 2, 3),
                                         (64, 48, 2, 9),
