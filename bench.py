@@ -426,10 +426,14 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
                 num_batch=num_batch)
 
 
-def epoch_leg(workload, tp, A, torch, positions=0, epochs=2):
+LEG_EPOCHS = {"c1": 20, "c2": 3, "c5": 3}
+
+
+def epoch_leg(workload, tp, A, torch, positions=0, epochs=None):
     """One short leg of another BASELINE configuration: one warm-up epoch
-    (cgrad: two -- the second occurrence of a CG call captures its graph),
-    then `epochs` timed ones (wall clock around synchronised epochs)."""
+    (cgrad: two -- its line searches learn their slot counts), then `epochs`
+    timed ones (wall clock around synchronised epochs; default LEG_EPOCHS)."""
+    epochs = epochs or LEG_EPOCHS.get(workload, 2)
     built = epoch_problem(workload, positions, 1, 0, tp, A)
     ctx = built["ctx"]
     try:
