@@ -72,14 +72,14 @@ def lstsq(a, b, weights=None):
     (..., M, N), b (..., M, K) -> x (..., N, K), through the normal equations
     x = (a^H a)^-1 a^H b; rows optionally weighted by `weights` (..., M)
     (linalg.py:33-61)."""
-    if tuple(a.shape[:-1]) != tuple(b.shape[:-1]):
+    rows = tuple(a.shape[:-1])
+    if rows != tuple(b.shape[:-1]):
         raise AssertionError(f"Leading dims of a {tuple(a.shape)} and b "
                              f"{tuple(b.shape)} must be same!")
+    if weights is not None and tuple(weights.shape) != rows:
+        raise AssertionError("one weight per row of a")
     if weights is not None:
-        if tuple(weights.shape) != tuple(a.shape[:-1]):
-            raise AssertionError("one weight per row of a")
-        row_scale = _sqrt(weights)[..., None]
-        a, b = a * row_scale, b * row_scale
+        a, b = (m * _sqrt(weights)[..., None] for m in (a, b))
     # Evaluated as (inverse(a^H a) a^H) b in the working precision, like the
     # reference: with float32 pixel coordinates (the affine position fit) the
     # normal equations are ill-conditioned enough (cond ~ 1e4-1e5) for a

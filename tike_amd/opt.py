@@ -140,14 +140,17 @@ def conjugate_gradient(array_module, x, cost_function, grad,
     directions; the first `num_search` of them (default: all) are followed by
     a backtracking line search that starts from the step length the previous
     search accepted, the others reuse that step length.  Returns (x, cost)."""
-    searched = min(num_iter, num_iter if num_search is None else num_search)
+    searches = num_iter if num_search is None else min(num_search, num_iter)
+    blind = num_iter - searches
     next_move = _ConjugateDirections(array_module, direction_dy, dir_multi)
-    for _ in range(searched):
-        step_length, cost, x = line_search(cost_function, x,
-                                           next_move(grad(x)), update_multi,
-                                           step_length, cost=cost)
-    if searched == num_iter:
+    while searches > 0:
+        searches -= 1
+        found = line_search(cost_function, x, next_move(grad(x)),
+                            update_multi, step_length, cost=cost)
+        step_length, cost, x = found
+    if blind == 0:
         return x, cost
-    for _ in range(searched, num_iter):  # the rest reuse the last step length
+    while blind > 0:  # the rest reuse the last accepted step length
+        blind -= 1
         x = update_multi(x, step_length, next_move(grad(x)))
     return x, cost_function(x)

@@ -253,15 +253,16 @@ def init_varying_probe(scan, shared_probe, num_eigen_probes,
     if varying > modes:
         raise ValueError(f"probes_with_modes ({varying}) cannot be more than "
                          f"the number of probes ({modes})!")
-    if num_eigen_probes < 1:
-        return None, None
-    weights = _jittered_weights((*scan.shape[:-1], num_eigen_probes, modes),
-                                varying)
-    if num_eigen_probes == 1:
-        return None, weights
-    noise = trandom.numpy_complex(*lead, num_eigen_probes - 1, varying, height,
-                                  width)
-    return noise / linalg.mnorm(noise, axis=(-2, -1), keepdims=True), weights
+    eigen_probe = weights = None
+    if num_eigen_probes >= 1:
+        weights = _jittered_weights(
+            (*scan.shape[:-1], num_eigen_probes, modes), varying)
+    if num_eigen_probes >= 2:
+        noise = trandom.numpy_complex(*lead, num_eigen_probes - 1, varying,
+                                      height, width)
+        eigen_probe = noise / linalg.mnorm(noise, axis=(-2, -1),
+                                           keepdims=True)
+    return eigen_probe, weights
 
 
 def finite_probe_support(probe, *, radius=0.5, degree=5.0, p=1.0):

@@ -174,6 +174,34 @@ def _clip_magnitude(x, a_max):
     return torch.where(magnitude > a_max, a_max * x / magnitude, x)
 
 
+def _check_data_shape(data, parameters):
+    """The diffraction patterns against the forward model's shapes
+    (reference ptycho.py:303-331: same conditions, same messages)."""
+    frames = tuple(int(n) for n in data.shape)
+    window = tuple(int(n) for n in parameters.probe.shape[-2:])
+    mask = tuple(parameters.exitwave_options.measured_pixels.shape)
+    masked = parameters.algorithm_options.name != "cgrad"  # cgrad: no mask
+    rules = (
+        (len(frames) == 3 and min(frames) >= 1 and frames[1] == frames[2],
+         f"data shape {data.shape} is incorrect. "
+         "It should be (N, W, H), "
+         "where N >= 1 is the number of square diffraction patterns."),
+        (frames[:1] == tuple(parameters.scan.shape[:1]),
+         f"data shape {data.shape} and scan shape {parameters.scan.shape} "
+         "are incompatible. They should have the same leading dimension."),
+        (all(w <= d for w, d in zip(window, frames[-2:])),
+         f"probe shape {parameters.probe.shape} "
+         f"and data shape {data.shape} are incompatible. "
+         "The probe width/height must be <= the data width/height ."),
+        (not masked or mask == frames[-2:],
+         f"exitwave_options.measured_pixels shape {mask} "
+         f"does not match the diffraction patterns {frames[-2:]}"),
+    )
+    for holds, complaint in rules:
+        if not holds:
+            raise ValueError(complaint)
+
+
 class Reconstruction():
     """Context manager keeping data and parameters on the GPU between
     ``iterate`` calls (ptycho.py:265-653).
@@ -210,32 +238,7 @@ class Reconstruction():
                 f"{len(_spawn.requested_devices(num_gpu))}`")
         if device is not None:
             torch.cuda.set_device(device)  # ptycho.py:344-345
-        if (np.any(np.asarray(data.shape) < 1) or data.ndim != 3
-                or data.shape[-2] != data.shape[-1]):
-            raise ValueError(
-                f"data shape {data.shape} is incorrect. "
-                "It should be (N, W, H), "
-                "where N >= 1 is the number of square diffraction patterns.")
-        if data.shape[0] != parameters.scan.shape[0]:
-            raise ValueError(
-                f"data shape {data.shape} and scan shape "
-                f"{parameters.scan.shape} "
-                "are incompatible. They should have the same leading dimension."
-            )
-        if np.any(
-                np.asarray(parameters.probe.shape[-2:]) > np.asarray(
-                    data.shape[-2:])):
-            raise ValueError(f"probe shape {parameters.probe.shape} "
-                             f"and data shape {data.shape} are incompatible. "
-                             "The probe width/height must be "
-                             f"<= the data width/height .")
-        mp = parameters.exitwave_options.measured_pixels
-        if (parameters.algorithm_options.name != "cgrad"  # cgrad: no mask
-                and tuple(mp.shape) != tuple(data.shape[-2:])):
-            raise ValueError(
-                f"exitwave_options.measured_pixels shape {tuple(mp.shape)} "
-                f"does not match the diffraction patterns "
-                f"{tuple(data.shape[-2:])}")
+        _check_data_shape(data, parameters)
         name = parameters.algorithm_options.name
         if not hasattr(solvers, name):
             raise NotImplementedError(

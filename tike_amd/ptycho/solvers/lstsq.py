@@ -963,15 +963,16 @@ def _update_position(scan, position_options, numerator, denominator, comm,
     po = position_options
     if epoch < po.update_start:
         return scan
-    ceiling = torch.clamp(comm.Allreduce_max(denominator.max()), min=1e-6)
-    shift = numerator / ((1 - alpha) * denominator + alpha * ceiling)
-    if po.update_magnitude_limit > 0:
-        shift = shift.clamp(-po.update_magnitude_limit,
-                            po.update_magnitude_limit)
-    shift = shift - _trimmed_mean(comm.Allgather_rows(shift))
+    damping = alpha * torch.clamp(comm.Allreduce_max(denominator.max()),
+                                  min=1e-6)
+    shift = numerator / ((1 - alpha) * denominator + damping)
+    limit = po.update_magnitude_limit
+    if limit > 0:
+        shift = shift.clamp(-limit, limit)
+    shift -= _trimmed_mean(comm.Allgather_rows(shift))
     if po.use_adaptive_moment:
-        shift, po.v, po.m = opt.adam(shift, po.v, po.m, vdecay=po.vdecay,
-                                     mdecay=po.mdecay)
+        moments = dict(vdecay=po.vdecay, mdecay=po.mdecay)
+        shift, po.v, po.m = opt.adam(shift, po.v, po.m, **moments)
     return scan - shift
 
 

@@ -86,24 +86,28 @@ class PtychoParameters():
         `exitwave_options` says otherwise."""
         scan, probe, psi = (tuple(int(n) for n in x.shape)
                             for x in (self.scan, self.probe, self.psi))
-        if len(scan) != 2 or scan[1] != 2 or scan[0] < 1:
-            raise ValueError(f"scan shape {self.scan.shape} is incorrect. "
-                             "It should be (N, 2) "
-                             "where N >= 1 is the number of scan positions.")
-        if (len(probe) != 5 or probe[:2] != (1, 1) or min(probe) < 1
-                or probe[3] != probe[4]):
-            raise ValueError(f"probe shape {self.probe.shape} is incorrect. "
-                             "It should be (1, 1, S, W, H) "
-                             "where S >=1 is the number of probes, and "
-                             "W, H >= 1 are the square probe grid dimensions.")
-        if len(psi) != 3 or psi[1] <= probe[3] or psi[2] <= probe[4]:
-            raise ValueError(
-                f"psi shape {self.psi.shape} is incorrect. "
-                "It should be (D, W, H) where W, H > probe.shape[-2:].")
+        rules = (
+            (len(scan) == 2 and scan[1:] == (2,) and scan[0] >= 1,
+             f"scan shape {self.scan.shape} is incorrect. "
+             "It should be (N, 2) "
+             "where N >= 1 is the number of scan positions."),
+            (len(probe) == 5 and probe[:2] == (1, 1) and min(probe) >= 1
+             and probe[3] == probe[4],
+             f"probe shape {self.probe.shape} is incorrect. "
+             "It should be (1, 1, S, W, H) "
+             "where S >=1 is the number of probes, and "
+             "W, H >= 1 are the square probe grid dimensions."),
+            (len(psi) == 3 and len(probe) == 5
+             and all(o > w for o, w in zip(psi[1:], probe[3:])),
+             f"psi shape {self.psi.shape} is incorrect. "
+             "It should be (D, W, H) where W, H > probe.shape[-2:]."),
+        )
+        for holds, complaint in rules:
+            if not holds:
+                raise ValueError(complaint)
         check_allowed_positions(self.scan, self.psi, self.probe.shape)
-        if self.exitwave_options is None:
-            self.exitwave_options = ExitWaveOptions(
-                measured_pixels=np.ones(probe[3:], dtype=np.bool_))
+        self.exitwave_options = self.exitwave_options or ExitWaveOptions(
+            measured_pixels=np.ones(probe[3:], dtype=np.bool_))
 
     def _map(self, f, fo):
         return PtychoParameters(
@@ -127,27 +131,23 @@ class PtychoParameters():
         default), the object by a cubic spline, positions scaled; the option
         objects rescale themselves."""
         interp = _resize_fft if interp is None else interp
-
-        def each(value, change):
-            return None if value is None else change(value)
-
+        rescaled = {
+            "probe": lambda x: interp(A.to_host(x), factor),
+            "psi": lambda x: _resize_spline(A.to_host(x), factor),
+            "scan": lambda x: A.to_host(x) * factor,
+            "eigen_probe": lambda x: interp(A.to_host(x), factor),
+            "eigen_weights": A.to_host,
+            "probe_options": lambda o: o.resample(factor, interp),
+            "object_options": lambda o: o.resample(factor, interp),
+            "position_options": lambda o: o.copy_to_host().resample(factor),
+            "exitwave_options": lambda o: o.resample(factor),
+        }
         return dataclasses.replace(
-            self,
-            probe=interp(A.to_host(self.probe), factor),
-            psi=_resize_spline(A.to_host(self.psi), factor),
-            scan=A.to_host(self.scan) * factor,
-            eigen_probe=each(self.eigen_probe,
-                             lambda e: interp(A.to_host(e), factor)),
-            eigen_weights=each(self.eigen_weights, A.to_host),
-            probe_options=each(self.probe_options,
-                               lambda o: o.resample(factor, interp)),
-            object_options=each(self.object_options,
-                                lambda o: o.resample(factor, interp)),
-            position_options=each(
-                self.position_options,
-                lambda o: o.copy_to_host().resample(factor)),
-            exitwave_options=each(self.exitwave_options,
-                                  lambda o: o.resample(factor)))
+            self, **{
+                name: change(getattr(self, name))
+                for name, change in rescaled.items()
+                if getattr(self, name) is not None
+            })
 
     def copy_to_device(self) -> "PtychoParameters":
         return self._map(
