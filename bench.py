@@ -427,17 +427,21 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
 
 
 LEG_EPOCHS = {"c1": 20, "c2": 3, "c5": 3}
+# untimed epochs in front (cgrad: at least two -- its line searches learn their
+# slot counts; c1's epochs are 3 ms: ten of them bring the clocks of a GPU
+# that idled during the set-up back up, profiles/r04_leg_probe.txt)
+LEG_WARM_EPOCHS = {"c1": 10, "c2": 2, "c5": 1}
 
 
 def epoch_leg(workload, tp, A, torch, positions=0, epochs=None):
-    """One short leg of another BASELINE configuration: one warm-up epoch
-    (cgrad: two -- its line searches learn their slot counts), then `epochs`
-    timed ones (wall clock around synchronised epochs; default LEG_EPOCHS)."""
+    """One short leg of another BASELINE configuration: LEG_WARM_EPOCHS
+    untimed epochs, then `epochs` timed ones (wall clock around synchronised
+    epochs; default LEG_EPOCHS)."""
     epochs = epochs or LEG_EPOCHS.get(workload, 2)
     built = epoch_problem(workload, positions, 1, 0, tp, A)
     ctx = built["ctx"]
     try:
-        ctx.iterate(2 if workload in ("c1", "c2") else 1)
+        ctx.iterate(LEG_WARM_EPOCHS.get(workload, 1))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ctx.iterate(epochs)
@@ -457,14 +461,17 @@ def epoch_leg(workload, tp, A, torch, positions=0, epochs=None):
                 iteration_fp32_frac=f_iter * rate / 1e12 / FP32_PEAK_TFLOPS)
 
 
-def forward_leg(ops, A, torch, det, S, N, iters=10):
-    """One short leg of the forward operator alone (hip-event timed)."""
+def forward_leg(ops, A, torch, det, S, N, iters=40, warm=8):
+    """One short leg of the forward operator alone (hip-event timed).  The
+    GPU has idled while the host generated the inputs: `warm` untimed calls
+    bring its clocks back up (with 2 warm-up + 10 timed calls the same
+    kernels measured 5 % slower than over 50 calls, tools/leg_probe.py)."""
     p = synthetic(N, S, det, 0, N)
     op = ops.Ptycho(probe_shape=det, detector_shape=det, nz=p["HW"], n=p["HW"])
     scan, psi, probe = (A.to_device(p[k]) for k in ("scan", "psi", "probe"))
     out = torch.empty((N, 1, S, det, det), dtype=torch.complex64,
                       device=psi.device)
-    for _ in range(2):
+    for _ in range(warm):
         op.fwd_device(probe, scan, psi, out=out)
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
@@ -673,6 +680,8 @@ def main():
                 torch.cuda.empty_cache()
                 return dict(workload=name, error=f"{type(e).__name__}: {e}")
 
+        del data
+        torch.cuda.empty_cache()
         secondary = [guarded("fwd256x1", forward_leg, ops, A, torch, 256, 1,
                              4096),
                      guarded("fwd128x1", forward_leg, ops, A, torch, 128, 1,
@@ -680,7 +689,6 @@ def main():
                      guarded("fwd256x8", forward_leg, ops, A, torch, 256, 8,
                              512)]
         # ... and the other BASELINE configurations, one short leg each
-        del data
         torch.cuda.empty_cache()
         secondary += [guarded(w, epoch_leg, w, tp, A, torch)
                       for w in ("c1", "c2", "c5")]
