@@ -472,6 +472,13 @@ if ONLY == "lstsq2":
           batch_method="compact", epochs=4, adaptive=True, no_probe=True,
           rng=np.random.default_rng(92))
     sys.exit(0)
+if ONLY == "bootstrap":
+    # round 4: the third minibatch selector the reference's options accept
+    # (cluster.py:380-462): random 95 % start, wobbly-center for the rest
+    recon("bootstrap", N=47, pw=16, det=24, S=2, eigen=0, num_batch=3,
+          batch_method="wobbly_center_random_bootstrap", epochs=3,
+          rng=np.random.default_rng(90))
+    sys.exit(0)
 if ONLY == "positions2":
     # round 4: position correction on data with unmeasured detector regions
     # (tests/ptycho/test_position.py:373-412): NaN-masked patterns

@@ -62,6 +62,16 @@ for i, (n, k, seed) in enumerate([(97, 5, 0), (256, 4, 1), (400, 10, 2),
     out[f"cluster_compact_{i}"] = labels_of(ref_cluster.compact(pop, k), n)
     out[f"cluster_compact_next_{i}"] = np.float64(np.random.random_sample())
     out[f"cluster_wobbly_{i}"] = labels_of(ref_cluster.wobbly_center(pop, k), n)
+    state = np.random.get_state()  # (added later: leaves the draws below alone)
+    np.random.seed(1000 + seed)
+    out[f"cluster_bootstrap_{i}"] = labels_of(
+        ref_cluster.wobbly_center_random_bootstrap(pop, k), n)
+    out[f"cluster_bootstrap_half_{i}"] = labels_of(
+        ref_cluster.wobbly_center_random_bootstrap(pop, k, boot_fraction=0.5), n)
+    out[f"cluster_bootstrap_next_{i}"] = np.float64(np.random.random_sample())
+    out[f"cluster_stripes_{i}"] = labels_of(
+        ref_cluster.stripes_equal_count(pop, k, dim=i % 2), n)
+    np.random.set_state(state)
 out["cluster_cases"] = np.int64(i + 1)
 
 # ---- tike.opt: a small complex least-squares problem |A x - b|^2

@@ -39,6 +39,19 @@ def test_cluster_labels_equal_the_reference(g, case):
     assert np.random.random_sample() == float(g[f"cluster_compact_next_{case}"])
     got = _labels(cluster.wobbly_center(pop, k), len(pop))
     np.testing.assert_array_equal(got, g[f"cluster_wobbly_{case}"])
+    # the randomly started variant (two fractions, same generator stream) and
+    # the equal-count stripes
+    np.random.seed(1000 + int(g[f"cluster_seed_{case}"]))
+    got = _labels(cluster.wobbly_center_random_bootstrap(pop, k), len(pop))
+    np.testing.assert_array_equal(got, g[f"cluster_bootstrap_{case}"])
+    got = _labels(
+        cluster.wobbly_center_random_bootstrap(pop, k, boot_fraction=0.5),
+        len(pop))
+    np.testing.assert_array_equal(got, g[f"cluster_bootstrap_half_{case}"])
+    assert np.random.random_sample() == float(
+        g[f"cluster_bootstrap_next_{case}"])
+    got = _labels(cluster.stripes_equal_count(pop, k, dim=case % 2), len(pop))
+    np.testing.assert_array_equal(got, g[f"cluster_stripes_{case}"])
 
 
 # ---------------------------------------------------------------- tike.opt

@@ -277,7 +277,7 @@ def _replay(g, second=False, solver="lstsq_grad"):
 @pytest.mark.parametrize("tag", ["compact", "wobbly_eigen", "poisson_all",
                                  "poisson_dominant", "noprobe",
                                  "compact_noprobe", "eigen_modes2",
-                                 "eigen2_modes2"])
+                                 "eigen2_modes2", "bootstrap"])
 def test_lstsq_reconstruction_vs_reference(golden, tag):
     g = golden(f"lstsq_recon_{tag}.npz")
     first, state, order = _replay(g, second=True)

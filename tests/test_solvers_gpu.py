@@ -205,7 +205,7 @@ def _reconstruct_like_reference(tp, g, second, algo="lstsq"):
                                  "poisson_dominant", "noprobe",
                                  "compact_noprobe", "constraints",
                                  "constraints_photons", "eigen_modes2",
-                                 "eigen2_modes2"])
+                                 "eigen2_modes2", "bootstrap"])
 def test_lstsq_reconstruct_twice_vs_reference(tp, golden, tag):
     """The reference's ReconstructTwice template (tests/ptycho/templates.py:
     115-129), asserted against the reference's own iterates."""

@@ -37,6 +37,42 @@ def wobbly_center(population, num_cluster):
     return [np.flatnonzero(owner == c) for c in range(num_cluster)]
 
 
+def wobbly_center_random_bootstrap(population, num_cluster,
+                                   boot_fraction=0.95):
+    """`wobbly_center` with a random start (the reference's batch method of
+    the same name, cluster.py:380-462, whose labels this reproduces): a
+    `boot_fraction` of the points -- rounded down to a multiple of
+    `num_cluster`, drawn without replacement from the legacy ``np.random``
+    generator -- is dealt to the clusters in turn; the clusters then take
+    turns claiming the free point farthest from their own current mean."""
+    points = np.asarray(population)
+    _check_cluster_count(num_cluster)
+    count = len(points)
+    if num_cluster == 1 or num_cluster >= count:
+        return contiguous(points, num_cluster)
+    dealt = int(count * boot_fraction)
+    dealt -= dealt % num_cluster
+    drawn = np.random.choice(count, size=dealt, replace=False)
+    owner = np.full(count, -1, dtype=np.int64)
+    owner[drawn] = np.arange(dealt) % num_cluster
+    for turn in range(count - dealt):
+        cluster = turn % num_cluster
+        free = np.flatnonzero(owner < 0)
+        centre = points[owner == cluster].mean(axis=0, keepdims=True)
+        reach = np.linalg.norm(points[free] - centre, axis=1)
+        owner[free[np.argmax(reach)]] = cluster
+    return [np.flatnonzero(owner == c) for c in range(num_cluster)]
+
+
+def stripes_equal_count(population, num_cluster, dim=0):
+    """Index sets of `num_cluster` stripes across dimension `dim` holding
+    (nearly) the same number of points each (cluster.py:265-299)."""
+    points = np.asarray(population)
+    if num_cluster == 1 or num_cluster >= len(points):
+        return contiguous(points, num_cluster)
+    return np.array_split(np.argsort(points[:, dim]), num_cluster)
+
+
 class _EqualSizeKMeans:
     """Equal-size k-means ("compact" batches): k-means++ seeds, a capacity-
     limited greedy assignment, then pairwise swaps that lower the summed
@@ -164,6 +200,7 @@ def contiguous(population, num_cluster):
 
 _METHODS = {
     "wobbly_center": wobbly_center,
+    "wobbly_center_random_bootstrap": wobbly_center_random_bootstrap,
     "compact": compact,
     "contiguous": contiguous,
 }
