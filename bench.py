@@ -331,6 +331,15 @@ def algorithmic_bytes(name, n, S, det, pw, C):
     return table.get(name, 0)
 
 
+def dominant_entry(summary, n, S, det, C):
+    """The tike_* entry with the most time among those with a byte model (a
+    composite such as tike_cgrad_line_search -- many small launches under one
+    name -- has none and cannot carry a roofline)."""
+    ks = {k: v for k, v in summary.items() if k.startswith("tike_")}
+    modelled = [k for k in ks if algorithmic_bytes(k, n, S, det, det, C)]
+    return max(modelled or ks, key=lambda k: ks[k]["total_ms"])
+
+
 def iteration_bounds(S, det, pw):
     """compulsory HBM bytes and flops of one lstsq_grad
     iteration per position (intermediates assumed cache-resident)."""
@@ -639,8 +648,7 @@ def main():
         counts.update(epoch=0, steps=0)
     if profile is not None:
         if dominant is None:
-            ks = {k: v for k, v in profile[0].items() if k.startswith("tike_")}
-            dominant = max(ks, key=lambda k: ks[k]["total_ms"])
+            dominant = dominant_entry(profile[0], launch_n, S, det, C)
         timers.only = {dominant.split(":")[0]}
     if graphs_on:
         _cg.USE_GRAPHS = True
@@ -699,9 +707,9 @@ def main():
         # timed steps themselves
         full, full_wall = profile if profile is not None else (summ, wall)
         kernels = {k: v for k, v in full.items() if k.startswith("tike_")}
-        if dominant is None:
-            dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
         pw = det
+        if dominant is None:
+            dominant = dominant_entry(full, launch_n, S, det, C)
         k = summ.get(dominant) or full[dominant]
         nbytes = algorithmic_bytes(dominant, launch_n, S, det, pw, C)
         achieved = nbytes / (k["avg_ms"] * 1e-3) / 1e9

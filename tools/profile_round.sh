@@ -12,7 +12,7 @@ mkdir -p $o/profiles_$tag
 python3 bench.py > $o/profiles_$tag/${tag}_bench_c3.json 2> $o/${tag}_bench_c3.err
 python3 bench.py --workload c2 --no-cpu-baseline > $o/profiles_$tag/${tag}_bench_c2.json 2>/dev/null
 python3 bench.py --workload c5 --no-cpu-baseline --steps 3 > $o/profiles_$tag/${tag}_bench_c5.json 2>/dev/null
-python3 bench.py --workload c1 --steps 20 --warmup 2 > $o/profiles_$tag/${tag}_bench_c1.json 2>/dev/null
+python3 bench.py --workload c1 --steps 20 --warmup 10 > $o/profiles_$tag/${tag}_bench_c1.json 2>/dev/null
 for w in fwd256x1 fwd256x8 fwd128x1; do
   python3 bench.py --workload $w --no-cpu-baseline --steps 40 --warmup 8 > $o/profiles_$tag/${tag}_bench_$w.json 2>/dev/null
 done
