@@ -302,3 +302,34 @@ def test_bench_gpus_flag_is_never_silently_ignored():
                        env=dict(env, WORLD_SIZE="2"), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_roofline_kernel_has_a_byte_model():
+    """bench.py's roofline object names the entry with the most time AMONG
+    those with an algorithmic byte model: a composite entry (the device line
+    search: many small launches under one name) must not take its place."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(
+        "bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    summary = {
+        "tike_cgrad_line_search": dict(total_ms=9.0),
+        "tike_lstsq_chunk_gradients": dict(total_ms=7.0),
+        "tike_scatter_patches": dict(total_ms=1.0),
+        "allreduce": dict(total_ms=50.0),
+    }
+    assert bench.dominant_entry(summary, 1000, 1, 256,
+                                0) == "tike_lstsq_chunk_gradients"
+    # nothing modelled: the largest tike_* entry, never a non-kernel row
+    assert bench.dominant_entry(
+        {"tike_cgrad_line_search": dict(total_ms=1.0),
+         "allreduce": dict(total_ms=5.0)}, 10, 1, 128,
+        0) == "tike_cgrad_line_search"
+    # T + 2P + 8 per position + the shared probe (DESIGN section 3)
+    n, S, det = 10, 8, 256
+    T, P = 8 * S * det * det, 8 * det * det
+    assert bench.algorithmic_bytes("tike_fwd_pass1", n, S, det, det,
+                                   1) == n * (T + 2 * P + 8) + (S + 1) * P

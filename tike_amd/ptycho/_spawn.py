@@ -15,6 +15,7 @@ started: ``num_gpu`` must then be the world size (or be left out).
 import logging
 import os
 import pickle
+import queue
 import socket
 import traceback
 import warnings
@@ -173,7 +174,7 @@ def reconstruct_spawned(data, parameters, devices, **kwargs):
         while message is None:
             try:
                 message = results.get(timeout=1.0)
-            except Exception:  # queue.Empty: is everybody still alive?
+            except queue.Empty:  # is everybody still alive?
                 dead = [(r, p.exitcode) for r, p in enumerate(procs)
                         if p.exitcode not in (None, 0)]
                 if dead:
