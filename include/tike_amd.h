@@ -38,7 +38,7 @@ extern "C" {
  * A binding compares tike_abi_version() of the loaded library with the
  * TIKE_ABI_VERSION it was written against before its first call
  * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
-#define TIKE_ABI_VERSION 5
+#define TIKE_ABI_VERSION 6
 
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
@@ -613,6 +613,23 @@ int tike_comm_create(const void* id, int nranks, int rank, void** comm);
 int tike_comm_destroy(void* comm);
 int tike_comm_allreduce_sum(void* comm, void* buf, long count, int f64, void* stream);
 int tike_comm_broadcast(void* comm, void* buf, long nbytes, int root, void* stream);
+
+/* ---- host side: the inner loops of the minibatch selectors (no GPU).
+ * tike_cluster_farthest_fill: the round robin of cluster.py:352-377 and
+ *   :445-462 (wobbly_center, wobbly_center_random_bootstrap).  points (n,2)
+ *   f32; owner (n) i64 in/out, -1 = free.  For turn = 0 .. turns-1 the cluster
+ *   turn % num_cluster claims the free point farthest from the float32 mean
+ *   of its members (first index among equals), exactly as the NumPy
+ *   expressions of the reference evaluate it.
+ * tike_cluster_swap_sweep: one sweep of the swap refinement of cluster.py:
+ *   568-626 (compact).  dist (n,k) f64 distances to the centroids; label (n)
+ *   i64 in/out; best (n) i64 nearest centroid; order (n) i64 the sweep order
+ *   (ascending regret); regret (n) f64 in/out; *moved = 1 if any pair was
+ *   exchanged. */
+int tike_cluster_farthest_fill(const float* points, long n, long* owner, int num_cluster,
+                               long turns);
+int tike_cluster_swap_sweep(const double* dist, long n, int k, long* label, const long* best,
+                            const long* order, double* regret, int* moved);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("TIKE_AMD_LIB") or os.path.join(
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
 # the header version this binding's prototypes were written against
-ABI_VERSION = 5
+ABI_VERSION = 6
 ERR_ARG = 1000001
 ERR_UNSUPPORTED = 1000002
 ERR_COMM = 2000000
@@ -127,6 +127,8 @@ _PROTOTYPES = {
     "tike_comm_destroy": [_p],
     "tike_comm_allreduce_sum": [_p, _p, _l, _i, _p],
     "tike_comm_broadcast": [_p, _p, _l, _i, _p],
+    "tike_cluster_farthest_fill": [_p, _l, _p, _i, _l],
+    "tike_cluster_swap_sweep": [_p, _l, _i, _p, _p, _p, _p, _p],
 }
 
 

@@ -3,7 +3,37 @@
 Once-per-run host code, out of the accelerated scope; restated so that
 ``reconstruct`` accepts the reference's ``batch_method`` names.
 """
+import ctypes
+
 import numpy as np
+
+
+def _native():
+    """The C entries of csrc/cluster_host.cpp (loaded with the library)."""
+    from ._lib import check, lib
+    return lib, check
+
+
+def _farthest_fill(points, owner, num_cluster, turns):
+    """`turns` rounds of "cluster turn % num_cluster claims the free point
+    farthest from its current mean" on `owner` (-1 = free), in place.  For
+    float32 (N, 2) populations -- scan positions -- the rounds run in the
+    library (tike_cluster_farthest_fill: one fused pass per round, the same
+    float32 arithmetic); anything else takes the NumPy expressions below."""
+    if points.dtype == np.float32 and points.ndim == 2 and points.shape[1] == 2:
+        lib, check = _native()
+        flat = np.ascontiguousarray(points)
+        check(lib.tike_cluster_farthest_fill(
+            flat.ctypes.data_as(ctypes.c_void_p), len(flat),
+            owner.ctypes.data_as(ctypes.c_void_p), num_cluster, turns),
+            "cluster farthest fill")
+        return
+    for turn in range(turns):
+        cluster = turn % num_cluster
+        free = np.flatnonzero(owner < 0)
+        centre = points[owner == cluster].mean(axis=0, keepdims=True)
+        reach = np.linalg.norm(points[free] - centre, axis=1)
+        owner[free[np.argmax(reach)]] = cluster  # first of the farthest
 
 
 def _check_cluster_count(num_cluster):
@@ -28,12 +58,7 @@ def wobbly_center(population, num_cluster):
     spread = np.linalg.norm(points - points.mean(axis=0, keepdims=True), axis=1)
     owner[np.argpartition(spread, num_cluster, axis=0)[:num_cluster]] = (
         np.arange(num_cluster))
-    for turn in range(count - num_cluster):
-        cluster = turn % num_cluster
-        centre = points[owner == cluster].mean(axis=0, keepdims=True)
-        reach = np.linalg.norm(points - centre, axis=1)
-        reach[owner >= 0] = -1.0  # claimed points are out of the race
-        owner[np.argmax(reach)] = cluster  # first of the farthest free points
+    _farthest_fill(points, owner, num_cluster, count - num_cluster)
     return [np.flatnonzero(owner == c) for c in range(num_cluster)]
 
 
@@ -55,12 +80,7 @@ def wobbly_center_random_bootstrap(population, num_cluster,
     drawn = np.random.choice(count, size=dealt, replace=False)
     owner = np.full(count, -1, dtype=np.int64)
     owner[drawn] = np.arange(dealt) % num_cluster
-    for turn in range(count - dealt):
-        cluster = turn % num_cluster
-        free = np.flatnonzero(owner < 0)
-        centre = points[owner == cluster].mean(axis=0, keepdims=True)
-        reach = np.linalg.norm(points[free] - centre, axis=1)
-        owner[free[np.argmax(reach)]] = cluster
+    _farthest_fill(points, owner, num_cluster, count - dealt)
     return [np.flatnonzero(owner == c) for c in range(num_cluster)]
 
 
@@ -142,6 +162,17 @@ class _EqualSizeKMeans:
             self.label[taken] = target[:stop + 1]
             room -= np.bincount(target[:stop + 1], minlength=self.k)
 
+    def _sweep(self, best, order, regret):
+        lib, check = _native()
+        moved = ctypes.c_int(0)
+        ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        dist, best, order = (np.ascontiguousarray(a, dtype=t) for a, t in (
+            (self.dist, np.float64), (best, np.int64), (order, np.int64)))
+        check(lib.tike_cluster_swap_sweep(
+            ptr(dist), self.n, self.k, ptr(self.label), ptr(best), ptr(order),
+            ptr(regret), ctypes.byref(moved)), "cluster swap sweep")
+        return bool(moved.value)
+
     def refine(self, max_iter):
         """Swap pairs of points between clusters while that lowers the sum of
         the two points' distances to their centroids, unhappiest point first;
@@ -151,25 +182,12 @@ class _EqualSizeKMeans:
             best = np.argmin(self.dist, axis=1)
             regret = self.dist[self.rows, best] - self.dist[self.rows,
                                                             self.label]
-            moved = False
-            for p in np.argsort(regret):
-                if not regret[p] < 0:
-                    continue
-                home = self.label[p]
-                # gain of exchanging p with every other point q:
-                # d(p, home) + d(q, own(q)) - d(p, own(q)) - d(q, home)
-                gain = self.dist[p, home] + self.dist[self.rows, self.label]
-                gain -= self.dist[p, self.label]
-                gain -= self.dist[:, home]
-                gain[(self.label == home) | ~(gain > 0)] = -np.inf
-                q = int(np.argmax(gain))
-                if gain[q] == -np.inf:
-                    continue
-                moved = True
-                self.label[q], self.label[p] = home, self.label[q]
-                for i in (q, p):
-                    regret[i] = self.dist[i, best[i]] - self.dist[i,
-                                                                  self.label[i]]
+            # one sweep, unhappiest point first (tike_cluster_swap_sweep): a
+            # point with negative regret is exchanged with the point q of
+            # another cluster that maximises the gain
+            #   d(p, home) + d(q, own(q)) - d(p, own(q)) - d(q, home) > 0
+            # (first q among equals); the regrets of both follow
+            moved = self._sweep(best, np.argsort(regret), regret)
             if not moved:
                 break
             for c in range(self.k):
