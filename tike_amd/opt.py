@@ -33,6 +33,26 @@ def is_converged(algorithm_options):
     return bool(flat)
 
 
+def batch_indicies(n, m=1, use_random=True):
+    """The indices 0 .. n-1 in m groups of (nearly) equal size, shuffled with
+    `tike_amd.random.randomizer_np` unless use_random is False (opt.py:47-56)."""
+    if not 0 < m <= n:
+        raise AssertionError((m, n))
+    from . import random as trandom
+    pool = trandom.randomizer_np.permutation(n) if use_random else np.arange(n)
+    return np.array_split(pool, m)
+
+
+def get_batch(x, b, n):
+    """Rows of x that belong to batch n of the index lists b."""
+    return x[b[n]]
+
+
+def put_batch(y, x, b, n):
+    """Store y as the rows of x that belong to batch n of b."""
+    x[b[n]] = y
+
+
 def momentum(g, v, m, vdecay=None, mdecay=0.9):
     """Exponential moving average of the search direction: returns
     (direction, None, average) like `adam` (opt.py:67-82)."""
