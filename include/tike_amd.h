@@ -499,6 +499,32 @@ int tike_cgrad_line_search(int variable, const void* x, const void* d, void* xs,
                            int S, int det, int H, int W, float fwd_scale, double count,
                            double* state, int* skip, int nslots, void* stream);
 
+/* ---- the same search with every step length evaluated in one pass.  The far
+ * plane is linear in the variable the search moves along: F(x + s d) = F(x) +
+ * s F(d), F(d) being the forward model with the direction in place of the object
+ * (variable 0) or of the probe (variable 1).  One forward pass 1 of the
+ * direction and one column pass over the two hand-offs give the gaussian costs
+ * of x and of x + step d, x + step/2 d, ... (16 step lengths, 8 per pass) from the per-pixel
+ * quadratic sum_m |A_m|^2 + 2 s sum_m Re(conj(A_m) B_m) + s^2 sum_m |B_m|^2; one
+ * small kernel then takes the decision of opt.py:216-278 (the first of those
+ * lengths whose cost is no larger than the cost at x) and xs = x + step d is
+ * formed with the accepted step (xs = x when none was).  Candidates, rule and
+ * state as tike_cgrad_line_search, results equal up to float32 rounding; the
+ * cost at x that decides is the one formed here (state[0] on entry is ignored).
+ *   far_a   (chunk,S,det,det) c64: with a_valid != 0 and nscan <= chunk it holds
+ *           what the gradient pass at x left in its `scratch` (the forward
+ *           hand-off of x; at 128^2 the far plane of x) and is read as it is;
+ *           otherwise workspace (x's forward pass is made here).
+ *   far_b   (chunk,S,det,det) c64 workspace; costs_k 17 * nscan + 1 f32 of workspace.
+ * Two passes of 8 step lengths are enqueued; the second returns at once when the
+ * first has accepted a step. */
+int tike_cgrad_line_search_linear(int variable, const void* x, const void* d, void* xs,
+                                  const void* other, const float* scan, const void* data,
+                                  int data_u16, void* far_a, int a_valid, void* far_b,
+                                  float* costs_k, int nscan, int chunk, int S, int det, int H,
+                                  int W, float fwd_scale, double count, double* state,
+                                  void* stream);
+
 /* ---- the packed minibatch tail: the arithmetic of tike_lstsq_step_sums / _solve,
  * tike_probe_update and the tike_eigen_* entries above for the common case of ONE
  * eigen probe (or none), in four launches after the step statistics and with two

@@ -429,6 +429,7 @@ def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
         monkeypatch.setattr(C, "LINE_SEARCH_SLOTS", slots)
         monkeypatch.setattr(C, "MAX_SLOTS", most)
         monkeypatch.setattr(C, "USE_GRAPHS", False)  # every call through the spy
+        monkeypatch.setattr(C, "LINEAR_LINE_SEARCH", False)  # (its own test)
         calls = []
         real = C._cg_device
 
@@ -470,6 +471,76 @@ def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
                                np.array(b.algorithm_options.costs), rtol=1e-5)
     assert_close(a.psi, b.psi, normwise=1e-5, maxabs=1e-4, what="psi")
     assert_close(a.probe, b.probe, normwise=1e-5, maxabs=1e-4, what="probe")
+
+
+@pytest.mark.parametrize("det,S,N,chunk,step", [
+    (256, 1, 12, None, 1.0), (256, 2, 7, None, 1.0), (256, 8, 6, None, 1.0),
+    (256, 2, 9, 2, 1.0),  # several kernel chunks per minibatch: F(x) formed anew
+    (512, 2, 4, None, 1.0), (128, 1, 10, None, 1.0), (128, 3, 6, None, 1.0),
+    # first step far too long: accepted in the SECOND pass of 8 step lengths
+    (256, 2, 7, None, 1024.0), (256, 2, 9, 2, 1024.0), (128, 1, 10, None, 1024.0),
+    # ... beyond all 16: the trial-by-trial search (30 slots) takes the call over
+    (256, 1, 8, None, 1e6)])
+def test_cgrad_all_steps_at_once_equals_trial_by_trial(tp, monkeypatch, det, S,
+                                                        N, chunk, step):
+    """tike_cgrad_line_search_linear (the far plane is linear in the variable
+    a search moves along: one forward pass of the direction, the costs of 16
+    step lengths from one pass over two hand-offs) takes the decisions of the
+    trial-by-trial searches -- the device one (tike_cgrad_line_search) and
+    opt.line_search on the host (opt.py:216-278): same costs, same iterates,
+    up to float32 rounding."""
+    import importlib
+    C = importlib.import_module("tike_amd.ptycho.solvers.cgrad")
+    L = importlib.import_module("tike_amd.ptycho.solvers.lstsq")
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=det + 5 * S, eigen=False)
+    if chunk:
+        monkeypatch.setattr(L, "CHUNK_POSITIONS_OVERRIDE", chunk)
+    monkeypatch.setattr(C, "USE_GRAPHS", False)
+    results, used = [], []
+    real = C._cg_device
+
+    def spy(*a, **k):
+        r = real(*a, **k)
+        used.append((bool(k.get("linear")), r is not None))
+        return r
+
+    monkeypatch.setattr(C, "_cg_device", spy)
+    for linear, on_device in ((True, True), (False, True), (False, False)):
+        monkeypatch.setattr(C, "LINEAR_LINE_SEARCH", linear)
+        monkeypatch.setattr(C, "DEVICE_LINE_SEARCH", on_device)
+        del used[:]
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+            scan=scan.copy(),
+            algorithm_options=tp.CgradOptions(num_batch=2, cg_iter=3,
+                                              num_iter=2, step_length=step,
+                                              batch_method="compact"),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions())
+        with tp.Reconstruction(data, params, order=np.arange(N),
+                               batches=np.array_split(np.arange(N), 2)) as ctx:
+            ctx.iterate(2)
+            results.append(ctx.get_result())
+        if linear and step < 1e5:
+            # every one of the 8 CG calls found its steps among the 16
+            assert used == [(True, True)] * 8, used
+        elif linear:
+            # a call whose search ran out is redone by the trial-by-trial search
+            assert (True, False) in used and (False, True) in used, used
+        elif on_device:
+            assert used and not any(lin for lin, _ in used)
+    a = results[0]
+    # (a first step of 1e6: accepted steps are 1e-5 of it and smaller, the
+    # float32 rounding of x + step d and of the costs is felt)
+    tol = 2e-5 if step < 1e5 else 3e-4
+    for b in results[1:]:
+        np.testing.assert_allclose(np.array(a.algorithm_options.costs),
+                                   np.array(b.algorithm_options.costs),
+                                   rtol=tol)
+        assert_close(a.psi, b.psi, normwise=tol, maxabs=10 * tol, what="psi")
+        assert_close(a.probe, b.probe, normwise=tol, maxabs=10 * tol,
+                     what="probe")
 
 
 @pytest.mark.parametrize("det,S,N", [(128, 1, 10), (256, 2, 7)])

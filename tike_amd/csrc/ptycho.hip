@@ -410,6 +410,7 @@ static int launch_fwd_pos(const cf* psi, const float* scan, const TkProbe& probe
 #ifndef TK_LDS128_MAX_MODES
 #define TK_LDS128_MAX_MODES 8
 #endif
+constexpr int TK_FG_PIX = 1024;  // pixels per workgroup of the stored-far-plane cost kernels
 static int launch_fwd128_lds(const cf* psi, const float* scan, const TkProbe& probe, cf* farplane,
                              float* intensity, int nscan, int S, int H, int W, float scale,
                              hipStream_t stream, cf* patches, const int* skip = nullptr);
@@ -1184,6 +1185,328 @@ extern "C" int tike_cgrad_line_search(int variable, const void* x, const void* d
   return TK_OK;
 }
 
+// ------------------------------------------- the same line search, all steps at once
+// The far plane is LINEAR in the variable a line search moves along: with
+// A = F(x) and B = F(d) (the forward model applied to the direction in place
+// of the object, or of the probe), F(x + s d) = A + s B for every step length
+// s.  A is the hand-off the gradient pass at x has just left behind; B costs
+// ONE forward pass 1; the intensity of a trial is the quadratic
+//   I(s) = sum_m |A_m|^2 + 2 s sum_m Re(conj(A_m) B_m) + s^2 sum_m |B_m|^2
+// in s per pixel, so one column pass over the TWO hand-offs gives the costs of
+// x and of x + step d, x + step/2 d, ... (TK_LS_STEPS of them) together, and
+// one small kernel takes the decision of the backtracking search
+// (opt.py:216-278): the first of those step lengths whose cost is no larger
+// than the cost at x.  Same candidates, same rule, same result as
+// tike_cgrad_line_search up to float32 rounding -- for one forward pass and
+// one two-stream column pass instead of a forward pass per trial.
+constexpr int TK_LS_STEPS = 8;   // step lengths per pass over the hand-offs
+constexpr int TK_LS_PASSES = 2;  // passes enqueued (the second returns at once if the first accepted)
+constexpr int TK_LS_ROWS = TK_LS_STEPS * TK_LS_PASSES + 1;  // cost rows: x, then every step
+
+// gaussian cost terms of RB pixels at step0 / 2^k, k < K (rows 1..K) and, FIRST,
+// at step 0 (row 0).  v_sqrt_f32 (1 ulp) instead of the correctly rounded sqrtf
+// (a dozen instructions each): K x RB square roots per thread are what this
+// kernel issues most, and the cost at x it is compared with is formed the same way.
+template <int K, int RB, bool FIRST, class DT>
+__device__ __forceinline__ void tk_ksteps_costs(const float (&I0)[RB], const float (&C)[RB],
+                                                const float (&I1)[RB], const DT (&raw)[RB],
+                                                float step0, float (&acc)[K + 1]) {
+#pragma unroll
+  for (int p = 0; p < RB; ++p) {
+    const float sd = __builtin_amdgcn_sqrtf((float)raw[p]);
+    if (FIRST) {
+      const float t0 = __builtin_amdgcn_sqrtf(I0[p]) - sd;
+      acc[0] = fmaf(t0, t0, acc[0]);
+    }
+    const float c2 = 2.0f * C[p];
+    float s = step0;
+#pragma unroll
+    for (int k = 0; k < K; ++k, s *= 0.5f) {
+      const float I = fmaxf(fmaf(s, fmaf(s, I1[p], c2), I0[p]), 0.0f);
+      const float t = __builtin_amdgcn_sqrtf(I) - sd;
+      acc[k + 1] = fmaf(t, t, acc[k + 1]);
+    }
+  }
+}
+
+// per-thread sums -> one atomic each into costs_k[row * stride + n]; acc[0] is
+// row 0 (FIRST only), acc[1..K] are rows row1 .. row1 + K - 1
+template <int K, bool FIRST>
+__device__ __forceinline__ void tk_ksteps_emit(float (&acc)[K + 1], float (*red)[K + 1],
+                                               float* __restrict__ costs_k, long stride, long n,
+                                               int row1, float inv_nmeasured) {
+#pragma unroll
+  for (int k = FIRST ? 0 : 1; k <= K; ++k) acc[k] = tk_wave_sum(acc[k]);
+  __syncthreads();  // the previous item's sums have been read
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k <= K; ++k) red[threadIdx.x >> 6][k] = acc[k];
+  }
+  __syncthreads();
+  const int k = threadIdx.x;
+  if (k <= K && (FIRST || k > 0)) {
+    const int row = k == 0 ? 0 : row1 + k - 1;
+    unsafeAtomicAdd(&costs_k[row * stride + n],
+                    (red[0][k] + red[1][k] + red[2][k] + red[3][k]) * inv_nmeasured);
+  }
+}
+
+// 256^2 / 512^2: the column pass of fwd_gradient_scale_kernel over the
+// hand-offs of x (col_a) and of the direction (col_b)
+template <int N, class DT, bool FIRST>
+__global__ __launch_bounds__(256, 2) void ls_ksteps_colpass_kernel(
+    const cf* __restrict__ col_a, const cf* __restrict__ col_b, const DT* __restrict__ data,
+    float* __restrict__ costs_k, long stride, long nitem, int S, float scale,
+    float inv_nmeasured, int row1, const double* __restrict__ state) {
+  constexpr int RB = N / 16, NH = N / 256, K = TK_LS_STEPS;
+  __shared__ float red[4][K + 1];
+  if (!FIRST && state[2] != 0.0) return;  // an earlier pass has accepted a step
+  const float s2 = scale * scale;
+  const float step0 = (float)state[1];
+  for (long v = blockIdx.x; v < nitem; v += gridDim.x) {
+    const int hb = (int)(v % NH);
+    const int k1 = (int)((v / NH) & 15);
+    const long n = nitem / (16 * NH) - 1 - v / (16 * NH);  // descending, as its siblings
+    const int t = hb * 256 + threadIdx.x;
+    float I0[RB], C[RB], I1[RB];
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) I0[k2] = C[k2] = I1[k2] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const long off = (n * S + s) * (long)N * N + k1 * N + t;
+      cf a[RB], b[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) a[r] = tk_ld_stream(col_a + off + (long)(16 * r) * N);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) b[r] = tk_ld_stream(col_b + off + (long)(16 * r) * N);
+      Dft<RB, false>::run(a);
+      Dft<RB, false>::run(b);
+#pragma unroll
+      for (int k2 = 0; k2 < RB; ++k2) {
+        I0[k2] += norm2(a[k2]) * s2;
+        C[k2] += (a[k2].x * b[k2].x + a[k2].y * b[k2].y) * s2;
+        I1[k2] += norm2(b[k2]) * s2;
+      }
+    }
+    DT raw[RB];
+    unsigned bits;
+    tk_request_data<N, RB>(data, nullptr, n, k1, t, raw, bits);
+    float acc[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) acc[k] = 0.f;
+    tk_ksteps_costs<K, RB, FIRST>(I0, C, I1, raw, step0, acc);
+    tk_ksteps_emit<K, FIRST>(acc, red, costs_k, stride, n, row1, inv_nmeasured);
+  }
+}
+
+// stored far planes (128^2): a workgroup covers TK_FG_PIX pixels of one position
+template <bool FIRST>
+__global__ __launch_bounds__(256) void ls_ksteps_farplane_kernel(
+    const cf* __restrict__ far_a, const cf* __restrict__ far_b, const float* __restrict__ data,
+    float* __restrict__ costs_k, long stride, int S, long npix, float inv_nmeasured, int row1,
+    const double* __restrict__ state) {
+  constexpr int K = TK_LS_STEPS;
+  __shared__ float red[4][K + 1];
+  if (!FIRST && state[2] != 0.0) return;
+  const float step0 = (float)state[1];
+  const long n = blockIdx.y;
+  const cf* __restrict__ FA = far_a + n * S * npix;
+  const cf* __restrict__ FB = far_b + n * S * npix;
+  const long p0 = (long)blockIdx.x * TK_FG_PIX;
+  const long p1 = p0 + TK_FG_PIX < npix ? p0 + TK_FG_PIX : npix;
+  float acc[K + 1];
+#pragma unroll
+  for (int k = 0; k <= K; ++k) acc[k] = 0.f;
+  for (long p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    float I0[1] = {0.f}, C[1] = {0.f}, I1[1] = {0.f};
+    const float raw[1] = {data[n * npix + p]};
+    for (int s = 0; s < S; ++s) {
+      const cf a = FA[s * npix + p], b = FB[s * npix + p];
+      I0[0] += norm2(a);
+      C[0] += a.x * b.x + a.y * b.y;
+      I1[0] += norm2(b);
+    }
+    tk_ksteps_costs<K, 1, FIRST>(I0, C, I1, raw, step0, acc);
+  }
+  tk_ksteps_emit<K, FIRST>(acc, red, costs_k, stride, n, row1, inv_nmeasured);
+}
+
+// One workgroup: the means of a pass's cost rows, then the backtracking
+// decision.  state { fx, step, done, trials, failures } as in ls_decide_kernel.
+// First pass: fx on entry is ignored -- the cost at x is row 0, formed with the
+// same arithmetic as the trials it is compared with -- and kept in state[0] for
+// the passes behind it.  A pass that accepts nothing leaves step = the next
+// length to try; the last one also counts a failure.
+__global__ __launch_bounds__(256) void ls_pick_kernel(const float* __restrict__ costs_k,
+                                                      long stride, int n, double inv_count,
+                                                      int row1, int first, int last,
+                                                      double* __restrict__ state,
+                                                      int* __restrict__ accepted) {
+  constexpr int K = TK_LS_STEPS;
+  __shared__ double red[256];
+  __shared__ double mean[K + 1];
+  if (!first && state[2] != 0.0) return;
+  for (int k = first ? 0 : 1; k <= K; ++k) {
+    const float* __restrict__ row = costs_k + (k == 0 ? 0 : row1 + k - 1) * stride;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += (double)row[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) mean[k] = red[0] * inv_count;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double fx = first ? mean[0] : state[0];
+    float s = (float)state[1];
+    int pick = -1;
+    for (int k = 0; k < K; ++k, s *= 0.5f) {
+      if (mean[k + 1] <= fx) {
+        pick = k;
+        break;
+      }
+    }
+    if (pick >= 0) {
+      state[0] = mean[pick + 1];
+      state[1] = (double)s;
+      state[2] = 1.0;
+      state[3] += (double)(pick + 1);
+      *accepted = 1;
+    } else {
+      state[0] = fx;
+      state[1] = (double)s;  // step / 2^K: the next length to try
+      state[2] = 0.0;
+      state[3] += (double)K;
+      if (last) state[4] += 1.0;
+    }
+  }
+}
+
+// xs = x + step d with the accepted step (x itself when none was)
+__global__ __launch_bounds__(256) void ls_apply_kernel(const cf* __restrict__ x,
+                                                       const cf* __restrict__ d,
+                                                       cf* __restrict__ xs, long n,
+                                                       const double* __restrict__ state) {
+  const float a = state[2] != 0.0 ? (float)state[1] : 0.0f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    const cf v = d[i];
+    xs[i] = mk(x[i].x + a * v.x, x[i].y + a * v.y);
+  }
+}
+
+extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const void* d, void* xs,
+                                             const void* other, const float* scan,
+                                             const void* data, int data_u16, void* far_a,
+                                             int a_valid, void* far_b, float* costs_k,
+                                             int nscan, int chunk, int S, int det, int H, int W,
+                                             float fwd_scale, double count, double* state,
+                                             void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 1 && chunk >= 1 && S >= 1 && H >= 1 && W >= 1 && count > 0 &&
+               (variable == 0 || variable == 1));
+  TK_CHECK_ARG(x && d && xs && other && scan && data && far_a && far_b && far_a != far_b &&
+               costs_k && state);
+  if (det != 128 && det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
+  if (det == 128 && data_u16) return TK_ERR_UNSUPPORTED;  // the 128^2 cost kernel reads float32
+  const long n = variable == 0 ? (long)H * W : (long)S * det * det;
+  // (+ one word behind the rows: raised once a step is accepted -- the forward
+  // passes of a later pass over a several-chunk minibatch read it and return)
+  int* accepted = reinterpret_cast<int*>(costs_k + (size_t)TK_LS_ROWS * nscan);
+  hipError_t e = hipMemsetAsync(
+      costs_k, 0, sizeof(float) * ((size_t)TK_LS_ROWS * nscan + 1), stream);
+  if (e != hipSuccess) return (int)e;
+  const bool reuse = a_valid && nscan <= chunk;  // the gradient pass left F(x) in far_a
+  const bool resident = nscan <= chunk;          // one chunk: both hand-offs stay put
+  const size_t dsz = data_u16 ? 2 : 4;
+  const float inv = 1.0f / (float)((long)det * det);
+  // forward model of the direction: d in place of the variable
+  const void* psi_b = variable == 0 ? d : other;
+  const void* probe_b = variable == 0 ? other : d;
+  const void* psi_a = variable == 0 ? x : other;
+  const void* probe_a = variable == 0 ? other : x;
+  for (int pass = 0; pass < TK_LS_PASSES; ++pass) {
+    const int row1 = 1 + pass * TK_LS_STEPS;
+    for (int lo = 0; lo < nscan; lo += chunk) {
+      const int m = nscan - lo < chunk ? nscan - lo : chunk;
+      const float* sc = scan + 2L * lo;
+      // the hand-offs of a chunk: formed in the first pass; a later pass (rare:
+      // the first one accepted nothing) finds them in place unless the
+      // minibatch has several chunks, which share the two buffers
+      const bool form = pass == 0 || !resident;
+      if (det == 128) {
+        if (form && !(reuse && pass == 0)) {
+          const TkProbe PA = tk_make_probe(probe_a, 0, nullptr, nullptr, 0, 0, S, det);
+          int rc = launch_fwd128_lds((const cf*)psi_a, sc, PA, (cf*)far_a, nullptr, m, S, H, W,
+                                     fwd_scale, stream, nullptr, pass ? accepted : nullptr);
+          if (rc) return rc;
+        }
+        if (form) {
+          const TkProbe PB = tk_make_probe(probe_b, 0, nullptr, nullptr, 0, 0, S, det);
+          int rc = launch_fwd128_lds((const cf*)psi_b, sc, PB, (cf*)far_b, nullptr, m, S, H, W,
+                                     fwd_scale, stream, nullptr, pass ? accepted : nullptr);
+          if (rc) return rc;
+        }
+        const long npix = (long)det * det;
+        const dim3 grid((unsigned)((npix + TK_FG_PIX - 1) / TK_FG_PIX), (unsigned)m);
+        const float* dchunk = (const float*)data + (size_t)lo * npix;
+        if (pass == 0)
+          hipLaunchKernelGGL(ls_ksteps_farplane_kernel<true>, grid, dim3(256), 0, stream,
+                             (const cf*)far_a, (const cf*)far_b, dchunk, costs_k + lo,
+                             (long)nscan, S, npix, inv, row1, state);
+        else
+          hipLaunchKernelGGL(ls_ksteps_farplane_kernel<false>, grid, dim3(256), 0, stream,
+                             (const cf*)far_a, (const cf*)far_b, dchunk, costs_k + lo,
+                             (long)nscan, S, npix, inv, row1, state);
+        continue;
+      }
+      if (form && !(reuse && pass == 0)) {
+        int rc = tk_fwd_pass1(psi_a, sc, probe_a, 0, nullptr, nullptr, nullptr, 0, 0, far_a,
+                              nullptr, m, S, det, det, H, W, stream, pass ? accepted : nullptr);
+        if (rc) return rc;
+      }
+      if (form) {
+        int rc = tk_fwd_pass1(psi_b, sc, probe_b, 0, nullptr, nullptr, nullptr, 0, 0, far_b,
+                              nullptr, m, S, det, det, H, W, stream, pass ? accepted : nullptr);
+        if (rc) return rc;
+      }
+      const long nitem = (long)m * 16 * (det / 256);
+      const dim3 grid(tk_grid(nitem, 32)), block(256);
+      const char* dchunk = (const char*)data + dsz * (size_t)lo * det * det;
+#define TK_LSK(N, DT, FIRST)                                                                  \
+  hipLaunchKernelGGL((ls_ksteps_colpass_kernel<N, DT, FIRST>), grid, block, 0, stream,           \
+                     (const cf*)far_a, (const cf*)far_b, (const DT*)dchunk, costs_k + lo,        \
+                     (long)nscan, nitem, S, fwd_scale, inv, row1, state)
+#define TK_LSK_N(N, DT)      \
+  do {                       \
+    if (pass == 0)           \
+      TK_LSK(N, DT, true);   \
+    else                     \
+      TK_LSK(N, DT, false);  \
+  } while (0)
+      if (det == 256 && data_u16)
+        TK_LSK_N(256, unsigned short);
+      else if (det == 256)
+        TK_LSK_N(256, float);
+      else if (data_u16)
+        TK_LSK_N(512, unsigned short);
+      else
+        TK_LSK_N(512, float);
+#undef TK_LSK_N
+#undef TK_LSK
+    }
+    hipLaunchKernelGGL(ls_pick_kernel, dim3(1), dim3(256), 0, stream, costs_k, (long)nscan,
+                       nscan, 1.0 / count, row1, (int)(pass == 0),
+                       (int)(pass + 1 == TK_LS_PASSES), state, accepted);
+  }
+  hipLaunchKernelGGL(ls_apply_kernel, dim3(tk_grid((n + 255) / 256, 8)), dim3(256), 0, stream,
+                     (const cf*)x, (const cf*)d, (cf*)xs, n, state);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 // ------------------------------------------- 128^2: the whole tile in LDS
 // A 128 x 128 complex tile is 128 KiB: it fits the 160 KiB LDS of a CU, so the
 // 2-D transform needs NO intermediate in memory -- the only HBM traffic of the
@@ -1720,7 +2043,6 @@ extern "C" int tike_ifft2_crop(const void* farplane, void* work, void* chi, long
 // data values (possibly NaN) are never read into the arithmetic.
 // Grid: (pixel blocks, positions); a workgroup covers TK_FG_PIX pixels of one
 // position and adds its share of the cost with one atomic.
-constexpr int TK_FG_PIX = 1024;
 
 template <int MODEL, bool GRAD>
 __global__ __launch_bounds__(256) void farplane_gradient_kernel(
