@@ -31,6 +31,10 @@ KERNELS = {
     "eigen_position_sums1_kernel": "tike_eigen_position_sums1",
     "ls_trial_kernel": "tike_cgrad_line_search:trial",
     "ls_decide_kernel": "tike_cgrad_line_search:decide",
+    "void ls_ksteps_colpass_kernel": "tike_cgrad_line_search_linear:costs",
+    "void ls_ksteps_farplane_kernel": "tike_cgrad_line_search_linear:costs",
+    "ls_pick_kernel": "tike_cgrad_line_search_linear:pick",
+    "ls_apply_kernel": "tike_cgrad_line_search_linear:apply",
     "void fwd_grad_ifft2_pass1_resident_kernel": "tike_fwd_grad_ifft2_pass1",
     "void grad_ifft2_pass1_512_kernel": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 1, false>": "tike_grad_ifft2_pass1",
@@ -85,8 +89,13 @@ def collect(d, counter, cgrad=False):
                 if r["Kernel_Name"].startswith(prefix):  # first match wins
                     if cgrad and entry == "tike_fwd_pass1" and nxt.get(
                             int(r["Dispatch_Id"]), "").startswith(
-                                "void fwd_gradient_scale_kernel"):
-                        entry += ":cost_only"
+                                ("void fwd_gradient_scale_kernel",
+                                 "void ls_ksteps_colpass_kernel")):
+                        entry += ":cost_only"  # (of a trial / of the direction)
+                    if cgrad and entry == "tike_ptycho_fwd" and nxt.get(
+                            int(r["Dispatch_Id"]), "").startswith(
+                                "void ls_ksteps_farplane_kernel"):
+                        entry += ":direction"
                     if cgrad and entry == "tike_fwd_gradient_scale":
                         entry += ":cost_only"
                     rows[entry].append((int(r["Grid_Size"]),
