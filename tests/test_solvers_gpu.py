@@ -477,6 +477,7 @@ def test_cgrad_device_line_search_equals_host_line_search(tp, monkeypatch, det,
     (256, 1, 12, None, 1.0), (256, 2, 7, None, 1.0), (256, 8, 6, None, 1.0),
     (256, 2, 9, 2, 1.0),  # several kernel chunks per minibatch: F(x) formed anew
     (512, 2, 4, None, 1.0), (128, 1, 10, None, 1.0), (128, 3, 6, None, 1.0),
+    (128, 2, 10, 3, 1.0), (512, 1, 5, 2, 1.0),
     # first step far too long: accepted in the SECOND pass of 8 step lengths
     (256, 2, 7, None, 1024.0), (256, 2, 9, 2, 1024.0), (128, 1, 10, None, 1024.0),
     # ... beyond all 16: the trial-by-trial search (30 slots) takes the call over
