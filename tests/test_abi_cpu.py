@@ -104,3 +104,37 @@ def test_fft_radix_host_unit_test_builds_and_passes(tmp_path):
     subprocess.run(cmd, check=True, capture_output=True, timeout=300)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_cluster_entries_on_the_host():
+    """tike_cluster_farthest_fill / tike_cluster_swap_sweep are host code: a
+    known small case by hand, and TIKE_ERR_ARG for unusable arguments."""
+    import numpy as np
+    lib = L.lib
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    # five points on a line, clusters 0 and 1 seeded at points 2 and 3:
+    # cluster 0 (mean 2) takes the farthest free point -- 0 and 4 tie, the
+    # first wins --, cluster 1 (mean 3) then takes 1 (2 away; 4 is 1 away),
+    # cluster 0 (mean 1) takes what is left
+    pts = np.array([[0, 0], [1, 0], [2, 0], [3, 0], [4, 0]], np.float32)
+    owner = np.array([-1, -1, 0, 1, -1], np.int64)
+    assert lib.tike_cluster_farthest_fill(ptr(pts), 5, ptr(owner), 2, 3) == 0
+    assert owner.tolist() == [0, 1, 0, 1, 0]
+    assert lib.tike_cluster_farthest_fill(ptr(pts), 5, ptr(owner), 2,
+                                          1) == 1000001  # nothing free
+    assert lib.tike_cluster_farthest_fill(None, 5, ptr(owner), 2, 0) == 1000001
+    # two clusters on a line whose labels are crossed: one swap repairs them
+    dist = np.array([[0., 3.], [1., 2.], [2., 1.], [3., 0.]])  # to centroids
+    label = np.array([0, 1, 0, 1], np.int64)
+    best = dist.argmin(axis=1).astype(np.int64)
+    regret = dist[np.arange(4), best] - dist[np.arange(4), label]
+    order = np.argsort(regret).astype(np.int64)
+    moved = ctypes.c_int(0)
+    assert lib.tike_cluster_swap_sweep(ptr(dist), 4, 2, ptr(label), ptr(best),
+                                       ptr(order), ptr(regret),
+                                       ctypes.byref(moved)) == 0
+    assert moved.value == 1 and label.tolist() == [0, 0, 1, 1]
+    assert np.all(regret == 0)
+    assert lib.tike_cluster_swap_sweep(ptr(dist), 0, 2, ptr(label), ptr(best),
+                                       ptr(order), ptr(regret),
+                                       ctypes.byref(moved)) == 1000001

@@ -749,6 +749,18 @@ def test_abi_edge_cases():
                                          st) == L.ERR_ARG
     assert lib.tike_ifft2_crop_scaled(p(x), p(f), 1, p(x), p(x), 1, 128, 128,
                                       1.0, st) == L.ERR_ARG
+    # the all-at-once line search: a detector size without its kernels, the two
+    # far-plane buffers aliased, a missing state
+    d = torch.zeros(8, dtype=torch.float64, device="cuda")
+    args = lambda det, fa, fb, state: (
+        0, p(x), p(x), p(x), p(x), p(s), p(f), 0, fa, 0, fb, p(f), 1, 1, 1, det,
+        200, 200, 1.0, 1.0, state, st)
+    assert lib.tike_cgrad_line_search_linear(
+        *args(64, p(x), p(x) + 8, p(d))) == L.ERR_UNSUPPORTED
+    assert lib.tike_cgrad_line_search_linear(
+        *args(128, p(x), p(x), p(d))) == L.ERR_ARG
+    assert lib.tike_cgrad_line_search_linear(
+        *args(128, p(x), p(x) + 8, z)) == L.ERR_ARG
 
 
 def test_comm_abi_single_rank():
