@@ -513,6 +513,13 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # TIKE_BENCH_SHARE_GPU=1 (tests only): the ranks share the visible GPUs
+    # and talk over gloo -- the N > 1 code path of this file (sharding, max
+    # over ranks, whole-job value, all-reduce summary) on a one-GPU box; RCCL
+    # refuses two ranks on one device, so no such number is ever a result
+    share_gpu = os.environ.get("TIKE_BENCH_SHARE_GPU") == "1"
+    if share_gpu and torch.cuda.device_count() > 0:
+        local %= torch.cuda.device_count()
     if torch.cuda.device_count() <= local:
         sys.exit(f"bench.py: rank {rank} has no GPU {local}")
     torch.cuda.set_device(local)
@@ -521,7 +528,9 @@ def main():
     # that path on a one-GPU box
     forced = (os.environ.get("TIKE_FORCE_COLLECTIVES") == "1"
               and "MASTER_ADDR" in os.environ)
-    if world > 1 or forced:
+    if share_gpu and world > 1:
+        dist.init_process_group("gloo")
+    elif world > 1 or forced:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import tike_amd._arrays as A
@@ -790,7 +799,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "c64",
-            "data": "synthetic",
+            "data": ("synthetic" if not share_gpu else
+                     "synthetic; TEST SWITCH: ranks share a GPU over gloo"),
             "config": workload,
             "roofline": roofline,
         }

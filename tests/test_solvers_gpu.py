@@ -1099,6 +1099,44 @@ def test_resident_gradient_kernel_vs_oracle_beyond_one_wave(tp, u16_and_mask):
                  what="patches")
 
 
+def test_bench_whole_job_line_of_two_ranks():
+    """The N > 1 code path of bench.py itself -- sharding of every global
+    minibatch, barrier + max over ranks, the whole-job value, the all-reduce
+    summary -- with two ranks sharing the test box's GPU over gloo
+    (TIKE_BENCH_SHARE_GPU=1; RCCL needs a device per rank, the driver's
+    8-GPU run is the measurement).  One JSON line, from rank 0."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TIKE_BENCH_SHARE_GPU="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus",
+         "2", "--steps", "2", "--warmup", "1", "--positions", "160"],
+        env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["positions_per_gpu"] == 160
+    # whole-job value = all ranks' positions over the slowest rank's time
+    np.testing.assert_allclose(
+        line["value"], 2 * 160 / (line["ms_per_step"] * 1e-3), rtol=1e-6)
+    np.testing.assert_allclose(line["per_gpu"] * 2, line["value"], rtol=1e-9)
+    assert "whole job on 2" in line["metric"]
+    assert "cpu_baseline" not in line or line["cpu_baseline"] is None
+    # the collectives of the shared minibatches were issued and timed
+    assert line["allreduce"]["calls_per_minibatch"] >= 3
+    assert line["allreduce"]["object_slice"]["bytes"] > 0
+
+
 def test_example_script_runs_and_converges():
     """examples/reconstruct_synthetic.py: the drop-in use shown to a tike user
     (simulate + reconstruct through the public API) runs and lowers the cost."""
