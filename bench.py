@@ -9,6 +9,8 @@ One "step" = one pass of the hot path over the whole synthetic dataset:
      detector, 8 probe modes + eigen-probe correction, 10 minibatches;
   c1: BASELINE configs[0] (256 positions, 128x128, 1 mode, cgrad);
   c2: 1 probe mode, cgrad;  c5: 512x512, 4 modes, position correction;
+  c3poisson / c3rpie: c3's shapes with the Poisson noise model / solved by
+     rpie (SURVEY 8 rows f2, f3: measured, not BASELINE configurations);
   fwdDxS: one launch of the fused forward operator (D = detector, S = modes).
 Inputs are HBM-resident before the timed region.  Rank 0 prints ONE JSON line.
 
@@ -378,7 +380,14 @@ EPOCH_DEFAULTS = {
     "c3": (256, 8, 10000, 10),
     # c5 = 80 000 positions over 8 GPUs
     "c5": (512, 4, 10000, 10),
+    # SURVEY 8 rows f2 / f3 at the headline shapes (not BASELINE configs; own
+    # lines in profiles/): c3 with the Poisson noise model; c3 solved by rpie
+    "c3poisson": (256, 8, 10000, 10),
+    "c3rpie": (256, 8, 10000, 10),
 }
+SOLVER_LABEL = {"c1": "cgrad (cg_iter=4)", "c2": "cgrad (cg_iter=4)",
+                "c3poisson": "lstsq_grad (poisson, all_modes)",
+                "c3rpie": "rpie"}
 
 
 def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
@@ -404,7 +413,7 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
     np.random.seed(1234 + rank)
     eigen_probe = eigen_weights = None
     C = 0
-    if workload == "c3":
+    if workload.startswith("c3"):
         import tike_amd.random
         tike_amd.random.randomizer_np = np.random.default_rng(4321)
         eigen_probe, eigen_weights = tp.init_varying_probe(
@@ -418,8 +427,14 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
         # BASELINE configs[0] / [1] name the conjugate-gradient solver
         algorithm_options=(tp.CgradOptions(num_batch=num_batch, cg_iter=4)
                            if workload in ("c1", "c2") else
+                           tp.RpieOptions(num_batch=num_batch,
+                                          batch_method="compact")
+                           if workload == "c3rpie" else
                            tp.LstsqOptions(num_batch=num_batch,
                                            batch_method="compact")),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool),
+            noise_model="poisson") if workload == "c3poisson" else None,
         probe_options=tp.ProbeOptions(force_orthogonality=True),
         object_options=tp.ObjectOptions(),
         position_options=tp.PositionOptions(
@@ -462,8 +477,8 @@ def epoch_leg(workload, tp, A, torch, positions=0, epochs=None):
     b_iter, f_iter = iteration_bounds(S, det, det)
     rate = N * epochs / dt
     return dict(workload=workload, positions=N, modes=S, detector=det,
-                solver="cgrad (cg_iter=4)" if workload in ("c1", "c2") else
-                "lstsq_grad", num_batch=built["num_batch"],
+                solver=SOLVER_LABEL.get(workload, "lstsq_grad"),
+                num_batch=built["num_batch"],
                 position_correction=workload == "c5", epochs=epochs,
                 ms_per_epoch=dt / epochs * 1e3, value=rate, unit="patterns/s",
                 iteration_hbm_frac=b_iter * rate / 1e9 / HBM_PEAK_GBS,
@@ -563,7 +578,7 @@ def main():
             cpu = cpu_baseline_fwd(p, S, det)
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, solver=None)
-    elif a.workload in ("c1", "c2", "c3", "c5"):
+    elif a.workload in EPOCH_DEFAULTS:
         # c2: 1 mode; c3 (default, = one GPU's share of c4): 8 modes + eigen
         # probes; c5: 512x512, 4 modes, position correction on
         # c1 = BASELINE configs[0], the reference's CPU-runnable case: 256
@@ -609,13 +624,13 @@ def main():
         units = N
         launch_n = min(chunk_positions(S, det, True), N // num_batch)
         dominant = None
-        if rank == 0 and not a.no_cpu_baseline and world == 1:
+        if (rank == 0 and not a.no_cpu_baseline and world == 1
+                and a.workload in ("c1", "c2", "c3", "c5")):
             cpu = (cpu_baseline_c1(p, data, det) if a.workload == "c1" else
                    cpu_baseline_epoch(p, data, S, det))
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, eigen_probes=C,
-                        solver="cgrad (cg_iter=4)" if a.workload in ("c1", "c2")
-                        else "lstsq_grad",
+                        solver=SOLVER_LABEL.get(a.workload, "lstsq_grad"),
                         num_batch=num_batch, chunk_positions=launch_n,
                         position_correction=a.workload == "c5")
         if a.data_on_host:

@@ -302,6 +302,39 @@ def test_ptycho_fwd_eigen_probe_on_the_fly(ops):
     assert_close(got.cpu().numpy(), want, what="fwd with eigen probes")
 
 
+@pytest.mark.parametrize("S,det,masked", [(1, 24, False), (3, 24, True),
+                                          (8, 32, True), (9, 16, True)])
+def test_poisson_step_lengths_vs_oracle(S, det, masked):
+    """tike_poisson_steps, all modes (exitwave.py:122-184): S <= 8 runs the
+    one-workgroup-per-position kernel (two sweeps), S = 9 the per-tile one;
+    masked-out pixels hold NaN counts and must not be touched."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    from oracle import solvers as osol
+    rng = np.random.default_rng(7 * S + det)
+    N = 5
+    far = rc(rng, N, 1, S, det, det)
+    inten = np.sum(np.abs(far)**2, axis=2)[:, 0].astype(np.float32)
+    data = (inten * rng.uniform(0.5, 1.5, inten.shape)).astype(np.float32)
+    mask = np.ones((det, det), bool)
+    if masked:
+        mask[rng.random((det, det)) < 0.2] = False
+        data[:, ~mask] = np.nan
+    xi = (1 - data / (inten + 1e-9))[:, None, None]
+    want = osol.poisson_steplength_all_modes(
+        xi, np.abs(far)**2, inten, data, mask,
+        np.full((N, 1, S, 1, 1), 0.7, np.float32), 0.4)
+    steps = torch.zeros((N, S), dtype=torch.float32, device="cuda")
+    m = A.to_device(mask.astype(np.uint8)) if masked else None
+    far_d, inten_d, data_d = (A.to_device(x) for x in (far, inten, data))
+    check(lib.tike_poisson_steps(
+        A.ptr(far_d), A.ptr(inten_d), A.ptr(data_d), A.ptr(m), A.ptr(steps), N,
+        S, det, 0.7, 0.4, 0, A.stream_ptr()), "poisson steps")
+    np.testing.assert_allclose(steps.cpu().numpy(), want[:, 0, :, 0, 0],
+                               rtol=2e-4)
+
+
 def test_farplane_gradient_fused(ops, oracle):
     """tike_farplane_gradient vs objective.py + lstsq.py:444-502, with a mask
     whose unmeasured pixels hold NaN data (reference tests put NaN there)."""

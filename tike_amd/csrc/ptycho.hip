@@ -2922,6 +2922,89 @@ __global__ __launch_bounds__(256) void poisson_steps_kernel(
   }
 }
 
+// All modes of a position in ONE workgroup and TWO sweeps (S <= 8, even pixel
+// count): the intensity and the counts of a pixel are read once for its S
+// modes, and the first fixed-point update (alpha = start: known) shares its
+// sweep with the denominator -- 9 MiB instead of 24 MiB per position at
+// 256^2 x 8.  A thread takes U pairs of neighbouring pixels per trip (16-byte
+// loads of the waves, 8-byte loads of intensity and counts), every operand
+// requested before the first is used: one workgroup per position, nothing else
+// hides the latency.  Unmeasured pixels (their counts may be NaN) are selected
+// away, never multiplied.
+template <int MAXS, int U>
+__global__ __launch_bounds__(256) void poisson_steps_allmodes_kernel(
+    const cf* __restrict__ farplane, const float* __restrict__ intensity,
+    const float* __restrict__ data, const unsigned char* __restrict__ mask,
+    float* __restrict__ steps, int S, long npix, float start, float w) {
+  typedef float tk_v4 __attribute__((ext_vector_type(4)));
+  typedef float tk_v2 __attribute__((ext_vector_type(2)));
+  __shared__ float red[4];
+  const long n = blockIdx.x;
+  const cf* __restrict__ F = farplane + n * S * npix;
+  const float* __restrict__ I = intensity + n * npix;
+  const float* __restrict__ d = data + n * npix;
+  const long npair = npix / 2;
+  float denom[MAXS], numer[MAXS], alpha[MAXS];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s) {
+    denom[s] = numer[s] = 0.f;
+    alpha[s] = start;
+  }
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    for (long q0 = threadIdx.x; q0 < npair; q0 += (long)U * 256) {
+      tk_v2 Ie[U], Im[U];
+      tk_v4 f[U][MAXS];
+      bool meas[U][2];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const long q = q0 + 256L * j;
+        const bool in = q < npair;
+        const long p = 2 * (in ? q : q0);
+        Ie[j] = *reinterpret_cast<const tk_v2*>(I + p);
+        Im[j] = *reinterpret_cast<const tk_v2*>(d + p);
+        meas[j][0] = in && (mask ? mask[p] != 0 : true);
+        meas[j][1] = in && (mask ? mask[p + 1] != 0 : true);
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+          if (s < S) f[j][s] = *reinterpret_cast<const tk_v4*>(F + s * npix + p);
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const float ie = h ? Ie[j].y : Ie[j].x, im = h ? Im[j].y : Im[j].x;
+          const float xi = 1.0f - im / (ie + 1e-9f);
+#pragma unroll
+          for (int s = 0; s < MAXS; ++s) {
+            if (s < S) {
+              const float a = h ? f[j][s].z * f[j][s].z + f[j][s].w * f[j][s].w
+                                : f[j][s].x * f[j][s].x + f[j][s].y * f[j][s].y;
+              const float xam1 = xi * alpha[s] - 1.0f;
+              const float t = xi * a * (1.0f + im * xam1 / (a * xam1 * xam1 + ie - a));
+              numer[s] += meas[j][h] ? t : 0.f;
+              if (sweep == 0) denom[s] += meas[j][h] ? xi * xi * a : 0.f;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < S) {  // uniform
+        if (sweep == 0) denom[s] = tk_block_sum256(denom[s], red);
+        const float nm = tk_block_sum256(numer[s], red);
+        alpha[s] = alpha[s] * (1.0f - w) + (nm / denom[s]) * w;
+        numer[s] = 0.f;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+      if (s < S) steps[n * S + s] = alpha[s];
+  }
+}
+
 extern "C" int tike_poisson_steps(const void* farplane, const float* intensity,
                                   const float* data, const unsigned char* measured,
                                   float* steps, int nscan, int S, int det, float step_start,
@@ -2934,6 +3017,10 @@ extern "C" int tike_poisson_steps(const void* farplane, const float* intensity,
   const long npix = (long)det * det;
   if (dominant_mode)
     hipLaunchKernelGGL((poisson_steps_kernel<true>), dim3(nscan), dim3(256), 0, stream,
+                       (const cf*)farplane, intensity, data, measured, steps, S, npix,
+                       step_start, weight);
+  else if (S <= 8 && npix % 2 == 0)
+    hipLaunchKernelGGL((poisson_steps_allmodes_kernel<8, 2>), dim3(nscan), dim3(256), 0, stream,
                        (const cf*)farplane, intensity, data, measured, steps, S, npix,
                        step_start, weight);
   else
