@@ -239,6 +239,20 @@ int tike_poisson_steps(const void* farplane, const float* intensity, const float
                        const unsigned char* measured, float* steps, int nscan, int S, int det,
                        float step_start, float weight, int dominant_mode, void* stream);
 
+/* The same per-mode step lengths (all modes, exitwave.py:122-184) WITHOUT a
+ * stored far plane, for the far-plane-free sizes (det 256 with S <= 8, 512 with
+ * S <= 4; TIKE_ERR_UNSUPPORTED otherwise): two column passes over the forward
+ * hand-off `scratch` of tike_fwd_pass1 with |F_s|^2 of all modes in registers.
+ * The first pass also leaves what tike_fwd_gradient_scale(model = 1) leaves:
+ * gscale (nscan,det,det) the poisson gradient factor, costs (nscan) or NULL.
+ * steps (nscan,S) out; sums (nscan,S,2) f32 workspace.  The inverse that
+ * follows is tike_grad_ifft2_pass1(scratch, gscale, steps, measured, ...). */
+int tike_poisson_steps_handoff(const void* scratch, const void* data, int data_u16,
+                               const unsigned char* measured, float* gscale, float* costs,
+                               float* steps, float* sums, int nscan, int S, int det, float scale,
+                               float unmeasured_scaling, long num_measured, float step_start,
+                               float weight, void* stream);
+
 /* tike_ifft2_crop_scaled with the factor of mode s multiplied by
  * mode_scale[n][s] on measured pixels (lstsq.py:487-489: farplane[measured] =
  * -step_length * grad_cost). */

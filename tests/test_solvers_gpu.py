@@ -684,14 +684,27 @@ def _oracle_state(g_psi, g_probe, scan, order):
     (256, 256, 2, 10, 1, False, "poisson:dominant_mode"),
     (48, 32, 2, 12, 2, True, "poisson:all_modes"),        # generic path: tike_scale_modes
     (512, 512, 2, 6, 2, True, "gaussian"),                # config-5 size: 512^2 position-major
-    (256, 256, 3, 8, 2, True, "poisson:all_modes"),       # 256^2 with the far plane kept (split forward)
+    (256, 256, 3, 8, 2, True, "poisson:all_modes"),       # 256^2: per-mode steps from the hand-off
     (512, 512, 4, 5, 1, False, "poisson:dominant_mode"),
+    (256, 256, 8, 6, 1, False, "poisson:all_modes"),      # ... at the headline mode count
+    (512, 512, 2, 5, 1, True, "poisson:all_modes"),       # ... and at 512^2
+    (256, 256, 3, 8, 2, True, "poisson:all_modes:kept"),  # the stored-far-plane pipeline
 ])
 def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
     """Two lstsq_grad epochs against the CPU oracle on seeded problems that
     exercise ragged minibatches, unmeasured pixels holding NaN (reference
     tests/ptycho/test_ptycho.py:334,553), pw < det and every FFT path."""
     from oracle import solvers as osol
+    if model.endswith(":kept"):
+        import importlib
+        import pytest as _pytest
+        L = importlib.import_module("tike_amd.ptycho.solvers.lstsq")
+        mp = _pytest.MonkeyPatch()
+        mp.setattr(L, "POISSON_FROM_HANDOFF", False)
+        request_cleanup = mp.undo
+        model = model[:-len(":kept")]
+    else:
+        request_cleanup = lambda: None
     rng = np.random.default_rng(det * 7 + N)
     side = int(np.ceil(np.sqrt(N)))
     ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
@@ -724,12 +737,15 @@ def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
             noise_model=model.split(":")[0],
             step_length_usemodes=(model.split(":") + ["all_modes"])[1]))
     import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")  # NaN in data warns, as the reference
-        with tp.Reconstruction(data, params, order=order,
-                               batches=batches) as ctx:
-            ctx.iterate(2)
-            got = ctx.get_result()
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # NaN in data warns, as the reference
+            with tp.Reconstruction(data, params, order=order,
+                                   batches=batches) as ctx:
+                ctx.iterate(2)
+                got = ctx.get_result()
+    finally:
+        request_cleanup()
     state = _oracle_state(psi0, probe0, scan, order)
     odata = np.where(mask, np.nan_to_num(data), 0).astype(np.float32)
     state = osol.rescale_probe(state, odata, det, measured_pixels=mask)

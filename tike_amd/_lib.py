@@ -61,6 +61,8 @@ _PROTOTYPES = {
     "tike_ifft2_crop_scaled_modes": [_p, _p, _p, _p, _i, _p, _p, _l, _i, _i, _f,
                                      _p],
     "tike_poisson_steps": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _i, _p],
+    "tike_poisson_steps_handoff": [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _f,
+                                   _f, _l, _f, _f, _p],
     "tike_scale_modes": [_p, _p, _p, _l, _i, _p],
     "tike_ptycho_fwd_intensity_only": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p,
                                        _i, _i, _i, _i, _i, _i, _f, _p],

@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
     // far-plane gradient applied on the fly: F_s * g, g per (position, pixel);
     // MODE 2 (poisson): times the step of this (position, mode) on measured pixels
     const float* __restrict__ gs = MODE ? gscale + (tile / S) * (long)N * N : nullptr;
-    const float ms = MODE == 2 ? mode_scale[tile] : 1.0f;
+    const float ms = MODE >= 2 ? mode_scale[tile] : 1.0f;
     for (int r = 0; r < G2::RB; ++r)
       fft2_pass1<N, true, !PASS2>(
           lds, twtab, tw, line, j, r,
@@ -1932,7 +1932,10 @@ __global__ __launch_bounds__(N, (N <= 256 ? TK_ICROP_WAVES : 2)) void ifft2_crop
             const cf f = tk_ld_stream(src + y * N + e);
             if (MODE == 0) return f;
             float g = gs[y * N + e];
-            if (MODE == 2 && (measured == nullptr || measured[y * N + e])) g *= ms;
+            // (MODE 3 = MODE 2 with a mask: its byte is requested with the
+            // factor and the step selected -- never a test around the load)
+            if (MODE == 2) g *= ms;
+            if (MODE == 3) g *= measured[y * N + e] ? ms : 1.0f;
             return f * g;
           },
           mid);
@@ -1960,7 +1963,9 @@ static int launch_icrop_v2(const cf* far, cf* work, cf* chi, long ntile, int pw,
   hipLaunchKernelGGL((ifft2_crop_v2_kernel<N, MODE, PASS2>), dim3(tk_grid(ntile, 4)), dim3(N), \
                      0, stream, far, work, chi, ntile, pw, scale, tw, gscale, S, mode_scale, \
                      measured)
-  if (gscale && mode_scale)
+  if (gscale && mode_scale && measured)
+    TK_ICROP(3);
+  else if (gscale && mode_scale)
     TK_ICROP(2);
   else if (gscale)
     TK_ICROP(1);
@@ -2293,12 +2298,33 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
         for (int r = 0; r < 16; ++r) un[r] = tk_ld_stream(src + (16 * r + k1 + 1) * N + t);
       }
       Dft<16, false>::run(u);
+      if constexpr (MODE == 2) {
+        // per-mode step on measured pixels: the 16 factors (and mask bytes)
+        // are requested together, the step is SELECTED -- a test per pixel
+        // around its mask load made 16 serial round trips of them (3.29 ms
+        // per 1000 positions x 8 modes against 1.6 ms without the steps)
+        float g[16];
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) {
-        const int p = (k1 + 16 * k2) * N + t;
-        float g = gs[p] * fwd_scale;
-        if (MODE == 2 && (measured == nullptr || measured[p])) g *= ms;
-        u[k2] = u[k2] * g;
+        for (int k2 = 0; k2 < 16; ++k2) g[k2] = gs[(k1 + 16 * k2) * N + t];
+        if (measured != nullptr) {  // uniform
+          unsigned char mb[16];
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) mb[k2] = measured[(k1 + 16 * k2) * N + t];
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) g[k2] *= mb[k2] ? ms : 1.0f;
+        } else {
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) g[k2] *= ms;
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) u[k2] = u[k2] * (g[k2] * fwd_scale);
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+          const int p = (k1 + 16 * k2) * N + t;
+          float g = gs[p] * fwd_scale;
+          u[k2] = u[k2] * g;
+        }
       }
       Dft<16, true>::run(u);
 #pragma unroll
@@ -2627,12 +2653,31 @@ __global__ __launch_bounds__(512, 2) void grad_ifft2_pass1_512_kernel(
 #pragma unroll
     for (int r = 0; r < 32; ++r) u[r] = tk_ld_stream(src + (16 * r + k1) * N + t);
     Dft<32, false>::run(u);
+    if constexpr (MODE == 2) {
+      // (factors and mask bytes requested together, the step selected: see
+      // grad_ifft2_crop_kernel)
+      float g[32];
 #pragma unroll
-    for (int k2 = 0; k2 < 32; ++k2) {
-      const int p = (k1 + 16 * k2) * N + t;
-      float g = gs[p] * fwd_scale;
-      if (MODE == 2 && (measured == nullptr || measured[p])) g *= ms;
-      u[k2] = u[k2] * g;
+      for (int k2 = 0; k2 < 32; ++k2) g[k2] = gs[(k1 + 16 * k2) * N + t];
+      if (measured != nullptr) {  // uniform
+        unsigned char mb[32];
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) mb[k2] = measured[(k1 + 16 * k2) * N + t];
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) g[k2] *= mb[k2] ? ms : 1.0f;
+      } else {
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) g[k2] *= ms;
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 32; ++k2) u[k2] = u[k2] * (g[k2] * fwd_scale);
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < 32; ++k2) {
+        const int p = (k1 + 16 * k2) * N + t;
+        float g = gs[p] * fwd_scale;
+        u[k2] = u[k2] * g;
+      }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -3003,6 +3048,165 @@ __global__ __launch_bounds__(256) void poisson_steps_allmodes_kernel(
     for (int s = 0; s < MAXS; ++s)
       if (s < S) steps[n * S + s] = alpha[s];
   }
+}
+
+// ---- the same step lengths WITHOUT a stored far plane (256^2 / 512^2): the
+// column pass of fwd_gradient_scale_kernel with |F_s|^2 of all S modes kept in
+// registers (S x RB floats), so that one read of the forward hand-off gives
+//   FIRST: the poisson gradient factor and the costs (what
+//          fwd_gradient_scale_kernel<N, 1, DT> stores) AND the first sweep of
+//          exitwave.py:122-184 (denominator; numerator at alpha = start);
+//   else : the second sweep (numerator at the alpha of the first).
+// sums (nscan, S, 2) = { denominator, numerator } accumulate by atomics (one per
+// wave, mode and sum); poisson_alpha_kernel turns them into alpha between and
+// after the sweeps.  The far plane itself is never written: the inverse that
+// follows (tike_grad_ifft2_pass1) re-forms it from the same hand-off.
+template <int N, class DT, bool FIRST>
+__global__ __launch_bounds__(256, 2) void poisson_colpass_kernel(
+    const cf* __restrict__ colin, const DT* __restrict__ data,
+    const unsigned char* __restrict__ mask, float* __restrict__ gscale,
+    float* __restrict__ costs, const float* __restrict__ alpha, float start,
+    float* __restrict__ sums, long nitem, int S, float scale, float unmeasured_scaling,
+    float inv_nmeasured) {
+  constexpr int RB = N / 16, NH = N / 256, MAXS = N == 256 ? 8 : 4;
+  __shared__ float red[4];
+  __shared__ float wsum[4][2 * MAXS];
+  const float s2 = scale * scale;
+  for (long v = blockIdx.x; v < nitem; v += gridDim.x) {
+    const int hb = (int)(v % NH);
+    const int k1 = (int)((v / NH) & 15);
+    const long n = nitem / (16 * NH) - 1 - v / (16 * NH);  // descending, as its siblings
+    const int t = hb * 256 + threadIdx.x;
+    float a[MAXS][RB], I[RB];
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) I[k2] = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < S) {  // uniform
+        const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
+        cf u[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) u[r] = tk_ld_stream(src + (long)(16 * r) * N);
+        Dft<RB, false>::run(u);
+#pragma unroll
+        for (int k2 = 0; k2 < RB; ++k2) {
+          a[s][k2] = norm2(u[k2]) * s2;
+          I[k2] += a[s][k2];
+        }
+      }
+    }
+    DT raw[RB];
+    unsigned bits;
+    tk_request_data<N, RB>(data, mask, n, k1, t, raw, bits);
+    float den[MAXS], num[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) den[s] = num[s] = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < S) {
+        const float al = FIRST ? start : alpha[n * S + s];  // uniform
+#pragma unroll
+        for (int k2 = 0; k2 < RB; ++k2) {
+          const bool meas = (bits >> k2) & 1u;
+          const float dv = (float)raw[k2];
+          const float xi = 1.0f - dv / (I[k2] + 1e-9f);
+          const float xam1 = xi * al - 1.0f;
+          const float av = a[s][k2];
+          const float tn = xi * av * (1.0f + dv * xam1 / (av * xam1 * xam1 + I[k2] - av));
+          num[s] += meas ? tn : 0.f;
+          if (FIRST) den[s] += meas ? xi * xi * av : 0.f;
+        }
+      }
+    }
+    if (FIRST) {
+      float cost = tk_gradient_factor<1, RB>(I, raw, bits, unmeasured_scaling, 1.0f);
+#pragma unroll
+      for (int k2 = 0; k2 < RB; ++k2)
+        gscale[n * (long)N * N + (long)(k1 + 16 * k2) * N + t] = I[k2];
+      if (costs) {
+        cost = tk_block_sum256(cost, red);
+        if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < S) {
+        num[s] = tk_wave_sum(num[s]);
+        if (FIRST) den[s] = tk_wave_sum(den[s]);
+      }
+    }
+    __syncthreads();  // the previous item's sums have been read
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) {
+        wsum[threadIdx.x >> 6][2 * s] = den[s];
+        wsum[threadIdx.x >> 6][2 * s + 1] = num[s];
+      }
+    }
+    __syncthreads();
+    const int q = threadIdx.x;  // q = 2 s + {0: denominator, 1: numerator}
+    if (q < 2 * S && (FIRST || (q & 1)))
+      unsafeAtomicAdd(&sums[n * 2 * S + q], wsum[0][q] + wsum[1][q] + wsum[2][q] + wsum[3][q]);
+  }
+}
+
+// alpha <- (1 - w) alpha + w numerator / denominator per (position, mode); the
+// numerator is cleared for the next sweep.  first: alpha = start on entry.
+__global__ __launch_bounds__(256) void poisson_alpha_kernel(float* __restrict__ sums,
+                                                            float* __restrict__ alpha, long ntile,
+                                                            float start, float w, int first) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < ntile; i += gridDim.x * 256L) {
+    const float prev = first ? start : alpha[i];
+    alpha[i] = prev * (1.0f - w) + (sums[2 * i + 1] / sums[2 * i]) * w;
+    sums[2 * i + 1] = 0.f;
+  }
+}
+
+extern "C" int tike_poisson_steps_handoff(const void* scratch, const void* data, int data_u16,
+                                          const unsigned char* measured, float* gscale,
+                                          float* costs, float* steps, float* sums, int nscan,
+                                          int S, int det, float scale, float unmeasured_scaling,
+                                          long num_measured, float step_start, float weight,
+                                          void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && num_measured > 0);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(scratch && data && gscale && steps && sums);
+  if (!((det == 256 && S <= 8) || (det == 512 && S <= 4))) return TK_ERR_UNSUPPORTED;
+  const long ntile = (long)nscan * S;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)ntile, stream);
+  if (e == hipSuccess && costs) e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
+  if (e != hipSuccess) return (int)e;
+  const long nitem = (long)nscan * 16 * (det / 256);
+  const float inv = 1.0f / (float)num_measured;
+  const dim3 grid(tk_grid(nitem, 32)), block(256);
+  const dim3 agrid(tk_grid((ntile + 255) / 256, 4));
+#define TK_PC(N, DT, FIRST)                                                                     \
+  hipLaunchKernelGGL((poisson_colpass_kernel<N, DT, FIRST>), grid, block, 0, stream,               \
+                     (const cf*)scratch, (const DT*)data, measured, gscale, costs, steps,          \
+                     step_start, sums, nitem, S, scale, unmeasured_scaling, inv)
+#define TK_PC_N(FIRST)                        \
+  do {                                        \
+    if (det == 256 && data_u16)               \
+      TK_PC(256, unsigned short, FIRST);      \
+    else if (det == 256)                      \
+      TK_PC(256, float, FIRST);               \
+    else if (data_u16)                        \
+      TK_PC(512, unsigned short, FIRST);      \
+    else                                      \
+      TK_PC(512, float, FIRST);               \
+  } while (0)
+  TK_PC_N(true);
+  hipLaunchKernelGGL(poisson_alpha_kernel, agrid, dim3(256), 0, stream, sums, steps, ntile,
+                     step_start, weight, 1);
+  TK_PC_N(false);
+  hipLaunchKernelGGL(poisson_alpha_kernel, agrid, dim3(256), 0, stream, sums, steps, ntile,
+                     step_start, weight, 0);
+#undef TK_PC_N
+#undef TK_PC
+  TK_LAUNCH_CHECK();
+  return TK_OK;
 }
 
 extern "C" int tike_poisson_steps(const void* farplane, const float* intensity,

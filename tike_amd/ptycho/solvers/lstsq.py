@@ -67,6 +67,11 @@ SPLIT_FORWARD_SIZES = (256, 512)
 
 import os as _os
 
+POISSON_FROM_HANDOFF = True
+"""Per-mode poisson step lengths at 256^2 / 512^2 from the forward hand-off
+(tike_poisson_steps_handoff) instead of from a stored far plane; tests set
+this to False to compare the two pipelines."""
+
 CHUNK_POSITIONS_OVERRIDE = (int(_os.environ["TIKE_CHUNK_POSITIONS"])
                             if _os.environ.get("TIKE_CHUNK_POSITIONS") else None)
 """Tests set this to force small kernel chunks (several per minibatch);
@@ -399,10 +404,14 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # steps of 'all_modes' need |F_s|^2 and keep the stored far plane)
     # (512^2: only together with the fused pass 2, the generic gradient +
     # inverse + crop kernel exists at 256^2 only)
+    # (round 4: with the fused pass 2 the per-mode steps come from two more
+    # column passes over the forward hand-off, tike_poisson_steps_handoff, and
+    # the far plane is not kept either)
+    all_modes = (poisson and exitwave_options.step_length_usemodes
+                 != "dominant_mode")
     no_farplane = (pos_major
                    and (det in NO_FARPLANE_SIZES or (det == 512 and fused))
-                   and not (poisson and exitwave_options.step_length_usemodes
-                            != "dominant_mode"))
+                   and not (all_modes and not (fused and POISSON_FROM_HANDOFF)))
     if poisson:
         # per-(position, mode) step lengths (exitwave.py:122-234)
         steps = ws.get("steps", (min(chunk, max(B, 1)), S), torch.float32,
@@ -456,7 +465,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         # float32 view of the chunk for the kernels without a 16-bit loader
         # (the 256^2 gaussian hot path reads uint16 directly)
         dchunk = None
-        if not (pos_major and no_farplane and not poisson):
+        if not (pos_major and no_farplane and not (poisson and dominant)):
             dchunk = A.data_f32(data, clo, chi_hi)
         if pos_major and no_farplane:
             # the far-plane waves never reach memory: the forward kernel forms
@@ -475,7 +484,20 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             # factor and the inverse's pass 1 are ONE launch (the factor never
             # goes through memory)
             one_launch = fused and det == 256 and not poisson
-            if one_launch:
+            if poisson and not dominant:
+                # gradient factor, costs and the per-mode step lengths from
+                # the hand-off: three reads of it, no far plane stored
+                sums = ws.get("poisson_sums", (min(chunk, max(B, 1)), S, 2),
+                              torch.float32, dev)
+                check(
+                    lib.tike_poisson_steps_handoff(
+                        A.ptr(far), A.ptr(data[clo:chi_hi]),
+                        int(data.dtype == torch.uint16), A.ptr(mask_u8),
+                        A.ptr(gscale), A.ptr(costs[blo:blo + n]),
+                        A.ptr(steps), A.ptr(sums), n, S, det, fwd_scale,
+                        unmeasured, nmeasured, step_start, step_weight, st),
+                    "forward pass 2 + poisson factor and step lengths")
+            elif one_launch:
                 check(
                     lib.tike_fwd_grad_ifft2_pass1(
                         A.ptr(far), A.ptr(data[clo:chi_hi]),
@@ -492,7 +514,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                         A.ptr(costs[blo:blo + n]), None, n, S, det, fwd_scale,
                         model, unmeasured, nmeasured, st),
                     "forward pass 2 + gradient scale")
-            if poisson:  # dominant mode: the steps need no far-plane waves
+            if poisson and dominant:  # the steps need no far-plane waves
                 check(
                     lib.tike_poisson_steps(
                         None, A.ptr(inten), A.ptr(dchunk),
