@@ -1311,12 +1311,16 @@ def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
                                    rtol=5e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("det,S", [(256, 2), (64, 1)])
-def test_uint16_data_stays_16_bit_and_matches_float(tp, det, S):
+@pytest.mark.parametrize("det,S,model", [(256, 2, "gaussian"),
+                                         (64, 1, "gaussian"),
+                                         (256, 3, "poisson")])
+def test_uint16_data_stays_16_bit_and_matches_float(tp, det, S, model):
     """Detector counts arriving as uint16 are kept as uint16 in HBM (reference
     ptycho.py:383-390) and give the iterates of the same counts as float32
-    (256^2: the 16-bit loader of the streamed column pass; 64^2: the
-    converted-chunk path)."""
+    (256^2: the 16-bit loader of the streamed column pass -- gaussian: the
+    one-launch gradient pass; poisson with per-mode steps: the two column
+    passes of tike_poisson_steps_handoff --; 64^2: the converted-chunk
+    path)."""
     import torch
     scan, psi_true, probe0, _, _, data = _headline_problem(
         tp, det, S, 8, seed=det + 11, eigen=False)
@@ -1331,7 +1335,8 @@ def test_uint16_data_stays_16_bit_and_matches_float(tp, det, S):
             probe_options=tp.ProbeOptions(force_orthogonality=True),
             object_options=tp.ObjectOptions(),
             exitwave_options=tp.ExitWaveOptions(
-                measured_pixels=np.ones((det, det), dtype=bool)))
+                measured_pixels=np.ones((det, det), dtype=bool),
+                noise_model=model))
         with tp.Reconstruction(d, params, order=np.arange(8),
                                batches=np.array_split(np.arange(8), 2)) as ctx:
             assert ctx.data.dtype == (torch.uint16 if d.dtype == np.uint16
