@@ -385,6 +385,16 @@ EPOCH_DEFAULTS = {
     "c3poisson": (256, 8, 10000, 10),
     "c3rpie": (256, 8, 10000, 10),
 }
+# The minibatches are contiguous chunks of the ONCE-SHUFFLED scan (SURVEY
+# 8(d)): each spans the whole field of view, like the batches the reference's
+# default selector `wobbly_center` makes -- and like them they are followed by
+# an object update each (`batch_method` names the update rule here; the
+# batches themselves are handed over).  TIKE_BENCH_BATCH_RULE=compact: the
+# rule for spatially disjoint batches (one summed object update per epoch),
+# which rounds 1-4 ran on these overlapping batches -- same kernels, same
+# time, but an iteration that stops converging after two epochs
+# (tools/soak_costs.py).
+BATCH_RULE = os.environ.get("TIKE_BENCH_BATCH_RULE", "wobbly_center")
 SOLVER_LABEL = {"c1": "cgrad (cg_iter=4)", "c2": "cgrad (cg_iter=4)",
                 "c3poisson": "lstsq_grad (poisson, all_modes)",
                 "c3rpie": "rpie"}
@@ -428,10 +438,10 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
         algorithm_options=(tp.CgradOptions(num_batch=num_batch, cg_iter=4)
                            if workload in ("c1", "c2") else
                            tp.RpieOptions(num_batch=num_batch,
-                                          batch_method="compact")
+                                          batch_method=BATCH_RULE)
                            if workload == "c3rpie" else
                            tp.LstsqOptions(num_batch=num_batch,
-                                           batch_method="compact")),
+                                           batch_method=BATCH_RULE)),
         exitwave_options=tp.ExitWaveOptions(
             measured_pixels=np.ones((det, det), dtype=bool),
             noise_model="poisson") if workload == "c3poisson" else None,
@@ -633,6 +643,11 @@ def main():
                         solver=SOLVER_LABEL.get(a.workload, "lstsq_grad"),
                         num_batch=num_batch, chunk_positions=launch_n,
                         position_correction=a.workload == "c5")
+        if a.workload not in ("c1", "c2"):
+            workload["object_update"] = (
+                "after every minibatch (batch_method wobbly_center)"
+                if BATCH_RULE != "compact" else
+                "once per epoch (batch_method compact)")
         if a.data_on_host:
             workload["data_residency"] = "pinned host, streamed per chunk"
     else:
