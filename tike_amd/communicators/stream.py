@@ -47,6 +47,50 @@ class PinnedData:
         self._last = None  # (lo, hi, slot, copy-done event, stream) handed out last
         self.copies = 0  # host-to-device copies issued
         self.hits = 0  # chunks that were already on their way when asked for
+        self._ranges = []  # row ranges the solver will walk next, in order
+
+    def hint(self, ranges):
+        """Tell the prefetcher which row ranges (minibatches) come next and in
+        which order: the solvers visit the minibatches of an epoch in a random
+        permutation, so "the rows behind this chunk" is the wrong guess at
+        every minibatch boundary (10 000 positions in 10 minibatches: 42 hits
+        in 130 copies, every miss an exposed 4.6 ms copy plus a wasted one)."""
+        self._ranges = [(int(a), int(b)) for a, b in ranges if b > a]
+        if self._ranges and self._last is not None and self._ready is None:
+            # the first chunk of the epoch, while the set-up work of the
+            # epoch (preconditioners, constraints) runs
+            n = self._last[1] - self._last[0]
+            a, b = self._ranges[0]
+            if (a, min(b, a + n)) != self._last[:2]:
+                other = 1 - self._last[2]
+                self._release(other, torch.cuda.current_stream(self.device))
+                self._ready = (a, min(b, a + n), other,
+                               self._issue(a, min(b, a + n), other))
+
+    def _predict(self, lo, hi):
+        """The chunk that will be asked for after rows [lo, hi)."""
+        n = hi - lo
+        for i, (a, b) in enumerate(self._ranges):
+            if a <= lo and hi <= b:
+                if hi < b:
+                    return hi, min(b, hi + n)
+                if i + 1 < len(self._ranges):
+                    a2, b2 = self._ranges[i + 1]
+                    return a2, min(b2, a2 + n)
+                return None  # the epoch ends here
+        nlo, nhi = hi, min(self.shape[0], hi + n)  # no hint: the rows behind
+        return (nlo, nhi) if nhi > nlo else None
+
+    def _release(self, slot, cur):
+        """Everything queued so far has finished with `slot`: it may be
+        rewritten behind the events recorded here."""
+        released = []
+        for stream in self._readers[slot] | {cur}:
+            event = torch.cuda.Event()
+            event.record(stream)
+            released.append(event)
+        self._free[slot] = released
+        self._readers[slot] = set()
 
     def __len__(self):
         return self.shape[0]
@@ -103,24 +147,19 @@ class PinnedData:
         cur.wait_event(done)
         # everything queued so far has finished with the other slot
         other = 1 - s
-        released = []
-        for stream in self._readers[other] | {cur}:
-            event = torch.cuda.Event()
-            event.record(stream)
-            released.append(event)
-        self._free[other] = released
-        self._readers[other] = set()
+        self._release(other, cur)
         self._readers[s] = {cur}
         self._last = (lo, hi, s, done, cur)
-        # the solvers walk a minibatch chunk by chunk: fetch the next one now
-        # (the guess `hi + n` misses on a shorter last chunk: copied on demand).
+        # the solvers walk a minibatch chunk by chunk and the minibatches in
+        # the order they announced (`hint`): fetch the next chunk now (without
+        # a hint: the rows behind this one; a miss is copied on demand).
         # cgrad re-walks the chunks of a minibatch for every line-search probe:
         # with data_on_host and several chunks per minibatch the minibatch
         # crosses PCIe once per probe -- size the chunks (or the minibatches)
         # so that a minibatch is one chunk when that matters.
-        nlo, nhi = hi, min(self.shape[0], hi + n)
-        if nhi > nlo:
-            self._ready = (nlo, nhi, other, self._issue(nlo, nhi, other))
+        nxt = self._predict(lo, hi)
+        if nxt is not None:
+            self._ready = (*nxt, other, self._issue(*nxt, other))
         return self._view(s, n)
 
     def _view(self, s, n):

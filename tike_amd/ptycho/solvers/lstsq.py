@@ -153,6 +153,8 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
     compact = algorithm_options.batch_method == "compact"
     order = (range(num_batch) if compact else
              trandom.randomizer_np.permutation(num_batch))
+    if hasattr(data, "hint"):  # patterns streamed from pinned host memory
+        data.hint([_lo_hi(batches[b]) for b in order])
 
     dev = psi.device
     H, W = psi.shape[-2:]

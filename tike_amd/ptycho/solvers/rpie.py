@@ -51,6 +51,9 @@ def rpie(parameters, data, batches, comm, *, op, epoch):
     compact = o.batch_method == "compact"
     order = (range(o.num_batch) if compact else
              trandom.randomizer_np.permutation(o.num_batch))
+    if hasattr(data, "hint"):  # patterns streamed from pinned host memory
+        data.hint([(int(batches[b][0]), int(batches[b][0]) + len(batches[b]))
+                   for b in order if len(batches[b])])
     dev = psi.device
     psi_num = probe_num = None
     batch_cost = torch.zeros(o.num_batch, dtype=torch.float32, device=dev)
