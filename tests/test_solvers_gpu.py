@@ -1115,6 +1115,40 @@ def test_resident_gradient_kernel_vs_oracle_beyond_one_wave(tp, u16_and_mask):
                  what="patches")
 
 
+def test_invalid_patterns_warn_like_the_reference(tp):
+    """ptycho.py:392-397: patterns that are negative or not finite draw a
+    UserWarning when the context is entered (checked on the device for
+    resident float data, on the host for streamed data); clean data and
+    16-bit counts draw none."""
+    import warnings
+    det, S, N = 32, 1, 6
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=3, eigen=False)
+
+    def enter(d, **kw):
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+            scan=scan.copy(),
+            algorithm_options=tp.LstsqOptions(num_batch=1),
+            probe_options=tp.ProbeOptions(), object_options=tp.ObjectOptions(),
+            exitwave_options=tp.ExitWaveOptions(
+                measured_pixels=np.ones((det, det), dtype=bool)))
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            with tp.Reconstruction(d, params, **kw):
+                pass
+        return [w for w in seen if "invalid data" in str(w.message)]
+
+    bad_nan, bad_neg = data.copy(), data.copy()
+    bad_nan[2, 5, 7] = np.nan
+    bad_neg[1, 0, 0] = -1.0
+    assert not enter(data) and not enter(data, data_on_host=True)
+    assert not enter(np.round(data * 100).astype(np.uint16))
+    for bad in (bad_nan, bad_neg):
+        assert len(enter(bad)) == 1
+        assert len(enter(bad, data_on_host=True)) == 1
+
+
 def test_bench_whole_job_line_of_two_ranks():
     """The N > 1 code path of bench.py itself -- sharding of every global
     minibatch, barrier + max over ranks, the whole-job value, the all-reduce

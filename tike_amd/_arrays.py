@@ -92,12 +92,17 @@ def data_to_device(x, order=None, device=None):
             return t.contiguous()
         return t.to(torch.float32).contiguous()
     a = np.asarray(x)
-    if order is not None:
-        a = a[order]
     if small:
+        if order is not None:
+            a = a[order]
         a = np.ascontiguousarray(np.clip(a, 0, None).astype(np.uint16))
         return torch.from_numpy(a.view(np.int16)).to(device).view(torch.uint16)
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+    # float patterns: uploaded as they lie, permuted on the device (a fancy
+    # index of 2.6 GB on the host costs more than the upload itself)
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+    if order is not None:
+        t = t.index_select(0, torch.as_tensor(np.asarray(order), device=device))
+    return t
 
 
 def data_f32(data, lo, hi):

@@ -174,6 +174,12 @@ def _clip_magnitude(x, a_max):
     return torch.where(magnitude > a_max, a_max * x / magnitude, x)
 
 
+def _warn_invalid_data():
+    warnings.warn(
+        "Diffraction patterns contain invalid data. "
+        "All data should be non-negative and finite.", UserWarning)
+
+
 def _check_data_shape(data, parameters):
     """The diffraction patterns against the forward model's shapes
     (reference ptycho.py:303-331: same conditions, same messages)."""
@@ -331,11 +337,14 @@ class Reconstruction():
         self.comm.__enter__()
         data = self._data_in
         host = A.to_host(data) if not A.is_device(data) else None
-        if host is not None and (not np.all(np.isfinite(host))
-                                 or np.any(host < 0)):
-            warnings.warn(
-                "Diffraction patterns contain invalid data. "
-                "All data should be non-negative and finite.", UserWarning)
+        # "non-negative and finite" (ptycho.py:392-397) is checked where the
+        # patterns end up: on the GPU for resident float data (one pass at HBM
+        # rate instead of 0.34 s of host time per 2.6 GB), on the host for
+        # integer counts and for patterns that stay in host memory
+        on_host = host is not None and (self._data_on_host
+                                        or host.dtype.kind in "iu")
+        if on_host and (not np.all(np.isfinite(host)) or np.any(host < 0)):
+            _warn_invalid_data()
         # every rank draws the same minibatch permutation / RANSAC subsets
         # (also when the caller sharded the data itself)
         self.comm.sync_random()
@@ -353,6 +362,11 @@ class Reconstruction():
         else:
             self.data = A.data_to_device(data if A.is_device(data) else host,
                                          order=self.local_order)
+            if (host is not None and not on_host
+                    and self.data.dtype == torch.float32
+                    and bool((~torch.isfinite(self.data)).any()
+                             | (self.data < 0).any())):
+                _warn_invalid_data()
         self.parameters = solvers.PtychoParameters.split(
             self.local_order,
             x=self._host_parameters()).copy_to_device()
