@@ -1442,7 +1442,7 @@ def test_streamed_patterns_follow_the_random_minibatch_order(tp, monkeypatch,
     behind the current chunk would be the right guess for half of them -- and
     the iterates are those of the resident run."""
     import tike_amd.ptycho.solvers.lstsq as L
-    monkeypatch.setattr(L, "CHUNK_POSITIONS_OVERRIDE", 4)
+    monkeypatch.setattr(L, "CHUNK_POSITIONS_OVERRIDE", 5)  # chunks of 5 + 3
     det, S, N, nb = 128, 2, 48, 6
     scan, psi_true, probe0, _, _, data = _headline_problem(
         tp, det, S, N, seed=det + 9, eigen=False)

@@ -48,6 +48,7 @@ class PinnedData:
         self.copies = 0  # host-to-device copies issued
         self.hits = 0  # chunks that were already on their way when asked for
         self._ranges = []  # row ranges the solver will walk next, in order
+        self._nmax = 0  # rows of the largest chunk asked for so far
 
     def hint(self, ranges):
         """Tell the prefetcher which row ranges (minibatches) come next and in
@@ -59,7 +60,7 @@ class PinnedData:
         if self._ranges and self._last is not None and self._ready is None:
             # the first chunk of the epoch, while the set-up work of the
             # epoch (preconditioners, constraints) runs
-            n = self._last[1] - self._last[0]
+            n = max(self._last[1] - self._last[0], self._nmax)
             a, b = self._ranges[0]
             if (a, min(b, a + n)) != self._last[:2]:
                 other = 1 - self._last[2]
@@ -68,8 +69,10 @@ class PinnedData:
                                self._issue(a, min(b, a + n), other))
 
     def _predict(self, lo, hi):
-        """The chunk that will be asked for after rows [lo, hi)."""
-        n = hi - lo
+        """The chunk that will be asked for after rows [lo, hi) (a full
+        chunk: the one just handed out may have been the short tail of its
+        minibatch)."""
+        n = max(hi - lo, self._nmax)
         for i, (a, b) in enumerate(self._ranges):
             if a <= lo and hi <= b:
                 if hi < b:
@@ -128,6 +131,7 @@ class PinnedData:
         if n == 0:
             return torch.empty((0, *self.shape[1:]), dtype=self.dtype,
                                device=self.device)
+        self._nmax = max(self._nmax, n)
         cur = torch.cuda.current_stream(self.device)
         if self._last is not None and self._last[:2] == (lo, hi):
             s = self._last[2]  # asked for twice in one chunk iteration
