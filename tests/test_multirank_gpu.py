@@ -275,6 +275,36 @@ def test_reconstruct_num_gpu_starts_the_ranks_itself(monkeypatch):
     assert after != np.random.default_rng(2).bit_generator.state
 
 
+@pytest.mark.parametrize("solver", ["cgrad", "rpie"])
+def test_other_solvers_on_two_ranks_match_one_rank(monkeypatch, solver):
+    """cgrad (cost and gradient summed over the ranks, every rank takes the
+    same step: the pattern of lamino/solvers/cgrad.py:58-92) and rpie on two
+    spawned ranks give the one-rank iterates."""
+    import tike_amd.ptycho as tp
+    import tike_amd.random
+    data, scan, probe, psi0, _, _ = _problem(False)
+    options = dict(cgrad=tp.CgradOptions(num_batch=2, num_iter=2, cg_iter=2),
+                   rpie=tp.RpieOptions(num_batch=2, num_iter=3,
+                                       batch_method="wobbly_center"))[solver]
+    results = []
+    for num_gpu in (None, 2):
+        np.random.seed(1)
+        tike_amd.random.randomizer_np = np.random.default_rng(2)
+        params = tp.PtychoParameters(
+            probe=probe.copy(), psi=psi0.copy(), scan=scan.copy(),
+            algorithm_options=__import__("copy").deepcopy(options),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions())
+        if num_gpu:
+            monkeypatch.setenv("TIKE_AMD_OVERSUBSCRIBE", "1")
+        results.append(tp.reconstruct(data, params, num_gpu=num_gpu))
+    a, b = results
+    np.testing.assert_allclose(np.array(b.algorithm_options.costs),
+                               np.array(a.algorithm_options.costs), rtol=1e-3)
+    assert_close(b.psi, a.psi, normwise=1e-3, maxabs=1e-2, what="psi")
+    assert_close(b.probe, a.probe, normwise=1e-3, maxabs=1e-2, what="probe")
+
+
 def test_reconstruction_context_refuses_num_gpu_it_cannot_honour(monkeypatch):
     import tike_amd.ptycho as tp
     data, scan, probe, psi0, _, _ = _problem(False)
