@@ -531,13 +531,19 @@ int tike_cgrad_line_search(int variable, const void* x, const void* d, void* xs,
  *           otherwise workspace (x's forward pass is made here).
  *   far_b   (chunk,S,det,det) c64 workspace; costs_k 17 * nscan + 1 f32 of workspace.
  * Two passes of 8 step lengths are enqueued; the second returns at once when the
- * first has accepted a step. */
+ * first has accepted a step.
+ *   stage 0: the whole search (one rank; sums unused).  Several ranks -- the cost
+ *   sums must be all-reduced between a cost pass and its decision; count is the
+ *   number of positions over all ranks --: stage 1 = first cost pass, leaving this
+ *   rank's row sums in sums (17 doubles); [all-reduce sums]; 2 = first decision
+ *   from sums; 3 = second cost pass -> sums; [all-reduce]; 4 = second decision,
+ *   then xs.  The same arguments in every stage. */
 int tike_cgrad_line_search_linear(int variable, const void* x, const void* d, void* xs,
                                   const void* other, const float* scan, const void* data,
                                   int data_u16, void* far_a, int a_valid, void* far_b,
                                   float* costs_k, int nscan, int chunk, int S, int det, int H,
                                   int W, float fwd_scale, double count, double* state,
-                                  void* stream);
+                                  int stage, double* sums, void* stream);
 
 /* ---- the packed minibatch tail: the arithmetic of tike_lstsq_step_sums / _solve,
  * tike_probe_update and the tike_eigen_* entries above for the common case of ONE

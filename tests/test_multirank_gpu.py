@@ -278,8 +278,10 @@ def test_reconstruct_num_gpu_starts_the_ranks_itself(monkeypatch):
 @pytest.mark.parametrize("solver", ["cgrad", "rpie"])
 def test_other_solvers_on_two_ranks_match_one_rank(monkeypatch, solver):
     """cgrad (cost and gradient summed over the ranks, every rank takes the
-    same step: the pattern of lamino/solvers/cgrad.py:58-92) and rpie on two
-    spawned ranks give the one-rank iterates."""
+    same step: the pattern of lamino/solvers/cgrad.py:58-92; its line
+    searches run on the device, the cost sums of each pass all-reduced
+    between the pass and its decision) and rpie on two spawned ranks give
+    the one-rank iterates."""
     import tike_amd.ptycho as tp
     import tike_amd.random
     data, scan, probe, psi0, _, _ = _problem(False)

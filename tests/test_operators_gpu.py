@@ -787,7 +787,7 @@ def test_abi_edge_cases():
     d = torch.zeros(8, dtype=torch.float64, device="cuda")
     args = lambda det, fa, fb, state: (
         0, p(x), p(x), p(x), p(x), p(s), p(f), 0, fa, 0, fb, p(f), 1, 1, 1, det,
-        200, 200, 1.0, 1.0, state, st)
+        200, 200, 1.0, 1.0, state, 0, z, st)
     assert lib.tike_cgrad_line_search_linear(
         *args(64, p(x), p(x) + 8, p(d))) == L.ERR_UNSUPPORTED
     assert lib.tike_cgrad_line_search_linear(

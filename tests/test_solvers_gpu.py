@@ -544,6 +544,69 @@ def test_cgrad_all_steps_at_once_equals_trial_by_trial(tp, monkeypatch, det, S,
                      what="probe")
 
 
+@pytest.mark.parametrize("det,S,N,chunk", [(256, 2, 9, None), (256, 2, 9, 4),
+                                           (128, 1, 10, None)])
+def test_cgrad_staged_search_equals_the_one_call_search(tp, monkeypatch, det,
+                                                        S, N, chunk):
+    """Several ranks run the all-at-once search in four stages (cost pass ->
+    [all-reduce of the row sums] -> decision, twice): on one rank, where the
+    all-reduce is the identity, the stages must take the decisions of the
+    one-call search (stage 0) -- same step lengths, costs and iterates."""
+    import importlib
+    import socket
+    import torch.distributed as dist
+    C = importlib.import_module("tike_amd.ptycho.solvers.cgrad")
+    L = importlib.import_module("tike_amd.ptycho.solvers.lstsq")
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=det + 7 * S, eigen=False)
+    if chunk:
+        monkeypatch.setattr(L, "CHUNK_POSITIONS_OVERRIDE", chunk)
+    monkeypatch.setattr(C, "USE_GRAPHS", False)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    results = []
+    for staged in (False, True):
+        if staged:
+            # a one-rank process group whose collectives are really issued
+            # (TIKE_FORCE_COLLECTIVES): every all-reduce is the identity
+            monkeypatch.setenv("TIKE_FORCE_COLLECTIVES", "1")
+            dist.init_process_group("gloo", rank=0, world_size=1,
+                                    init_method=f"tcp://127.0.0.1:{port}")
+        try:
+            results += _staged_runs(tp, data, scan, psi_true, probe0, N)
+        finally:
+            if staged:
+                dist.destroy_process_group()
+    for a, b in zip(results[:2], results[2:]):
+        np.testing.assert_allclose(np.array(a.algorithm_options.costs),
+                                   np.array(b.algorithm_options.costs),
+                                   rtol=1e-6)
+        assert_close(a.psi, b.psi, normwise=1e-6, maxabs=1e-5, what="psi")
+        assert_close(a.probe, b.probe, normwise=1e-6, maxabs=1e-5,
+                     what="probe")
+
+
+def _staged_runs(tp, data, scan, psi_true, probe0, N):
+    results = []
+    if True:
+        for step in (1.0, 1024.0):  # first- and second-pass acceptance
+            params = tp.PtychoParameters(
+                probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+                scan=scan.copy(),
+                algorithm_options=tp.CgradOptions(num_batch=1, cg_iter=3,
+                                                  num_iter=2,
+                                                  step_length=step),
+                probe_options=tp.ProbeOptions(force_orthogonality=True),
+                object_options=tp.ObjectOptions())
+            with tp.Reconstruction(data, params, order=np.arange(N),
+                                   batches=[np.arange(N)]) as ctx:
+                ctx.iterate(2)
+                results.append(ctx.get_result())
+    return results
+
+
 @pytest.mark.parametrize("det,S,N", [(128, 1, 10), (256, 2, 7)])
 def test_cgrad_graph_replay_equals_eager_launches(tp, monkeypatch, det, S, N):
     """From its second occurrence on a CG call is replayed from a captured HIP

@@ -125,7 +125,8 @@ _PROTOTYPES = {
     "tike_cgrad_line_search": [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i,
                                _i, _i, _i, _i, _f, _d, _p, _p, _i, _p],
     "tike_cgrad_line_search_linear": [_i, _p, _p, _p, _p, _p, _p, _i, _p, _i, _p,
-                                      _p, _i, _i, _i, _i, _i, _i, _f, _d, _p, _p],
+                                      _p, _i, _i, _i, _i, _i, _i, _f, _d, _p, _i,
+                                      _p, _p],
     "tike_comm_unique_id": [_p],
     "tike_comm_create": [_p, _i, _i, ctypes.POINTER(_p)],
     "tike_comm_destroy": [_p],

@@ -164,6 +164,14 @@ class Comm:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def Allreduce_f64(self, t):
+        """Sum a float64 DEVICE tensor across ranks in place (a handful of
+        scalars that stay on the device: the cost sums between a line search's
+        cost pass and its decision)."""
+        if self.collective:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
     def Allreduce_count(self, n: int) -> float:
         """Sum of a host integer over ranks, returned as a host float
         (used once per run for the global minibatch sizes)."""

@@ -1384,6 +1384,63 @@ __global__ __launch_bounds__(256) void ls_pick_kernel(const float* __restrict__ 
   }
 }
 
+// Several ranks: the sums of a pass's cost rows over THIS rank's positions,
+// to be all-reduced between the cost pass and the decision (row 0 only for
+// the first pass).  One workgroup; sums (TK_LS_ROWS doubles).
+__global__ __launch_bounds__(256) void ls_rowsum_kernel(const float* __restrict__ costs_k,
+                                                        long stride, int n, int row1, int first,
+                                                        const double* __restrict__ state,
+                                                        double* __restrict__ sums) {
+  constexpr int K = TK_LS_STEPS;
+  __shared__ double red[256];
+  const bool skip = !first && state[2] != 0.0;  // accepted already: leave zeros
+  for (int k = first ? 0 : 1; k <= K; ++k) {
+    const int rowi = k == 0 ? 0 : row1 + k - 1;
+    double a = 0.0;
+    if (!skip)
+      for (int i = threadIdx.x; i < n; i += 256) a += (double)costs_k[rowi * stride + i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[rowi] = red[0];
+    __syncthreads();
+  }
+}
+
+// The decision of ls_pick_kernel from (all-reduced) row sums.
+__global__ void ls_pick_sums_kernel(const double* __restrict__ sums, double inv_count, int row1,
+                                    int first, int last, double* __restrict__ state,
+                                    int* __restrict__ accepted) {
+  constexpr int K = TK_LS_STEPS;
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (!first && state[2] != 0.0) return;
+  const double fx = first ? sums[0] * inv_count : state[0];
+  float s = (float)state[1];
+  int pick = -1;
+  for (int k = 0; k < K; ++k, s *= 0.5f) {
+    if (sums[row1 + k] * inv_count <= fx) {
+      pick = k;
+      break;
+    }
+  }
+  if (pick >= 0) {
+    state[0] = sums[row1 + pick] * inv_count;
+    state[1] = (double)s;
+    state[2] = 1.0;
+    state[3] += (double)(pick + 1);
+    *accepted = 1;
+  } else {
+    state[0] = fx;
+    state[1] = (double)s;
+    state[2] = 0.0;
+    state[3] += (double)K;
+    if (last) state[4] += 1.0;
+  }
+}
+
 // xs = x + step d with the accepted step (x itself when none was)
 __global__ __launch_bounds__(256) void ls_apply_kernel(const cf* __restrict__ x,
                                                        const cf* __restrict__ d,
@@ -1402,22 +1459,29 @@ extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const 
                                              int a_valid, void* far_b, float* costs_k,
                                              int nscan, int chunk, int S, int det, int H, int W,
                                              float fwd_scale, double count, double* state,
-                                             void* stream_) {
+                                             int stage, double* sums, void* stream_) {
   TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(nscan >= 1 && chunk >= 1 && S >= 1 && H >= 1 && W >= 1 && count > 0 &&
                (variable == 0 || variable == 1));
   TK_CHECK_ARG(x && d && xs && other && scan && data && far_a && far_b && far_a != far_b &&
                costs_k && state);
+  // stage 0: the whole search (one rank).  Several ranks, whose cost sums
+  // must be all-reduced between a cost pass and its decision: 1 = first cost
+  // pass -> sums; 2 = first decision from sums; 3 = second cost pass -> sums;
+  // 4 = second decision from sums, then xs.
+  TK_CHECK_ARG(stage >= 0 && stage <= 4 && (stage == 0 || sums != nullptr));
   if (det != 128 && det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
   if (det == 128 && data_u16) return TK_ERR_UNSUPPORTED;  // the 128^2 cost kernel reads float32
   const long n = variable == 0 ? (long)H * W : (long)S * det * det;
   // (+ one word behind the rows: raised once a step is accepted -- the forward
   // passes of a later pass over a several-chunk minibatch read it and return)
   int* accepted = reinterpret_cast<int*>(costs_k + (size_t)TK_LS_ROWS * nscan);
-  hipError_t e = hipMemsetAsync(
-      costs_k, 0, sizeof(float) * ((size_t)TK_LS_ROWS * nscan + 1), stream);
-  if (e != hipSuccess) return (int)e;
+  if (stage <= 1) {
+    hipError_t e = hipMemsetAsync(
+        costs_k, 0, sizeof(float) * ((size_t)TK_LS_ROWS * nscan + 1), stream);
+    if (e != hipSuccess) return (int)e;
+  }
   const bool reuse = a_valid && nscan <= chunk;  // the gradient pass left F(x) in far_a
   const bool resident = nscan <= chunk;          // one chunk: both hand-offs stay put
   const size_t dsz = data_u16 ? 2 : 4;
@@ -1427,9 +1491,13 @@ extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const 
   const void* probe_b = variable == 0 ? other : d;
   const void* psi_a = variable == 0 ? x : other;
   const void* probe_a = variable == 0 ? other : x;
+  static_assert(TK_LS_PASSES == 2, "stages 1-4 name two passes");
   for (int pass = 0; pass < TK_LS_PASSES; ++pass) {
     const int row1 = 1 + pass * TK_LS_STEPS;
-    for (int lo = 0; lo < nscan; lo += chunk) {
+    const bool costs_now = stage == 0 || stage == 1 + 2 * pass;
+    const bool decide_now = stage == 0 || stage == 2 + 2 * pass;
+    if (!costs_now && !decide_now) continue;
+    for (int lo = 0; costs_now && lo < nscan; lo += chunk) {
       const int m = nscan - lo < chunk ? nscan - lo : chunk;
       const float* sc = scan + 2L * lo;
       // the hand-offs of a chunk: formed in the first pass; a later pass (rare:
@@ -1497,9 +1565,21 @@ extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const 
 #undef TK_LSK_N
 #undef TK_LSK
     }
-    hipLaunchKernelGGL(ls_pick_kernel, dim3(1), dim3(256), 0, stream, costs_k, (long)nscan,
-                       nscan, 1.0 / count, row1, (int)(pass == 0),
-                       (int)(pass + 1 == TK_LS_PASSES), state, accepted);
+    if (stage == 0)
+      hipLaunchKernelGGL(ls_pick_kernel, dim3(1), dim3(256), 0, stream, costs_k, (long)nscan,
+                         nscan, 1.0 / count, row1, (int)(pass == 0),
+                         (int)(pass + 1 == TK_LS_PASSES), state, accepted);
+    else if (costs_now)
+      hipLaunchKernelGGL(ls_rowsum_kernel, dim3(1), dim3(256), 0, stream, costs_k, (long)nscan,
+                         nscan, row1, (int)(pass == 0), state, sums);
+    else
+      hipLaunchKernelGGL(ls_pick_sums_kernel, dim3(1), dim3(64), 0, stream, sums, 1.0 / count,
+                         row1, (int)(pass == 0), (int)(pass + 1 == TK_LS_PASSES), state,
+                         accepted);
+  }
+  if (stage != 0 && stage != 4) {
+    TK_LAUNCH_CHECK();
+    return TK_OK;
   }
   hipLaunchKernelGGL(ls_apply_kernel, dim3(tk_grid((n + 255) / 256, 8)), dim3(256), 0, stream,
                      (const cf*)x, (const cf*)d, (cf*)xs, n, state);

@@ -301,6 +301,8 @@ def _cg_enqueue(plan, op, comm, x, other, variable, num_iter, step_init,
         # one chunk: the gradient pass leaves the forward hand-off of x (at
         # 128^2 its far plane) in plan.far, which the search reads as it is
         a_valid = int(len(plan.chunks) == 1)
+        row_sums = torch.zeros(LINEAR_STEPS + 1, dtype=torch.float64,
+                               device=dev)
     for i in range(num_iter):
         a, b = (x, other) if variable == 0 else (other, x)  # psi, probe
         costs, acc, mpu = plan.gradients(op, comm, a, b, variable == 0,
@@ -314,13 +316,19 @@ def _cg_enqueue(plan, op, comm, x, other, variable, num_iter, step_init,
             "cgrad direction")
         xs = bufs[i % 2]
         if linear:
-            check(
-                lib.tike_cgrad_line_search_linear(
-                    variable, A.ptr(x), A.ptr(d), A.ptr(xs), A.ptr(other),
-                    scan_ptr, data_ptr, plan.u16, A.ptr(plan.far), a_valid,
-                    A.ptr(far_b), A.ptr(costs_k), N, plan.far.shape[0], S,
-                    det, H, W, plan.fwd_scale, count, A.ptr(state), st_ptr),
-                "cgrad line search (all steps at once)")
+            # one rank: the whole search in one call; several: the cost sums of
+            # each pass are all-reduced between the pass and its decision
+            for stage in ((1, 2, 3, 4) if comm.collective else (0,)):
+                check(
+                    lib.tike_cgrad_line_search_linear(
+                        variable, A.ptr(x), A.ptr(d), A.ptr(xs), A.ptr(other),
+                        scan_ptr, data_ptr, plan.u16, A.ptr(plan.far), a_valid,
+                        A.ptr(far_b), A.ptr(costs_k), N, plan.far.shape[0], S,
+                        det, H, W, plan.fwd_scale, count, A.ptr(state), stage,
+                        A.ptr(row_sums), st_ptr),
+                    "cgrad line search (all steps at once)")
+                if stage in (1, 3):
+                    comm.Allreduce_f64(row_sums)
         else:
             check(
                 lib.tike_cgrad_line_search(
@@ -403,6 +411,16 @@ class _CgGraph:
         return self.result.clone(), self.out
 
 
+def _every_rank(comm, op, lo, hi, mine):
+    """True when `mine` holds on every rank (asked once per minibatch and
+    reconstruction: minibatch sizes and data placement are static)."""
+    cache = op.__dict__.setdefault("_tike_amd_every_rank", {})
+    key = (lo, hi, comm.size)
+    if key not in cache:
+        cache[key] = comm.Allreduce_count(int(bool(mine))) == comm.size
+    return cache[key]
+
+
 def _cg_on_device(plan, op, comm, psi, probe, variable, o, count, data, scan,
                   lo, hi):
     """One CG call on the device with the slot counts this reconstruction has
@@ -418,6 +436,8 @@ def _cg_on_device(plan, op, comm, psi, probe, variable, o, count, data, scan,
                        o.step_length, count, data, scan, lo, hi, linear=True)
         if r is not None:
             return r[0], r[1]
+        if comm.collective:
+            return None  # (the host-side search sums its costs over the ranks)
         # a search found none of its 16 step lengths acceptable (steps below
         # step / 2^15): the trial-by-trial search below reaches 2^-29
         policy.widen(variable)
@@ -509,9 +529,15 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
                          psi.shape[-2], psi.shape[-1], psi.device)
         # line searches decided on the device: one rank, HBM-resident data,
         # the far-plane-free sizes and 128^2
-        on_device = (DEVICE_LINE_SEARCH and not comm.collective and hi > lo
+        # (several ranks: the all-at-once search, whose cost sums are
+        # all-reduced between its cost passes and its decisions -- every rank
+        # must take the same route, so every rank must hold positions)
+        on_device = (DEVICE_LINE_SEARCH and hi > lo
                      and isinstance(d, torch.Tensor)
                      and plan.supports_gradients())
+        if comm.collective:
+            on_device = (LINEAR_LINE_SEARCH and not USE_GRAPHS
+                         and _every_rank(comm, op, lo, hi, on_device))
         count = global_count(comm, op, lo, hi)
         done_psi = done_probe = False
         if recover_psi and on_device:
