@@ -44,8 +44,12 @@ READ_CEILING_GBS = 6450.0  # tools/probe/bw_probe.hip: best pure read stream
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=5)
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--steps", type=int, default=None,
+                   help="timed steps (default 10; forward workloads 40)")
+    p.add_argument("--warmup", type=int, default=None,
+                   help="untimed steps in front (default 2; forward workloads 8: "
+                   "their calls are ~1 ms and the clocks of an idle GPU need a "
+                   "few of them, profiles/r04_leg_probe.txt)")
     p.add_argument("--workload", default="c3")
     p.add_argument("--positions", type=int, default=0,
                    help="override the number of scan positions per GPU")
@@ -57,7 +61,13 @@ def parse():
                         "PCIe-inclusive rate; never the headline value)")
     p.add_argument("--breakdown", action="store_true",
                    help="print the per-kernel time breakdown to stderr")
-    return p.parse_args()
+    a = p.parse_args()
+    fwd = a.workload.startswith("fwd")
+    if a.steps is None:
+        a.steps = 40 if fwd else 10
+    if a.warmup is None:
+        a.warmup = 8 if fwd else 2
+    return a
 
 
 def launch_ranks(a):
