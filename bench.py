@@ -45,11 +45,11 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None,
-                   help="timed steps (default 10; forward workloads 40)")
+                   help="timed steps (default 10; forward workloads and c1: 40)")
     p.add_argument("--warmup", type=int, default=None,
-                   help="untimed steps in front (default 2; forward workloads 8: "
-                   "their calls are ~1 ms and the clocks of an idle GPU need a "
-                   "few of them, profiles/r04_leg_probe.txt)")
+                   help="untimed steps in front (default 2; forward workloads and "
+                   "c1 10: their steps take 1-3 ms and the clocks of an idle GPU "
+                   "need a few of them, profiles/r04_leg_probe.txt)")
     p.add_argument("--workload", default="c3")
     p.add_argument("--positions", type=int, default=0,
                    help="override the number of scan positions per GPU")
@@ -62,11 +62,11 @@ def parse():
     p.add_argument("--breakdown", action="store_true",
                    help="print the per-kernel time breakdown to stderr")
     a = p.parse_args()
-    fwd = a.workload.startswith("fwd")
+    short = a.workload.startswith("fwd") or a.workload == "c1"  # ms-sized steps
     if a.steps is None:
-        a.steps = 40 if fwd else 10
+        a.steps = 40 if short else 10
     if a.warmup is None:
-        a.warmup = 8 if fwd else 2
+        a.warmup = 10 if short else 2
     return a
 
 
@@ -577,6 +577,7 @@ def main():
     timers = KernelTimers(lib, [n for n in _PROTOTYPES if n != "tike_init"])
     counts = dict(epoch=0, steps=0, in_minibatch=False)
     cpu = None
+    cpu_job = None
     C = 0
     ctx = None
 
@@ -595,7 +596,7 @@ def main():
 
         units, launch_n, dominant = N, N, "tike_ptycho_fwd"
         if rank == 0 and not a.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline_fwd(p, S, det)
+            cpu_job = lambda: cpu_baseline_fwd(p, S, det)
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, solver=None)
     elif a.workload in EPOCH_DEFAULTS:
@@ -646,8 +647,14 @@ def main():
         dominant = None
         if (rank == 0 and not a.no_cpu_baseline and world == 1
                 and a.workload in ("c1", "c2", "c3", "c5")):
-            cpu = (cpu_baseline_c1(p, data, det) if a.workload == "c1" else
-                   cpu_baseline_epoch(p, data, S, det))
+            # (the slice the host leg works on; the leg itself runs AFTER
+            # everything timed on the GPU: its 256 FFT threads, run first, cost
+            # the epochs behind them 2 % -- launches issued late)
+            sample = np.array(data if a.workload == "c1" else data[:256])
+            cpu_job = (
+                (lambda: cpu_baseline_c1(p, sample, det))
+                if a.workload == "c1" else
+                (lambda: cpu_baseline_epoch(p, sample, S, det)))
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, eigen_probes=C,
                         solver=SOLVER_LABEL.get(a.workload, "lstsq_grad"),
@@ -877,6 +884,8 @@ def main():
                     (big["avg_ms"] * 1e-3) / 1e9)
         if secondary is not None:
             line["secondary"] = secondary
+        if cpu_job is not None:
+            cpu = cpu_job()
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
