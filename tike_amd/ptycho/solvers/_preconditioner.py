@@ -35,19 +35,33 @@ def _psi_preconditioner_multislice(parameters, operator):
     (Patch.adj of one patch per position)."""
     psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
     pw = probe.shape[-1]
-    patch = operator.diffraction.patch
-    out = torch.zeros(tuple(psi.shape), dtype=torch.complex64,
-                      device=psi.device)
+    D, H, W = psi.shape
+    N = scan.shape[0]
+    st = A.stream_ptr()
+    out = torch.zeros((D, H, W), dtype=torch.float32, device=psi.device)
     probe1 = probe[:, 0]  # (1, S, pw, pw)
-    amp = torch.sum(probe1 * probe1.conj(), dim=-3)  # (1, pw, pw)
-    patch.adj(positions=scan, patches=amp, images=out[0], patch_width=pw)
-    for i in range(1, len(psi)):
+    # first slice: the shared probe's amplitude at every position
+    amp = torch.sum(torch.square(probe1.abs()), dim=-3)[0].contiguous()
+    check(
+        lib.tike_psi_preconditioner(A.ptr(amp), A.ptr(scan), A.ptr(out[0]), N,
+                                    pw, H, W, st), "psi preconditioner")
+    acc = torch.empty((2, H, W), dtype=torch.float32, device=psi.device)
+    for i in range(1, D):
         probe1 = operator.diffraction.propagation.fwd(
             operator.diffraction.diffraction.fwd(probe=probe1, scan=scan,
                                                  psi=psi[i - 1]))
+        # one amplitude patch per position: the grouped footprint scatter
+        # (8 neighbouring positions summed on chip, one atomic per box pixel:
+        # 0.2 ms per 1000 positions) instead of Patch.adj's atomic per pixel
+        # and position (7.7 ms per 2000 positions at 256^2)
         amp = torch.sum(probe1 * probe1.conj(), dim=-3).contiguous()
-        patch.adj(positions=scan, patches=amp, images=out[i], patch_width=pw)
-    return out.real.contiguous()
+        acc.zero_()
+        check(
+            lib.tike_scatter_patches(A.ptr(amp), A.ptr(scan), A.ptr(acc), N,
+                                     pw, H, W, st),
+            "psi preconditioner (slice)")
+        out[i] = acc[0]
+    return out
 
 
 def _probe_preconditioner(parameters, operator):
