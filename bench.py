@@ -11,7 +11,9 @@ One "step" = one pass of the hot path over the whole synthetic dataset:
   c2: 1 probe mode, cgrad;  c5: 512x512, 4 modes, position correction;
   c3poisson / c3rpie: c3's shapes with the Poisson noise model / solved by
      rpie (SURVEY 8 rows f2, f3: measured, not BASELINE configurations);
-  fwdDxS: one launch of the fused forward operator (D = detector, S = modes).
+  fwdDxS: one launch of the fused forward operator (D = detector, S = modes);
+  adjDxS: one call of the fused adjoint operator (stored far plane ->
+     object gradient + per-position probe gradients).
 Inputs are HBM-resident before the timed region.  Rank 0 prints ONE JSON line.
 
 Multi-GPU: one process per GPU over RCCL.  Either launch through
@@ -62,7 +64,7 @@ def parse():
     p.add_argument("--breakdown", action="store_true",
                    help="print the per-kernel time breakdown to stderr")
     a = p.parse_args()
-    short = a.workload.startswith("fwd") or a.workload == "c1"  # ms-sized steps
+    short = a.workload.startswith(("fwd", "adj")) or a.workload == "c1"  # ms-sized steps
     if a.steps is None:
         a.steps = 40 if short else 10
     if a.warmup is None:
@@ -289,11 +291,43 @@ def cpu_baseline_fwd(p, S, det, seconds=10.0):
                 f"{det}x{det}, scipy.fft workers={cores}")
 
 
+def cpu_baseline_adj(p, S, det, seconds=10.0):
+    from oracle import operators as oops
+    cores = os.cpu_count() or 1
+    oops.set_workers(cores)
+    rng = np.random.default_rng(0)
+    n, done, t0 = 16, 0, time.perf_counter()
+    far = (rng.random((n, 1, S, det, det, 2), dtype=np.float32) - 0.5).view(
+        np.complex64)[..., 0]
+    probe = np.broadcast_to(p["probe"], (n, 1, S, det, det))
+    while True:
+        oops.ptycho_adj(far, probe, p["scan"][:n], p["psi"])
+        done += n
+        if time.perf_counter() - t0 > seconds:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=done / dt, unit="patterns/s", cores=cores, kind="port",
+                cpu=cpu_model(), seconds=dt,
+                sample=f"oracle Ptycho.adj on {done} positions x {S} modes "
+                f"{det}x{det}, scipy.fft workers={cores}")
+
+
 # ------------------------------------------------- algorithmic bytes / launch
 def fwd_bytes(n, S, det, pw, C=0):
     """SURVEY 8(d) B_fwd: far-plane store + object-patch gather + scan per
     position, shared probe once per call."""
     return n * (8 * S * det * det + 8 * pw * pw + 8) + 8 * (S + C) * pw * pw
+
+
+def adj_bytes(n, S, det, pw, per_position_probe=False):
+    """Algorithmic bytes of Ptycho.adj: far plane in + probe_adj out + object
+    patch gather + object read-modify-write (counted once, as SURVEY 8(d)
+    counts the gradient scatter) + scan per position; the shared probe once
+    per call (a per-position probe: once per position)."""
+    per = 8 * S * det * det + 8 * S * pw * pw + 2 * 8 * pw * pw + 8
+    if per_position_probe:
+        return n * (per + 8 * S * pw * pw)
+    return n * per + 8 * S * pw * pw
 
 
 def algorithmic_bytes(name, n, S, det, pw, C):
@@ -303,6 +337,7 @@ def algorithmic_bytes(name, n, S, det, pw, C):
     D = 4 * det * det
     table = {
         "tike_ptycho_fwd": fwd_bytes(n, S, det, pw, C),
+        "tike_ptycho_adj": adj_bytes(n, S, det, pw),
         # forward pass 1 hands a far-plane-sized array to the next kernel and
         # stores the object patches
         "tike_fwd_pass1": n * (T + 2 * P + 8) + (S + C) * P,
@@ -467,7 +502,8 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
         data_on_host=data_on_host)
     ctx.__enter__()
     return dict(ctx=ctx, p=p, data=data, det=det, S=S, N=N, C=C,
-                num_batch=num_batch)
+                num_batch=num_batch, eigen_probe=eigen_probe,
+                eigen_weights=eigen_weights)
 
 
 LEG_EPOCHS = {"c1": 20, "c2": 3, "c5": 3}
@@ -528,6 +564,50 @@ def forward_leg(ops, A, torch, det, S, N, iters=40, warm=8):
     nbytes = fwd_bytes(N, S, det, det)
     del out
     return dict(workload=f"fwd{det}x{S}", positions=N, ms_per_launch=ms,
+                value=N / (ms * 1e-3), unit="patterns/s",
+                achieved_GBs=nbytes / (ms * 1e-3) / 1e9,
+                frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+
+
+def adjoint_problem(ops, A, torch, det, S, N, lo=0, hi=None, total=None):
+    """Inputs of the adjoint operator alone: SURVEY 8(d)'s object, probe and
+    scan (listed leaf by leaf of a k-d tree, as the solvers list every
+    minibatch: the grouped scatter sums neighbours on chip) and a random far
+    plane."""
+    from tike_amd.cluster import spatial_order
+    total = total or N
+    hi = N if hi is None else hi
+    p = synthetic(total, S, det, lo, hi)
+    p["scan"] = p["scan"][spatial_order(p["scan"])]
+    op = ops.Ptycho(probe_shape=det, detector_shape=det, nz=p["HW"], n=p["HW"])
+    scan, psi, probe = (A.to_device(p[k]) for k in ("scan", "psi", "probe"))
+    n = len(p["scan"])
+    g = torch.Generator(device=psi.device).manual_seed(1234)
+    far = torch.view_as_complex(
+        torch.rand((n, 1, S, det, det, 2), generator=g, device=psi.device) - 0.5)
+    out = (torch.empty_like(psi),
+           torch.empty((n, 1, S, det, det), dtype=torch.complex64,
+                       device=psi.device))
+    return p, op, (far, probe, scan, psi), out
+
+
+def adjoint_leg(ops, A, torch, det, S, N, iters=40, warm=8):
+    """One short leg of the adjoint operator alone (hip-event timed, like
+    forward_leg): Ptycho.adj of a stored far plane -> (psi_adj, probe_adj)."""
+    p, op, args, out = adjoint_problem(ops, A, torch, det, S, N)
+    for _ in range(warm):
+        op.adj_device(*args, psi_adj=out[0], probe_adj=out[1])
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        op.adj_device(*args, psi_adj=out[0], probe_adj=out[1])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = adj_bytes(N, S, det, det)
+    del args, out
+    return dict(workload=f"adj{det}x{S}", positions=N, ms_per_launch=ms,
                 value=N / (ms * 1e-3), unit="patterns/s",
                 achieved_GBs=nbytes / (ms * 1e-3) / 1e9,
                 frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
@@ -599,6 +679,22 @@ def main():
             cpu_job = lambda: cpu_baseline_fwd(p, S, det)
         workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
                         detector=det, solver=None)
+    elif a.workload.startswith("adj"):
+        det, S = [int(v) for v in a.workload[3:].split("x")]
+        N = a.positions or max(256, 4096 // S)
+        p, op, adj_args, adj_out = adjoint_problem(
+            ops, A, torch, det, S, N, rank * N, (rank + 1) * N, N * world)
+
+        def step():
+            op.adj_device(*adj_args, psi_adj=adj_out[0], probe_adj=adj_out[1])
+
+        units, launch_n, dominant = N, N, "tike_ptycho_adj"
+        if rank == 0 and not a.no_cpu_baseline and world == 1:
+            cpu_job = lambda: cpu_baseline_adj(p, S, det)
+        workload = dict(workload=a.workload, positions_per_gpu=N, modes=S,
+                        detector=det, solver=None,
+                        positions="k-d-tree leaf order (as the solvers list a "
+                        "minibatch)")
     elif a.workload in EPOCH_DEFAULTS:
         # c2: 1 mode; c3 (default, = one GPU's share of c4): 8 modes + eigen
         # probes; c5: 512x512, 4 modes, position correction on
@@ -751,6 +847,13 @@ def main():
                      guarded("fwd128x1", forward_leg, ops, A, torch, 128, 1,
                              16384),
                      guarded("fwd256x8", forward_leg, ops, A, torch, 256, 8,
+                             512),
+                     # ... and its adjoint (north_star names both)
+                     guarded("adj256x1", adjoint_leg, ops, A, torch, 256, 1,
+                             4096),
+                     guarded("adj128x1", adjoint_leg, ops, A, torch, 128, 1,
+                             16384),
+                     guarded("adj256x8", adjoint_leg, ops, A, torch, 256, 8,
                              512)]
         # ... and the other BASELINE configurations, one short leg each
         torch.cuda.empty_cache()
@@ -814,7 +917,7 @@ def main():
                 f"measured read-stream ceiling ({READ_CEILING_GBS:.0f} GB/s) and "
                 "no PMC traffic figure is committed for this kernel")
             roofline["achieved"] = roofline["frac"] = None
-        if not a.workload.startswith("fwd"):
+        if not a.workload.startswith(("fwd", "adj")):
             # the whole iteration against SURVEY 8(d)'s compulsory bytes and
             # flops (report both fractions)
             b_iter, f_iter = iteration_bounds(S, det, pw)

@@ -38,7 +38,7 @@ extern "C" {
  * A binding compares tike_abi_version() of the loaded library with the
  * TIKE_ABI_VERSION it was written against before its first call
  * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
-#define TIKE_ABI_VERSION 6
+#define TIKE_ABI_VERSION 7
 
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
@@ -86,11 +86,34 @@ int tike_fft2(const void* in, void* out, long ntile, int n, int inverse, float s
  * The probe at position n is probe[n|0][s] or, when eigen_weights != NULL,
  * weights[n][0][s]*probe[0][s] + sum_c weights[n][c+1][s]*eigen[c][s]
  * (ptycho/probe.py:272-303); eigen_probe (num_eigen, eigen_modes, pw, pw),
- * eigen_weights (nscan, num_eigen+1, S) f32. farplane (nscan,S,det,det). */
+ * eigen_weights (nscan, num_eigen+1, S) f32. farplane (nscan,S,det,det).
+ * sub_batch: det = 256 / 512 run as two streaming kernels per sub-batch of
+ * that many positions, so that the hand-off between them stays in the
+ * Infinity Cache (0 = the library's default, 256 MiB of far plane; < 0 = one
+ * batch); results do not depend on it. */
 int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe, int probe_per_scan,
                     const void* eigen_probe, const float* eigen_weights, int num_eigen,
                     int eigen_modes, void* farplane, int nscan, int S, int pw, int det, int H,
-                    int W, float scale, void* stream);
+                    int W, float scale, int sub_batch, void* stream);
+
+/* ---- Ptycho.adj fused (operators/cupy/ptycho.py:148-176 = propagation.py:59-73
+ * IFFT2, then convolution.py:103-127 `adj` and :129-154 `adj_probe`):
+ *   chi[n][s]       = scale * IFFT2( farplane[n][s] )
+ *   probe_adj[n][s] = conj( patch_n(psi) ) * chi[n][s]          (nscan,S,pw,pw)
+ *   psi_adj         = sum_n scatter_n( sum_s conj(probe[n|0][s]) * chi[n][s] )   (H,W), OVERWRITTEN
+ * Probe window = detector, det in {128, 256, 512}, S <= 8 (TIKE_ERR_UNSUPPORTED
+ * otherwise: use tike_ifft2_crop + tike_conv_adj + tike_conv_adj_probe).
+ * Scan positions must keep the patch and its +1 taps inside the image
+ * (ptycho/position.py:600-628 check_allowed_positions, which the reference
+ * relies on too, convolution.cu:113-133); pixels falling outside are dropped.
+ * farplane is read only.  probe_adj doubles as the workspace of the two-pass
+ * inverse transform (it must not alias farplane).  Caller-owned scratch:
+ * objproj_work (nscan,pw,pw) c64, acc_work (2,H,W) f32; nothing is allocated.
+ * sub_batch as in tike_ptycho_fwd. */
+int tike_ptycho_adj(const void* farplane, const void* probe, int probe_per_scan,
+                    const float* scan, const void* psi, void* psi_adj, void* probe_adj,
+                    void* objproj_work, float* acc_work, int nscan, int S, int pw, int det,
+                    int H, int W, float scale, int sub_batch, void* stream);
 
 /* ---- Ptycho.fwd + intensity, position-major (one workgroup per position
  * walks all S modes): same far-plane as tike_ptycho_fwd plus

@@ -283,6 +283,115 @@ def test_ptycho_fused_vs_oracle(ops, oracle, det, pw, S, shared):
     assert_close(probe_adj, o_probe, what="probe_adj")
 
 
+@pytest.mark.parametrize("probes", ["shared", "per_position", "eigen"])
+@pytest.mark.parametrize("det,S,N,sub", [(256, 2, 40, 16), (512, 2, 21, 8)])
+def test_ptycho_fwd_sub_batches_vs_oracle(ops, oracle, det, S, N, sub, probes):
+    """The 256^2 / 512^2 forward operator walks its positions in sub-batches
+    (two streaming kernels each): three of them here, the last one ragged, with
+    a shared probe, one probe per position, and eigen probes + weights -- the
+    scan, probe, weight and far-plane offsets of every sub-batch against the
+    oracle, and against the same call as ONE batch."""
+    from oracle import solvers as sol
+    rng = np.random.default_rng(det + N)
+    pw, HW = det, det + 40
+    assert N > 2 * sub and N % sub != 0
+    scan = (rng.random((N, 2)) * 36 + 1.5).astype(np.float32)
+    psi = rc(rng, 1, HW, HW)
+    probe = rc(rng, N if probes == "per_position" else 1, 1, S, pw, pw)
+    eigen = w = None
+    used = probe
+    if probes == "eigen":
+        eigen = rc(rng, 1, 2, 1, pw, pw)
+        w = rng.standard_normal((N, 3, S)).astype(np.float32)
+        used = sol.get_varying_probe(probe, eigen, w)
+    want = oracle.ptycho_fwd(used, scan, psi, det)
+    with ops.Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+        dev = [None if x is None else op.asarray(x)
+               for x in (probe, scan, psi, eigen, w)]
+        got = op.fwd_device(*dev, sub_batch=sub).cpu().numpy()
+        one = op.fwd_device(*dev, sub_batch=-1).cpu().numpy()
+    assert_close(got, want, what=f"fwd in sub-batches of {sub} ({probes})")
+    assert_close(one, want, what=f"fwd as one batch ({probes})")
+    assert np.array_equal(got, one)  # the split changes no arithmetic
+
+
+@pytest.mark.parametrize("det,S,N,sub,shared,layout", [
+    (256, 1, 40, 16, True, "raster"),     # MW = 1: a lone mode-wave, no LDS sum
+    (256, 2, 21, 8, False, "random"),     # one probe per position
+    (256, 3, 19, -1, True, "random"),     # an idle mode-wave (3 modes, 4 waves)
+    (256, 5, 11, 4, True, "raster"),      # two modes per wave, one of them idle
+    (256, 8, 13, 5, False, "raster"),     # the headline mode count, per-position probes
+    (256, 8, 10, 0, True, "random"),
+    (128, 1, 50, 16, True, "raster"),
+    (128, 4, 23, 9, False, "random"),
+    (128, 8, 9, -1, True, "raster"),
+    (512, 1, 9, 4, True, "raster"),
+    (512, 2, 9, 4, False, "random"),
+    (512, 4, 7, 3, True, "raster"),
+    (512, 7, 5, -1, True, "random"),
+])
+def test_ptycho_adj_fused_vs_oracle(ops, oracle, det, S, N, sub, shared, layout):
+    """tike_ptycho_adj (inverse pass 1 -> pass 2 in place with both products
+    -> grouped scatter) against the oracle's Ptycho.adj and against the general
+    kernels: every (mode-waves, modes per wave) instantiation, shared and
+    per-position probes, sub-batches with a ragged tail, neighbouring positions
+    (summed in LDS by the grouped scatter) and far-apart ones (its fallback),
+    integer positions (zero-weight taps) among them."""
+    import torch
+    rng = np.random.default_rng(11 * det + S)
+    pw = det
+    if layout == "raster":
+        side = int(np.ceil(np.sqrt(N)))
+        ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
+                                  indexing="ij"), -1).reshape(-1, 2)[:N]
+        scan = (1 + 6.0 * ij + rng.random((N, 2))).astype(np.float32)
+        HW = 6 * side + pw + 4
+    else:
+        HW = pw + 300
+        scan = (rng.random((N, 2)) * (HW - pw - 3) + 1).astype(np.float32)
+    scan[0] = np.floor(scan[0])          # an integer position
+    scan[-1, 1] = np.floor(scan[-1, 1])  # and a half-integer one
+    probe = rc(rng, 1 if shared else N, 1, S, pw, pw)
+    psi = rc(rng, 1, HW, HW)
+    far = rc(rng, N, 1, S, det, det)
+    bprobe = np.broadcast_to(probe, (N, 1, S, pw, pw))
+    o_psi, o_probe = oracle.ptycho_adj(far, bprobe, scan, psi)
+    with ops.Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+        assert op.fused_adjoint_shapes(S)
+        d = [op.asarray(x) for x in (far, probe, scan, psi)]
+        keep = d[0].clone()
+        psi_adj, probe_adj = op.adj_device(*d, sub_batch=sub)
+        assert torch.equal(d[0], keep)  # the far plane is read only
+        # the same through the operator API (numpy in, numpy out)
+        api_psi, api_probe = op.adj(farplane=far, probe=probe, scan=scan,
+                                    psi=psi)
+    assert_close(psi_adj.cpu().numpy(), o_psi, what="psi_adj")
+    assert_close(probe_adj.cpu().numpy(), o_probe, what="probe_adj")
+    assert_close(api_psi, o_psi, what="psi_adj (API)")
+    assert_close(api_probe, o_probe, what="probe_adj (API)")
+    assert api_probe.shape == (N, 1, S, pw, pw) and api_psi.shape == psi.shape
+
+
+def test_ptycho_adj_positions_outside_take_the_general_kernels(ops, oracle):
+    """A scan position whose taps leave the image is not for the fused
+    adjoint (it drops what falls outside; the reference addresses the taps
+    linearly, convolution.cu:113-133): Ptycho.adj must route it to the
+    general kernels and still match the oracle."""
+    rng = np.random.default_rng(2)
+    det = pw = 128
+    N, S, HW = 6, 2, 180
+    scan = (rng.random((N, 2)) * 40 + 2).astype(np.float32)
+    scan[2] = (0.0, HW - pw)  # violates check_allowed_positions on both axes
+    probe, psi = rc(rng, N, 1, S, pw, pw), rc(rng, 1, HW, HW)
+    far = rc(rng, N, 1, S, det, det)
+    with ops.Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+        psi_adj, probe_adj = op.adj(farplane=far, probe=probe, scan=scan,
+                                    psi=psi)
+    o_psi, o_probe = oracle.ptycho_adj(far, probe, scan, psi)
+    assert_close(psi_adj, o_psi, what="psi_adj")
+    assert_close(probe_adj, o_probe, what="probe_adj")
+
+
 def test_ptycho_fwd_eigen_probe_on_the_fly(ops):
     """Varying probe synthesised inside the kernel == get_varying_probe."""
     from oracle import solvers as sol

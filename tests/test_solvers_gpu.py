@@ -893,7 +893,7 @@ def test_reconstruct_multigrid_vs_reference(tp, golden):
                  what="probe")
 
 
-def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0):
+def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0, margin=8):
     """Small problem with the shapes of BASELINE configs[2] / [4]."""
     import tike_amd.random
     rng = np.random.default_rng(seed)
@@ -901,8 +901,9 @@ def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0):
     side = int(np.ceil(np.sqrt(N)))
     ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
                               indexing="ij"), -1).reshape(-1, 2)[:N]
-    scan = (2 + pitch * ij + rng.random((N, 2))).astype(np.float32)
-    HW = int(pitch * (side - 1)) + pw + 8
+    scan = (2 + (margin - 8) // 2 + pitch * ij +
+            rng.random((N, 2))).astype(np.float32)
+    HW = int(pitch * (side - 1)) + pw + margin
     psi_true = ((0.75 + 0.25 * rng.random((1, HW, HW))) * np.exp(
         1j * np.pi * (rng.random((1, HW, HW)) - 0.5))).astype(np.complex64)
     w = tp.gaussian(pw, rin=0.6)
@@ -923,23 +924,32 @@ def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0):
     return scan, psi_true, probe0, ep, ew, data
 
 
-@pytest.mark.parametrize("spatial_sort", [False, True])
+@pytest.mark.parametrize("spatial_sort,batch_method", [
+    (False, "compact"), (True, "compact"),
+    # the update rule bench.py runs since round 4 (an object update after
+    # every minibatch, minibatches in a random order, lstsq.py:134-205)
+    (True, "wobbly_center")])
 @pytest.mark.parametrize("tag,det,S,N,num_batch", [
     ("c3", 256, 8, 20, 2),  # BASELINE configs[2]: 8 modes + eigen probe, far-plane-free
     ("c3-4modes", 256, 4, 12, 2),
     ("c5", 512, 4, 8, 2),   # BASELINE configs[4]: 512^2, 4 modes, position correction
 ])
 def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
-                                         spatial_sort):
+                                         spatial_sort, batch_method):
     """The code path bench.py times (c3: 256^2, S = 8, one eigen probe,
     several minibatches; c5: 512^2, S = 4, position correction with ADAM and
-    affine regularisation): two epochs against the CPU oracle."""
+    affine regularisation): two epochs against the CPU oracle, under both
+    object-update rules."""
     import tike_amd.random
     from oracle import solvers as osol
     eigen = tag.startswith("c3")
     positions = tag == "c5"
+    # (position correction under the per-minibatch rule moves the corner
+    # positions further: more room around the scan, or check_allowed_positions
+    # -- the reference's rule -- stops the run)
     scan, psi_true, probe0, ep, ew, data = _headline_problem(
-        tp, det, S, N, seed=det + S, eigen=eigen)
+        tp, det, S, N, seed=det + S, eigen=eigen,
+        margin=24 if positions and batch_method != "compact" else 8)
     psi0 = np.full_like(psi_true, 0.5)
     batches = np.array_split(np.arange(N), num_batch)
     order = np.arange(N)
@@ -950,7 +960,7 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
         eigen_probe=None if ep is None else ep.copy(),
         eigen_weights=None if ew is None else ew.copy(),
         algorithm_options=tp.LstsqOptions(num_batch=num_batch, num_iter=2,
-                                          batch_method="compact"),
+                                          batch_method=batch_method),
         probe_options=tp.ProbeOptions(force_orthogonality=True),
         object_options=tp.ObjectOptions(),
         position_options=tp.PositionOptions(scan.copy(), **popts)
@@ -974,7 +984,7 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
             momentum=np.zeros((N, 4), dtype=np.float32), **popts)
     state = osol.rescale_probe(state, data, det)
     state = osol.iterate(state, data, batches, 2, detector_shape=det,
-                         batch_method="compact", force_orthogonality=True,
+                         batch_method=batch_method, force_orthogonality=True,
                          rng=np.random.default_rng(11))
     np.testing.assert_allclose(
         np.array(got.algorithm_options.costs), np.array(state["costs"]),
@@ -991,6 +1001,54 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
     if positions:
         assert np.abs(got.scan - scan).max() > 0.02  # positions did move
         np.testing.assert_allclose(got.scan, state["scan"], atol=5e-3)
+
+
+def test_bench_c3_one_epoch_vs_oracle(tp):
+    """ONE epoch of bench.py's own c3 problem -- its generator (SURVEY 8(d):
+    ramp modes, shuffled raster), its eigen-probe set-up, its update rule, its
+    presharded Reconstruction -- at 200 positions against the oracle's epoch.
+    (Over MANY epochs product and oracle part on these inputs: the ramp modes
+    have a Gram matrix conditioned 1 : 7e-7, profiles/r04_bench_convergence.md;
+    the first epoch is what can be, and is, pinned.)"""
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    import tike_amd._arrays as A
+    import tike_amd.random
+    from oracle import solvers as osol
+    built = bench.epoch_problem("c3", 200, 1, 0, tp, A)
+    ctx, p, det = built["ctx"], built["p"], built["det"]
+    assert built["S"] == 8 and det == 256 and built["num_batch"] == 10
+    assert built["eigen_probe"] is not None and built["C"] == 1
+    N = built["N"]
+    batches = np.array_split(np.arange(N), built["num_batch"])
+    psi0 = np.full_like(p["psi"], 0.5 + 0j)
+    state = dict(psi=psi0.copy(), probe=p["probe"].copy(),
+                 scan=p["scan"].copy(), costs=[],
+                 eigen_probe=built["eigen_probe"].copy(),
+                 eigen_weights=built["eigen_weights"].copy())
+    try:
+        tike_amd.random.randomizer_np = np.random.default_rng(11)
+        ctx.iterate(1)
+        got = ctx.get_result()
+    finally:
+        ctx.__exit__(None, None, None)
+    state = osol.rescale_probe(state, built["data"], det)
+    state = osol.iterate(state, built["data"], batches, 1, detector_shape=det,
+                         batch_method=bench.BATCH_RULE,
+                         force_orthogonality=True,
+                         rng=np.random.default_rng(11))
+    np.testing.assert_allclose(
+        np.array(got.algorithm_options.costs), np.array(state["costs"]),
+        rtol=1e-3)
+    assert_close(got.psi, state["psi"], normwise=1e-3, maxabs=1e-2, what="psi")
+    assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe")
+    assert_close(got.eigen_weights, state["eigen_weights"], normwise=5e-3,
+                 maxabs=5e-2, what="eigen_weights")
 
 
 @pytest.mark.parametrize("det,S,N,eigen", [(256, 8, 9, True), (256, 4, 7, True),

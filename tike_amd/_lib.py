@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("TIKE_AMD_LIB") or os.path.join(
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
 # the header version this binding's prototypes were written against
-ABI_VERSION = 6
+ABI_VERSION = 7
 ERR_ARG = 1000001
 ERR_UNSUPPORTED = 1000002
 ERR_COMM = 2000000
@@ -52,7 +52,9 @@ _PROTOTYPES = {
     "tike_fft2": [_p, _p, _l, _i, _i, _f, _p],
     "tike_fresnel_spect_prop": [_p, _p, _p, _l, _i, _i, _f, _f, _p],
     "tike_ptycho_fwd": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i,
-                        _i, _i, _f, _p],
+                        _i, _i, _f, _i, _p],
+    "tike_ptycho_adj": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,
+                        _i, _f, _i, _p],
     "tike_ifft2_crop": [_p, _p, _p, _l, _i, _i, _f, _p],
     "tike_ptycho_fwd_intensity": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _p, _p,
                                   _i, _i, _i, _i, _i, _i, _f, _p],

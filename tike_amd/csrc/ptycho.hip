@@ -1843,7 +1843,7 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
                                int probe_per_scan, const void* eigen_probe,
                                const float* eigen_weights, int num_eigen, int eigen_modes,
                                void* farplane, int nscan, int S, int pw, int det, int H, int W,
-                               float scale, void* stream_) {
+                               float scale, int sub_batch, void* stream_) {
   TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
   TK_CHECK_ARG(psi && scan && probe && farplane);
@@ -1868,12 +1868,14 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
     // follows reads it from there and overwrites it in place, so HBM sees the
     // far plane once (256^2 x 1 mode: 2.83 -> 2.95 M patterns/s; smaller
     // sub-batches lose more to their launches than the cache returns,
-    // profiles/r04_experiments.md).  TIKE_FWD_SUB_MIB overrides the size.
-    static const long sub_mib =
-        getenv("TIKE_FWD_SUB_MIB") ? atol(getenv("TIKE_FWD_SUB_MIB")) : 256;
+    // profiles/r04_experiments.md).  sub_batch = positions per sub-batch
+    // (0: the 256 MiB default; < 0: one batch) -- an argument, the entry
+    // reads no environment.
     const size_t tile_bytes = sizeof(cf) * (size_t)det * det;
-    long sub = sub_mib > 0 ? (sub_mib << 20) / (long)(tile_bytes * S) : nscan;
-    if (sub < 16) sub = 16;
+    long sub = sub_batch > 0   ? sub_batch
+               : sub_batch < 0 ? nscan
+                               : (256L << 20) / (long)(tile_bytes * S);
+    if (sub < 1) sub = 1;
     const bool keep = sub < nscan;
     for (long lo = 0; lo < nscan; lo += sub) {
       const int m = (int)(nscan - lo < sub ? nscan - lo : sub);

@@ -1,10 +1,13 @@
 """The ptychography operator (reference operators/cupy/ptycho.py:26-204).
 
 ``fwd`` and ``adj`` keep the reference's signatures and shapes but run as
-fused HIP kernels: patch gather * probe -> FFT2 in one launch
-(``tike_ptycho_fwd``), IFFT2 -> crop (``tike_ifft2_crop``) followed by the
-object scatter-add and the probe gradient.
+fused HIP kernels: patch gather * probe -> FFT2 (``tike_ptycho_fwd``) and,
+for the adjoint, the two-pass inverse transform whose second pass forms both
+products in place (``tike_ptycho_adj``; other shapes: ``tike_ifft2_crop``
+followed by the unfused object scatter-add and probe product).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -14,6 +17,37 @@ from . import objective
 from .multislice import Multislice
 from .operator import Operator
 from .propagation import Propagation, fft_scales
+
+
+def sub_batch_positions(S, det, mib=None):
+    """Positions per sub-batch of the two-kernel 256^2 / 512^2 operators: the
+    ``sub_batch`` argument of ``tike_ptycho_fwd`` / ``tike_ptycho_adj``
+    (0 = the library's default of 256 MiB of far plane, -1 = one batch).
+    ``TIKE_FWD_SUB_MIB`` is read HERE, on the host side of the C ABI."""
+    if mib is None:
+        mib = os.environ.get("TIKE_FWD_SUB_MIB")
+    if mib is None:
+        return 0
+    mib = float(mib)
+    if mib <= 0:
+        return -1
+    return max(1, int(mib * 2**20) // (8 * S * det * det))
+
+
+def _positions_allowed(scan, psi_shape, pw):
+    """check_allowed_positions as a predicate (position.py:600-628): every
+    patch and its +1 taps inside the object.  Host arrays are tested on the
+    host; a device tensor costs one small reduction and a read-back."""
+    hi_y, hi_x = psi_shape[-2] - pw - 1, psi_shape[-1] - pw - 1
+    if isinstance(scan, torch.Tensor):
+        c = torch.floor(scan)
+        lo = c.amin(dim=0)
+        hi = c.amax(dim=0)
+        ok = (lo >= 1).all() & (hi[0] <= hi_y) & (hi[1] <= hi_x)
+        return bool(ok.item())
+    c = np.floor(scan)
+    return bool(c.min() >= 1 and c[..., 0].max() <= hi_y
+                and c[..., 1].max() <= hi_x)
 
 
 class Ptycho(Operator):
@@ -58,11 +92,12 @@ class Ptycho(Operator):
 
     # -- device-level entry points used by the solvers ---------------------
     def fwd_device(self, probe, scan, psi, eigen_probe=None,
-                   eigen_weights=None, out=None):
+                   eigen_weights=None, out=None, sub_batch=None):
         """Fused forward on device tensors; optional on-the-fly eigen probes.
 
         probe (1|N,1,S,pw,pw); eigen_probe (1,C,Sm,pw,pw) and eigen_weights
-        (N,C+1,S) select the varying probe of probe.py:272-303.
+        (N,C+1,S) select the varying probe of probe.py:272-303.  sub_batch:
+        positions per sub-batch at 256^2 / 512^2 (None: sub_batch_positions).
         """
         Multislice._one_slice(psi)
         N = scan.shape[0]
@@ -86,8 +121,9 @@ class Ptycho(Operator):
                 A.ptr(psi), A.ptr(scan), A.ptr(probe),
                 int(probe.shape[0] != 1), A.ptr(eigen_probe),
                 A.ptr(eigen_weights), C, Sm, A.ptr(out), N, S, pw, det,
-                psi.shape[-2], psi.shape[-1],
-                fft_scales(det, self.norm)[0], A.stream_ptr()), "Ptycho.fwd")
+                psi.shape[-2], psi.shape[-1], fft_scales(det, self.norm)[0],
+                sub_batch_positions(S, det) if sub_batch is None else
+                int(sub_batch), A.stream_ptr()), "Ptycho.fwd")
         return out
 
     def fwd(self, probe, scan, psi, **kwargs):
@@ -116,9 +152,49 @@ class Ptycho(Operator):
         return (A.like_input(far.unsqueeze(-4), psi),
                 A.like_input(beams, psi))
 
+    def fused_adjoint_shapes(self, S):
+        """Shapes the fused adjoint (``tike_ptycho_adj``) takes: probe window =
+        detector in {128, 256, 512}, at most 8 modes."""
+        return (self.probe_shape == self.detector_shape
+                and self.detector_shape in (128, 256, 512) and S <= 8)
+
+    def adj_device(self, farplane, probe, scan, psi, psi_adj=None,
+                   probe_adj=None, sub_batch=None):
+        """Fused adjoint on device tensors (``tike_ptycho_adj``): inverse pass 1
+        into ``probe_adj``, pass 2 in place with both products, grouped
+        footprint scatter.  Requires ``fused_adjoint_shapes`` and scan positions
+        that satisfy ``check_allowed_positions`` (position.py:600-628: what the
+        solvers guarantee; ``adj`` checks it).  ``farplane`` is not modified.
+        """
+        Multislice._one_slice(psi)
+        N, S = scan.shape[0], farplane.shape[-3]
+        pw, det = self.probe_shape, self.detector_shape
+        assert tuple(farplane.shape) == (N, 1, S, det, det), farplane.shape
+        assert probe.shape[0] in (1, N) and probe.shape[-3] == S
+        H, W = psi.shape[-2:]
+        dev = psi.device
+        if probe_adj is None:
+            probe_adj = torch.empty((N, 1, S, pw, pw), dtype=torch.complex64,
+                                    device=dev)
+        if psi_adj is None:
+            psi_adj = torch.empty_like(psi)
+        objproj = torch.empty((max(N, 1), pw, pw), dtype=torch.complex64,
+                              device=dev)
+        acc = torch.empty((2, H, W), dtype=torch.float32, device=dev)
+        check(
+            lib.tike_ptycho_adj(
+                A.ptr(farplane), A.ptr(probe), int(probe.shape[0] != 1),
+                A.ptr(scan), A.ptr(psi), A.ptr(psi_adj), A.ptr(probe_adj),
+                A.ptr(objproj), A.ptr(acc), N, S, pw, det, H, W,
+                fft_scales(det, self.norm)[1],
+                sub_batch_positions(S, det) if sub_batch is None else
+                int(sub_batch), A.stream_ptr()), "Ptycho.adj")
+        return psi_adj, probe_adj
+
     def adj(self, farplane, probe, scan, psi, overwrite=False, **kwargs):
         kind = farplane
         farplane_in = farplane
+        host_scan = None if A.is_device(scan) else np.asarray(scan)
         farplane = A.to_device(farplane, np.complex64)
         psi = A.to_device(psi, np.complex64)
         scan = A.to_device(scan, np.float32)
@@ -134,6 +210,14 @@ class Ptycho(Operator):
         pw, det = self.probe_shape, self.detector_shape
         assert tuple(farplane.shape) == (N, 1, S, det, det), farplane.shape
         assert probe.shape[0] in (1, N) and probe.shape[-3] == S
+        if N > 0 and self.fused_adjoint_shapes(S) and _positions_allowed(
+                scan if host_scan is None else host_scan, psi.shape, pw):
+            psi_adj, probe_adj = self.adj_device(farplane, probe, scan, psi)
+            return A.like_input(psi_adj, kind), A.like_input(probe_adj, kind)
+        # general shapes (probe window narrower than the detector, other
+        # sizes, more than 8 modes) and positions whose taps leave the image
+        # (the reference's linear tap addressing, convolution.cu:113-133):
+        # IFFT2 + crop, then the unfused Convolution adjoints
         in_place = (overwrite and A.is_device(farplane_in)
                     and farplane.data_ptr() == farplane_in.data_ptr())
         work = farplane if in_place else torch.empty_like(farplane)

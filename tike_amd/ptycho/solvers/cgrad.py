@@ -87,7 +87,7 @@ class _CostPlan:
                 check(
                     lib.tike_ptycho_fwd(ppsi, sc.data_ptr(), pprobe, 0, None,
                                         None, 0, 0, pfar, n, S, pw, det, H, W,
-                                        self.fwd_scale, st), "cgrad forward")
+                                        self.fwd_scale, 0, st), "cgrad forward")
                 check(
                     lib.tike_farplane_gradient(pfar, d.data_ptr(), None, None,
                                                cost.data_ptr(), n, S, det, 0,

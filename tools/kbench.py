@@ -98,7 +98,7 @@ def main():
     far = y[:N * S]
     ms = timeit(lambda: check(lib.tike_ptycho_fwd(
         psi.data_ptr(), scan.data_ptr(), probe.data_ptr(), 0, None, None, 0, 0,
-        far.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, st)), a.reps)
+        far.data_ptr(), N, S, n, n, HW, HW, 1.0 / n, 0, st)), a.reps)
     rows.append((f"ptycho_fwd S={S}", ms, N * S * tile_bytes + N * tile_bytes))
     if n in (128, 256, 512):
         inten = torch.empty(N, n, n, dtype=torch.float32, device=dev)
