@@ -119,14 +119,16 @@ __device__ __forceinline__ void scatter_footprint(ValueFn&& value, const TkCorne
 // ------------------------------------------- grouped footprint scatter-add
 // Footprints of neighbouring scan positions overlap almost entirely (pw =
 // 256 against a pitch of tens of pixels), so TK_GROUP CONSECUTIVE positions
-// are summed in LDS first -- over the bounding box of their footprints, one
-// strip of TK_GROWS image rows per workgroup -- and the image then takes ONE
-// atomic per box pixel instead of one per position and pixel.  The caller
-// orders positions so that consecutive ones are neighbours (the solver sorts
-// every minibatch spatially); a group whose box is wider than the LDS strip
-// falls back to the per-position atomics, so any order gives the same sums.
+// are summed on chip first -- over the bounding box of their footprints, one
+// strip of TK_GROWS image rows per workgroup, one thread per box column with
+// the row sums in registers (rounds 2-4: in LDS, a barrier per position) --
+// and the image then takes ONE atomic per box pixel instead of one per
+// position and pixel.  The caller orders positions so that consecutive ones
+// are neighbours (the solver sorts every minibatch spatially); a group whose
+// box is wider than TK_GSPREAD allows falls back to the per-position
+// atomics, so any order gives the same sums.
 constexpr int TK_GROUP = 8;
-constexpr int TK_GROWS = 8;     // image rows per workgroup (A/B: 8 beats 4, 6, 16, 32)
+constexpr int TK_GROWS = 8;     // image rows per workgroup
 constexpr int TK_GSPREAD = 112;  // extra box width and height beyond one footprint
 
 struct TkGroupBox {
@@ -146,18 +148,46 @@ __device__ __forceinline__ TkGroupBox tk_group_box(const float* __restrict__ sca
   return b;
 }
 
-// value(n, y, x): patch value of position n.  lds: TK_GROWS * wmax floats per plane.
-template <bool REAL_ONLY, class ValueFn>
-__device__ __forceinline__ void scatter_group(ValueFn&& value, const float* __restrict__ scan,
-                                              long n0, long n1, int strip, float* lds, int wmax,
+// lane i receives lane i - 1 (wave_shr:1); lane 0 receives 0
+__device__ __forceinline__ float tk_lane_down(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+
+// value(n, y, x): patch value of position n.  Round 5: a thread owns a COLUMN
+// of the box and keeps its TK_GROWS row sums in registers -- no LDS, no
+// barrier, and (inside a group) a fixed summation order.  For position n the
+// thread's column is patch column x' = X - sx_n; it needs v[y'][x'] of the
+// TK_GROWS + 1 patch rows that reach the strip and, for the tap to the left,
+// its left neighbour's values: lane - 1 holds x' - 1 of the same position (DPP
+// wave shift).  Lane 0 of every wave is a HALO lane: it repeats the last
+// column of the wave before it, feeds lane 1 and writes nothing -- a wave
+// covers 63 box columns and no lane ever needs a value from another wave
+// (loading those at a wave-uniform address made scalar loads of them, each
+// waited for on its own: 9 serial latencies per position).  Every load is
+// unconditional (clamped address, value selected): the rows of the next
+// position are requested before the sums of this one.
+constexpr int TK_GCOLS = 63;  // box columns per wave
+
+// rowptr(n, y): (uniform) pointer to row y of the patch of position n -- cf, or
+// float when REAL_ONLY.  Columns outside the patch take weight 0 instead of a
+// select per row (their clamped loads return finite values of the same row).
+template <bool REAL_ONLY, class RowFn>
+__device__ __forceinline__ void scatter_group(RowFn&& rowptr, const float* __restrict__ scan,
+                                              long n0, long n1, int strip, int wmax,
                                               float* __restrict__ re, float* __restrict__ im,
                                               int pw, int H, int W) {
+  using T = std::conditional_t<REAL_ONLY, float, cf>;
+  auto ld = [](const T* p) {
+    if constexpr (REAL_ONLY) return mk(*p, 0.f);
+    else return *p;
+  };
   const TkGroupBox b = tk_group_box(scan, n0, n1, pw);
   const int wb = b.xmax - b.xmin + 1;
   const int hb = b.ymax - b.ymin + 1;
   const int nstrip_direct = (pw + 1 + TK_STRIP - 1) / TK_STRIP;
   if (wb > wmax || hb > pw + 1 + TK_GSPREAD) {
-    // positions too far apart for one LDS strip: per-position atomics; the
+    // positions too far apart for one box: per-position atomics; the
     // first workgroups of the group share the (position, strip) items
     const int nwg = (pw + 1 + TK_GSPREAD + TK_GROWS - 1) / TK_GROWS;
     for (long w = strip; w < (n1 - n0) * nstrip_direct; w += nwg) {
@@ -165,80 +195,112 @@ __device__ __forceinline__ void scatter_group(ValueFn&& value, const float* __re
       const TkCorner c = tk_corner(scan, n);
       const float fy = scan[2 * n] - floorf(scan[2 * n]);
       const float fx = scan[2 * n + 1] - floorf(scan[2 * n + 1]);
-      scatter_footprint<REAL_ONLY>([&](int y, int x) { return value(n, y, x); }, c, fx, fy, re,
-                                   im, pw, H, W, (int)(w % nstrip_direct));
+      scatter_footprint<REAL_ONLY>([&](int y, int x) { return ld(rowptr(n, y) + x); }, c, fx,
+                                   fy, re, im, pw, H, W, (int)(w % nstrip_direct));
     }
     return;
   }
   const int Y0 = b.ymin + strip * TK_GROWS;
   if (Y0 > b.ymax) return;
-  const int Y1 = min(b.ymax + 1, Y0 + TK_GROWS);
-  float* lre = lds;
-  float* lim = lds + TK_GROWS * wmax;
-  const int cells = TK_GROWS * wmax;
-  for (int i = threadIdx.x; i < cells; i += blockDim.x) {
-    lre[i] = 0.f;
-    if (!REAL_ONLY) lim[i] = 0.f;
-  }
-  __syncthreads();
-  for (long n = n0; n < n1; ++n) {
-    const float py = scan[2 * n], px = scan[2 * n + 1];
-    const int sy = (int)floorf(py), sx = (int)floorf(px);
-    const float fy = py - floorf(py), fx = px - floorf(px);
-    const int r0 = max(0, Y0 - sy), r1 = min(pw + 1, Y1 - sy);  // rows y' of this strip
-    if (r0 < r1) {
-      const int xoff = sx - b.xmin;
-      scatter_footprint_rows<REAL_ONLY>(
-          [&](int y, int x) { return value(n, y, x); }, fx, fy, pw, r0, r1,
-          [&](int yp, int xp, float vr, float vi) {
-            const int cell = (sy + yp - Y0) * wmax + xoff + xp;
-            lre[cell] += vr;
-            if (!REAL_ONLY) lim[cell] += vi;
-          });
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nwave = (int)blockDim.x >> 6;
+  const int lane = threadIdx.x & 63;
+  constexpr int R = TK_GROWS + 1;  // patch rows y'_0 - 1 .. y'_0 + TK_GROWS - 1
+  for (int c0 = wave * TK_GCOLS; c0 < wb; c0 += nwave * TK_GCOLS) {  // uniform
+    const int X = b.xmin + c0 + lane - 1;  // lane 0: the column left of the wave's first
+    // rows of position n at this thread's column; (wv, wl) = weights of the
+    // thread's own value and of its left neighbour's in u = (1-fx) v + fx v_left
+    auto load = [&](long n, cf (&v)[R], float& wv, float& wl) {
+      const float py = scan[2 * n], px = scan[2 * n + 1];
+      const int sy = (int)floorf(py), sx = (int)floorf(px);
+      const float fx = px - floorf(px);
+      const int xq = X - sx;
+      const bool okx = (unsigned)xq < (unsigned)pw;
+      wv = okx ? 1.0f - fx : 0.f;
+      wl = (unsigned)(xq - 1) < (unsigned)pw ? fx : 0.f;
+      const unsigned off = (unsigned)(okx ? xq : 0) * (unsigned)sizeof(T);
+      const int y0 = Y0 - sy - 1;
+      if (y0 >= 0 && y0 + R <= pw) {  // uniform: every row inside the patch
+        const T* __restrict__ base = rowptr(n, y0);
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = ld(tk_at(base + (long)j * pw, off));
+      } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int y = y0 + j;
+          const bool oky = y >= 0 && y < pw;
+          const cf a = ld(tk_at(rowptr(n, oky ? y : 0), off));
+          v[j] = oky ? a : mk(0.f, 0.f);
+        }
+      }
+    };
+    float ar[TK_GROWS], ai[TK_GROWS];
+#pragma unroll
+    for (int k = 0; k < TK_GROWS; ++k) ar[k] = ai[k] = 0.f;
+    cf v[R], nv[R];
+    float wv, wl, nwv = 0.f, nwl = 0.f;
+    load(n0, v, wv, wl);
+    for (long n = n0; n < n1; ++n) {
+      if (n + 1 < n1) load(n + 1, nv, nwv, nwl);
+      const float py = scan[2 * n];
+      const float fy = py - floorf(py);
+      cf u[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const cf left = mk(tk_lane_down(v[j].x), REAL_ONLY ? 0.f : tk_lane_down(v[j].y));
+        u[j] = mk(wv * v[j].x + wl * left.x, REAL_ONLY ? 0.f : wv * v[j].y + wl * left.y);
+      }
+#pragma unroll
+      for (int k = 0; k < TK_GROWS; ++k) {
+        ar[k] += (1.0f - fy) * u[k + 1].x + fy * u[k].x;
+        if (!REAL_ONLY) ai[k] += (1.0f - fy) * u[k + 1].y + fy * u[k].y;
+      }
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[j] = nv[j];
+      wv = nwv;
+      wl = nwl;
     }
-    __syncthreads();  // the next position maps columns to other threads
-  }
-  for (int i = threadIdx.x; i < (Y1 - Y0) * wb; i += blockDim.x) {
-    const int ry = i / wb, rx = i % wb;
-    const int Y = Y0 + ry, X = b.xmin + rx;
-    if (Y < 0 || Y >= H || X < 0 || X >= W) continue;
-    const float vr = lre[ry * wmax + rx];
-    const long ii = (long)Y * W + X;
-    if (REAL_ONLY) {
-      if (vr != 0.f) TK_ATOMIC_ADD(&re[ii], vr);
-    } else {
-      const float vi = lim[ry * wmax + rx];
-      if (vr != 0.f || vi != 0.f) {
-        TK_ATOMIC_ADD(&re[ii], vr);
-        TK_ATOMIC_ADD(&im[ii], vi);
+    if (lane > 0 && X <= b.xmax && X >= 0 && X < W) {
+#pragma unroll
+      for (int k = 0; k < TK_GROWS; ++k) {
+        const int Y = Y0 + k;
+        if (Y > b.ymax || Y < 0 || Y >= H) continue;
+        const long ii = (long)Y * W + X;
+        if (REAL_ONLY) {
+          if (ar[k] != 0.f) TK_ATOMIC_ADD(&re[ii], ar[k]);
+        } else if (ar[k] != 0.f || ai[k] != 0.f) {
+          TK_ATOMIC_ADD(&re[ii], ar[k]);
+          TK_ATOMIC_ADD(&im[ii], ai[k]);
+        }
       }
     }
   }
-  __syncthreads();
 }
 
 // ----------------------------------------------------------- object gradient
 // acc (2,H,W) planar f32 += scatter_n( objproj_n ),  objproj (nscan,pw,pw) c64 =
 // sum_s conj(P_n,s) chi_n,s  computed by tike_lstsq_gradients
 // (lstsq.py:510-520 = conj multiply + Patch.adj with nrepeat = S).
-__global__ __launch_bounds__(256) void scatter_patches_kernel(const cf* __restrict__ proj,
-                                                              const float* __restrict__ scan,
-                                                              float* __restrict__ acc, int nscan,
-                                                              int pw, int H, int W, int wmax) {
-  extern __shared__ float tk_scatter_lds[];
+__global__ __launch_bounds__(1024) void scatter_patches_kernel(const cf* __restrict__ proj,
+                                                               const float* __restrict__ scan,
+                                                               float* __restrict__ acc, int nscan,
+                                                               int pw, int H, int W, int wmax) {
   const long P = (long)pw * pw;
   float* __restrict__ re = acc;
   float* __restrict__ im = acc + (long)H * W;
   const long g = blockIdx.y;
   const long n0 = g * TK_GROUP, n1 = min((long)nscan, n0 + TK_GROUP);
-  scatter_group<false>([&](long n, int y, int x) { return proj[n * P + (long)y * pw + x]; },
-                       scan, n0, n1, blockIdx.x, tk_scatter_lds, wmax, re, im, pw, H, W);
+  scatter_group<false>([&](long n, int y) { return proj + n * P + (long)y * pw; }, scan, n0, n1,
+                       blockIdx.x, wmax, re, im, pw, H, W);
 }
 
-// (strips per group, LDS width) of the grouped scatter for a probe width
-static inline void tk_group_geometry(int pw, int* nstrip, int* wmax) {
+// (strips per group, widest box, threads per workgroup) of the grouped scatter
+// for a probe width: one thread per box column, whole waves
+static inline void tk_group_geometry(int pw, int* nstrip, int* wmax, int* threads) {
   *wmax = pw + 1 + TK_GSPREAD;
   *nstrip = (pw + 1 + TK_GSPREAD + TK_GROWS - 1) / TK_GROWS;
+  const int t = (*wmax + TK_GCOLS - 1) / TK_GCOLS * 64;  // a wave covers TK_GCOLS columns
+  *threads = t > 1024 ? 1024 : t;
 }
 
 extern "C" int tike_scatter_patches(const void* objproj, const float* scan, float* acc,
@@ -247,17 +309,10 @@ extern "C" int tike_scatter_patches(const void* objproj, const float* scan, floa
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(objproj && scan && acc);
-  int nstrip, wmax;
-  tk_group_geometry(pw, &nstrip, &wmax);
-  const size_t lds = sizeof(float) * 2 * TK_GROWS * wmax;
-  TK_CHECK_ARG(lds <= 160 * 1024);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)scatter_patches_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
+  int nstrip, wmax, threads;
+  tk_group_geometry(pw, &nstrip, &wmax, &threads);
   const dim3 grid(nstrip, (nscan + TK_GROUP - 1) / TK_GROUP);
-  hipLaunchKernelGGL(scatter_patches_kernel, grid, dim3(256), lds, (hipStream_t)stream,
+  hipLaunchKernelGGL(scatter_patches_kernel, grid, dim3(threads), 0, (hipStream_t)stream,
                      (const cf*)objproj, scan, acc, nscan, pw, H, W, wmax);
   TK_LAUNCH_CHECK();
   return TK_OK;
@@ -266,15 +321,14 @@ extern "C" int tike_scatter_patches(const void* objproj, const float* scan, floa
 // ------------------------------------------------------ psi preconditioner
 // out (H,W) float32 += scatter_n( probe_amp ),  probe_amp = sum_s |probe_s|^2 (pw,pw) f32
 // (solvers/_preconditioner.py:48-104: Patch.adj of one broadcast patch).
-__global__ __launch_bounds__(256) void psi_precond_kernel(const float* __restrict__ amp,
-                                                          const float* __restrict__ scan,
-                                                          float* __restrict__ out, int nscan,
-                                                          int pw, int H, int W, int wmax) {
-  extern __shared__ float tk_scatter_lds[];
+__global__ __launch_bounds__(1024) void psi_precond_kernel(const float* __restrict__ amp,
+                                                           const float* __restrict__ scan,
+                                                           float* __restrict__ out, int nscan,
+                                                           int pw, int H, int W, int wmax) {
   const long g = blockIdx.y;
   const long n0 = g * TK_GROUP, n1 = min((long)nscan, n0 + TK_GROUP);
-  scatter_group<true>([&](long, int y, int x) { return mk(amp[(long)y * pw + x], 0.f); }, scan,
-                      n0, n1, blockIdx.x, tk_scatter_lds, wmax, out, out, pw, H, W);
+  scatter_group<true>([&](long, int y) { return amp + (long)y * pw; }, scan, n0, n1,
+                      blockIdx.x, wmax, out, out, pw, H, W);
 }
 
 extern "C" int tike_psi_preconditioner(const float* probe_amp, const float* scan, void* out,
@@ -283,17 +337,10 @@ extern "C" int tike_psi_preconditioner(const float* probe_amp, const float* scan
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(probe_amp && scan && out);
-  int nstrip, wmax;
-  tk_group_geometry(pw, &nstrip, &wmax);
-  const size_t lds = sizeof(float) * TK_GROWS * wmax;
-  TK_CHECK_ARG(lds <= 160 * 1024);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)psi_precond_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
+  int nstrip, wmax, threads;
+  tk_group_geometry(pw, &nstrip, &wmax, &threads);
   const dim3 grid(nstrip, (nscan + TK_GROUP - 1) / TK_GROUP);
-  hipLaunchKernelGGL(psi_precond_kernel, grid, dim3(256), lds, (hipStream_t)stream, probe_amp,
+  hipLaunchKernelGGL(psi_precond_kernel, grid, dim3(threads), 0, (hipStream_t)stream, probe_amp,
                      scan, (float*)out, nscan, pw, H, W, wmax);
   TK_LAUNCH_CHECK();
   return TK_OK;

@@ -25,9 +25,11 @@ def main():
     name, args = sys.argv[1], sys.argv[2:]
     assert len(args) % 3 == 0, __doc__
     os.makedirs(WORK, exist_ok=True)
-    for f in glob.glob(os.path.join(SRC, "*.hip")) + glob.glob(
-            os.path.join(SRC, "*.h")):
-        shutil.copy(f, WORK)
+    for f in (glob.glob(os.path.join(SRC, "*.hip")) + glob.glob(
+            os.path.join(SRC, "*.h")) + glob.glob(os.path.join(SRC, "*.cpp"))):
+        text = open(f).read().replace('"../../include/tike_amd.h"',
+                                      '"tike_amd.h"')
+        open(os.path.join(WORK, os.path.basename(f)), "w").write(text)
     mk = open(os.path.join(SRC, "Makefile")).read()
     mk = mk.replace("-I../../include", f"-I{ROOT}/include").replace(
         "../../include/tike_amd.h", f"{ROOT}/include/tike_amd.h")
@@ -37,7 +39,7 @@ def main():
         text = open(path).read()
         assert args[i + 1] in text, f"no match in {args[i]}: {args[i + 1][:60]}"
         open(path, "w").write(text.replace(args[i + 1], args[i + 2], 1))
-    out = subprocess.run(["make", "-C", WORK, "-B"], capture_output=True,
+    out = subprocess.run(["make", "-C", WORK, "-B", "-j6"], capture_output=True,
                          text=True)
     if out.returncode:
         sys.exit(out.stdout[-3000:] + out.stderr[-3000:])
