@@ -1845,3 +1845,39 @@ def test_chunk_gradients_entry_matches_the_staged_pipeline(tp, det, S, N, eigen,
         A.ptr(work), A.ptr(gscale), A.ptr(patches), A.ptr(costs),
         A.ptr(objproj), A.ptr(chi0), A.ptr(mpu), 0.5, A.ptr(acc), N, 9, det, H,
         W, fwd_scale, inv_scale, A.stream_ptr()) == 1000002
+
+
+def test_data_upload_moves_only_the_rows_it_is_asked_for(monkeypatch):
+    """data_to_device (round-4 advisor finding): a rank's share of the rows,
+    a full permutation, the identity and a row named twice all arrive in their
+    final order, block by block -- with blocks of three rows here -- and the
+    upload of a share never touches the rows of other ranks."""
+    import torch
+    import tike_amd._arrays as A
+    rng = np.random.default_rng(0)
+    a = rng.random((23, 5, 7)).astype(np.float64)  # widened/narrowed on the way
+    monkeypatch.setattr(A, "_upload_block_rows", lambda arr: 3)
+    seen = []
+    real = torch.from_numpy
+
+    def spy(x):
+        if x.ndim == 3:
+            seen.append(x.shape[0])
+        return real(x)
+
+    monkeypatch.setattr(A.torch, "from_numpy", spy)
+    share = np.array([20, 1, 2, 3, 11, 22, 0])
+    for order in (share, rng.permutation(23), None, np.array([4, 4, 9])):
+        seen.clear()
+        t = A.data_to_device(a, order=order)
+        want = a if order is None else a[order]
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        np.testing.assert_array_equal(t.cpu().numpy(), want.astype(np.float32))
+        assert sum(seen) == len(want)  # no other row crossed to the device
+    bad = a.astype(np.float32)
+    assert not A.has_invalid_counts(A.data_to_device(bad))
+    bad[17, 2, 3] = -1.0
+    monkeypatch.setattr(A.torch, "from_numpy", real)
+    assert A.has_invalid_counts(A.data_to_device(bad), block_bytes=3 * 140)
+    bad[17, 2, 3] = np.nan
+    assert A.has_invalid_counts(A.data_to_device(bad), block_bytes=3 * 140)

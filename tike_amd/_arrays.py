@@ -97,12 +97,58 @@ def data_to_device(x, order=None, device=None):
             a = a[order]
         a = np.ascontiguousarray(np.clip(a, 0, None).astype(np.uint16))
         return torch.from_numpy(a.view(np.int16)).to(device).view(torch.uint16)
-    # float patterns: uploaded as they lie, permuted on the device (a fancy
-    # index of 2.6 GB on the host costs more than the upload itself)
-    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
-    if order is not None:
-        t = t.index_select(0, torch.as_tensor(np.asarray(order), device=device))
-    return t
+    # float patterns: uploaded block by block into their final, permuted place
+    # -- only the rows `order` names ever cross PCIe (a rank's share of a
+    # multi-GPU job), and HBM never holds more than the result + one block
+    if order is None:
+        order = np.arange(a.shape[0])
+    order = np.asarray(order, dtype=np.int64)
+    out = torch.empty((len(order),) + tuple(a.shape[1:]), dtype=torch.float32,
+                      device=device)
+    if len(order) == 0:
+        return out
+    where = np.full(a.shape[0], -1, dtype=np.int64)  # source row -> place
+    where[order] = np.arange(len(order))
+    if np.count_nonzero(where >= 0) != len(order):
+        # a row named twice: no inverse map; gather on the host block-wise
+        for lo in range(0, len(order), _upload_block_rows(a)):
+            hi = min(len(order), lo + _upload_block_rows(a))
+            out[lo:hi] = torch.from_numpy(np.ascontiguousarray(
+                a[order[lo:hi]], dtype=np.float32)).to(device)
+        return out
+    step = _upload_block_rows(a)
+    for lo in range(0, a.shape[0], step):
+        hi = min(a.shape[0], lo + step)
+        place = where[lo:hi]
+        wanted = place >= 0
+        if not wanted.any():
+            continue
+        # (a block this job wants in full goes up as it lies: no host gather)
+        rows = a[lo:hi] if wanted.all() else a[lo:hi][wanted]
+        blk = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)).to(
+            device)
+        out.index_copy_(0, torch.from_numpy(place[wanted]).to(device), blk)
+    return out
+
+
+def _upload_block_rows(a, block_bytes=256 << 20):
+    """Rows of `a` per upload block (about 256 MiB of float32)."""
+    row = 4 * int(np.prod(a.shape[1:], dtype=np.int64)) or 4
+    return max(1, block_bytes // row)
+
+
+def has_invalid_counts(t, block_bytes=256 << 20):
+    """True when the resident float patterns hold a negative or non-finite
+    value (ptycho.py:392-397), tested block by block: the temporaries are a
+    block's, not the dataset's; one read-back at the end."""
+    if t.numel() == 0:
+        return False
+    step = max(1, block_bytes // max(1, 4 * t[0].numel()))
+    bad = torch.zeros((), dtype=torch.bool, device=t.device)
+    for lo in range(0, t.shape[0], step):
+        blk = t[lo:lo + step]
+        bad |= (~torch.isfinite(blk)).any() | (blk < 0).any()
+    return bool(bad)
 
 
 def data_f32(data, lo, hi):

@@ -29,6 +29,10 @@ class Comm:
         self.enabled = dist.is_available() and dist.is_initialized()
         self.size = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
+        # index of the minibatch the solver is working on (the same on every
+        # rank): part of the key of per-minibatch cached collectives, see
+        # solvers/lstsq.py `minibatch_key`
+        self.minibatch = None
         # collectives are skipped for a single rank; TIKE_FORCE_COLLECTIVES=1
         # issues them anyway (used to exercise RCCL on a one-GPU test box)
         self.collective = self.size > 1 or (
@@ -37,10 +41,11 @@ class Comm:
         # buffers of every minibatch) go through the library's own RCCL entry
         # (tike_comm_allreduce_sum, include/tike_amd.h) instead of
         # torch.distributed; the process group only hands out the unique id.
-        # Both issue on the caller's current stream and this class never uses
-        # torch's async_op collectives, so the two RCCL communicators of the
-        # process are ordered by that stream; do not mix `cabi` with
-        # asynchronous torch collectives on other streams.
+        # With `cabi` every sum -- `Allreduce_start` included, which then
+        # completes at once -- is issued on the caller's current stream, so
+        # the two RCCL communicators of the process are ordered by that
+        # stream.  (Without it, `Allreduce_start` is torch's async_op
+        # all-reduce on the process group's own stream.)
         self._cabi = None
         if self.collective and os.environ.get("TIKE_COMM_BACKEND") == "cabi":
             self._cabi = self._create_cabi()

@@ -949,7 +949,23 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
           __builtin_memcpy(&u, reinterpret_cast<const char*>(gobj) + off, sizeof(u));
           __builtin_memcpy(&l, reinterpret_cast<const char*>(gobj) + off + (unsigned)W * 8u,
                            sizeof(l));
-          o = patches[n * P + p];
+          if (HAVE_PATCHES) {
+            o = patches[n * P + p];
+          } else {
+            // O_n from the object itself: the same two 16-byte tap loads at
+            // the same offsets as the update's (L2) instead of 8 bytes of HBM
+            tk_v4f uo, lo_;
+            __builtin_memcpy(&uo, reinterpret_cast<const char*>(psi) + off, sizeof(uo));
+            __builtin_memcpy(&lo_, reinterpret_cast<const char*>(psi) + off + (unsigned)W * 8u,
+                             sizeof(lo_));
+            o = mk(uo.x * c.w00, uo.y * c.w00);
+            o.x += uo.z * c.w01;
+            o.y += uo.w * c.w01;
+            o.x += lo_.x * c.w10;
+            o.y += lo_.y * c.w10;
+            o.x += lo_.z * c.w11;
+            o.y += lo_.w * c.w11;
+          }
           g = mk(u.x * c.w00, u.y * c.w00);
           g.x += u.z * c.w01;
           g.y += u.w * c.w01;
@@ -1019,12 +1035,12 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
         }
       }
     };
-    const bool hot = HAVE_PATCHES && interior && same_p && mpu != nullptr;
+    const bool hot = interior && same_p && mpu != nullptr;
     if (hot && nE == 1 && same_e)
       body(std::integral_constant<int, 3>{});
     else if (hot && nE == 0 && eigen_proj == nullptr)
       body(std::integral_constant<int, 2>{});
-    else if (HAVE_PATCHES && interior)
+    else if (interior)
       body(std::integral_constant<int, 1>{});
     else
       body(std::integral_constant<int, 0>{});

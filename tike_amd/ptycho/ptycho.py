@@ -364,8 +364,7 @@ class Reconstruction():
                                          order=self.local_order)
             if (host is not None and not on_host
                     and self.data.dtype == torch.float32
-                    and bool((~torch.isfinite(self.data)).any()
-                             | (self.data < 0).any())):
+                    and A.has_invalid_counts(self.data)):
                 _warn_invalid_data()
         self.parameters = solvers.PtychoParameters.split(
             self.local_order,

@@ -20,7 +20,8 @@ from ..._lib import check, lib
 from ...operators.propagation import fft_scales
 from ..exitwave import ExitWaveOptions
 from .lstsq import (SPLIT_FORWARD_SIZES, _get_nearplane_gradients, _workspace,
-                    chunk_positions, fused_gradients, global_count)
+                    chunk_positions, fused_gradients, global_count,
+                    minibatch_key)
 
 
 logger = logging.getLogger(__name__)
@@ -226,9 +227,34 @@ class _SlotPolicy:
     not in every call of every epoch (round-3 advisor finding).  Counts change
     rarely, which keeps the captured launch sequences (`_CgGraph`) valid."""
 
+    # calls of a variable that skip the all-at-once search after it has found
+    # none of its 16 step lengths acceptable (doubled per repeated failure)
+    LINEAR_PAUSE = 16
+
     def __init__(self):
         self.slots = {v: list(LINE_SEARCH_SLOTS) for v in (0, 1)}
         self.generous = {v: [0, 0] for v in (0, 1)}
+        self.linear_skip = {0: 0, 1: 0}
+        self.linear_pause = {0: self.LINEAR_PAUSE, 1: self.LINEAR_PAUSE}
+
+    def linear_allowed(self, variable):
+        """The all-at-once search keeps no steps below step / 2^15: a problem
+        that needs them would run it, throw it away and repeat the whole CG
+        call trial by trial -- in every call (round-4 advisor finding).  After
+        a failure the variable goes straight to the trial-by-trial search for
+        a while, then the all-at-once search gets another try."""
+        if self.linear_skip[variable] > 0:
+            self.linear_skip[variable] -= 1
+            return False
+        return True
+
+    def linear_result(self, variable, ok):
+        if ok:
+            self.linear_pause[variable] = self.LINEAR_PAUSE
+        else:
+            self.linear_skip[variable] = self.linear_pause[variable]
+            self.linear_pause[variable] = min(1024,
+                                              2 * self.linear_pause[variable])
 
     def get(self, variable):
         return tuple(self.slots[variable])
@@ -415,7 +441,7 @@ def _every_rank(comm, op, lo, hi, mine):
     """True when `mine` holds on every rank (asked once per minibatch and
     reconstruction: minibatch sizes and data placement are static)."""
     cache = op.__dict__.setdefault("_tike_amd_every_rank", {})
-    key = (lo, hi, comm.size)
+    key = minibatch_key(comm, lo, hi)
     if key not in cache:
         cache[key] = comm.Allreduce_count(int(bool(mine))) == comm.size
     return cache[key]
@@ -432,8 +458,14 @@ def _cg_on_device(plan, op, comm, psi, probe, variable, o, count, data, scan,
     x = psi if variable == 0 else probe
     other = probe if variable == 0 else psi
     if LINEAR_LINE_SEARCH and not USE_GRAPHS:
-        r = _cg_device(plan, op, comm, psi, probe, variable, o.cg_iter,
-                       o.step_length, count, data, scan, lo, hi, linear=True)
+        # (the policy is fed by results every rank sees alike -- the staged
+        # search decides on all-reduced sums -- so the ranks stay in step)
+        r = None
+        if policy.linear_allowed(variable):
+            r = _cg_device(plan, op, comm, psi, probe, variable, o.cg_iter,
+                           o.step_length, count, data, scan, lo, hi,
+                           linear=True)
+            policy.linear_result(variable, r is not None)
         if r is not None:
             return r[0], r[1]
         if comm.collective:
@@ -519,9 +551,10 @@ def cgrad(parameters, data, batches, comm, *, op, epoch):
                      and epoch >= parameters.probe_options.update_start)
     psi, probe, scan = parameters.psi, parameters.probe, parameters.scan
     batch_cost = []
-    for b in batches:
+    for batch_index, b in enumerate(batches):
         lo = int(b[0]) if len(b) else 0
         hi = lo + len(b)
+        comm.minibatch = batch_index
         d, s = data, scan
         cost = None
         finish = lambda total: _finish_cost(total, comm, op, lo, hi)

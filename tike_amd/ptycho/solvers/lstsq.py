@@ -18,6 +18,7 @@ Differences from the reference that do not change the mathematics:
     iterates up to summation order.
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -102,10 +103,19 @@ def global_count(comm, op, lo, hi):
     host float; minibatch sizes are static, so this is all-reduced once and
     cached on the operator."""
     cache = op.__dict__.setdefault("_tike_amd_counts", {})
-    key = (lo, hi, comm.size)
+    key = minibatch_key(comm, lo, hi)
     if key not in cache:
         cache[key] = comm.Allreduce_count(hi - lo)
     return cache[key]
+
+
+def minibatch_key(comm, lo, hi):
+    """Cache key of a per-minibatch collective.  The LOCAL bounds alone are
+    not one: a rank whose shares of two minibatches are both empty sees the
+    same (lo, hi) twice and would skip a collective the other ranks issue.
+    The solvers name the minibatch they are in (`comm.minibatch`, the same
+    index on every rank) before they touch it."""
+    return (getattr(comm, "minibatch", None), lo, hi, comm.size)
 
 
 def mask_info(exitwave_options, det=None):
@@ -195,6 +205,7 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
 
     for batch_index in order:
         lo, hi = _lo_hi(batches[batch_index])
+        comm.minibatch = int(batch_index)
         g = _get_nearplane_gradients(
             data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi, comm,
             num_batch=num_batch, exitwave_options=exitwave_options, op=op,
@@ -325,6 +336,10 @@ psi (L2) instead of streaming the stored ones (HBM): 0.186 -> 0.160 ms per 1000
 positions at 256^2.  (The position sums can do the same -- the entry takes psi
 -- but are bound by their L1 requests, not by HBM: 0.215 -> 0.221 ms.)"""
 
+STATS_PATCH_RECOMPUTE = os.environ.get("TIKE_STATS_GATHER", "0") == "1"
+"""The step statistics gather O_n from the object with the two 16-byte tap
+loads they already issue for the preconditioned update (same offsets)."""
+
 PACKED_TAIL = True
 """Tests set this to False to run the staged tail (one entry per step of the
 reference's _update_nearplane / _precondition_nearplane_gradients)."""
@@ -382,6 +397,9 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     m_probe_update = (torch.view_as_complex(
         grads[n_obj:].view(*probe.shape, 2)) if recover_probe else None)
     probe_sum = None  # handle of the early all-reduce of the probe gradient
+    # ... started as soon as pass 2 has finished that slice; decided from what
+    # every rank knows alike (never from this rank's share of the positions)
+    early = bool(comm.collective and recover_psi and recover_probe)
     chi0 = None  # allocated below unless chi itself can be handed on
     patches = None
     pos_major = det in POSITION_MAJOR_SIZES
@@ -669,8 +687,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     A.ptr(position_terms[0][clo:chi_hi]),
                     A.ptr(position_terms[1][clo:chi_hi]), n, S, pw, st),
                 "position shift sums")
-        if (chi_hi == hi and comm.collective and recover_psi
-                and recover_probe):
+        if chi_hi == hi and early:
             # the probe gradient is complete: its slice of the flat buffer
             # travels while the last object scatter runs
             probe_sum = comm.Allreduce_start(grads[n_obj:])
@@ -683,13 +700,19 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         if not single_chunk and not fused:
             chi0[blo:blo + n] = chi[:n, 0, 0]
 
-    # complete the sums over positions across ranks
+    # complete the sums over positions across ranks.  Which collectives are
+    # issued, and in which order, depends on rank-invariant facts only
+    # (`early`): a rank whose share of this minibatch is EMPTY never entered
+    # the chunk loop and starts the probe slice here, so that every rank
+    # issues the same two all-reduces in the same order
     if comm.collective and grads.numel():
-        if probe_sum is None:
-            comm.Allreduce(grads)
-        else:
+        if early:
+            if probe_sum is None:
+                probe_sum = comm.Allreduce_start(grads[n_obj:])
             comm.Allreduce(grads[:n_obj])
             probe_sum.wait()
+        else:
+            comm.Allreduce(grads)
     count = global_count(comm, op, lo, hi)
     if recover_probe and not fused:
         m_probe_update = m_probe_update / num_batch  # (fused: in the kernel)
@@ -748,6 +771,8 @@ def _step_stats(g, psi, scan, probe, eigen_probe, object_update_precond, lo,
             A.ptr(g["chi0"]), A.ptr(scan[lo:hi]), A.ptr(psi),
             A.ptr(object_update_precond), A.ptr(probe), A.ptr(ep),
             A.ptr(w_old), C, Sm, None, A.ptr(g["m_probe_update"]),
+            None if (STATS_PATCH_RECOMPUTE and psi.shape[0] == 1
+                     and object_update_precond is not None) else
             A.ptr(g["patches"]), A.ptr(stats), B,
             S, g["chi_modes"], pw, psi.shape[-2], psi.shape[-1],
             A.ptr(eigen0), A.ptr(eproj), A.stream_ptr()),

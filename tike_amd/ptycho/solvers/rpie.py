@@ -60,6 +60,7 @@ def rpie(parameters, data, batches, comm, *, op, epoch):
     for n in order:
         lo = int(batches[n][0]) if len(batches[n]) else 0
         hi = lo + len(batches[n])
+        comm.minibatch = int(n)
         if psi_num is None:
             psi_num = torch.zeros_like(psi)
         cost, probe_num = _get_nearplane_gradients(
