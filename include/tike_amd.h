@@ -430,6 +430,47 @@ int tike_position_sums(const void* patches, const void* chi, int chi_modes, cons
                        int eigen_modes, const float* taps, int radius, float* numerator,
                        float* denominator, int nscan, int S, int pw, void* stream);
 
+/* ---- the stages of a multislice object, fused (operators/cupy/multislice.py:
+ * 69-92,144-194 = Convolution + FresnelSpectProp slice by slice;
+ * fresnelspectprop.py:52-113; ptycho/solvers/rpie.py:367-495).  A Fresnel
+ * step FFT2 -> x propagator -> IFFT2 runs as
+ *   pass 1 (tike_fwd_pass1 with the incident probes as per-position probes:
+ *   patch x probe formed on the fly; or tike_fft2_pass1 on a stored wave)
+ *   -> tike_fresnel_colpass -> inverse pass 2 (tike_fft2_pass2_inplace, or
+ *   tike_ifft2_pass2_products on the way back),
+ * three launches with two hand-offs instead of four transforms and a multiply.
+ * Tiles are det x det c64, det in {128, 256, 512} unless noted. */
+
+/* pass 1 of the two-pass transform on plain tiles: rows + radix-16 column
+ * stage; out (ntile,det,det) must not alias in. */
+int tike_fft2_pass1(const void* in, void* out, long ntile, int det, int inverse, void* stream);
+
+/* pass 2 alone, in place, every element times `scale`. */
+int tike_fft2_pass2_inplace(void* tiles, long ntile, int det, int inverse, float scale,
+                            void* stream);
+
+/* forward column pass -> x propagator (conj when `adjoint`) x scale -> inverse
+ * pass 1 (fresnelspectprop.py:86-113): colin = output of a FORWARD pass 1,
+ * work = input of an INVERSE pass 2; propagator (det,det) c64 in FFT order
+ * (fresnelspectprop.py:115-137).  det = 256 (TIKE_ERR_UNSUPPORTED otherwise:
+ * use tike_fresnel_spect_prop). */
+int tike_fresnel_colpass(const void* colin, const void* propagator, int adjoint, void* work,
+                         long ntile, int det, float scale, void* stream);
+
+/* inverse pass 2 in place fused with the numerators of one slice
+ * (rpie.py:444-472): with chi = inv_scale * (pass 2 of work),
+ *   objproj[n]       = sum_s conj(probe[n|0][s]) * chi[n][s]      (nscan,det,det)
+ *   probe_numerator += numerator_scale * sum_n conj(patch_n(psi)) * chi[n][s]
+ *                                                   (S,det,det) c64, may be NULL
+ *   keep_chi != 0: work <- chi (all modes: the wave the Fresnel step back to
+ *                  the slice in front transforms); else chi0[n] <- chi[n][0]
+ *                  (nscan,det,det; may be NULL) and work is left as it was.
+ * psi (H,W) is the slice; scan as in tike_ptycho_adj.  S <= 8. */
+int tike_ifft2_pass2_products(void* work, const void* psi, const float* scan, const void* probe,
+                              int probe_per_scan, void* objproj, void* probe_numerator,
+                              float numerator_scale, void* chi0, int keep_chi, int nscan, int S,
+                              int det, int H, int W, float inv_scale, void* stream);
+
 /* ---- FresnelSpectProp.fwd / .adj (operators/cupy/fresnelspectprop.py:52-113):
  * out = IFFT2(FFT2(in) * propagator) (adjoint != 0: conj(propagator)) for ntile
  * n x n tiles sharing one (n,n) c64 propagator; fwd_scale / inv_scale are the

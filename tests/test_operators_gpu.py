@@ -392,6 +392,73 @@ def test_ptycho_adj_positions_outside_take_the_general_kernels(ops, oracle):
     assert_close(probe_adj, o_probe, what="probe_adj")
 
 
+@pytest.mark.parametrize("adjoint", [False, True])
+def test_fresnel_step_in_three_launches_vs_oracle(oracle, adjoint):
+    """tike_fft2_pass1 -> tike_fresnel_colpass -> tike_fft2_pass2_inplace ==
+    FresnelSpectProp.fwd / .adj (fresnelspectprop.py:52-113) of the oracle,
+    for few tiles (k1 split over workgroups) and for many."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    rng = np.random.default_rng(4)
+    n = 256
+    H = oracle.fresnel_spectrum_propagator((n, n), (2e-6, 2e-6), 1e-6, 1e-10)
+    st = A.stream_ptr()
+    for ntile in (3, 40):
+        x = rc(rng, ntile, n, n)
+        want = (oracle.fresnel_adj if adjoint else oracle.fresnel_fwd)(x, H)
+        xd, Hd = A.to_device(x), A.to_device(H)
+        a, b = torch.empty_like(xd), torch.empty_like(xd)
+        check(lib.tike_fft2_pass1(A.ptr(xd), A.ptr(a), ntile, n, 0, st))
+        check(lib.tike_fresnel_colpass(A.ptr(a), A.ptr(Hd), int(adjoint),
+                                       A.ptr(b), ntile, n, 1.0 / n**2, st))
+        check(lib.tike_fft2_pass2_inplace(A.ptr(b), ntile, n, 1, 1.0, st))
+        assert_close(b.cpu().numpy(), want, what=f"fresnel, {ntile} tiles")
+
+
+@pytest.mark.parametrize("det,S,N,shared,keep", [
+    (256, 8, 9, False, True), (256, 8, 9, True, False), (256, 3, 7, False, False),
+    (256, 1, 11, False, True), (256, 2, 6, True, True), (128, 5, 10, False, True),
+    (128, 1, 20, True, False)])
+def test_ifft2_pass2_products_vs_oracle(oracle, det, S, N, shared, keep):
+    """tike_ifft2_pass2_products (rpie.py:444-472 for one slice): object
+    projection, probe numerator (accumulated over the positions, scaled) and
+    chi kept in place / mode 0 of chi, against NumPy."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    rng = np.random.default_rng(det + S + N)
+    pw, HW = det, det + 60
+    scan = (rng.random((N, 2)) * 50 + 1.5).astype(np.float32)
+    psi = rc(rng, HW, HW)
+    probe = rc(rng, 1 if shared else N, S, pw, pw)
+    far = rc(rng, N, S, det, det)
+    chi = np.fft.ifft2(far, norm="ortho").astype(np.complex64)
+    patches = oracle.patch_fwd(psi, scan, patch_width=pw)  # (N, pw, pw)
+    want_obj = np.sum(np.conj(probe) * chi, axis=1)
+    want_num = 0.5 * np.sum(np.conj(patches[:, None]) * chi, axis=0)
+    st = A.stream_ptr()
+    d = {k: A.to_device(v) for k, v in dict(far=far, psi=psi, scan=scan,
+                                            probe=probe).items()}
+    work = torch.empty_like(d["far"])
+    check(lib.tike_fft2_pass1(A.ptr(d["far"]), A.ptr(work), N * S, det, 1, st))
+    before = work.clone()
+    objproj = torch.empty((N, pw, pw), dtype=torch.complex64, device="cuda")
+    num = torch.zeros((S, pw, pw), dtype=torch.complex64, device="cuda")
+    chi0 = torch.zeros((N, pw, pw), dtype=torch.complex64, device="cuda")
+    check(lib.tike_ifft2_pass2_products(
+        A.ptr(work), A.ptr(d["psi"]), A.ptr(d["scan"]), A.ptr(d["probe"]),
+        int(not shared), A.ptr(objproj), A.ptr(num), 0.5, A.ptr(chi0),
+        int(keep), N, S, det, HW, HW, 1.0 / det, st))
+    assert_close(objproj.cpu().numpy(), want_obj, what="objproj")
+    assert_close(num.cpu().numpy(), want_num, normwise=2e-5, what="numerator")
+    if keep:
+        assert_close(work.cpu().numpy(), chi, what="chi in place")
+    else:
+        assert torch.equal(work, before)
+        assert_close(chi0.cpu().numpy(), chi[:, 0], what="chi0")
+
+
 def test_ptycho_fwd_eigen_probe_on_the_fly(ops):
     """Varying probe synthesised inside the kernel == get_varying_probe."""
     from oracle import solvers as sol

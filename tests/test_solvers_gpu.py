@@ -1466,6 +1466,82 @@ def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
                                    rtol=5e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("depth,S,N,eigen,u16", [(2, 8, 10, False, False),
+                                                  (3, 2, 9, False, True),
+                                                  (2, 1, 12, False, False),
+                                                  (2, 5, 7, True, False)])
+def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16):
+    """A multislice object at 256^2 on the fused kernels (`tike_fwd_pass1`
+    with the incident probes -> `tike_fresnel_colpass` ->
+    `tike_fft2_pass2_inplace`; `tike_ifft2_pass2_products` on the way back):
+    two rpie epochs against the CPU oracle (rpie.py:367-495,
+    multislice.py:69-92, fresnelspectprop.py:52-113) and against the
+    slice-by-slice composition of the general operators."""
+    import importlib
+    import tike_amd.random
+    from oracle import operators as oops
+    from oracle import solvers as osol
+    R = importlib.import_module("tike_amd.ptycho.solvers.rpie")
+    det = 256
+    scan, psi_true, probe0, ep, ew, data = _headline_problem(
+        tp, det, S, N, seed=13 * depth + S, eigen=eigen)
+    phys = dict(wavelength=1e-10, fov=(2e-6, 2e-6), distance=1e-6)
+    psi0 = np.repeat(np.full_like(psi_true, 0.5), depth, axis=0)
+    psi0[1:] = 1.0
+    if u16:
+        data = np.round(data * (20000.0 / data.max())).astype(np.uint16)
+    batches = np.array_split(np.arange(N), 2)
+
+    def run(fused):
+        R.FUSED_MULTISLICE = fused
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
+            eigen_probe=None if ep is None else ep.copy(),
+            eigen_weights=None if ew is None else ew.copy(),
+            algorithm_options=tp.RpieOptions(num_batch=2, num_iter=2,
+                                             batch_method="compact",
+                                             alpha=1.0),
+            probe_options=tp.ProbeOptions(
+                force_orthogonality=True, probe_wavelength=phys["wavelength"],
+                probe_FOV_lengths=phys["fov"]),
+            object_options=tp.ObjectOptions(
+                multislice_propagation_distance=phys["distance"]),
+            exitwave_options=tp.ExitWaveOptions(
+                measured_pixels=np.ones((det, det), dtype=bool)))
+        try:
+            with tp.Reconstruction(data, params, order=np.arange(N),
+                                   batches=batches) as ctx:
+                ctx.iterate(2)
+                return ctx.get_result()
+        finally:
+            R.FUSED_MULTISLICE = True
+
+    got, slow = run(True), run(False)
+    np.testing.assert_allclose(np.array(got.algorithm_options.costs),
+                               np.array(slow.algorithm_options.costs),
+                               rtol=1e-4)
+    assert_close(got.psi, slow.psi, normwise=2e-4, maxabs=2e-3,
+                 what="psi vs slice by slice")
+    assert_close(got.probe, slow.probe, normwise=2e-4, maxabs=2e-3,
+                 what="probe vs slice by slice")
+    propagator = oops.fresnel_spectrum_propagator(
+        (det, det), phys["fov"], phys["distance"], phys["wavelength"])
+    fdata = data.astype(np.float32)
+    state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
+                 costs=[], eigen_probe=None if ep is None else ep.copy(),
+                 eigen_weights=None if ew is None else ew.copy())
+    state = osol.rescale_probe(state, fdata, det, propagator=propagator)
+    state = osol.iterate(state, fdata, batches, 2, detector_shape=det,
+                         solver="rpie", alpha=1.0, batch_method="compact",
+                         force_orthogonality=True, propagator=propagator)
+    np.testing.assert_allclose(np.array(got.algorithm_options.costs),
+                               np.array(state["costs"]), rtol=1e-3)
+    assert_close(got.psi, state["psi"], normwise=SOLVER_NORMWISE, maxabs=1e-2,
+                 what="psi")
+    assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe")
+
+
 @pytest.mark.parametrize("det,S,model", [(256, 2, "gaussian"),
                                          (64, 1, "gaussian"),
                                          (256, 3, "poisson")])

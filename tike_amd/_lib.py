@@ -51,6 +51,11 @@ _PROTOTYPES = {
     "tike_conv_adj_probe": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "tike_fft2": [_p, _p, _l, _i, _i, _f, _p],
     "tike_fresnel_spect_prop": [_p, _p, _p, _l, _i, _i, _f, _f, _p],
+    "tike_fft2_pass1": [_p, _p, _l, _i, _i, _p],
+    "tike_fft2_pass2_inplace": [_p, _l, _i, _i, _f, _p],
+    "tike_fresnel_colpass": [_p, _p, _i, _p, _l, _i, _f, _p],
+    "tike_ifft2_pass2_products": [_p, _p, _p, _p, _i, _p, _p, _f, _p, _i, _i, _i,
+                                  _i, _i, _i, _f, _p],
     "tike_ptycho_fwd": [_p, _p, _p, _i, _p, _p, _i, _i, _p, _i, _i, _i, _i,
                         _i, _i, _f, _i, _p],
     "tike_ptycho_adj": [_p, _p, _i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i,

@@ -23,11 +23,12 @@
 #include "internal.h"
 #include "tike_amd.h"
 
-// ----------------------------------------------------- inverse pass 1 alone
-// KEEP: plain stores (retained by the Infinity Cache, where pass 2 of the same
-// sub-batch finds them); otherwise non-temporal.
-template <int N, bool KEEP>
-__global__ __launch_bounds__(N, (N <= 256 ? 4 : 2)) void adj_ifft2_pass1_kernel(
+// ------------------------------------------- pass 1 alone, on plain tiles
+// (inverse: Ptycho.adj; forward and inverse: the Fresnel steps of a
+// multislice object).  KEEP: plain stores (retained by the Infinity Cache,
+// where pass 2 of the same sub-batch finds them); otherwise non-temporal.
+template <int N, bool INV, bool KEEP>
+__global__ __launch_bounds__(N, (N <= 256 ? 4 : 2)) void plain_pass1_kernel(
     const cf* __restrict__ farplane, cf* __restrict__ work, long ntile,
     const cf* __restrict__ twtab) {
   using G2 = Fft2Geom<N>;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(N, (N <= 256 ? 4 : 2)) void adj_ifft2_pass1_kernel(
     asm volatile("" : "+v"(line), "+v"(j));
     const FftTwLds<N> tw{twl, j};
     for (int r = 0; r < G2::RB; ++r)
-      fft2_pass1<N, true, !KEEP>(
+      fft2_pass1<N, INV, !KEEP>(
           lds, twtab, tw, line, j, r,
           [&](int y, int e, auto) { return tk_ld_stream(src + y * N + e); }, mid);
   }
@@ -68,11 +69,23 @@ __device__ __forceinline__ float tk_lane_up(float v) {
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
 }
 
-template <int N, int MW, int MPW, bool PER_POS>
-__global__ __launch_bounds__(256, (N == 512 || MW > 1) ? 2 : 3) void ifft2_pass2_adjoint_kernel(
+// OUT selects what becomes of chi and of conj(O) chi:
+//   0  Ptycho.adj: the tile is overwritten with conj(O_n) chi (probe_adj, one
+//      array per position);
+//   1  a slice of a multislice object that has slices in front of it
+//      (rpie.py:444-472): sum_n conj(O_n) chi accumulates in registers over the
+//      chunk (one atomic per pixel, mode and chunk into `pnum`, times
+//      `pnum_scale`) and the tile is overwritten with chi itself, which the
+//      Fresnel step back to the slice in front transforms next;
+//   2  the first slice: the same sums, and only mode 0 of chi is kept (`chi0`,
+//      for the eigen-probe weights).
+template <int N, int MW, int MPW, bool PER_POS, int OUT>
+__global__ __launch_bounds__(256, (N == 512 || MW > 1 || OUT > 0) ? 2 : 3)
+void ifft2_pass2_adjoint_kernel(
     cf* work, const cf* __restrict__ psi, const float* __restrict__ scan,
-    const cf* __restrict__ probe, cf* __restrict__ objproj, int nscan, int S, int H, int W,
-    float inv_scale, int chunk) {
+    const cf* __restrict__ probe, cf* __restrict__ objproj, float* __restrict__ pnum,
+    float pnum_scale, cf* __restrict__ chi0, int nscan, int S, int H, int W, float inv_scale,
+    int chunk) {
   constexpr int RB = N / 16;
   constexpr int CW = 4 / MW;
   constexpr int NCB = N / (64 * CW);
@@ -82,8 +95,9 @@ __global__ __launch_bounds__(256, (N == 512 || MW > 1) ? 2 : 3) void ifft2_pass2
   static_assert(NCB >= 1 && NSLICE % 8 == 0, "slice layout");
   static_assert(MW > 1 || MPW == 1, "a lone mode-wave writes objproj straight from one mode");
   // shared probe hoisted in registers when it fits beside one butterfly
-  // (two modes per wave: 64 more registers would leave one wave per SIMD)
-  constexpr bool HOIST = !PER_POS && RB <= 16 && MPW == 1;
+  // (two modes per wave, or the numerator's accumulators: 64 more registers
+  // would leave one wave per SIMD or spill)
+  constexpr bool HOIST = !PER_POS && RB <= 16 && MPW == 1 && OUT == 0;
   constexpr int NBUF = RB <= 16 ? 2 : 1;
   __shared__ cf part[REDUCE ? NBUF * 4 * RB * 64 : 1];  // [buf][wave][yb][lane]
   constexpr long P = (long)N * N;
@@ -104,6 +118,13 @@ __global__ __launch_bounds__(256, (N == 512 || MW > 1) ? 2 : 3) void ifft2_pass2
   const long slice0 = (long)ya * N + x0;
   const unsigned lb = (unsigned)lane * (unsigned)sizeof(cf);
   const long total = (long)H * W;
+  cf acc[OUT > 0 ? MPW : 1][OUT > 0 ? RB : 1];
+  if (OUT > 0) {
+#pragma unroll
+    for (int m = 0; m < MPW; ++m)
+#pragma unroll
+      for (int yb = 0; yb < RB; ++yb) acc[m][yb] = mk(0.f, 0.f);
+  }
   cf Pc[HOIST ? MPW : 1][HOIST ? RB : 1];
   if (HOIST) {
 #pragma unroll
@@ -186,7 +207,15 @@ __global__ __launch_bounds__(256, (N == 512 || MW > 1) ? 2 : 3) void ifft2_pass2
 #pragma unroll
           for (int i = 0; i < G; ++i) {
             const cf chi = u[g + i] * inv_scale;  // chi of row ya + 16 (g + i)
-            tk_st_stream(tk_at(tile + (g + i) * ROW, lo), oc[i] * chi);
+            if (OUT == 0) {
+              tk_st_stream(tk_at(tile + (g + i) * ROW, lo), oc[i] * chi);
+            } else {
+              acc[m][g + i] = acc[m][g + i] + oc[i] * chi;
+              if (OUT == 1)
+                tk_st_stream(tk_at(tile + (g + i) * ROW, lo), chi);
+              else if (s == 0 && chi0 != nullptr)
+                tk_st_stream(tk_at(chi0 + (long)n * P + slice0 + (g + i) * ROW, lo), chi);
+            }
             const cf t = pc[i] * chi;
             if (REDUCE)
               slot[(g + i) * 64] = m == 0 ? t : slot[(g + i) * 64] + t;
@@ -212,6 +241,20 @@ __global__ __launch_bounds__(256, (N == 512 || MW > 1) ? 2 : 3) void ifft2_pass2
       if (NBUF == 1) __syncthreads();
     }
   }
+  if (OUT > 0 && pnum != nullptr) {
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+      const int s = mw + MW * m;
+      if (s < S) {
+#pragma unroll
+        for (int yb = 0; yb < RB; ++yb) {
+          float* o = tk_at(pnum + 2 * ((long)s * P + slice0 + yb * ROW), lb);
+          unsafeAtomicAdd(o, acc[m][yb].x * pnum_scale);
+          unsafeAtomicAdd(o + 1, acc[m][yb].y * pnum_scale);
+        }
+      }
+    }
+  }
 }
 
 // psi_adj (H,W) c64 = planar accumulator (2,H,W) f32
@@ -222,22 +265,42 @@ __global__ __launch_bounds__(256) void adj_interleave_kernel(const float* __rest
 }
 
 template <int N>
-static int launch_adj_pass1(const cf* far, cf* work, long ntile, bool keep, hipStream_t stream) {
+static int launch_plain_pass1(const cf* in, cf* out, long ntile, bool inverse, bool keep,
+                              hipStream_t stream) {
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
-  if (keep)
-    hipLaunchKernelGGL((adj_ifft2_pass1_kernel<N, true>), dim3(tk_grid(ntile, 4)), dim3(N), 0,
-                       stream, far, work, ntile, tw);
+#define TK_PP1(INV, KEEP)                                                                     \
+  hipLaunchKernelGGL((plain_pass1_kernel<N, INV, KEEP>), dim3(tk_grid(ntile, 4)), dim3(N), 0, \
+                     stream, in, out, ntile, tw)
+  if (inverse && keep)
+    TK_PP1(true, true);
+  else if (inverse)
+    TK_PP1(true, false);
+  else if (keep)
+    TK_PP1(false, true);
   else
-    hipLaunchKernelGGL((adj_ifft2_pass1_kernel<N, false>), dim3(tk_grid(ntile, 4)), dim3(N), 0,
-                       stream, far, work, ntile, tw);
+    TK_PP1(false, false);
+#undef TK_PP1
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
 
-static int launch_adj_pass2(cf* work, const cf* psi, const float* scan, const cf* probe,
-                            int probe_per_scan, cf* objproj, int nscan, int S, int det, int H,
-                            int W, float inv_scale, hipStream_t stream) {
+int tk_fft2_pass1(const cf* in, cf* out, long ntile, int det, bool inverse, bool keep,
+                  hipStream_t stream) {
+  switch (det) {
+    case 128: return launch_plain_pass1<128>(in, out, ntile, inverse, keep, stream);
+    case 256: return launch_plain_pass1<256>(in, out, ntile, inverse, keep, stream);
+    case 512: return launch_plain_pass1<512>(in, out, ntile, inverse, keep, stream);
+    default: return TK_ERR_UNSUPPORTED;
+  }
+}
+
+// out: 0 probe_adj per position, 1 probe numerator + chi in place, 2 probe
+// numerator + chi0 (see the kernel)
+int tk_ifft2_pass2_products(cf* work, const cf* psi, const float* scan, const cf* probe,
+                            int probe_per_scan, cf* objproj, float* pnum, float pnum_scale,
+                            cf* chi0, int out, int nscan, int S, int det, int H, int W,
+                            float inv_scale, hipStream_t stream) {
   int MW = S >= 3 ? 4 : S;
   if (det == 128 && MW == 1) MW = 2;  // a 128-wide tile has only two 64-column waves
   const int MPW = S > 4 ? 2 : 1;
@@ -249,35 +312,55 @@ static int launch_adj_pass2(cf* work, const cf* psi, const float* scan, const cf
   if (chunk < 8) chunk = 8;
   nchunk = (nscan + chunk - 1) / chunk;
   const dim3 grid((unsigned)(nslice * nchunk)), block(256);
-#define TK_ADJ(N, MW_, MPW_)                                                                   \
-  do {                                                                                         \
-    if (probe_per_scan)                                                                        \
-      hipLaunchKernelGGL((ifft2_pass2_adjoint_kernel<N, MW_, MPW_, true>), grid, block, 0,     \
-                         stream, work, psi, scan, probe, objproj, nscan, S, H, W, inv_scale,   \
-                         chunk);                                                               \
-    else                                                                                       \
-      hipLaunchKernelGGL((ifft2_pass2_adjoint_kernel<N, MW_, MPW_, false>), grid, block, 0,    \
-                         stream, work, psi, scan, probe, objproj, nscan, S, H, W, inv_scale,   \
-                         chunk);                                                               \
+#define TK_ADJ_O(N, MW_, MPW_, PP, OUT_)                                                       \
+  hipLaunchKernelGGL((ifft2_pass2_adjoint_kernel<N, MW_, MPW_, PP, OUT_>), grid, block, 0,     \
+                     stream, work, psi, scan, probe, objproj, pnum, pnum_scale, chi0, nscan, S, \
+                     H, W, inv_scale, chunk)
+#define TK_ADJ(N, MW_, MPW_)                        \
+  do {                                              \
+    if (probe_per_scan && out == 0)                 \
+      TK_ADJ_O(N, MW_, MPW_, true, 0);              \
+    else if (probe_per_scan && out == 1)            \
+      TK_ADJ_O(N, MW_, MPW_, true, 1);              \
+    else if (probe_per_scan)                        \
+      TK_ADJ_O(N, MW_, MPW_, true, 2);              \
+    else if (out == 0)                              \
+      TK_ADJ_O(N, MW_, MPW_, false, 0);             \
+    else if (out == 1)                              \
+      TK_ADJ_O(N, MW_, MPW_, false, 1);             \
+    else                                            \
+      TK_ADJ_O(N, MW_, MPW_, false, 2);             \
   } while (0)
-#define TK_ADJ_N(N)                    \
-  do {                                 \
-    if (MW == 1)                       \
-      TK_ADJ(N < 256 ? 256 : N, 1, 1); \
-    else if (MW == 2)                  \
-      TK_ADJ(N, 2, 1);                 \
-    else if (MPW == 1)                 \
-      TK_ADJ(N, 4, 1);                 \
-    else                               \
-      TK_ADJ(N, 4, 2);                 \
+#define TK_ADJ_N(N, A)               \
+  do {                               \
+    if (MW == 1)                     \
+      A(N < 256 ? 256 : N, 1, 1);    \
+    else if (MW == 2)                \
+      A(N, 2, 1);                    \
+    else if (MPW == 1)               \
+      A(N, 4, 1);                    \
+    else                             \
+      A(N, 4, 2);                    \
   } while (0)
+  // (512^2: only Ptycho.adj -- with the numerator's accumulators beside a
+  // radix-32 butterfly the kernel would spill 70 registers)
+#define TK_ADJ512(N, MW_, MPW_)             \
+  do {                                      \
+    if (probe_per_scan)                     \
+      TK_ADJ_O(N, MW_, MPW_, true, 0);      \
+    else                                    \
+      TK_ADJ_O(N, MW_, MPW_, false, 0);     \
+  } while (0)
+  if (det == 512 && out != 0) return TK_ERR_UNSUPPORTED;
   switch (det) {
-    case 128: TK_ADJ_N(128); break;
-    case 256: TK_ADJ_N(256); break;
-    default: TK_ADJ_N(512); break;
+    case 128: TK_ADJ_N(128, TK_ADJ); break;
+    case 256: TK_ADJ_N(256, TK_ADJ); break;
+    default: TK_ADJ_N(512, TK_ADJ512); break;
   }
+#undef TK_ADJ512
 #undef TK_ADJ_N
 #undef TK_ADJ
+#undef TK_ADJ_O
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -313,14 +396,11 @@ extern "C" int tike_ptycho_adj(const void* farplane, const void* probe, int prob
       cf* work = (cf*)probe_adj + lo * S * det * det;
       const cf* pr = (const cf*)probe + (probe_per_scan ? lo * S * det * det : 0L);
       int rc;
-      switch (det) {
-        case 128: rc = launch_adj_pass1<128>(far, work, (long)m * S, keep, stream); break;
-        case 256: rc = launch_adj_pass1<256>(far, work, (long)m * S, keep, stream); break;
-        default: rc = launch_adj_pass1<512>(far, work, (long)m * S, keep, stream); break;
-      }
+      rc = tk_fft2_pass1(far, work, (long)m * S, det, true, keep, stream);
       if (rc) return rc;
-      rc = launch_adj_pass2(work, (const cf*)psi, scan + 2 * lo, pr, probe_per_scan,
-                            (cf*)objproj_work, m, S, det, H, W, scale, stream);
+      rc = tk_ifft2_pass2_products(work, (const cf*)psi, scan + 2 * lo, pr, probe_per_scan,
+                                   (cf*)objproj_work, nullptr, 0.f, nullptr, 0, m, S, det, H, W,
+                                   scale, stream);
       if (rc) return rc;
       rc = tike_scatter_patches(objproj_work, scan + 2 * lo, acc_work, m, pw, H, W, stream_);
       if (rc) return rc;

@@ -1,0 +1,178 @@
+// Fused stages of a multislice object (reference operators/cupy/multislice.py:
+// 69-92,144-194; fresnelspectprop.py:52-113; ptycho/solvers/rpie.py:367-495).
+//
+// The free-space step between two slices is FFT2 -> x propagator -> IFFT2
+// (FresnelSpectProp).  As generic transforms that is four trips of every wave
+// through memory plus one for the multiply; here it is three launches with
+// two hand-offs, built from the two-pass engine (fft_engine2.h):
+//   1. forward pass 1          rows + radix-16 column stage.  The first one of
+//                              a slice is tike_fwd_pass1 (it forms patch x
+//                              incident probe on the fly); on a stored wave
+//                              (the way back) it is tike_fft2_pass1;
+//   2. tike_fresnel_colpass    forward column pass -> x H (or conj H, the
+//                              adjoint) -> inverse radix-16 over k2, twiddle,
+//                              LDS transpose, inverse row transforms: the
+//                              spectrum never exists in memory;
+//   3. inverse pass 2          in place: tike_fft2_pass2_inplace on the way
+//                              forward (the result is the next slice's
+//                              incident probe), tike_ifft2_pass2_products on
+//                              the way back (fused with both numerators of the
+//                              slice in front).
+#include "fft_engine2.h"
+#include "internal.h"
+#include "tike_amd.h"
+
+// Work item = (tile, k1): a thread owns column t of the 16 rows {16 r + k1} of
+// the hand-off, software pipelined over k1 (the rows of k1 + 1 are requested
+// before the butterflies of k1).  H (N,N): the propagator in FFT order, shared
+// by every tile (L2).  N = 256.
+template <bool CONJ>
+__global__ __launch_bounds__(256, 4) void fresnel_colpass_kernel(
+    const cf* __restrict__ colin, cf* __restrict__ work, long ntile, float scale,
+    const cf* __restrict__ twtab, const cf* __restrict__ Hprop, int ksplit) {
+  constexpr int N = 256;
+  using G2 = Fft2Geom<N>;
+  static_assert(G2::RB == 16, "one radix-16 per direction");
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int kn = 16 / ksplit;
+  for (long w = blockIdx.x; w < ntile * ksplit; w += gridDim.x) {
+    // tiles in DESCENDING order: pass 1 wrote them ascending
+    const long tile = ntile - 1 - w / ksplit;
+    const int kbeg = (int)(w % ksplit) * kn;
+    const cf* __restrict__ src = colin + tile * (long)N * N;
+    cf* mid = work + tile * (long)N * N;
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    cf un[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) un[r] = tk_ld_stream(src + (16 * r + kbeg) * N + t);
+    for (int k1 = kbeg; k1 < kbeg + kn; ++k1) {
+      cf u[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = un[r];
+      if (k1 + 1 < kbeg + kn) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) un[r] = tk_ld_stream(src + (16 * r + k1 + 1) * N + t);
+      }
+      cf h[16];
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) h[k2] = Hprop[(k1 + 16 * k2) * N + t];
+      Dft<16, false>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2)
+        u[k2] = (u[k2] * (CONJ ? conjf(h[k2]) : h[k2])) * scale;
+      Dft<16, true>::run(u);
+#pragma unroll
+      for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
+      fft2_rows_from_columns<N, true, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
+    }
+  }
+}
+
+// Pass 2 alone, in place: rows {k1 + 16 r} of a tile in, the same rows out.
+// Work item = (tile, k1, 256-column block), tiles in descending order.
+template <int N, bool INV>
+__global__ __launch_bounds__(256, N == 512 ? 2 : 4) void colpass_inplace_kernel(cf* tiles,
+                                                                               long ntile,
+                                                                               float scale) {
+  constexpr int RB = N / 16, NH = N >= 256 ? N / 256 : 1, NT = N >= 256 ? 256 : N;
+  const long nitem = ntile * 16 * NH;
+  if ((int)threadIdx.x >= NT) return;
+  for (long v = blockIdx.x; v < nitem; v += gridDim.x) {
+    const int hb = (int)(v % NH);
+    const int k1 = (int)((v / NH) & 15);
+    const long tile = ntile - 1 - v / (16 * NH);
+    cf* p = tiles + tile * (long)N * N + (long)k1 * N + hb * 256 + threadIdx.x;
+    cf u[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) u[r] = p[(long)(16 * r) * N];
+    Dft<RB, INV>::run(u);
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) tk_st_stream(p + (long)(16 * k2) * N, u[k2] * scale);
+  }
+}
+
+extern "C" int tike_fft2_pass1(const void* in, void* out, long ntile, int det, int inverse,
+                               void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(ntile >= 0 && det >= 1);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(in && out && in != out);
+  return tk_fft2_pass1((const cf*)in, (cf*)out, ntile, det, inverse != 0, false,
+                       (hipStream_t)stream);
+}
+
+extern "C" int tike_fft2_pass2_inplace(void* tiles, long ntile, int det, int inverse, float scale,
+                                       void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && det >= 1);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(tiles != nullptr);
+  const long nitem = ntile * 16 * (det >= 256 ? det / 256 : 1);
+  const dim3 grid(tk_grid(nitem, 32)), block(256);
+#define TK_CP(N)                                                                              \
+  do {                                                                                        \
+    if (inverse)                                                                              \
+      hipLaunchKernelGGL((colpass_inplace_kernel<N, true>), grid, block, 0, stream, (cf*)tiles, \
+                         ntile, scale);                                                       \
+    else                                                                                      \
+      hipLaunchKernelGGL((colpass_inplace_kernel<N, false>), grid, block, 0, stream,          \
+                         (cf*)tiles, ntile, scale);                                           \
+  } while (0)
+  switch (det) {
+    case 128: TK_CP(128); break;
+    case 256: TK_CP(256); break;
+    case 512: TK_CP(512); break;
+    default: return TK_ERR_UNSUPPORTED;
+  }
+#undef TK_CP
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_fresnel_colpass(const void* colin, const void* propagator, int adjoint,
+                                    void* work, long ntile, int det, float scale,
+                                    void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(ntile >= 0 && det >= 1);
+  if (ntile == 0) return TK_OK;
+  TK_CHECK_ARG(colin && propagator && work && work != colin);
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  // few tiles: the 16 values of k1 of a tile are independent work items
+  int ksplit = 1;
+  while (ksplit < 16 && ntile * ksplit < 2048) ksplit *= 2;
+  const dim3 grid(tk_grid(ntile * ksplit, 4)), block(256);
+  if (adjoint)
+    hipLaunchKernelGGL((fresnel_colpass_kernel<true>), grid, block, 0, stream, (const cf*)colin,
+                       (cf*)work, ntile, scale, tw, (const cf*)propagator, ksplit);
+  else
+    hipLaunchKernelGGL((fresnel_colpass_kernel<false>), grid, block, 0, stream, (const cf*)colin,
+                       (cf*)work, ntile, scale, tw, (const cf*)propagator, ksplit);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_ifft2_pass2_products(void* work, const void* psi, const float* scan,
+                                         const void* probe, int probe_per_scan, void* objproj,
+                                         void* probe_numerator, float numerator_scale,
+                                         void* chi0, int keep_chi, int nscan, int S, int det,
+                                         int H, int W, float inv_scale, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1 && H >= 1 && W >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(work && psi && scan && probe && objproj);
+  if ((det != 128 && det != 256 && det != 512) || S > 8) return TK_ERR_UNSUPPORTED;
+  return tk_ifft2_pass2_products((cf*)work, (const cf*)psi, scan, (const cf*)probe,
+                                 probe_per_scan, (cf*)objproj, (float*)probe_numerator,
+                                 numerator_scale, (cf*)chi0, keep_chi ? 1 : 2, nscan, S, det, H,
+                                 W, inv_scale, (hipStream_t)stream);
+}

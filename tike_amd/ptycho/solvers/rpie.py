@@ -188,10 +188,141 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     return (tot[0] / count).to(torch.float32), probe_num
 
 
+FUSED_MULTISLICE = True
+"""256^2 tiles with probe window = detector, at most 8 modes, the gaussian
+model and the object being recovered: a multislice minibatch runs on the
+two-pass kernels (`_gradients_multislice_fused`).  False: the slice-by-slice
+composition of the general operators, which remains the path of every other
+configuration."""
+
+
+def _fused_multislice_shapes(op, S, pw, exitwave_options, recover_psi, data):
+    return (FUSED_MULTISLICE and recover_psi and pw == op.detector_shape
+            and pw == 256 and S <= 8
+            and exitwave_options.noise_model == "gaussian"
+            and isinstance(data, torch.Tensor))
+
+
+def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
+                                eigen_weights, lo, hi, comm, psi_num,
+                                probe_num, *, op, exitwave_options):
+    """rpie.py:367-495 for an object of several slices on the fused kernels.
+
+    Way forward, per slice d < D - 1: `tike_fwd_pass1` (patch of slice d x
+    incident probe, formed on the fly, through the first pass of the
+    transform) -> `tike_fresnel_colpass` (column pass x propagator -> inverse
+    pass 1) -> `tike_fft2_pass2_inplace`: the probe incident on slice d + 1,
+    kept for the way back.  Last slice: `tike_fwd_pass1` ->
+    `tike_fwd_grad_ifft2_pass1` (far field, cost, gradient factor and the
+    inverse's first pass in one launch; the far plane is never stored).
+    Way back, per slice tt: `tike_ifft2_pass2_products` finishes the inverse
+    and forms both numerators of the slice (object: through the grouped
+    scatter), then `tike_fft2_pass1` -> `tike_fresnel_colpass` (conjugated
+    propagator) hand the wave to the slice in front."""
+    dev = psi.device
+    B = hi - lo
+    D = psi.shape[0]
+    S, pw = probe.shape[-3], probe.shape[-1]
+    det = op.detector_shape
+    H, W = psi.shape[-2:]
+    st = A.stream_ptr()
+    fwd_scale, inv_scale = fft_scales(det, op.norm)
+    nmeasured, mask_u8 = L.mask_info(exitwave_options, det)
+    unmeasured = float(exitwave_options.unmeasured_pixels_scaling)
+    ws = L._workspace(op)
+    costs = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
+    chi0 = torch.empty((max(B, 1), pw, pw), dtype=torch.complex64, device=dev)
+    patches0 = (torch.empty_like(chi0) if eigen_weights is not None else None)
+    chunk = L.chunk_positions(S * D, det)
+    nmax = max(1, min(chunk, B))
+    far = ws.get("ms_far", (nmax, S, det, det), torch.complex64, dev)
+    mid = ws.get("ms_mid", (nmax, S, det, det), torch.complex64, dev)
+    beams = ws.get("ms_beams", (max(D - 1, 1), nmax, S, pw, pw),
+                   torch.complex64, dev)
+    objproj = ws.get("ms_objproj", (nmax, pw, pw), torch.complex64, dev)
+    acc = torch.zeros((D, 2, H, W), dtype=torch.float32, device=dev)
+    pacc = torch.zeros((D, S, pw, pw), dtype=torch.complex64, device=dev)
+    prop = op.diffraction.propagation._propagator((pw, pw), dev)
+    u16 = int(data.dtype == torch.uint16)
+    for clo in range(lo, hi, chunk):
+        chi_hi = min(hi, clo + chunk)
+        n = chi_hi - clo
+        blo = clo - lo
+        sc = scan[clo:chi_hi]
+        w_c = None if eigen_weights is None else eigen_weights[clo:chi_hi]
+        unique = get_varying_probe(probe, eigen_probe, w_c).contiguous()
+        # the probe incident on slice d: (tensor, one per position?)
+        incident = [(unique, int(unique.shape[0] != 1))]
+        for d in range(D - 1):
+            beam, per = incident[d]
+            check(
+                lib.tike_fwd_pass1(
+                    A.ptr(psi[d]), A.ptr(sc), A.ptr(beam), per, None, None,
+                    None, 0, 0, A.ptr(far),
+                    A.ptr(patches0[blo:blo + n])
+                    if d == 0 and patches0 is not None else None, n, S, pw,
+                    det, H, W, st), "slice exit wave, pass 1")
+            nxt = beams[d, :n]
+            check(
+                lib.tike_fresnel_colpass(A.ptr(far), A.ptr(prop), 0,
+                                         A.ptr(nxt), n * S, det,
+                                         fwd_scale * inv_scale, st),
+                "Fresnel step: column passes")
+            check(
+                lib.tike_fft2_pass2_inplace(A.ptr(nxt), n * S, det, 1, 1.0,
+                                            st), "Fresnel step: pass 2")
+            incident.append((nxt, 1))
+        beam, per = incident[D - 1]
+        check(
+            lib.tike_fwd_pass1(A.ptr(psi[D - 1]), A.ptr(sc), A.ptr(beam), per,
+                               None, None, None, 0, 0, A.ptr(far), None, n, S,
+                               pw, det, H, W, st), "last slice, pass 1")
+        check(
+            lib.tike_fwd_grad_ifft2_pass1(
+                A.ptr(far), A.ptr(data[clo:chi_hi]), u16, A.ptr(mask_u8),
+                A.ptr(costs[blo:blo + n]), A.ptr(mid), n, S, det, fwd_scale,
+                0, unmeasured, nmeasured, st),
+            "far field + gradient + inverse pass 1")
+        for tt in range(D - 1, -1, -1):
+            beam, per = incident[tt]
+            check(
+                lib.tike_ifft2_pass2_products(
+                    A.ptr(mid), A.ptr(psi[tt]), A.ptr(sc), A.ptr(beam), per,
+                    A.ptr(objproj), A.ptr(pacc[tt]), 1.0,
+                    A.ptr(chi0[blo:blo + n]) if tt == 0 else None,
+                    int(tt > 0), n, S, det, H, W, inv_scale, st),
+                "inverse pass 2 + numerators")
+            check(
+                lib.tike_scatter_patches(A.ptr(objproj), A.ptr(sc),
+                                         A.ptr(acc[tt]), n, pw, H, W, st),
+                "object numerator")
+            if tt == 0:
+                break
+            check(lib.tike_fft2_pass1(A.ptr(mid), A.ptr(far), n * S, det, 0,
+                                      st), "Fresnel step back: pass 1")
+            # (the inverse transform's normalisation is applied by the pass
+            # 2 that follows: tike_ifft2_pass2_products)
+            check(
+                lib.tike_fresnel_colpass(A.ptr(far), A.ptr(prop), 1,
+                                         A.ptr(mid), n * S, det, fwd_scale,
+                                         st),
+                "Fresnel step back: column passes")
+    if comm.collective:
+        comm.Allreduce(acc, pacc)
+    psi_num += torch.complex(acc[:, 0], acc[:, 1]) / S
+    probe_num[:, 0, 0] = pacc
+    return costs[:B], chi0[:B], None if patches0 is None else patches0[:B]
+
+
 def _gradients_multislice(data, psi, scan, probe, eigen_probe, eigen_weights,
                           lo, hi, comm, psi_num, probe_num, *, op,
                           exitwave_options, recover_psi):
     """rpie.py:367-495 for an object of several slices, slice by slice."""
+    if _fused_multislice_shapes(op, probe.shape[-3], probe.shape[-1],
+                                exitwave_options, recover_psi, data):
+        return _gradients_multislice_fused(
+            data, psi, scan, probe, eigen_probe, eigen_weights, lo, hi, comm,
+            psi_num, probe_num, op=op, exitwave_options=exitwave_options)
     dev = psi.device
     B = hi - lo
     D = psi.shape[0]

@@ -1,11 +1,19 @@
 #!/bin/bash
-# Same-box A/B of an environment switch: tools/ab_env.sh <reps> VAR=a VAR=b ...
-# alternating runs of the default bench (STEPS, WL as in ab_libs.sh).
+# Same-box A/B of environment switches: tools/ab_env.sh <reps> "<VAR=val ...>" "<VAR=val ...>" ...
+# (WL=c5 STEPS=4 for another workload); prints value + the per-entry averages
 reps=$1; shift
 for rep in $(seq $reps); do
-  for kv in "$@"; do
-    v=$(env $kv python3 bench.py --no-cpu-baseline --no-secondary --steps ${STEPS:-10} ${WL:+--workload $WL} 2>/dev/null |
-      python3 -c "import sys, json; print('%.0f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['value'])")
-    echo "$kv $v"
+  for e in "$@"; do
+    env $e python3 bench.py --no-cpu-baseline --no-secondary --breakdown --steps ${STEPS:-10} ${WL:+--workload $WL} 2>&1 |
+      python3 -c "
+import sys, json, re
+k = {}
+for line in sys.stdin:
+    m = re.match(r'\s+(tike_\w+)\s+calls\s+\d+ avg\s+([\d.]+) ms', line)
+    if m: k[m.group(1)] = float(m.group(2))
+    if line.startswith('{'): v = json.loads(line)['value']
+names = ['tike_fwd_pass1', 'tike_fwd_gradient_scale', 'tike_grad_ifft2_pass1', 'tike_fwd_grad_ifft2_pass1', 'tike_ifft2_pass2_gradients', 'tike_lstsq_step_stats', 'tike_scatter_patches', 'tike_eigen_pixel_update1', 'tike_eigen_position_sums1', 'tike_position_sums']
+print('%-28s %8.0f  ' % ('$e', v) + '  '.join('%.3f' % k.get(n, 0) for n in names))
+"
   done
 done
