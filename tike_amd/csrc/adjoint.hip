@@ -19,6 +19,8 @@
 //      planar accumulator; one psi-sized kernel interleaves it at the end.
 // chi is never stored; HBM sees the far plane once (read), probe_adj once
 // (write) when a sub-batch's intermediate stays in the Infinity Cache.
+#include <type_traits>
+
 #include "fft_engine2.h"
 #include "internal.h"
 #include "tike_amd.h"
@@ -98,7 +100,9 @@ void ifft2_pass2_adjoint_kernel(
   // (two modes per wave, or the numerator's accumulators: 64 more registers
   // would leave one wave per SIMD or spill)
   constexpr bool HOIST = !PER_POS && RB <= 16 && MPW == 1 && OUT == 0;
-  constexpr int NBUF = RB <= 16 ? 2 : 1;
+  // (two slot sets = one barrier per position; with two column-waves the
+  // shared patch takes their place: LDS must hold two workgroups per CU)
+  constexpr int NBUF = RB <= 16 && MW == 4 ? 2 : 1;
   __shared__ cf part[REDUCE ? NBUF * 4 * RB * 64 : 1];  // [buf][wave][yb][lane]
   constexpr long P = (long)N * N;
   const int v = blockIdx.x;
@@ -136,54 +140,78 @@ void ifft2_pass2_adjoint_kernel(
         Pc[m][yb] = conjf(*tk_at(probe + (long)sc * P + slice0 + yb * ROW, lb));
     }
   }
-  for (int n = b0; n < b1; ++n) {
-    unsigned lo = lb;
-    asm volatile("" : "+v"(lo));
+  // conj(O_n) of CNT rows yb = yb0 + i * step of this thread's column
+  auto patch_rows = [&](int n, auto cnt_tag, int yb0, int step, auto& o) {
+    constexpr int CNT = decltype(cnt_tag)::value;
     const TkCorner c = tk_corner(scan, n);
     const bool interior = c.sy >= 0 && c.sx >= 0 && c.sy + N < H && c.sx + N < W &&
                           total < (1L << 28);  // wave-uniform
-    // conj(O_n) of rows g .. g + G - 1 of this thread's column
-    auto patch_rows = [&](int g, cf (&o)[G]) {
-      if (interior) {
-        const cf* __restrict__ top = psi + (long)(c.sy + ya + 16 * g) * W + c.sx + x0;
-        cf a[G], d[G], ea[G], ed[G];
+    if (interior) {
+      const cf* __restrict__ top = psi + (long)(c.sy + ya + 16 * yb0) * W + c.sx + x0;
+      const long rstep = (long)(16 * step) * W;
+      cf a[CNT], d[CNT], ea[CNT], ed[CNT];
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-          a[i] = *tk_at(top + (long)(16 * i) * W, lo);
-          d[i] = *tk_at(top + (long)(16 * i + 1) * W, lo);
-          // the column right of the wave's last one: a uniform address
-          ea[i] = top[(long)(16 * i) * W + 64];
-          ed[i] = top[(long)(16 * i + 1) * W + 64];
-        }
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-          cf b = mk(tk_lane_up(a[i].x), tk_lane_up(a[i].y));
-          cf e = mk(tk_lane_up(d[i].x), tk_lane_up(d[i].y));
-          if (lane == 63) {
-            b = ea[i];
-            e = ed[i];
-          }
-          cf r = mk(a[i].x * c.w00, a[i].y * c.w00);
-          r.x += b.x * c.w01;
-          r.y += b.y * c.w01;
-          r.x += d[i].x * c.w10;
-          r.y += d[i].y * c.w10;
-          r.x += e.x * c.w11;
-          r.y += e.y * c.w11;
-          o[i] = conjf(r);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < G; ++i) {
-          const int y = c.sy + ya + 16 * (g + i), x = c.sx + x0 + lane;
-          const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-          const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
-          const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
-          const cf r = tk_gather(psi, (long)yc * W + xc, W, total, c);
-          o[i] = ok ? conjf(r) : mk(0.f, 0.f);
-        }
+      for (int i = 0; i < CNT; ++i) {
+        a[i] = *tk_at(top + i * rstep, lb);
+        d[i] = *tk_at(top + i * rstep + W, lb);
+        // the column right of the wave's last one: a uniform address
+        ea[i] = top[i * rstep + 64];
+        ed[i] = top[i * rstep + W + 64];
       }
-    };
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) {
+        cf b = mk(tk_lane_up(a[i].x), tk_lane_up(a[i].y));
+        cf e = mk(tk_lane_up(d[i].x), tk_lane_up(d[i].y));
+        if (lane == 63) {
+          b = ea[i];
+          e = ed[i];
+        }
+        cf r = mk(a[i].x * c.w00, a[i].y * c.w00);
+        r.x += b.x * c.w01;
+        r.y += b.y * c.w01;
+        r.x += d[i].x * c.w10;
+        r.y += d[i].y * c.w10;
+        r.x += e.x * c.w11;
+        r.y += e.y * c.w11;
+        o[i] = conjf(r);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CNT; ++i) {
+        const int y = c.sy + ya + 16 * (yb0 + i * step), x = c.sx + x0 + lane;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+        const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+        const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+        const cf r = tk_gather(psi, (long)yc * W + xc, W, total, c);
+        o[i] = ok ? conjf(r) : mk(0.f, 0.f);
+      }
+    }
+  };
+  // Several mode-waves work on the SAME pixels: each gathers 1 / MW of the
+  // rows of conj(O_n) and leaves them in LDS for the others -- for position
+  // n + 1 while position n is being processed, so that the barrier that
+  // closes the sum over the modes also publishes the next patch.
+  // (512^2: the slots of the mode sum alone take 64 KiB; a shared patch beside
+  // them would leave one workgroup per CU)
+  constexpr bool SHARE = MW > 1 && N <= 256;
+  constexpr int QR = RB / MW;  // rows gathered per wave
+  __shared__ cf osh[SHARE ? 2 * CW * RB * 64 : 1];  // [buf][column-wave][yb][lane]
+  auto publish = [&](int n, int buf) {
+    cf o[QR];
+    patch_rows(n, std::integral_constant<int, QR>{}, mw, MW, o);
+#pragma unroll
+    for (int i = 0; i < QR; ++i) osh[((buf * CW + cw) * RB + mw + MW * i) * 64 + lane] = o[i];
+  };
+  if (SHARE) {
+    if (b0 < b1) publish(b0, 0);
+    __syncthreads();
+  }
+  for (int n = b0; n < b1; ++n) {
+    unsigned lo = lb;
+    asm volatile("" : "+v"(lo));
+    const int obuf = (n - b0) & 1;
+    if (SHARE && n + 1 < b1) publish(n + 1, obuf ^ 1);
+    const cf* __restrict__ on = osh + ((obuf * CW + cw) * RB) * 64 + lane;
     cf* slot = part + ((((n - b0) & (NBUF - 1)) * 4 + w) * RB) * 64 + lane;
     const cf* slots = part + ((((n - b0) & (NBUF - 1)) * 4 + cw * MW) * RB) * 64 + lane;
 #pragma unroll
@@ -200,7 +228,12 @@ void ifft2_pass2_adjoint_kernel(
 #pragma unroll
         for (int g = 0; g < RB; g += G) {
           cf oc[G], pc[G];
-          patch_rows(g, oc);
+          if (SHARE) {
+#pragma unroll
+            for (int i = 0; i < G; ++i) oc[i] = on[(g + i) * 64];
+          } else {
+            patch_rows(n, std::integral_constant<int, G>{}, g, 1, oc);
+          }
 #pragma unroll
           for (int i = 0; i < G; ++i)
             pc[i] = HOIST ? Pc[m][g + i] : conjf(tk_ld_stream(tk_at(Ps + (g + i) * ROW, lo)));
