@@ -9,8 +9,9 @@ One "step" = one pass of the hot path over the whole synthetic dataset:
      detector, 8 probe modes + eigen-probe correction, 10 minibatches;
   c1: BASELINE configs[0] (256 positions, 128x128, 1 mode, cgrad);
   c2: 1 probe mode, cgrad;  c5: 512x512, 4 modes, position correction;
-  c3poisson / c3rpie: c3's shapes with the Poisson noise model / solved by
-     rpie (SURVEY 8 rows f2, f3: measured, not BASELINE configurations);
+  c3poisson / c3rpie / c3rpie2: c3's shapes with the Poisson noise model /
+     solved by rpie / by rpie on a two-slice object (SURVEY 8 rows f2, f3:
+     measured, not BASELINE configurations);
   fwdDxS: one launch of the fused forward operator (D = detector, S = modes);
   adjDxS: one call of the fused adjoint operator (stored far plane ->
      object gradient + per-position probe gradients).
@@ -429,6 +430,8 @@ EPOCH_DEFAULTS = {
     # lines in profiles/): c3 with the Poisson noise model; c3 solved by rpie
     "c3poisson": (256, 8, 10000, 10),
     "c3rpie": (256, 8, 10000, 10),
+    # ... and by rpie on a two-slice object (row f3, multislice part)
+    "c3rpie2": (256, 8, 10000, 10),
 }
 # The minibatches are contiguous chunks of the ONCE-SHUFFLED scan (SURVEY
 # 8(d)): each spans the whole field of view, like the batches the reference's
@@ -442,7 +445,7 @@ EPOCH_DEFAULTS = {
 BATCH_RULE = os.environ.get("TIKE_BENCH_BATCH_RULE", "wobbly_center")
 SOLVER_LABEL = {"c1": "cgrad (cg_iter=4)", "c2": "cgrad (cg_iter=4)",
                 "c3poisson": "lstsq_grad (poisson, all_modes)",
-                "c3rpie": "rpie"}
+                "c3rpie": "rpie", "c3rpie2": "rpie, two-slice object"}
 
 
 def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
@@ -475,23 +478,33 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
             p["scan"], p["probe"], num_eigen_probes=2, probes_with_modes=1)
         C = eigen_probe.shape[-4]
     data = tp.simulate(det, p["probe"], p["scan"], p["psi"])
+    psi0 = np.full_like(p["psi"], 0.5 + 0j)
+    multislice = {}
+    if workload == "c3rpie2":
+        # two slices, the one behind starts transparent; 0.1 nm, 2 um field
+        # of view, 1 um between the slices (tools/soak_multislice.py)
+        psi0 = np.concatenate([psi0, np.ones_like(psi0)])
+        multislice = dict(probe_wavelength=1e-10,
+                          probe_FOV_lengths=(2e-6, 2e-6))
     params = tp.PtychoParameters(
         probe=p["probe"].copy(),
-        psi=np.full_like(p["psi"], 0.5 + 0j), scan=p["scan"],
+        psi=psi0, scan=p["scan"],
         eigen_probe=eigen_probe, eigen_weights=eigen_weights,
         # BASELINE configs[0] / [1] name the conjugate-gradient solver
         algorithm_options=(tp.CgradOptions(num_batch=num_batch, cg_iter=4)
                            if workload in ("c1", "c2") else
                            tp.RpieOptions(num_batch=num_batch,
                                           batch_method=BATCH_RULE)
-                           if workload == "c3rpie" else
+                           if workload in ("c3rpie", "c3rpie2") else
                            tp.LstsqOptions(num_batch=num_batch,
                                            batch_method=BATCH_RULE)),
         exitwave_options=tp.ExitWaveOptions(
             measured_pixels=np.ones((det, det), dtype=bool),
             noise_model="poisson") if workload == "c3poisson" else None,
-        probe_options=tp.ProbeOptions(force_orthogonality=True),
-        object_options=tp.ObjectOptions(),
+        probe_options=tp.ProbeOptions(force_orthogonality=True, **multislice),
+        object_options=tp.ObjectOptions(
+            **(dict(multislice_propagation_distance=1e-6)
+               if multislice else {})),
         position_options=tp.PositionOptions(
             p["scan"].copy(), use_adaptive_moment=True,
             update_magnitude_limit=1.0) if workload == "c5" else None)

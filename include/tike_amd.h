@@ -359,6 +359,12 @@ int tike_probe_grad(const void* chi, const float* scan, const void* psi, void* p
 int tike_psi_preconditioner(const float* probe_amp, const float* scan, void* out, int nscan,
                             int pw, int H, int W, void* stream);
 
+/* the same with one real patch PER POSITION: out (H,W) f32 +=
+ * scatter_n( amp[n] ), amp (nscan,pw,pw) f32 -- the illumination of a slice
+ * behind the first one of a multislice object (_preconditioner.py:82-95). */
+int tike_scatter_amplitudes(const float* amp, const float* scan, float* out, int nscan, int pw,
+                            int H, int W, void* stream);
+
 /* out (pw,pw) c64: real part += sum_n |patch_n(psi)|^2
  * (solvers/_preconditioner.py:116-167). */
 int tike_probe_preconditioner(const float* scan, const void* psi, void* out, int nscan, int pw,

@@ -115,6 +115,7 @@ _PROTOTYPES = {
     "tike_probe_grad": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "tike_probe_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_psi_preconditioner": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "tike_scatter_amplitudes": [_p, _p, _p, _i, _i, _i, _i, _p],
     "tike_lstsq_step_stats": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p,
                               _p, _i, _i, _i, _i, _i, _i, _p, _p, _p],
     "tike_eigen_pixel_update1": [_p, _p, _p, _p, _p, _p, _l, _p, _p, _i, _i, _i,

@@ -346,6 +346,36 @@ extern "C" int tike_psi_preconditioner(const float* probe_amp, const float* scan
   return TK_OK;
 }
 
+// out (H,W) float32 += scatter_n( amp_n ), amp (nscan,pw,pw) f32: one real
+// patch PER POSITION (the illumination of a slice behind the first of a
+// multislice object, _preconditioner.py:82-95).
+__global__ __launch_bounds__(1024) void scatter_amplitudes_kernel(const float* __restrict__ amp,
+                                                                  const float* __restrict__ scan,
+                                                                  float* __restrict__ out,
+                                                                  int nscan, int pw, int H, int W,
+                                                                  int wmax) {
+  const long P = (long)pw * pw;
+  const long g = blockIdx.y;
+  const long n0 = g * TK_GROUP, n1 = min((long)nscan, n0 + TK_GROUP);
+  scatter_group<true>([&](long n, int y) { return amp + n * P + (long)y * pw; }, scan, n0, n1,
+                      blockIdx.x, wmax, out, out, pw, H, W);
+}
+
+extern "C" int tike_scatter_amplitudes(const float* amp, const float* scan, float* out,
+                                       int nscan, int pw, int H, int W, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(amp && scan && out);
+  int nstrip, wmax, threads;
+  tk_group_geometry(pw, &nstrip, &wmax, &threads);
+  const dim3 grid(nstrip, (nscan + TK_GROUP - 1) / TK_GROUP);
+  hipLaunchKernelGGL(scatter_amplitudes_kernel, grid, dim3(threads), 0, (hipStream_t)stream, amp,
+                     scan, out, nscan, pw, H, W, wmax);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 // ------------------------------------------------------------ probe gradient
 // One thread per probe pixel, a workgroup walks a chunk of positions keeping S
 // complex accumulators in registers; one atomic pair per (pixel, mode, chunk).

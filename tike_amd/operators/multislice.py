@@ -17,6 +17,41 @@ from .operator import Operator
 from .propagation import ZeroPropagation
 
 
+def fused_slices(probe_shape, detector_shape, S):
+    """Shapes whose slice-to-slice step runs on the two-pass kernels
+    (`next_incident_probe`): 256^2 tiles, probe window = detector, <= 8 modes."""
+    return probe_shape == detector_shape == 256 and S <= 8
+
+
+def next_incident_probe(psi_slice, scan, beam, scratch, out, propagator,
+                        scale, patches=None):
+    """The probe incident on the NEXT slice, fused (multislice.py:86-91 =
+    Convolution.fwd + FresnelSpectProp.fwd): `tike_fwd_pass1` forms patch x
+    incident probe on the fly and runs the first pass of the transform,
+    `tike_fresnel_colpass` the column pass x propagator -> inverse pass 1,
+    `tike_fft2_pass2_inplace` finishes in `out` (n, S, pw, pw).  beam
+    (1|n, ..., S, pw, pw) device tensor; scratch: a workspace shaped like
+    `out`; scale = forward x inverse normalisation; patches (n, pw, pw), if
+    given, receives the object patches of this slice."""
+    from .._lib import check, lib
+    n = scan.shape[0]
+    S, pw = out.shape[-3], out.shape[-1]
+    H, W = psi_slice.shape[-2:]
+    st = A.stream_ptr()
+    check(
+        lib.tike_fwd_pass1(A.ptr(psi_slice), A.ptr(scan), A.ptr(beam),
+                           int(beam.shape[0] != 1), None, None, None, 0, 0,
+                           A.ptr(scratch), A.ptr(patches), n, S, pw, pw, H, W,
+                           st), "slice exit wave, pass 1")
+    check(
+        lib.tike_fresnel_colpass(A.ptr(scratch), A.ptr(propagator), 0,
+                                 A.ptr(out), n * S, pw, scale, st),
+        "Fresnel step: column passes")
+    check(lib.tike_fft2_pass2_inplace(A.ptr(out), n * S, pw, 1, 1.0, st),
+          "Fresnel step: pass 2")
+    return out
+
+
 class Multislice(Operator):
     """Multiple-slice wavefield propagation."""
 

@@ -10,6 +10,8 @@ import torch
 
 from ... import _arrays as A
 from ..._lib import check, lib
+from ...operators.multislice import fused_slices, next_incident_probe
+from ...operators.propagation import fft_scales
 
 
 def _psi_preconditioner(parameters, operator):
@@ -45,6 +47,35 @@ def _psi_preconditioner_multislice(parameters, operator):
     check(
         lib.tike_psi_preconditioner(A.ptr(amp), A.ptr(scan), A.ptr(out[0]), N,
                                     pw, H, W, st), "psi preconditioner")
+    S = probe.shape[-3]
+    if fused_slices(pw, operator.detector_shape, S):
+        # slice by slice on the two-pass kernels, a chunk of positions at a
+        # time: the incident probes of all N positions never exist at once
+        fwd_scale, inv_scale = fft_scales(pw, operator.norm)
+        prop = operator.diffraction.propagation._propagator((pw, pw),
+                                                            psi.device)
+        chunk = max(1, min(N, 128))
+        bufs = [torch.empty((chunk, S, pw, pw), dtype=torch.complex64,
+                            device=psi.device) for _ in range(3)]
+        amp = torch.empty((chunk, pw, pw), dtype=torch.float32,
+                          device=psi.device)
+        for lo in range(0, N, chunk):
+            n = min(chunk, N - lo)
+            sc = scan[lo:lo + n]
+            beam = probe1
+            for i in range(1, D):
+                beam = next_incident_probe(
+                    psi[i - 1], sc, beam, bufs[2][:n], bufs[i % 2][:n], prop,
+                    fwd_scale * inv_scale)
+                check(
+                    lib.tike_intensity(A.ptr(beam), A.ptr(amp), n, S, pw * pw,
+                                       st), "illumination of a slice")
+                check(
+                    lib.tike_scatter_amplitudes(A.ptr(amp), A.ptr(sc),
+                                                A.ptr(out[i]), n, pw, H, W,
+                                                st),
+                    "psi preconditioner (slice)")
+        return out
     acc = torch.empty((2, H, W), dtype=torch.float32, device=psi.device)
     for i in range(1, D):
         probe1 = operator.diffraction.propagation.fwd(

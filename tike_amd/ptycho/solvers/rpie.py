@@ -27,6 +27,7 @@ from ... import linalg
 from ... import opt
 from ... import random as trandom
 from ..._lib import check, lib
+from ...operators.multislice import fused_slices, next_incident_probe
 from ...operators.propagation import fft_scales
 from ..probe import get_varying_probe
 from . import lstsq as L
@@ -197,8 +198,8 @@ configuration."""
 
 
 def _fused_multislice_shapes(op, S, pw, exitwave_options, recover_psi, data):
-    return (FUSED_MULTISLICE and recover_psi and pw == op.detector_shape
-            and pw == 256 and S <= 8
+    return (FUSED_MULTISLICE and recover_psi
+            and fused_slices(pw, op.detector_shape, S)
             and exitwave_options.noise_model == "gaussian"
             and isinstance(data, torch.Tensor))
 
@@ -233,7 +234,10 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
     costs = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
     chi0 = torch.empty((max(B, 1), pw, pw), dtype=torch.complex64, device=dev)
     patches0 = (torch.empty_like(chi0) if eigen_weights is not None else None)
-    chunk = L.chunk_positions(S * D, det)
+    # (a chunk holds far + mid + D - 1 sets of incident probes: 1.5 GiB per
+    # 256 positions at 8 modes and two slices; the launches of a 100-position
+    # chunk are too short to fill the chip more than twice)
+    chunk = L.chunk_positions(S, det)
     nmax = max(1, min(chunk, B))
     far = ws.get("ms_far", (nmax, S, det, det), torch.complex64, dev)
     mid = ws.get("ms_mid", (nmax, S, det, det), torch.complex64, dev)
@@ -254,23 +258,11 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
         # the probe incident on slice d: (tensor, one per position?)
         incident = [(unique, int(unique.shape[0] != 1))]
         for d in range(D - 1):
-            beam, per = incident[d]
-            check(
-                lib.tike_fwd_pass1(
-                    A.ptr(psi[d]), A.ptr(sc), A.ptr(beam), per, None, None,
-                    None, 0, 0, A.ptr(far),
-                    A.ptr(patches0[blo:blo + n])
-                    if d == 0 and patches0 is not None else None, n, S, pw,
-                    det, H, W, st), "slice exit wave, pass 1")
-            nxt = beams[d, :n]
-            check(
-                lib.tike_fresnel_colpass(A.ptr(far), A.ptr(prop), 0,
-                                         A.ptr(nxt), n * S, det,
-                                         fwd_scale * inv_scale, st),
-                "Fresnel step: column passes")
-            check(
-                lib.tike_fft2_pass2_inplace(A.ptr(nxt), n * S, det, 1, 1.0,
-                                            st), "Fresnel step: pass 2")
+            nxt = next_incident_probe(
+                psi[d], sc, incident[d][0], far[:n], beams[d, :n], prop,
+                fwd_scale * inv_scale,
+                patches=patches0[blo:blo + n]
+                if d == 0 and patches0 is not None else None)
             incident.append((nxt, 1))
         beam, per = incident[D - 1]
         check(
