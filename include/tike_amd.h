@@ -43,6 +43,21 @@ extern "C" {
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
 
+/* Deterministic mode (process-wide switch; off by default).  Off: sums that
+ * several workgroups contribute to -- the object gradient, the probe gradient,
+ * per-pattern costs, the sums of the step-size statistics -- are float atomics,
+ * as in the reference (operators/cupy/convolution.cu:51-66): their order and
+ * with it the last bits of every result change from run to run.  On: every
+ * such sum of the lstsq_grad / rpie path (gaussian model, one object slice)
+ * has one contributor per address, or its partial sums are written to
+ * `scratch` and added in a fixed order -- two runs give bit-identical
+ * iterates.  scratch: caller-owned DEVICE memory of `bytes` bytes that the
+ * library may use from then on (one user at a time: launches on one stream);
+ * 256 MiB serve a 256 x 256 x 8-mode minibatch; an entry that needs more
+ * returns TIKE_ERR_ARG.  Not covered: cgrad's line-search sums, the poisson
+ * step lengths. */
+int tike_set_deterministic(int on, void* scratch, long bytes);
+
 /* Create the per-device constant tables (FFT twiddles).  Allocates; call once
  * per device before capturing graphs.  Every other call does it lazily. */
 int tike_init(void);

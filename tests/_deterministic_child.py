@@ -1,0 +1,67 @@
+"""Child process of test_deterministic_mode: runs the reference's
+ReconstructTwice configuration (fixture lstsq_recon_compact) and a headline-shaped
+problem (256^2, 8 modes + eigen probe, the fused kernels) and prints one JSON
+line with hashes of every result and the errors against the fixture.  The
+parent runs it twice under TIKE_DETERMINISTIC=1 and once without."""
+import hashlib
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import numpy as np  # noqa: E402
+
+import tike_amd.ptycho as tp  # noqa: E402
+import tike_amd.random  # noqa: E402
+from test_solvers_gpu import (_headline_problem,  # noqa: E402
+                              _reconstruct_like_reference)
+from util import relerr  # noqa: E402
+
+
+def digest(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def main():
+    out = {}
+    g = np.load(os.path.join(HERE, "golden", "lstsq_recon_compact.npz"),
+                allow_pickle=False)
+    r1, r2 = _reconstruct_like_reference(tp, g, second=True)
+    out["compact"] = digest(r1.psi, r1.probe, np.array(r1.algorithm_options.costs),
+                            r2.psi, r2.probe, np.array(r2.algorithm_options.costs))
+    out["compact_err2"] = [float(relerr(r2.psi, g["psi_2"])),
+                           float(relerr(r2.probe, g["probe_2"]))]
+    out["compact_cost2"] = float(np.max(np.abs(
+        np.array(r2.algorithm_options.costs) / g["costs_2"] - 1)))
+    det, S, N = 256, 8, 24
+    scan, psi_true, probe0, ep, ew, data = _headline_problem(
+        tp, det, S, N, seed=5, eigen=True)
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=np.full_like(psi_true, 0.5), scan=scan.copy(),
+        eigen_probe=ep.copy(), eigen_weights=ew.copy(),
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
+                                          batch_method="wobbly_center"),
+        probe_options=tp.ProbeOptions(force_orthogonality=True),
+        object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    tike_amd.random.randomizer_np = np.random.default_rng(3)
+    os.environ.setdefault("TIKE_CHUNK_POSITIONS", "")
+    with tp.Reconstruction(data, params, order=np.arange(N),
+                           batches=np.array_split(np.arange(N), 2)) as ctx:
+        ctx.iterate(2)
+        r = ctx.get_result()
+    out["headline"] = digest(r.psi, r.probe, r.eigen_probe, r.eigen_weights,
+                             np.array(r.algorithm_options.costs))
+    out["headline_cost"] = [float(c[0]) for c in r.algorithm_options.costs]
+    out["headline_psi_norm"] = float(np.linalg.norm(r.psi))
+    print("RESULT " + json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1957,3 +1957,40 @@ def test_data_upload_moves_only_the_rows_it_is_asked_for(monkeypatch):
     assert A.has_invalid_counts(A.data_to_device(bad), block_bytes=3 * 140)
     bad[17, 2, 3] = np.nan
     assert A.has_invalid_counts(A.data_to_device(bad), block_bytes=3 * 140)
+
+
+def test_deterministic_mode_gives_bit_identical_runs():
+    """TIKE_DETERMINISTIC=1 (include/tike_amd.h `tike_set_deterministic`):
+    fixed-order sums instead of float atomics.  Two fresh processes produce
+    bit-identical objects, probes, eigen probes, weights and costs -- on the
+    general-shape kernels (the reference's ReconstructTwice run, fixture
+    lstsq_recon_compact, both calls) and on the fused 256^2 kernels (8 modes +
+    eigen probe) -- and the SECOND call of the fixture, whose tolerance is
+    5e-3 with atomics, agrees with the reference's run to 1e-3."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def child(det):
+        env = dict(os.environ, TIKE_DETERMINISTIC="1" if det else "0")
+        env.pop("TIKE_CHUNK_POSITIONS", None)
+        out = subprocess.run(
+            [sys.executable, os.path.join(here, "_deterministic_child.py")],
+            capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")]
+        return json.loads(line[-1][len("RESULT "):])
+
+    a, b, free = child(True), child(True), child(False)
+    assert a["compact"] == b["compact"]
+    assert a["headline"] == b["headline"]
+    assert a["headline_cost"] == b["headline_cost"]
+    # the same algorithm: the atomics run agrees to float32 round-off
+    np.testing.assert_allclose(a["headline_cost"], free["headline_cost"],
+                               rtol=1e-4)
+    np.testing.assert_allclose(a["headline_psi_norm"],
+                               free["headline_psi_norm"], rtol=1e-5)
+    assert max(a["compact_err2"]) < 1e-3, a["compact_err2"]
+    assert a["compact_cost2"] < 1e-3, a["compact_cost2"]

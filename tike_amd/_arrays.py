@@ -29,6 +29,9 @@ def require_gpu():
 
 def current_device():
     require_gpu()
+    from . import _lib
+    if _lib.DETERMINISTIC:
+        _lib.ensure_deterministic()
     return torch.device("cuda", torch.cuda.current_device())
 
 

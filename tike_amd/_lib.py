@@ -44,6 +44,7 @@ _d = ctypes.c_double
 _PROTOTYPES = {
     "tike_abi_version": [],
     "tike_init": [],
+    "tike_set_deterministic": [_i, _p, _l],
     "tike_patch_fwd": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "tike_patch_adj": [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "tike_conv_fwd": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -190,3 +191,25 @@ def check(rc, what=""):
     if rc >= ERR_COMM:
         raise RuntimeError(f"{what}: RCCL error {rc - ERR_COMM}")
     raise RuntimeError(f"{what}: HIP error {rc}")
+
+
+# TIKE_DETERMINISTIC=1: fixed-order sums instead of float atomics (bit-identical
+# iterates from run to run; include/tike_amd.h `tike_set_deterministic`).  The
+# scratch buffer the library needs is allocated here, on the device in use
+# when the first tensor goes to the GPU (tike_amd._arrays.current_device).
+DETERMINISTIC = os.environ.get("TIKE_DETERMINISTIC", "0") == "1"
+DETERMINISTIC_SCRATCH_MIB = int(os.environ.get("TIKE_DETERMINISTIC_MIB", "256"))
+_det_scratch = None
+
+
+def ensure_deterministic():
+    """Hand the library its scratch buffer once (no-op unless
+    TIKE_DETERMINISTIC=1)."""
+    global _det_scratch
+    if not DETERMINISTIC or _det_scratch is not None:
+        return
+    _det_scratch = torch.empty(DETERMINISTIC_SCRATCH_MIB << 20,
+                               dtype=torch.uint8, device="cuda")
+    check(lib.tike_set_deterministic(1, _det_scratch.data_ptr(),
+                                     _det_scratch.numel()),
+          "tike_set_deterministic")

@@ -343,6 +343,8 @@ int tk_ifft2_pass2_products(cf* work, const cf* psi, const float* scan, const cf
   int nchunk = (1536 + nslice - 1) / nslice;
   int chunk = (nscan + nchunk - 1) / nchunk;
   if (chunk < 8) chunk = 8;
+  // deterministic mode: the probe numerator has one contributor per address
+  if (out != 0 && tk_deterministic()) chunk = nscan > 8 ? nscan : 8;
   nchunk = (nscan + chunk - 1) / chunk;
   const dim3 grid((unsigned)(nslice * nchunk)), block(256);
 #define TK_ADJ_O(N, MW_, MPW_, PP, OUT_)                                                       \

@@ -9,6 +9,7 @@
 #include <mutex>
 
 #include "fft_engine2.h"
+#include "internal.h"
 #include "tike_amd.h"
 
 // ---------------------------------------------------------------- twiddles
@@ -36,6 +37,77 @@ const cf* tk_twiddles() {
 extern "C" int tike_abi_version(void) { return TIKE_ABI_VERSION; }
 
 extern "C" int tike_init(void) { return tk_twiddles() ? TK_OK : (int)hipErrorNotInitialized; }
+
+// ------------------------------------------------------- deterministic mode
+static bool g_det_on = false;
+static float* g_det_scratch = nullptr;
+static size_t g_det_bytes = 0;
+
+extern "C" int tike_set_deterministic(int on, void* scratch, long bytes) {
+  TK_CHECK_ARG(bytes >= 0 && (scratch != nullptr || bytes == 0));
+  g_det_on = on != 0;
+  g_det_scratch = on ? (float*)scratch : nullptr;
+  g_det_bytes = on ? (size_t)bytes : 0;
+  return TK_OK;
+}
+
+bool tk_deterministic() { return g_det_on; }
+
+float* tk_det_scratch(size_t bytes) {
+  return g_det_on && bytes <= g_det_bytes ? g_det_scratch : nullptr;
+}
+
+__global__ __launch_bounds__(256) void ordered_sum_kernel(float* __restrict__ out,
+                                                          const float* __restrict__ part,
+                                                          long n, int nparts, int accumulate) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+    float s = accumulate ? out[i] : 0.f;
+    for (int c = 0; c < nparts; ++c) s += part[(long)c * n + i];
+    out[i] = s;
+  }
+}
+
+int tk_ordered_sum(float* out, const float* part, long n, int nparts, bool accumulate,
+                   hipStream_t stream) {
+  if (n <= 0) return TK_OK;
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3(tk_grid((n + 255) / 256, 8)), dim3(256), 0, stream,
+                     out, part, n, nparts, accumulate ? 1 : 0);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// costs[n] = sum_slot part[n * nslots + slot], slots ascending
+__global__ __launch_bounds__(256) void cost_finish_kernel(float* __restrict__ costs,
+                                                          const float* __restrict__ part,
+                                                          long nscan, int nslots) {
+  for (long n = blockIdx.x * 256L + threadIdx.x; n < nscan; n += gridDim.x * 256L) {
+    float s = 0.f;
+    for (int k = 0; k < nslots; ++k) s += part[n * nslots + k];
+    costs[n] = s;
+  }
+}
+
+int tk_cost_sink(float* costs, long nscan, int nslots, hipStream_t stream, TkCostSink* sink) {
+  sink->costs = costs;
+  sink->part = nullptr;
+  sink->nslots = nslots;
+  if (costs == nullptr) return TK_OK;
+  if (tk_deterministic()) {
+    sink->part = tk_det_scratch(sizeof(float) * (size_t)nscan * nslots);
+    if (sink->part == nullptr) return TK_ERR_ARG;  // scratch buffer too small
+    return TK_OK;
+  }
+  hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
+  return e == hipSuccess ? TK_OK : (int)e;
+}
+
+int tk_cost_finish(const TkCostSink& sink, long nscan, hipStream_t stream) {
+  if (sink.part == nullptr || sink.costs == nullptr || nscan <= 0) return TK_OK;
+  hipLaunchKernelGGL(cost_finish_kernel, dim3(tk_grid((nscan + 255) / 256, 8)), dim3(256), 0,
+                     stream, sink.costs, sink.part, nscan, sink.nslots);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
 
 // ------------------------------------------------------------ pow2 kernel
 template <int N, bool INV>

@@ -277,6 +277,100 @@ __device__ __forceinline__ void scatter_group(RowFn&& rowptr, const float* __res
   }
 }
 
+// Deterministic form of the same sum (tike_set_deterministic): a wave OWNS 63
+// image columns of a strip of TK_GROWS rows and walks ALL positions in index
+// order, adding the footprint values of those that reach its pixels in
+// registers; the image is then updated by plain read-modify-writes -- every
+// pixel has one owner, every sum one order.  Same arithmetic per position as
+// scatter_group; no group boxes, so any position order costs the same.
+template <bool REAL_ONLY, class RowFn>
+__device__ __forceinline__ void scatter_ordered(RowFn&& rowptr, const float* __restrict__ scan,
+                                                long nscan, float* __restrict__ re,
+                                                float* __restrict__ im, int pw, int H, int W) {
+  using T = std::conditional_t<REAL_ONLY, float, cf>;
+  auto ld = [](const T* p) {
+    if constexpr (REAL_ONLY) return mk(*p, 0.f);
+    else return *p;
+  };
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int nwave = (int)blockDim.x >> 6;
+  const int lane = threadIdx.x & 63;
+  constexpr int R = TK_GROWS + 1;
+  const int Y0 = blockIdx.x * TK_GROWS;
+  const int Xw = ((int)blockIdx.y * nwave + wave) * TK_GCOLS;  // first owned column (uniform)
+  if (Y0 >= H || Xw >= W) return;
+  const int X = Xw + lane - 1;  // lane 0: the halo column left of the first owned one
+  float ar[TK_GROWS], ai[TK_GROWS];
+#pragma unroll
+  for (int k = 0; k < TK_GROWS; ++k) ar[k] = ai[k] = 0.f;
+  for (long n = 0; n < nscan; ++n) {
+    const float py = scan[2 * n], px = scan[2 * n + 1];
+    const int sy = (int)floorf(py), sx = (int)floorf(px);
+    // footprint rows [sy, sy + pw], columns [sx, sx + pw]: does it reach this
+    // wave's pixels?  (uniform)
+    if (sy > Y0 + TK_GROWS - 1 || sy + pw < Y0 || sx > Xw + TK_GCOLS - 1 || sx + pw < Xw) continue;
+    const float fy = py - floorf(py), fx = px - floorf(px);
+    const int xq = X - sx;
+    const bool okx = (unsigned)xq < (unsigned)pw;
+    const float wv = okx ? 1.0f - fx : 0.f;
+    const float wl = (unsigned)(xq - 1) < (unsigned)pw ? fx : 0.f;
+    const unsigned off = (unsigned)(okx ? xq : 0) * (unsigned)sizeof(T);
+    const int y0 = Y0 - sy - 1;
+    cf v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int y = y0 + j;
+      const bool oky = y >= 0 && y < pw;
+      const cf a = ld(tk_at(rowptr(n, oky ? y : 0), off));
+      v[j] = oky ? a : mk(0.f, 0.f);
+    }
+    cf u[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const cf left = mk(tk_lane_down(v[j].x), REAL_ONLY ? 0.f : tk_lane_down(v[j].y));
+      u[j] = mk(wv * v[j].x + wl * left.x, REAL_ONLY ? 0.f : wv * v[j].y + wl * left.y);
+    }
+#pragma unroll
+    for (int k = 0; k < TK_GROWS; ++k) {
+      ar[k] += (1.0f - fy) * u[k + 1].x + fy * u[k].x;
+      if (!REAL_ONLY) ai[k] += (1.0f - fy) * u[k + 1].y + fy * u[k].y;
+    }
+  }
+  if (lane > 0 && X < W) {
+#pragma unroll
+    for (int k = 0; k < TK_GROWS; ++k) {
+      const int Y = Y0 + k;
+      if (Y >= H) continue;
+      const long ii = (long)Y * W + X;
+      re[ii] += ar[k];
+      if (!REAL_ONLY) im[ii] += ai[k];
+    }
+  }
+}
+
+// grid of the ordered form: (strips of the image, blocks of 4 x 63 columns)
+static inline dim3 tk_ordered_grid(int H, int W) {
+  return dim3((unsigned)((H + TK_GROWS - 1) / TK_GROWS),
+              (unsigned)((W + 4 * TK_GCOLS - 1) / (4 * TK_GCOLS)));
+}
+
+__global__ __launch_bounds__(256) void scatter_patches_ordered_kernel(
+    const cf* __restrict__ proj, const float* __restrict__ scan, float* __restrict__ acc,
+    int nscan, int pw, int H, int W) {
+  const long P = (long)pw * pw;
+  scatter_ordered<false>([&](long n, int y) { return proj + n * P + (long)y * pw; }, scan, nscan,
+                         acc, acc + (long)H * W, pw, H, W);
+}
+
+__global__ __launch_bounds__(256) void psi_precond_ordered_kernel(const float* __restrict__ amp,
+                                                                  const float* __restrict__ scan,
+                                                                  float* __restrict__ out,
+                                                                  int nscan, int pw, int H, int W,
+                                                                  long amp_stride) {
+  scatter_ordered<true>([&](long n, int y) { return amp + n * amp_stride + (long)y * pw; }, scan,
+                        nscan, out, out, pw, H, W);
+}
+
 // ----------------------------------------------------------- object gradient
 // acc (2,H,W) planar f32 += scatter_n( objproj_n ),  objproj (nscan,pw,pw) c64 =
 // sum_s conj(P_n,s) chi_n,s  computed by tike_lstsq_gradients
@@ -309,6 +403,12 @@ extern "C" int tike_scatter_patches(const void* objproj, const float* scan, floa
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(objproj && scan && acc);
+  if (tk_deterministic()) {
+    hipLaunchKernelGGL(scatter_patches_ordered_kernel, tk_ordered_grid(H, W), dim3(256), 0,
+                       (hipStream_t)stream, (const cf*)objproj, scan, acc, nscan, pw, H, W);
+    TK_LAUNCH_CHECK();
+    return TK_OK;
+  }
   int nstrip, wmax, threads;
   tk_group_geometry(pw, &nstrip, &wmax, &threads);
   const dim3 grid(nstrip, (nscan + TK_GROUP - 1) / TK_GROUP);
@@ -337,6 +437,12 @@ extern "C" int tike_psi_preconditioner(const float* probe_amp, const float* scan
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(probe_amp && scan && out);
+  if (tk_deterministic()) {
+    hipLaunchKernelGGL(psi_precond_ordered_kernel, tk_ordered_grid(H, W), dim3(256), 0,
+                       (hipStream_t)stream, probe_amp, scan, (float*)out, nscan, pw, H, W, 0L);
+    TK_LAUNCH_CHECK();
+    return TK_OK;
+  }
   int nstrip, wmax, threads;
   tk_group_geometry(pw, &nstrip, &wmax, &threads);
   const dim3 grid(nstrip, (nscan + TK_GROUP - 1) / TK_GROUP);
@@ -367,6 +473,12 @@ extern "C" int tike_scatter_amplitudes(const float* amp, const float* scan, floa
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && H >= 1 && W >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(amp && scan && out);
+  if (tk_deterministic()) {
+    hipLaunchKernelGGL(psi_precond_ordered_kernel, tk_ordered_grid(H, W), dim3(256), 0,
+                       (hipStream_t)stream, amp, scan, out, nscan, pw, H, W, (long)pw * pw);
+    TK_LAUNCH_CHECK();
+    return TK_OK;
+  }
   int nstrip, wmax, threads;
   tk_group_geometry(pw, &nstrip, &wmax, &threads);
   const dim3 grid(nstrip, (nscan + TK_GROUP - 1) / TK_GROUP);
@@ -505,6 +617,10 @@ static void launch_probe_grad(dim3 grid, hipStream_t stream, const cf* chi, cons
 }
 
 static int probe_chunk(int nscan) {
+  // deterministic mode: one chunk, so that every sum over the positions has a
+  // single contributor per address (its one atomic then only adds to what
+  // earlier, stream-ordered launches left there)
+  if (tk_deterministic()) return nscan > 8 ? nscan : 8;
   // enough position chunks to fill the chip, at least 8 positions each
   int chunk = (nscan + 31) / 32;
   return chunk < 8 ? 8 : chunk;
@@ -587,7 +703,7 @@ template <int N, int MW, int MPW, bool HAVE_PROJ, bool EIG = true>
 __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
     const cf* __restrict__ mid, const cf* __restrict__ patches, const TkProbe probe,
     cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, float mpu_scale,
-    int nscan, int S, float inv_scale, int chunk) {
+    int nscan, int S, float inv_scale, int chunk, float* __restrict__ mpu_part) {
   constexpr int RB = N / 16;
   constexpr int CW = 4 / MW;            // column-waves per workgroup
   constexpr int NCB = N / (64 * CW);    // column blocks
@@ -778,9 +894,18 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
       if (s < S) {
 #pragma unroll
         for (int yb = 0; yb < RB; ++yb) {
-          float* o = tk_at(mpu + 2 * ((long)s * P + slice0 + yb * ROW), lb);
-          unsafeAtomicAdd(o, acc[m][yb].x * mpu_scale);
-          unsafeAtomicAdd(o + 1, acc[m][yb].y * mpu_scale);
+          if (mpu_part != nullptr) {
+            // deterministic mode: this chunk's partial sum, added up in chunk
+            // order by tk_ordered_sum after the launch
+            const long ci = (nchunk_ - 1) - b0 / chunk;
+            float* o = tk_at(mpu_part + 2 * ((ci * S + s) * P + slice0 + yb * ROW), lb);
+            o[0] = acc[m][yb].x * mpu_scale;
+            o[1] = acc[m][yb].y * mpu_scale;
+          } else {
+            float* o = tk_at(mpu + 2 * ((long)s * P + slice0 + yb * ROW), lb);
+            unsafeAtomicAdd(o, acc[m][yb].x * mpu_scale);
+            unsafeAtomicAdd(o + 1, acc[m][yb].y * mpu_scale);
+          }
         }
       }
     }
@@ -825,6 +950,14 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
   if (chunk < 8) chunk = 8;
   nchunk = (nscan + chunk - 1) / chunk;
   const dim3 grid((unsigned)(nslice * nchunk)), block(256);
+  // deterministic mode: per-chunk partial sums of the probe gradient in the
+  // caller's scratch buffer (one chunk when it is too small)
+  float* mpu_part = nullptr;
+  const long mpu_len = 2L * S * det * det;
+  if (m_probe_update && tk_deterministic()) {
+    mpu_part = tk_det_scratch(sizeof(float) * (size_t)mpu_len * nchunk);
+    if (mpu_part == nullptr) return TK_ERR_ARG;
+  }
   // LDS for the eigen-probe slices (only when they are applied on the fly)
   size_t eig_lds = 0;
   if (objproj && eigen_weights && eigen_probe)
@@ -837,18 +970,18 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
                          eig_lds,                                                            \
                          stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
                          (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
-                         chunk);                                                             \
+                         chunk, mpu_part);                                                   \
     else if (objproj)                                                                        \
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true, false>), grid,    \
                          block, 0,                                                           \
                          stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
                          (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
-                         chunk);                                                             \
+                         chunk, mpu_part);                                                   \
     else                                                                                     \
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, false>), grid, block,   \
                          0, stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,   \
                          (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
-                         chunk);                                                             \
+                         chunk, mpu_part);                                                   \
   } while (0)
 #define TK_P2G_N(N)                     \
   do {                                  \
@@ -869,6 +1002,8 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
 #undef TK_P2G_N
 #undef TK_P2G
   TK_LAUNCH_CHECK();
+  if (mpu_part != nullptr)
+    return tk_ordered_sum((float*)m_probe_update, mpu_part, mpu_len, nchunk, true, stream);
   return TK_OK;
 }
 
@@ -1115,6 +1250,7 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
   int nsplit = 1;
   while (nsplit < 16 && (long)nscan * nsplit * 2 <= 8192 && ((long)pw * pw) % (2048L * nsplit) == 0)
     nsplit *= 2;
+  if (tk_deterministic()) nsplit = 1;  // one workgroup per position: no atomics
   if (nsplit > 1) {
     hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * 8 * (size_t)nscan, (hipStream_t)stream);
     if (e == hipSuccess && eigen_proj)
@@ -1314,6 +1450,19 @@ __global__ __launch_bounds__(256) void eigen_pixel_update1_kernel(
   unsafeAtomicAdd(&update[2 * p + 1], acc.y);
 }
 
+// out[0] += scale * sum_n table[n * stride + col]: one workgroup, thread t takes
+// rows t, t + 256, ..., then the fixed tree of tk_block_sum256
+__global__ __launch_bounds__(256) void column_sum_ordered_kernel(const float* __restrict__ table,
+                                                                 int stride, int col, int n,
+                                                                 float scale,
+                                                                 float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += table[(long)i * stride + col] * scale;
+  a = tk_block_sum256(a, red);
+  if (threadIdx.x == 0) out[0] += a;
+}
+
 // Position sums against the (already updated) first eigen probe, plus
 // dsum[0] += sum_n sums[n][2] / P (the denominator mean, probe.py:463-469).
 __global__ __launch_bounds__(256) void eigen_position_sums1_kernel(
@@ -1368,7 +1517,7 @@ __global__ __launch_bounds__(256) void eigen_position_sums1_kernel(
       const float v = tk_block_sum256(a[k], red);
       if (threadIdx.x == 0) {
         sums[(long)n * 5 + k] = v;
-        if (k == 2) unsafeAtomicAdd(dsum, v / (float)R.P);
+        if (k == 2 && dsum != nullptr) unsafeAtomicAdd(dsum, v / (float)R.P);
       }
     }
   }
@@ -1476,8 +1625,13 @@ extern "C" int tike_eigen_position_sums1(const void* patches, const void* chi0,
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen0 && sums && dsum);
   const TkResidual R = make_residual(patches, chi0, mpu0, eigen0, nullptr, 1, 1, 0, pw, chi_modes);
+  const bool det = tk_deterministic();
   hipLaunchKernelGGL(eigen_position_sums1_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
-                     (hipStream_t)stream, R, sums, dsum, nscan, (const cf*)psi, scan, pw, H, W);
+                     (hipStream_t)stream, R, sums, det ? nullptr : dsum, nscan, (const cf*)psi,
+                     scan, pw, H, W);
+  if (det)  // dsum += sum_n sums[n][2] / P, one workgroup, a fixed order
+    hipLaunchKernelGGL(column_sum_ordered_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums,
+                       5, 2, nscan, 1.0f / (float)((long)pw * pw), dsum);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -1607,6 +1761,7 @@ extern "C" int tike_position_sums(const void* patches, const void* chi, int chi_
       tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes, S, pw);
   int nsplit = 1;
   while (nsplit < 16 && (long)nscan * nsplit * 2 <= 8192 && pw >= 64) nsplit *= 2;
+  if (tk_deterministic()) nsplit = 1;
   if (nsplit > 1) {
     hipError_t e = hipMemsetAsync(numerator, 0, sizeof(float) * 2 * (size_t)nscan,
                                   (hipStream_t)stream);

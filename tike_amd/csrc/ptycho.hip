@@ -831,7 +831,7 @@ template <int N, int MODEL, class DT>
 __global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, float* __restrict__ gscale,
-    float* __restrict__ intensity, float* __restrict__ costs, cf* __restrict__ farplane,
+    float* __restrict__ intensity, const TkCostSink costs, cf* __restrict__ farplane,
     long nitem, int S, float scale, float unmeasured_scaling, float inv_nmeasured,
     const int* __restrict__ skip) {
   constexpr int RB = N / 16;    // radix of the column pass
@@ -904,9 +904,9 @@ __global__ __launch_bounds__(256, N == 256 ? 4 : 2) void fwd_gradient_scale_kern
       for (int k2 = 0; k2 < RB; ++k2)
         gscale[n * (long)N * N + (long)(k1 + 16 * k2) * N + t] = I[k2];
     }
-    if (costs) {
+    if (costs.costs) {
       cost = tk_block_sum256(cost, red);
-      if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+      if (threadIdx.x == 0) tk_cost_add(costs, n, k1 * NH + hb, cost * inv_nmeasured);
     }
   }
 }
@@ -924,7 +924,13 @@ static int tk_fwd_gradient_scale(const void* scratch, const void* data, int data
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(scratch && data && (gscale || costs) && farplane != scratch);
   if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
-  if (costs) {
+  // (a speculative launch may return at once: its cost slots would be stale,
+  // so the line searches keep the zeroed atomics)
+  TkCostSink sink{costs, nullptr, 0};
+  if (skip == nullptr) {
+    int rc = tk_cost_sink(costs, nscan, 16 * (det / 256), stream, &sink);
+    if (rc) return rc;
+  } else if (costs) {
     hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
     if (e != hipSuccess) return (int)e;
   }
@@ -933,7 +939,7 @@ static int tk_fwd_gradient_scale(const void* scratch, const void* data, int data
   const dim3 grid(tk_grid(nitem, 32)), block(256);
 #define TK_FGS(N, M, DT)                                                                     \
   hipLaunchKernelGGL((fwd_gradient_scale_kernel<N, M, DT>), grid, block, 0, stream,             \
-                     (const cf*)scratch, (const DT*)data, measured, gscale, intensity, costs,   \
+                     (const cf*)scratch, (const DT*)data, measured, gscale, intensity, sink,    \
                      (cf*)farplane, nitem, S, scale, unmeasured_scaling, inv, skip)
 #define TK_FGS_N(N)                     \
   do {                                  \
@@ -953,7 +959,7 @@ static int tk_fwd_gradient_scale(const void* scratch, const void* data, int data
 #undef TK_FGS_N
 #undef TK_FGS
   TK_LAUNCH_CHECK();
-  return TK_OK;
+  return tk_cost_finish(sink, nscan, stream);
 }
 
 extern "C" int tike_fwd_gradient_scale(const void* scratch, const void* data, int data_u16,
@@ -2135,7 +2141,7 @@ template <int MODEL, bool GRAD>
 __global__ __launch_bounds__(256) void farplane_gradient_kernel(
     cf* __restrict__ farplane, const float* __restrict__ data,
     const unsigned char* __restrict__ mask, float* __restrict__ intensity,
-    float* __restrict__ costs, int nscan, int S, int det, float unmeasured_scaling,
+    const TkCostSink costs, int nscan, int S, int det, float unmeasured_scaling,
     float inv_nmeasured, const int* __restrict__ skip) {
   __shared__ float red[4];
   if (skip != nullptr && *skip != 0) return;  // speculative launch, not needed
@@ -2170,9 +2176,9 @@ __global__ __launch_bounds__(256) void farplane_gradient_kernel(
     if (GRAD)
       for (int s = 0; s < S; ++s) F[s * npix + p] = F[s * npix + p] * g;
   }
-  if (costs) {
+  if (costs.costs) {
     cost = tk_block_sum256(cost, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+    if (threadIdx.x == 0) tk_cost_add(costs, n, (int)blockIdx.x, cost * inv_nmeasured);
   }
 }
 
@@ -2185,16 +2191,20 @@ static int tk_farplane_gradient(void* farplane, const float* data, const unsigne
   TK_CHECK_ARG(num_measured > 0);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(farplane && data);
-  if (costs) {
-    hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
-    if (e != hipSuccess) return (int)e;
-  }
   const float inv = 1.0f / (float)num_measured;
   const long npix = (long)det * det;
   const dim3 grid((unsigned)((npix + TK_FG_PIX - 1) / TK_FG_PIX), (unsigned)nscan), block(256);
+  TkCostSink sink{costs, nullptr, 0};
+  if (skip == nullptr) {
+    int rc = tk_cost_sink(costs, nscan, (int)grid.x, stream, &sink);
+    if (rc) return rc;
+  } else if (costs) {
+    hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
+    if (e != hipSuccess) return (int)e;
+  }
 #define TK_FG(M, G)                                                                          \
   hipLaunchKernelGGL((farplane_gradient_kernel<M, G>), grid, block, 0, stream, (cf*)farplane, \
-                     data, measured, intensity, costs, nscan, S, det, unmeasured_scaling, inv,    \
+                     data, measured, intensity, sink, nscan, S, det, unmeasured_scaling, inv,     \
                      skip)
   if (model == 0 && apply_gradient) TK_FG(0, true);
   if (model == 0 && !apply_gradient) TK_FG(0, false);
@@ -2202,7 +2212,7 @@ static int tk_farplane_gradient(void* farplane, const float* data, const unsigne
   if (model == 1 && !apply_gradient) TK_FG(1, false);
 #undef TK_FG
   TK_LAUNCH_CHECK();
-  return TK_OK;
+  return tk_cost_finish(sink, nscan, stream);
 }
 
 extern "C" int tike_farplane_gradient(void* farplane, const float* data,
@@ -2224,7 +2234,7 @@ template <int MODEL>
 __global__ __launch_bounds__(256) void gradient_scale_kernel(
     const float* __restrict__ intensity, const float* __restrict__ data,
     const unsigned char* __restrict__ mask, float* __restrict__ gscale,
-    float* __restrict__ costs, int det, float unmeasured_scaling, float inv_nmeasured) {
+    const TkCostSink costs, int det, float unmeasured_scaling, float inv_nmeasured) {
   __shared__ float red[4];
   const long npix = (long)det * det;
   const long n = blockIdx.y;
@@ -2248,9 +2258,9 @@ __global__ __launch_bounds__(256) void gradient_scale_kernel(
     cost += measured ? term : 0.f;
     gscale[n * npix + p] = measured ? g : unmeasured_scaling - 1.0f;
   }
-  if (costs) {
+  if (costs.costs) {
     cost = tk_block_sum256(cost, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+    if (threadIdx.x == 0) tk_cost_add(costs, n, (int)blockIdx.x, cost * inv_nmeasured);
   }
 }
 
@@ -2263,21 +2273,20 @@ extern "C" int tike_gradient_scale(const float* intensity, const float* data,
   TK_CHECK_ARG(nscan >= 0 && det >= 1 && (model == 0 || model == 1) && num_measured > 0);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(intensity && data && gscale);
-  if (costs) {
-    hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
-    if (e != hipSuccess) return (int)e;
-  }
   const float inv = 1.0f / (float)num_measured;
   const long npix = (long)det * det;
   const dim3 grid((unsigned)((npix + TK_FG_PIX - 1) / TK_FG_PIX), (unsigned)nscan), block(256);
+  TkCostSink sink;
+  int rc = tk_cost_sink(costs, nscan, (int)grid.x, stream, &sink);
+  if (rc) return rc;
   if (model == 0)
     hipLaunchKernelGGL((gradient_scale_kernel<0>), grid, block, 0, stream, intensity, data,
-                       measured, gscale, costs, det, unmeasured_scaling, inv);
+                       measured, gscale, sink, det, unmeasured_scaling, inv);
   else
     hipLaunchKernelGGL((gradient_scale_kernel<1>), grid, block, 0, stream, intensity, data,
-                       measured, gscale, costs, det, unmeasured_scaling, inv);
+                       measured, gscale, sink, det, unmeasured_scaling, inv);
   TK_LAUNCH_CHECK();
-  return TK_OK;
+  return tk_cost_finish(sink, nscan, stream);
 }
 
 // IFFT2 + crop of (farplane * gscale): gscale (ntile / S, det, det) f32 is
@@ -2445,7 +2454,7 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
 template <int MODEL, class DT>
 __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
-    const unsigned char* __restrict__ mask, float* __restrict__ costs, cf* __restrict__ work,
+    const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
     long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
     const cf* __restrict__ twtab) {
   constexpr int N = 256;
@@ -2496,9 +2505,9 @@ __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
       tk_request_data16(data, mask, n, k1, t, raw, bits);
       cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
     }
-    if (costs) {
+    if (costs.costs) {
       cost = tk_block_sum256(cost, red);
-      if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+      if (threadIdx.x == 0) tk_cost_add(costs, n, k1, cost * inv_nmeasured);
     }
     // ---- sweep B: modes S - 1 .. 0, gradient and the inverse's pass 1
     for (int s = S - 1; s >= 0; --s) {
@@ -2527,7 +2536,7 @@ __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
 template <int MODEL, class DT>
 __global__ __launch_bounds__(256, 4) void fwd_grad_ifft2_pass1_single_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
-    const unsigned char* __restrict__ mask, float* __restrict__ costs, cf* __restrict__ work,
+    const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
     long nscan, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
     const cf* __restrict__ twtab) {
   constexpr int N = 256;
@@ -2559,9 +2568,9 @@ __global__ __launch_bounds__(256, 4) void fwd_grad_ifft2_pass1_single_kernel(
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) I[k2] = norm2(u[k2]) * s2;
     float cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
-    if (costs) {
+    if (costs.costs) {
       cost = tk_block_sum256(cost, red);
-      if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+      if (threadIdx.x == 0) tk_cost_add(costs, n, k1, cost * inv_nmeasured);
     }
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) u[k2] = u[k2] * I[k2];
@@ -2609,7 +2618,7 @@ __device__ __forceinline__ void fft2_rows_from_columns_half(cf* __restrict__ lds
 template <int MH, int MODEL, class DT>
 __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
-    const unsigned char* __restrict__ mask, float* __restrict__ costs, cf* __restrict__ work,
+    const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
     long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
     const cf* __restrict__ twtab) {
   constexpr int N = 256;
@@ -2679,9 +2688,10 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
       __syncthreads();
     }
     float cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
-    if (costs && h == 0) {
+    if (costs.costs && h == 0) {
       cost = tk_wave_sum(cost);
-      if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
+      if ((threadIdx.x & 63) == 0)
+        tk_cost_add(costs, n, k1 * 4 + (int)(threadIdx.x >> 6), cost * inv_nmeasured);
     }
     const long vn = v + gridDim.x;
 #pragma unroll
@@ -2841,17 +2851,20 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
   if (det != 256) return TK_ERR_UNSUPPORTED;
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
-  if (costs) {
-    hipError_t e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
-    if (e != hipSuccess) return (int)e;
+  const bool resident = S >= TK_FG_RESIDENT_MIN_MODES && S <= 8;
+  // contributors per pattern: (k1, wave of the first half) / (k1)
+  TkCostSink sink;
+  {
+    int rc = tk_cost_sink(costs, nscan, resident ? 64 : 16, stream, &sink);
+    if (rc) return rc;
   }
   const float inv = 1.0f / (float)num_measured;
-  if (S >= TK_FG_RESIDENT_MIN_MODES && S <= 8) {
+  if (resident) {
     // one 512-thread workgroup per CU (it takes the whole register file)
     const dim3 grid(tk_grid((long)nscan * 16, 1)), block(512);
 #define TK_FGR(MH, M, DT)                                                                     \
   hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT>), grid, block, 0,       \
-                     stream, (const cf*)scratch, (const DT*)data, measured, costs, (cf*)work, \
+                     stream, (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work, \
                      (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
 #define TK_FGR_M(MH)                                                                          \
   do {                                                                                        \
@@ -2871,13 +2884,13 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
 #undef TK_FGR_M
 #undef TK_FGR
     TK_LAUNCH_CHECK();
-    return TK_OK;
+    return tk_cost_finish(sink, nscan, stream);
   }
   const dim3 grid(tk_grid((long)nscan * 16, 12)), block(256);
   if (S == 1) {
 #define TK_FG1(M, DT)                                                                         \
   hipLaunchKernelGGL((fwd_grad_ifft2_pass1_single_kernel<M, DT>), grid, block, 0, stream,     \
-                     (const cf*)scratch, (const DT*)data, measured, costs, (cf*)work,         \
+                     (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work,         \
                      (long)nscan, fwd_scale, unmeasured_scaling, inv, tw)
     if (model == 0 && data_u16)
       TK_FG1(0, unsigned short);
@@ -2889,11 +2902,11 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
       TK_FG1(1, float);
 #undef TK_FG1
     TK_LAUNCH_CHECK();
-    return TK_OK;
+    return tk_cost_finish(sink, nscan, stream);
   }
 #define TK_FG(M, DT)                                                                          \
   hipLaunchKernelGGL((fwd_grad_ifft2_pass1_kernel<M, DT>), grid, block, 0, stream,            \
-                     (const cf*)scratch, (const DT*)data, measured, costs, (cf*)work,         \
+                     (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work,         \
                      (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
   if (model == 0 && data_u16)
     TK_FG(0, unsigned short);
@@ -2905,7 +2918,7 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
     TK_FG(1, float);
 #undef TK_FG
   TK_LAUNCH_CHECK();
-  return TK_OK;
+  return tk_cost_finish(sink, nscan, stream);
 }
 
 extern "C" int tike_grad_ifft2_pass1(const void* colin, const float* gscale,

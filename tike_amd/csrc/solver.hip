@@ -292,7 +292,7 @@ extern "C" int tike_eigen_normalise(void* eigen, const void* update, double coun
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(work, 0, 4 * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
-  const int grid = npix >= 256 * 64 ? 64 : (npix + 255) / 256;
+  const int grid = tk_deterministic() ? 1 : (npix >= 256 * 64 ? 64 : (npix + 255) / 256);
   hipLaunchKernelGGL(eigen_normalise_sums_kernel, dim3(grid), dim3(256), 0, st, (const cf*)eigen,
                      (const cf*)update, npix, work);
   hipLaunchKernelGGL(eigen_normalise_apply_kernel, dim3(grid), dim3(256), 0, st, (cf*)eigen,
@@ -446,7 +446,11 @@ extern "C" int tike_lstsq_tail_mid(void* eigen0, const void* update, int npix, f
   TK_ENTER();
   TK_CHECK_ARG(B >= 0 && count > 0 && sums3 && tail3 && (B == 0 || stats));
   TK_CHECK_ARG(!eigen0 || (update && nacc && npix >= 1));
-  const int grid = !eigen0 ? 0 : (npix >= 256 * 64 ? 64 : (npix + 255) / 256);
+  // (deterministic mode: ONE summing workgroup, so the three sums have one
+  // contributor each)
+  const int grid = !eigen0 ? 0
+                           : (tk_deterministic() ? 1
+                                                 : (npix >= 256 * 64 ? 64 : (npix + 255) / 256));
   hipLaunchKernelGGL(lstsq_tail_mid_kernel, dim3(grid + 1), dim3(256), 0, (hipStream_t)stream,
                      (const cf*)eigen0, (const cf*)update, npix, nacc, stats, B, eps, sums3,
                      (float)(1.0 / count), recover_psi, recover_probe, tail3);
