@@ -1,10 +1,12 @@
 """Guard of the "from scratch" rule (build container only): no function of
-tike_amd/ with >= 8 body lines may resemble its namesake in the reference.
-`tools/similarity.py` compares token streams (docstrings stripped, formatting
-normalised).  The limit is 0.6, on the whole function (signature included,
-although parameter lists are the drop-in contract) and on the body alone.
-Skipped where /root/reference does not exist (the GPU box)."""
+tike_amd/ with >= 8 body lines may resemble ANY function of the reference of
+comparable size (0.5x .. 2x the tokens) -- not only its namesake: a renamed
+copy has none.  `tools/similarity.py` compares token streams (docstrings
+stripped, formatting normalised).  The limit is 0.6, on the whole function
+(signature included, although parameter lists are the drop-in contract) and on
+the body alone.  Skipped where /root/reference does not exist (the GPU box)."""
 import os
+import re
 import subprocess
 import sys
 
@@ -15,16 +17,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src/tike"),
                     reason="needs the reference tree (build container only)")
-def test_no_function_resembles_its_reference_namesake():
+def test_no_function_resembles_any_reference_function():
     out = subprocess.run(
         [sys.executable, os.path.join(ROOT, "tools", "similarity.py"),
-         "--threshold", "0.6", "--min-lines", "8"],
-        capture_output=True, text=True, timeout=600)
+         "--threshold", "0.6", "--min-lines", "8", "--all"],
+        capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:]
-    listing = subprocess.run(
-        [sys.executable, os.path.join(ROOT, "tools", "similarity.py"),
-         "--threshold", "0.0", "--min-lines", "8"],
-        capture_output=True, text=True, timeout=600).stdout
-    bodies = [float(line.split("(body ")[1].split(")")[0])
-              for line in listing.splitlines() if "(body " in line]
-    assert bodies and max(bodies) < 0.6, max(bodies)
+    scores = [(float(m.group(1)), float(m.group(2)))
+              for m in re.finditer(r"^(\d\.\d+) \(body (\d\.\d+),", out.stdout,
+                                   flags=re.M)]
+    assert len(scores) > 100, out.stdout[-2000:]
+    assert max(max(s) for s in scores) < 0.6
+    assert "every reference function of comparable size" in out.stdout

@@ -1912,33 +1912,15 @@ extern "C" int tike_ptycho_fwd(const void* psi, const float* scan, const void* p
     // share and the tile-major kernel below, with its higher occupancy, is
     // 7 % faster); the varying-probe case needs tike_varying_probe first and
     // is served by tike_ptycho_fwd_intensity
-    switch (det) {
-      case 128:
-        return launch_fwd_pos<128>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale,
-                                   stream);
-      case 256:
-        return launch_fwd_pos<256>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale,
-                                   stream);
-      case 512:
-        return launch_fwd_pos<512>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale,
-                                   stream);
-      default: break;
-    }
+    // (256 / 512 never get here: the two streaming kernels above)
+    if (det == 128)
+      return launch_fwd_pos<128>(psi_, scan, P, far, nullptr, nscan, S, pw, H, W, scale, stream);
   }
-  {
-    switch (det) {
-      case 128: return launch_fwd_v2<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
-      case 256: return launch_fwd_v2<256>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
-      case 512: return launch_fwd_v2<512>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
-      default: break;
-    }
-  }
+  if (det == 128)
+    return launch_fwd_v2<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
   switch (det) {
     case 32: return launch_fwd<32>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
     case 64: return launch_fwd<64>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
-    case 128: return launch_fwd<128>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
-    case 256: return launch_fwd<256>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
-    case 512: return launch_fwd<512>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
     case 1024: return launch_fwd<1024>(psi_, scan, P, far, ntile, S, pw, H, W, scale, stream);
     default: break;
   }

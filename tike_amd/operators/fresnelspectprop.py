@@ -12,17 +12,21 @@ from .propagation import fft_scales
 
 
 def fresnel_spectrum_propagator(N, probe_FOV, distance, wavelength):
-    """exp(i z sqrt(k^2 - Kx^2 - Ky^2)), FFT-shifted, complex64 (N[0], N[1])
-    (fresnelspectprop.py:115-137; float64 arithmetic like the reference's
-    ``linspace`` defaults)."""
-    xgrid = (0.5 + np.linspace(-0.5 * N[1], 0.5 * N[1] - 1, num=N[1])) / N[1]
-    ygrid = (0.5 + np.linspace(-0.5 * N[0], 0.5 * N[0] - 1, num=N[0])) / N[0]
-    kx = 2 * np.pi * N[1] * xgrid / probe_FOV[1]
-    ky = 2 * np.pi * N[0] * ygrid / probe_FOV[0]
-    Kx, Ky = np.meshgrid(kx, ky, indexing="xy")
-    prop = np.exp(1j * distance * np.sqrt((2 * np.pi / wavelength)**2 -
-                                          Kx**2 - Ky**2))
-    return np.fft.fftshift(prop).astype(np.complex64)
+    """exp(i z sqrt(k^2 - kx^2 - ky^2)) on the FFT's own frequency order,
+    complex64 (N[0], N[1]) -- what fresnelspectprop.py:115-137 builds centred
+    and then fft-shifts.  The reference samples the frequencies half a bin off
+    centre, (m + 1/2 - n/2) * 2 pi / FOV for m = 0..n-1; here each axis is put
+    into FFT order (a roll by n // 2, the 1-D form of the 2-D shift) before
+    the outer sum, in float64 like the reference's grids."""
+
+    def squared_frequencies(n, fov):
+        centred = (np.arange(n, dtype=np.float64) + 0.5 - 0.5 * n) / n
+        return np.roll(2 * np.pi * n * centred / fov, n // 2)**2
+
+    k2 = (2 * np.pi / wavelength)**2
+    kz = np.sqrt(k2 - squared_frequencies(N[0], probe_FOV[0])[:, None]
+                 - squared_frequencies(N[1], probe_FOV[1])[None, :])
+    return np.exp(1j * distance * kz).astype(np.complex64)
 
 
 class FresnelSpectProp(Operator):

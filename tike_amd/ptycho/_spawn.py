@@ -16,7 +16,6 @@ import logging
 import os
 import pickle
 import queue
-import socket
 import traceback
 import warnings
 
@@ -86,14 +85,6 @@ def resolve(num_gpu):
     return "spawn", tuple(d % available for d in devices)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
-
-
 def _share(array):
     """NumPy array -> (shared-memory torch tensor, dtype to view it back as)."""
     array = np.ascontiguousarray(array)
@@ -103,7 +94,49 @@ def _share(array):
     return torch.from_numpy(array).share_memory_(), view
 
 
-def _rank_main(rank, devices, port, backend, shared, view, blob, results):
+UPLOAD_BLOCK_BYTES = 256 << 20
+
+
+def _as_resident(block):
+    """A block of patterns in the form they are kept in HBM: uint16 when they
+    arrived as <= 16-bit integers (ptycho.py:383-390), float32 otherwise --
+    the conversion of `_arrays.data_to_device`."""
+    from .. import _arrays as A
+    if A.is_small_integer(block.dtype):
+        return np.ascontiguousarray(np.clip(block, 0, None).astype(np.uint16))
+    return np.ascontiguousarray(block, dtype=np.float32)
+
+
+def _receive_rows(inbox, n_local, frame, small, on_host):
+    """This rank's patterns, block by block from the parent: into a device
+    tensor in the rank's local order (or a host array with data_on_host)."""
+    dtype = np.uint16 if small else np.float32
+    if on_host:
+        rows = np.empty((n_local,) + frame, dtype=dtype)
+    else:
+        rows = torch.empty((n_local,) + frame,
+                           dtype=torch.uint16 if small else torch.float32,
+                           device="cuda")
+    while True:
+        message = inbox.get()
+        if message[0] == "done":
+            break
+        _, lo, shared = message
+        block = shared.numpy().view(dtype)
+        if on_host:
+            rows[lo:lo + len(block)] = block
+        else:
+            t = torch.from_numpy(block.view(np.int16) if small else block)
+            dst = rows[lo:lo + len(block)]
+            (dst.view(torch.int16) if small else dst).copy_(t)
+            torch.cuda.synchronize()
+        del shared, block
+        inbox.task_done()
+    inbox.task_done()
+    return rows
+
+
+def _rank_main(rank, devices, store_path, backend, inbox, meta, blob, results):
     """One rank of a spawned reconstruction (runs in a fresh interpreter)."""
     import torch.distributed as dist
     try:
@@ -111,8 +144,8 @@ def _rank_main(rank, devices, port, backend, shared, view, blob, results):
         extra = {}
         if backend == "nccl":  # bind the communicator to this rank's GPU
             extra["device_id"] = torch.device("cuda", devices[rank])
-        dist.init_process_group(backend,
-                                init_method=f"tcp://127.0.0.1:{port}",
+        # rendezvous through a file the parent owns: no port to lose a race for
+        dist.init_process_group(backend, init_method=f"file://{store_path}",
                                 rank=rank, world_size=len(devices), **extra)
         try:
             import tike_amd.random
@@ -123,8 +156,13 @@ def _rank_main(rank, devices, port, backend, shared, view, blob, results):
             # process would have drawn
             np.random.set_state(legacy)
             tike_amd.random.randomizer_np = rng
-            data = shared.numpy().view(view)
-            with Reconstruction(data, parameters, **kwargs) as context:
+            shape, dtype, small, n_local = meta
+            rows = _receive_rows(inbox, n_local[rank], tuple(shape[1:]), small,
+                                 bool(kwargs.get("data_on_host")))
+            # the whole dataset's shape and dtype, none of its memory
+            stand_in = np.broadcast_to(np.zeros((), dtype=dtype), shape)
+            with Reconstruction(stand_in, parameters, local_data=rows,
+                                **kwargs) as context:
                 context.iterate(parameters.algorithm_options.num_iter)
                 result = context.get_result()
             if rank == 0:
@@ -138,30 +176,91 @@ def _rank_main(rank, devices, port, backend, shared, view, blob, results):
         raise
 
 
+def _plan_shares(parameters, n_total, size, kwargs):
+    """The clustering of the whole job, computed ONCE (here, in the caller's
+    process -- it draws from the caller's generators exactly as an in-process
+    call would), and the rows of every rank in the rank's local order."""
+    from .. import _arrays as A
+    from .. import cluster
+    from .ptycho import _check_batches, rank_share, spatially_sorted
+    scan = A.to_host(parameters.scan)
+    o = parameters.algorithm_options
+    order, batches = kwargs.get("order"), kwargs.get("batches")
+    if (order is None) != (batches is None):
+        raise ValueError("`order` and `batches` must be given together")
+    if order is None:
+        order, batches = cluster.batches_contiguous(scan, o.batch_method,
+                                                    o.num_batch)
+    order = np.asarray(order)
+    batches = [np.asarray(b) for b in batches]
+    _check_batches(order, batches, n_total)
+    listed = (spatially_sorted(scan, order, batches)
+              if kwargs.get("spatial_sort", True) else order)
+    rows = [rank_share(listed, batches, size, r)[0] for r in range(size)]
+    return order, batches, rows
+
+
+def _check_shm(need):
+    """Blocks travel through /dev/shm (torch shared-memory tensors): fail with
+    a clear message instead of a bus error when it is too small."""
+    try:
+        import shutil
+        free = shutil.disk_usage("/dev/shm").free
+    except OSError:
+        return
+    if free < need:
+        raise RuntimeError(
+            f"reconstruct(num_gpu=N) needs {need >> 20} MiB of /dev/shm to "
+            f"hand the patterns to its ranks, {free >> 20} MiB are free "
+            "(containers: raise --shm-size)")
+
+
 def reconstruct_spawned(data, parameters, devices, **kwargs):
-    """Run `reconstruct` on len(devices) child ranks; return rank 0's result."""
+    """Run `reconstruct` on len(devices) child ranks; return rank 0's result.
+
+    The parent clusters once, then streams to every rank ONLY that rank's rows,
+    in blocks of UPLOAD_BLOCK_BYTES through shared memory (each block is
+    uploaded and released before the next one is cut): no process holds a
+    second copy of the dataset, and nothing depends on a probed TCP port."""
+    import tempfile
     import torch.multiprocessing as mp
     import tike_amd.random
     from .. import _arrays as A
+    if kwargs.get("presharded"):
+        raise ValueError("presharded=True means the caller runs the ranks "
+                         "itself; reconstruct(num_gpu=N) shards for them")
     distinct = len(set(devices)) == len(devices)
     backend = "nccl" if distinct else "gloo"
     if not distinct:
         logger.warning("ranks share GPUs %s: collectives over gloo", devices)
-    shared, view = _share(A.to_host(data))
+    size = len(devices)
+    host = A.to_host(data)
+    order, batches, rows = _plan_shares(parameters, host.shape[0], size,
+                                        kwargs)
+    kwargs = dict(kwargs, order=order, batches=batches)
+    small = A.is_small_integer(host.dtype)
+    frame_bytes = int(np.prod(host.shape[1:])) * (2 if small else 4)
+    step = max(1, UPLOAD_BLOCK_BYTES // max(frame_bytes, 1))
+    _check_shm(2 * min(step, max(len(r) for r in rows)) * frame_bytes)
+    # (drawn AFTER the clustering: the ranks continue the caller's sequences)
     blob = pickle.dumps((parameters, kwargs, np.random.get_state(),
                          tike_amd.random.randomizer_np))
+    meta = (tuple(host.shape), host.dtype, small, [len(r) for r in rows])
     ctx = mp.get_context("spawn")
     results = ctx.Queue()
-    port = _free_port()
+    inboxes = [ctx.JoinableQueue() for _ in range(size)]
+    handle, store_path = tempfile.mkstemp(prefix="tike_amd_rendezvous_")
+    os.close(handle)
+    os.unlink(store_path)  # FileStore creates it; the name is ours
     env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update({k: v for k, v in env.items() if saved[k] is None})
     try:
         procs = [
             ctx.Process(target=_rank_main,
-                        args=(r, devices, port, backend, shared, view, blob,
-                              results), daemon=True)
-            for r in range(len(devices))
+                        args=(r, devices, store_path, backend, inboxes[r],
+                              meta, blob, results), daemon=True)
+            for r in range(size)
         ]
         for p in procs:
             p.start()
@@ -169,27 +268,70 @@ def reconstruct_spawned(data, parameters, devices, **kwargs):
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
+
+    def alive_or_raise():
+        dead = [(r, p.exitcode) for r, p in enumerate(procs)
+                if p.exitcode not in (None, 0)]
+        if dead:
+            raise RuntimeError(
+                f"reconstruct(num_gpu={size}): rank(s) {dead} exited without "
+                "a result")
+
+    def wait_for(inbox):
+        """inbox.join() that notices a rank dying (it would never return)."""
+        import threading
+        done = threading.Event()
+        t = threading.Thread(target=lambda: (inbox.join(), done.set()),
+                             daemon=True)
+        t.start()
+        while not done.wait(0.5):
+            alive_or_raise()
+
     message = None
     try:
+        # every rank's rows, a block at a time, round robin over the ranks so
+        # that their uploads overlap; a block is released once it is uploaded
+        cursor = [0] * size
+        while any(cursor[r] < len(rows[r]) for r in range(size)):
+            for r in range(size):
+                lo = cursor[r]
+                if lo >= len(rows[r]):
+                    continue
+                block = _as_resident(host[rows[r][lo:lo + step]])
+                shared, _ = _share(block)
+                inboxes[r].put(("rows", lo, shared))
+                cursor[r] = lo + len(block)
+                del block, shared
+            for r in range(size):
+                wait_for(inboxes[r])
+        for r in range(size):
+            inboxes[r].put(("done",))
         while message is None:
             try:
                 message = results.get(timeout=1.0)
             except queue.Empty:  # is everybody still alive?
-                dead = [(r, p.exitcode) for r, p in enumerate(procs)
-                        if p.exitcode not in (None, 0)]
-                if dead:
-                    raise RuntimeError(
-                        f"reconstruct(num_gpu={len(devices)}): rank(s) "
-                        f"{dead} exited without a result")
+                alive_or_raise()
                 if all(p.exitcode == 0 for p in procs):
                     raise RuntimeError(
                         "reconstruct: every rank exited but rank 0 sent no "
                         "result")
         if message[0] == "error":
             raise RuntimeError(
-                f"reconstruct(num_gpu={len(devices)}): rank {message[1]} "
+                f"reconstruct(num_gpu={size}): rank {message[1]} "
                 f"failed:\n{message[2]}")
     except BaseException:
+        # a rank that failed has said why: prefer its traceback
+        try:
+            late = results.get(timeout=2.0)
+            if late[0] == "error":
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise RuntimeError(
+                    f"reconstruct(num_gpu={size}): rank {late[1]} failed:\n"
+                    f"{late[2]}") from None
+        except queue.Empty:
+            pass
         for p in procs:
             if p.is_alive():
                 p.terminate()
@@ -197,6 +339,10 @@ def reconstruct_spawned(data, parameters, devices, **kwargs):
     finally:
         for p in procs:
             p.join(60)
+        try:
+            os.unlink(store_path)
+        except OSError:
+            pass
     result, legacy, rng = pickle.loads(message[1])
     # the generators advance as they would have in an in-process call
     np.random.set_state(legacy)

@@ -30,15 +30,8 @@ class ExitWaveOptions:
     """'ortho', 'forward' or 'backward' FFT scaling of the forward model."""
 
     def _copy(self, measured_pixels):
-        return ExitWaveOptions(
-            measured_pixels=measured_pixels,
-            noise_model=self.noise_model,
-            propagation_normalization=self.propagation_normalization,
-            step_length_start=self.step_length_start,
-            step_length_usemodes=self.step_length_usemodes,
-            step_length_weight=self.step_length_weight,
-            unmeasured_pixels_scaling=self.unmeasured_pixels_scaling,
-        )
+        """The same settings around another mask array."""
+        return dataclasses.replace(self, measured_pixels=measured_pixels)
 
     def resample(self, factor: float) -> "ExitWaveOptions":
         """The mask cropped in Fourier space to the rescaled detector

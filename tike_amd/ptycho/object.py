@@ -42,21 +42,13 @@ class ObjectOptions:
     multislice_propagation_distance: float = 1.0e-9
 
     def _copy(self, f):
-        o = ObjectOptions(
-            convergence_tolerance=self.convergence_tolerance,
-            positivity_constraint=self.positivity_constraint,
-            smoothness_constraint=self.smoothness_constraint,
-            use_adaptive_moment=self.use_adaptive_moment,
-            vdecay=self.vdecay,
-            mdecay=self.mdecay,
-            clip_magnitude=self.clip_magnitude,
-            multislice_propagation_distance=self.
-            multislice_propagation_distance,
-        )
-        o.update_mnorm = copy.copy(self.update_mnorm)
-        o.v, o.m = f(self.v), f(self.m)
-        o.preconditioner = f(self.preconditioner)
-        return o
+        """The settings as they are; the arrays the solver keeps here (ADAM
+        moments, preconditioner) passed through `f`."""
+        twin = dataclasses.replace(self)  # every constructor field
+        twin.update_mnorm = list(self.update_mnorm)
+        for name in ("v", "m", "preconditioner"):
+            setattr(twin, name, f(getattr(self, name)))
+        return twin
 
     def resample(self, factor: float, interp=None) -> "ObjectOptions":
         """Settings for a grid rescaled by `factor`; the momentum and the

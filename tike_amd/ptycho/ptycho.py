@@ -208,6 +208,34 @@ def _check_data_shape(data, parameters):
             raise ValueError(complaint)
 
 
+def spatially_sorted(scan_host, order, batches):
+    """`order` with the positions of every minibatch re-listed leaf by leaf of
+    a k-d tree (cluster.spatial_order): neighbours in space become neighbours
+    in memory; batch membership, and therefore every sum over a batch, is
+    unchanged."""
+    order = np.array(order, copy=True)
+    for b in batches:
+        if len(b) > 1:
+            idx = order[b]
+            order[b] = idx[cluster.spatial_order(scan_host[idx])]
+    return order
+
+
+def rank_share(order, batches, size, rank):
+    """Rank `rank`'s share of a job of `size` ranks: every global minibatch is
+    split evenly (contiguously) over the ranks.  Returns (rows of the global
+    arrays this rank holds, in its local order; its minibatches as contiguous
+    ranges of that local order)."""
+    local, local_batches, start = [], [], 0
+    for b in batches:
+        share = np.array_split(b, size)[rank]
+        local.append(order[share])
+        local_batches.append(np.arange(start, start + len(share)))
+        start += len(share)
+    return (np.concatenate(local) if local else np.zeros(0, dtype=np.int64),
+            local_batches)
+
+
 class Reconstruction():
     """Context manager keeping data and parameters on the GPU between
     ``iterate`` calls (ptycho.py:265-653).
@@ -221,6 +249,9 @@ class Reconstruction():
       spatial_sort: list the positions of every minibatch along a Z-order
         curve (default) so that the grouped scatter kernels find neighbours
         next to each other; results change only by summation order.
+      local_data: this rank's rows of the dataset as a device tensor in its
+        local order (internal: how `reconstruct(num_gpu=N)` hands every child
+        only its own rows); `data` is then a shape/dtype stand-in.
       data_on_host: keep the diffraction patterns in pinned host memory and
         stream them to the GPU chunk by chunk (datasets larger than HBM; what
         the reference always does, communicators/stream.py:285-404) instead
@@ -229,7 +260,7 @@ class Reconstruction():
 
     def __init__(self, data, parameters, num_gpu=None, use_mpi=False, *,
                  presharded=False, order=None, batches=None,
-                 spatial_sort=True, data_on_host=False):
+                 spatial_sort=True, data_on_host=False, local_data=None):
         # a context lives in ONE process with ONE GPU: `num_gpu` must agree
         # with the process group it runs in (`reconstruct` is the entry that
         # starts ranks by itself)
@@ -263,6 +294,11 @@ class Reconstruction():
         self._parameters_in = parameters
         self._presharded = presharded
         self._data_on_host = bool(data_on_host)
+        # this rank's patterns, already in its local order and on the device
+        # (`reconstruct(num_gpu=N)` uploads every rank's rows block by block:
+        # no process ever holds rows that are not its own); `data` then only
+        # carries the shape and dtype of the whole dataset
+        self._local_data = local_data
         self._order_in = order
         self._batches_in = batches
         self._spatial_sort = spatial_sort
@@ -313,29 +349,19 @@ class Reconstruction():
         # some positions depends on which positions an index names
         self.cluster_order = np.array(order, copy=True)
         if self._spatial_sort:
-            # neighbours in space become neighbours in memory inside every
-            # minibatch (see cluster.spatial_order); batch membership and
-            # therefore every sum over a batch is unchanged
-            order = np.array(order, copy=True)
-            for b in batches:
-                if len(b) > 1:
-                    idx = order[b]
-                    order[b] = idx[cluster.spatial_order(scan_host[idx])]
+            order = spatially_sorted(scan_host, order, batches)
         if self._presharded or self.comm.size == 1:
             return order, order, batches
-        # split every global batch evenly (contiguously) over the ranks
-        local, local_batches, start = [], [], 0
-        for b in batches:
-            share = np.array_split(b, self.comm.size)[self.comm.rank]
-            local.append(order[share])
-            local_batches.append(np.arange(start, start + len(share)))
-            start += len(share)
-        return order, np.concatenate(local), local_batches
+        local, local_batches = rank_share(order, batches, self.comm.size,
+                                          self.comm.rank)
+        return order, local, local_batches
 
     def __enter__(self):
         self.operator.__enter__()
         self.comm.__enter__()
         data = self._data_in
+        if self._local_data is not None:
+            return self._enter_with_local_data()
         host = A.to_host(data) if not A.is_device(data) else None
         # "non-negative and finite" (ptycho.py:392-397) is checked where the
         # patterns end up: on the GPU for resident float data (one pass at HBM
@@ -366,6 +392,9 @@ class Reconstruction():
                     and self.data.dtype == torch.float32
                     and A.has_invalid_counts(self.data)):
                 _warn_invalid_data()
+        return self._finish_enter()
+
+    def _finish_enter(self):
         self.parameters = solvers.PtychoParameters.split(
             self.local_order,
             x=self._host_parameters()).copy_to_device()
@@ -376,6 +405,26 @@ class Reconstruction():
             self.parameters = _rescale_probe(self.operator, self.comm,
                                              self.data, self.parameters)
         return self
+
+    def _enter_with_local_data(self):
+        """`__enter__` when the patterns of this rank are on the device
+        already (see `local_data`)."""
+        self.comm.sync_random()
+        self.order, self.local_order, self.batches = self._shard(
+            self._data_in.shape[0])
+        self.data = self._local_data
+        if self._data_on_host:
+            from ..communicators.stream import PinnedData
+            self.data = PinnedData(np.asarray(self._local_data))
+        if self.data.shape[0] != len(self.local_order):
+            raise ValueError(
+                f"local_data holds {self.data.shape[0]} patterns, this rank's "
+                f"share is {len(self.local_order)}")
+        if (isinstance(self.data, torch.Tensor)
+                and self.data.dtype == torch.float32
+                and A.has_invalid_counts(self.data)):
+            _warn_invalid_data()
+        return self._finish_enter()
 
     def _host_parameters(self):
         p = self._parameters_in

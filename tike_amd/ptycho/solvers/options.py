@@ -109,21 +109,23 @@ class PtychoParameters():
         self.exitwave_options = self.exitwave_options or ExitWaveOptions(
             measured_pixels=np.ones(probe[3:], dtype=np.bool_))
 
+    _ARRAYS = (("probe", "cfloating"), ("psi", "cfloating"),
+               ("scan", "floating"), ("eigen_probe", "cfloating"),
+               ("eigen_weights", "floating"))
+    _OPTIONS = ("exitwave_options", "probe_options", "object_options",
+                "position_options")
+
     def _map(self, f, fo):
-        return PtychoParameters(
-            probe=f(self.probe, precision.cfloating),
-            psi=f(self.psi, precision.cfloating),
-            scan=f(self.scan, precision.floating),
-            eigen_probe=f(self.eigen_probe, precision.cfloating)
-            if self.eigen_probe is not None else None,
-            eigen_weights=f(self.eigen_weights, precision.floating)
-            if self.eigen_weights is not None else None,
-            algorithm_options=self.algorithm_options,
-            exitwave_options=fo(self.exitwave_options),
-            probe_options=fo(self.probe_options),
-            object_options=fo(self.object_options),
-            position_options=fo(self.position_options),
-        )
+        """A copy with every array field through f(array, dtype) and every
+        option object through fo(options); absent arrays stay absent."""
+        changes = {}
+        for name, kind in self._ARRAYS:
+            value = getattr(self, name)
+            if value is not None:
+                changes[name] = f(value, getattr(precision, kind))
+        changes.update((name, fo(getattr(self, name)))
+                       for name in self._OPTIONS)
+        return dataclasses.replace(self, **changes)
 
     def resample(self, factor: float, interp=None) -> "PtychoParameters":
         """Host copy of the parameters on a grid rescaled by `factor`
