@@ -213,8 +213,8 @@ int tike_grad_ifft2_crop(const void* colin, const float* gscale, const float* mo
  * [* mode_scale on measured pixels] (tike_ifft2_pass1_scaled, det in
  * {128,256,512}; operands as tike_ifft2_crop_scaled_modes, mode_scale /
  * measured may be NULL).  work must not alias the input. */
-/* The column pass + gradient factor + inverse pass 1 in ONE launch (det = 256;
- * gaussian, or poisson without per-mode step lengths): what
+/* The column pass + gradient factor + inverse pass 1 in ONE launch (det = 256
+ * or 512; gaussian, or poisson without per-mode step lengths): what
  * tike_fwd_gradient_scale followed by tike_grad_ifft2_pass1 compute, without
  * the factor going through memory (a work item = (position, k1) sweeps the
  * hand-off rows of all S modes twice: for the intensity, then -- newest first --

@@ -793,10 +793,12 @@ def test_position_major_forward_gradient_inverse(ops, oracle, det, pw, S):
                      maxabs=1e-4, what="chi with mode steps")
 
 
-@pytest.mark.parametrize("S", [1, 4, 6, 7, 8])
+@pytest.mark.parametrize("S,det", [(1, 256), (4, 256), (6, 256), (7, 256),
+                                   (8, 256), (1, 512), (3, 512), (4, 512)])
 @pytest.mark.parametrize("model,u16,masked", [(0, False, False), (0, True, True),
                                                (1, False, True), (1, True, False)])
-def test_one_launch_gradient_pass_matches_the_two_launches(S, model, u16, masked):
+def test_one_launch_gradient_pass_matches_the_two_launches(S, det, model, u16,
+                                                           masked):
     """tike_fwd_grad_ifft2_pass1 == tike_fwd_gradient_scale +
     tike_grad_ifft2_pass1 on the same hand-off, with enough positions that
     every workgroup walks several work items (the register-resident kernel
@@ -806,7 +808,7 @@ def test_one_launch_gradient_pass_matches_the_two_launches(S, model, u16, masked
     import torch
     import tike_amd._arrays as A
     from tike_amd._lib import lib, check
-    N, det = 300, 256
+    N = 300 if det == 256 else 70  # (512^2: the two-sweep kernel of round 5)
     dev = A.current_device()
     g = torch.Generator(device=dev).manual_seed(S + 10 * model)
     scratch = torch.view_as_complex(

@@ -14,6 +14,7 @@
 // fixtures).  Built with -ffp-contract=off: a fused multiply-add would round
 // differently from NumPy.  No GPU involved; plain C ABI like the rest of
 // include/tike_amd.h.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -24,53 +25,124 @@ namespace {
 
 constexpr int kBadArgument = TIKE_ERR_ARG;
 
-// float32 mean of the rows of `points` owned by `cluster`, summed in index
-// order (what ndarray.mean(axis=0) does for an (m, 2) float32 array)
-inline void mean_of(const float* points, const int64_t* owner, int64_t n, int64_t cluster,
-                    float* cx, float* cy) {
-  float sx = 0.0f, sy = 0.0f;
-  int64_t m = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    if (owner[i] == cluster) {
-      sx += points[2 * i];
-      sy += points[2 * i + 1];
-      ++m;
-    }
+// d2[f] = squared float32 distance of free point f to (cx, cy) -- -1 for a
+// tombstone (NaN coordinates) or a NaN distance, which must never win -- and
+// the largest of them.  Non-negative floats order like their bit patterns, so
+// the maximum is an INTEGER reduction, which the compiler vectorises without
+// any licence to reorder float arithmetic (there is none here to reorder).
+__attribute__((target_clones("avx2", "default")))
+float squared_distances(const float* __restrict__ px, const float* __restrict__ py, float cx,
+                        float cy, float* __restrict__ d2, size_t count) {
+  int32_t top = -1;
+  for (size_t f = 0; f < count; ++f) {
+    const float dx = px[f] - cx, dy = py[f] - cy;
+    float d = dx * dx + dy * dy;
+    d = d == d ? d : -1.0f;
+    d2[f] = d;
+    int32_t bits;
+    __builtin_memcpy(&bits, &d, sizeof(bits));
+    top = bits > top ? bits : top;  // (-1.0f is a negative integer)
   }
-  *cx = sx / (float)m;
-  *cy = sy / (float)m;
+  float out;
+  __builtin_memcpy(&out, &top, sizeof(out));
+  return top < 0 ? -1.0f : out;
 }
 
 }  // namespace
 
+// Round 5: the same turns in O(members + free) instead of O(n + free + a
+// memmove of the free list) each.  What fixes the labels is kept to the bit:
+//   * the mean of a cluster is the float32 sum of its members in ASCENDING
+//     index order (what ndarray.mean(axis=0) does for an (m, 2) float32
+//     array) -- the members are kept as a sorted list, a newcomer is inserted
+//     at its place;
+//   * the winner is the FIRST free point whose float32 distance
+//     sqrt(dx^2 + dy^2) is the largest: sqrt is monotonic, so that is the
+//     first point whose rounded distance equals sqrt(max d^2) -- one
+//     vectorisable pass for the largest SQUARED distance, then a scan that
+//     takes a square root only of the few candidates within rounding of it;
+//   * the free points stay in ascending order: a claimed one becomes a
+//     tombstone (NaN coordinates never win a comparison) and the arrays are
+//     compacted, order preserved, when half of them are tombstones.
+// (80 000 positions in 80 clusters: 8.1 s -> well under a second.)
 extern "C" int tike_cluster_farthest_fill(const float* points, long n, long* owner_,
                                           int num_cluster, long turns) {
   if (!points || !owner_ || n < 1 || num_cluster < 1 || turns < 0) return kBadArgument;
   static_assert(sizeof(long) == sizeof(int64_t), "LP64");
   int64_t* owner = reinterpret_cast<int64_t*>(owner_);
-  // the free points, ascending: the first of several farthest ones wins
-  std::vector<int64_t> free_;
-  free_.reserve(n);
-  for (int64_t i = 0; i < n; ++i)
-    if (owner[i] < 0) free_.push_back(i);
-  if ((int64_t)free_.size() < turns) return kBadArgument;
+  std::vector<std::vector<int64_t>> members(num_cluster);
+  std::vector<float> fx, fy, d2;
+  std::vector<int64_t> fid;
+  fx.reserve(n);
+  fy.reserve(n);
+  fid.reserve(n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (owner[i] < 0) {
+      fx.push_back(points[2 * i]);
+      fy.push_back(points[2 * i + 1]);
+      fid.push_back(i);
+    } else if (owner[i] < num_cluster) {
+      members[owner[i]].push_back(i);  // ascending by construction
+    }
+  }
+  size_t alive = fid.size();
+  if ((int64_t)alive < turns) return kBadArgument;
+  d2.resize(fid.size());
+  const float nan = std::nanf("");
   for (long turn = 0; turn < turns; ++turn) {
     const int64_t cluster = turn % num_cluster;
-    float cx, cy;
-    mean_of(points, owner, n, cluster, &cx, &cy);
-    float reach = -1.0f;
-    size_t at = 0;
-    for (size_t f = 0; f < free_.size(); ++f) {
-      const float dx = points[2 * free_[f]] - cx;
-      const float dy = points[2 * free_[f] + 1] - cy;
-      const float d = std::sqrt(dx * dx + dy * dy);
-      if (d > reach) {
-        reach = d;
-        at = f;
+    std::vector<int64_t>& mine = members[cluster];
+    float sx = 0.0f, sy = 0.0f;
+    for (const int64_t i : mine) {
+      sx += points[2 * i];
+      sy += points[2 * i + 1];
+    }
+    const float cx = sx / (float)mine.size(), cy = sy / (float)mine.size();
+    const size_t count = fid.size();
+    const float* __restrict__ px = fx.data();
+    const float* __restrict__ py = fy.data();
+    float* __restrict__ pd = d2.data();
+    // (a NaN never wins: tombstones, the mean of an empty cluster)
+    const float top = squared_distances(px, py, cx, cy, pd, count);
+    size_t at = count;
+    if (top >= 0.0f) {
+      const float reach = std::sqrt(top);
+      const float near = top * 0.99999f;  // wider than any rounding of sqrt
+      for (size_t f = 0; f < count; ++f) {
+        if (pd[f] >= near && std::sqrt(pd[f]) == reach) {
+          at = f;
+          break;
+        }
       }
     }
-    owner[free_[at]] = cluster;
-    free_.erase(free_.begin() + at);
+    if (at == count) {  // no distance compared greater than -1: the first free point
+      for (size_t f = 0; f < count; ++f) {
+        if (fid[f] >= 0) {
+          at = f;
+          break;
+        }
+      }
+    }
+    const int64_t winner = fid[at];
+    owner[winner] = cluster;
+    mine.insert(std::upper_bound(mine.begin(), mine.end(), winner), winner);
+    fid[at] = -1;
+    fx[at] = fy[at] = nan;
+    --alive;
+    if (alive * 2 < fid.size() && fid.size() > 64) {
+      size_t w = 0;
+      for (size_t f = 0; f < fid.size(); ++f) {
+        if (fid[f] >= 0) {
+          fid[w] = fid[f];
+          fx[w] = fx[f];
+          fy[w] = fy[f];
+          ++w;
+        }
+      }
+      fid.resize(w);
+      fx.resize(w);
+      fy.resize(w);
+    }
   }
   return 0;
 }

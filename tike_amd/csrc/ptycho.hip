@@ -2767,6 +2767,98 @@ __global__ __launch_bounds__(512, 2) void grad_ifft2_pass1_512_kernel(
   }
 }
 
+// ---- 512^2: column pass + gradient factor + inverse pass 1 in ONE launch.
+// The resident form of 256^2 does not exist here -- F of four modes is 4 x 32
+// values per column = 256 registers before anything else, and splitting the
+// 512 columns over two half-workgroups (as the modes are split at 256^2) would
+// break the inverse's row transforms, which need whole rows -- so this is the
+// two-sweep form: sweep A re-forms F_s mode by mode for the intensity (F
+// discarded, the factor stays in 32 registers), sweep B re-reads the 32 rows
+// of every mode, newest first -- 512 KiB per work item, in flight 128 MiB over
+// the chip: the second read is the Infinity Cache's, not HBM's -- applies the
+// factor and sends the two 16-row groups it holds (residues k1 and k1 + 16 mod
+// 32) through the inverse's pass 1.  Against the two launches it replaces
+// (tike_fwd_gradient_scale + tike_grad_ifft2_pass1) the factor never goes
+// through memory and HBM sees the hand-off once.
+__device__ __forceinline__ float tk_block_sum512(float v, float* red) {
+  v = tk_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
+template <int MODEL, class DT>
+__global__ __launch_bounds__(512, 2) void fwd_grad_ifft2_pass1_512_kernel(
+    const cf* __restrict__ colin, const DT* __restrict__ data,
+    const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
+    long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
+    const cf* __restrict__ twtab) {
+  constexpr int N = 512;
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  __shared__ float red[8];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int t = threadIdx.x;
+  const float s2 = fwd_scale * fwd_scale;
+  for (long v = blockIdx.x; v < nscan * 16; v += gridDim.x) {
+    const int k1 = (int)(v & 15);
+    const long n = nscan - 1 - (v >> 4);  // descending: see fwd_gradient_scale_kernel
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    // ---- sweep A: intensity of rows k1 + 16 k2 over the modes
+    float I[32];
+#pragma unroll
+    for (int k2 = 0; k2 < 32; ++k2) I[k2] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
+      cf u[32];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) u[r] = src[(long)(16 * r) * N];
+      Dft<32, false>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 32; ++k2) I[k2] += norm2(u[k2]) * s2;
+    }
+    // ---- the factor (times the forward scale the inverse applies to F), the cost
+    float cost;
+    {
+      DT raw[32];
+      unsigned bits;
+      tk_request_data<N, 32>(data, mask, n, k1, t, raw, bits);
+      cost = tk_gradient_factor<MODEL, 32>(I, raw, bits, unmeasured_scaling, fwd_scale);
+    }
+    if (costs.costs) {
+      cost = tk_block_sum512(cost, red);
+      if (threadIdx.x == 0) tk_cost_add(costs, n, k1, cost * inv_nmeasured);
+    }
+    // ---- sweep B: modes S - 1 .. 0 (the likeliest to be cached still first)
+    for (int s = S - 1; s >= 0; --s) {
+      const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
+      cf* __restrict__ mid = work + (n * S + s) * (long)N * N;
+      cf u[32];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) u[r] = tk_ld_stream(src + (long)(16 * r) * N);
+      Dft<32, false>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 32; ++k2) u[k2] = u[k2] * I[k2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // rows k1 + 16 h + 32 y2 (column t) -> row layout of pass-1 group k1 + 16 h
+#pragma unroll
+        for (int y2 = 0; y2 < 16; ++y2) lds[y2 * G2::LS + tk_pad16(t)] = u[2 * y2 + h];
+        __syncthreads();
+        const cf* __restrict__ lrow = lds + line * G2::LS;
+        fft2_pass1<N, true, true>(
+            lds, twtab, tw, line, j, k1 + 16 * h,
+            [&](int, int e, auto) { return lrow[tk_pad16(e)]; }, mid);
+      }
+    }
+  }
+}
+
 static int launch_grad_ifft2(const void* colin, const float* gscale, const float* mode_scale,
                              const unsigned char* measured, int S, void* work, void* chi,
                              long ntile, int pw, float fwd_scale, float inv_scale,
@@ -2818,7 +2910,7 @@ extern "C" int tike_grad_ifft2_crop(const void* colin, const float* gscale,
 // Pass 1 only of tike_grad_ifft2_crop: `work` receives the input of the inverse
 // column pass (rows 16 k1 + ya), consumed by tike_ifft2_pass2_gradients.
 // scratch: from tike_fwd_pass1.  costs (may be NULL) must not need zeroing by
-// the caller (done here); work must not alias scratch.  det = 256.
+// the caller (done here); work must not alias scratch.  det = 256 or 512.
 extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, int data_u16,
                                          const unsigned char* measured, float* costs,
                                          void* work, int nscan, int S, int det, float fwd_scale,
@@ -2830,9 +2922,31 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
                num_measured > 0);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(scratch && data && work && work != scratch);
-  if (det != 256) return TK_ERR_UNSUPPORTED;
+  if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
+  if (det == 512) {
+    TkCostSink sink512;
+    int rc = tk_cost_sink(costs, nscan, 16, stream, &sink512);
+    if (rc) return rc;
+    const float inv512 = 1.0f / (float)num_measured;
+    const dim3 grid(tk_grid((long)nscan * 16, 2)), block(512);
+#define TK_FG512(M, DT)                                                                       \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_512_kernel<M, DT>), grid, block, 0, stream,        \
+                     (const cf*)scratch, (const DT*)data, measured, sink512, (cf*)work,       \
+                     (long)nscan, S, fwd_scale, unmeasured_scaling, inv512, tw)
+    if (model == 0 && data_u16)
+      TK_FG512(0, unsigned short);
+    else if (model == 0)
+      TK_FG512(0, float);
+    else if (data_u16)
+      TK_FG512(1, unsigned short);
+    else
+      TK_FG512(1, float);
+#undef TK_FG512
+    TK_LAUNCH_CHECK();
+    return tk_cost_finish(sink512, nscan, stream);
+  }
   const bool resident = S >= TK_FG_RESIDENT_MIN_MODES && S <= 8;
   // contributors per pattern: (k1, wave of the first half) / (k1)
   TkCostSink sink;

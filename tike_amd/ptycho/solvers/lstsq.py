@@ -68,6 +68,13 @@ SPLIT_FORWARD_SIZES = (256, 512)
 
 import os as _os
 
+ONE_LAUNCH_GRADIENT_SIZES = (256, 512)
+"""Detector sizes whose forward column pass, gradient factor and inverse pass
+1 are one launch (tike_fwd_grad_ifft2_pass1; 512^2 since round 5); A/B runs
+and tests shorten it to fall back to the two launches."""
+if _os.environ.get("TIKE_ONE_LAUNCH_512", "1") == "0":
+    ONE_LAUNCH_GRADIENT_SIZES = (256,)
+
 POISSON_FROM_HANDOFF = True
 """Per-mode poisson step lengths at 256^2 / 512^2 from the forward hand-off
 (tike_poisson_steps_handoff) instead of from a stored far plane; tests set
@@ -503,7 +510,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             # 256^2 without poisson step lengths: the column pass, the gradient
             # factor and the inverse's pass 1 are ONE launch (the factor never
             # goes through memory)
-            one_launch = fused and det == 256 and not poisson
+            one_launch = (fused and not poisson
+                          and det in ONE_LAUNCH_GRADIENT_SIZES)
             if poisson and not dominant:
                 # gradient factor, costs and the per-mode step lengths from
                 # the hand-off: three reads of it, no far plane stored
