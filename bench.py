@@ -911,6 +911,13 @@ def main():
                       "step after the warm-up, every launch bracketed"
             if profile is not None else "timed steps: every launch bracketed",
         }
+        if roofline["traffic"]:
+            # the same launch priced on the bytes the counters saw cross the
+            # HBM interface (an algorithmic figure above the stream ceiling --
+            # c2's composite entry -- is Infinity-Cache hits, not bandwidth)
+            moved = roofline["traffic"] / (k["avg_ms"] * 1e-3) / 1e9
+            roofline["traffic_achieved"] = moved
+            roofline["traffic_frac"] = moved / HBM_PEAK_GBS
         if graphs_on:
             roofline["events"] = (
                 "launch time and shares: an untimed step launched one by one "

@@ -36,6 +36,10 @@ KERNELS = {
     "ls_pick_kernel": "tike_cgrad_line_search_linear:pick",
     "ls_apply_kernel": "tike_cgrad_line_search_linear:apply",
     "void fwd_grad_ifft2_pass1_resident_kernel": "tike_fwd_grad_ifft2_pass1",
+    "void fwd_grad_ifft2_pass1_512_kernel": "tike_fwd_grad_ifft2_pass1",
+    "void plain_pass1_kernel": "tike_ptycho_adj:pass1",
+    "void ifft2_pass2_adjoint_kernel": "tike_ptycho_adj:pass2",
+    "adj_interleave_kernel": "tike_ptycho_adj:interleave",
     "void grad_ifft2_pass1_512_kernel": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 1, false>": "tike_grad_ifft2_pass1",
     "void grad_ifft2_crop_kernel<256, 2, false>": "tike_grad_ifft2_pass1",
@@ -66,7 +70,9 @@ SOLVER_ONLY = ("psi_precond_kernel", "void fwd_gradient_scale_kernel",
                "void fwd_grad_ifft2_pass1_resident_kernel",
                "void step_stats_kernel", "void probe_grad_kernel",
                "void gradient_scale_kernel", "void farplane_gradient_kernel",
-               "void fwd_grad_ifft2_pass1_single_kernel", "ls_trial_kernel")
+               "void fwd_grad_ifft2_pass1_single_kernel", "ls_trial_kernel",
+               "void fwd_grad_ifft2_pass1_512_kernel",
+               "void ifft2_pass2_adjoint_kernel")
 
 
 def collect(d, counter, cgrad=False):
@@ -150,6 +156,20 @@ def main():
                 "parts": list(parts),
                 "hbm_bytes_per_launch": sum(
                     doc["kernels"][k]["hbm_bytes_per_launch"] for k in parts)}}
+    if workload.startswith("adj"):
+        # one Ptycho.adj call = the launches of all its sub-batches: inverse
+        # pass 1, pass 2 with both products, the grouped scatter, one
+        # interleave (the first pass-1 launch precedes the marker kernel:
+        # counted by its launches-per-call below)
+        parts = [k for k in doc["kernels"]
+                 if k.startswith("tike_ptycho_adj:") or k == "tike_scatter_patches"]
+        calls = max(1, doc["kernels"].get("tike_ptycho_adj:interleave",
+                                          {}).get("launches", 1))
+        doc["composite"] = {"tike_ptycho_adj": {
+            "parts": parts,
+            "hbm_bytes_per_launch": sum(
+                doc["kernels"][k]["hbm_bytes_per_launch"] *
+                doc["kernels"][k]["launches"] for k in parts) / calls}}
     doc["setup_kernels_excluded_from_step"] = list(setup)
     doc["hbm_bytes_per_step"] = sum(
         k["hbm_bytes_per_launch"] * k["launches"]
