@@ -148,6 +148,7 @@ class KernelTimers:
         self.events = collections.defaultdict(list)
         self.enabled = False
         self.only = None  # bracket these entries only (None: all of them)
+        self.label_cost_only = False  # (cgrad workloads: see COST_ONLY_ARG)
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
         self.next = 0
         for name in names:
@@ -166,7 +167,7 @@ class KernelTimers:
                 e1.record()
                 # cost-only launches (cgrad's line search: no patches / no
                 # gradient factor stored) move fewer bytes: own line
-                out = COST_ONLY_ARG.get(_name)
+                out = COST_ONLY_ARG.get(_name) if self.label_cost_only else None
                 if out is not None and args[out] is None:
                     _name = _name + ":cost_only"
                 self.events[_name].append((e0, e1))
@@ -670,6 +671,7 @@ def main():
     from tike_amd.ptycho.solvers.lstsq import chunk_positions
 
     timers = KernelTimers(lib, [n for n in _PROTOTYPES if n != "tike_init"])
+    timers.label_cost_only = a.workload in ("c1", "c2")
     counts = dict(epoch=0, steps=0, in_minibatch=False)
     cpu = None
     cpu_job = None

@@ -81,7 +81,11 @@ __device__ __forceinline__ float tk_lane_up(float v) {
 //      Fresnel step back to the slice in front transforms next;
 //   2  the first slice: the same sums, and only mode 0 of chi is kept (`chi0`,
 //      for the eigen-probe weights).
-template <int N, int MW, int MPW, bool PER_POS, int OUT>
+// PW: position-waves.  A 128-wide tile has only two 64-column waves; with ONE
+// mode the other two waves of the workgroup take every second position of the
+// chunk instead of idling as a second mode-wave (no sum over modes: the waves
+// stay independent).
+template <int N, int MW, int MPW, bool PER_POS, int OUT, int PW = 1>
 __global__ __launch_bounds__(256, (N == 512 || MW > 1 || OUT > 0) ? 2 : 3)
 void ifft2_pass2_adjoint_kernel(
     cf* work, const cf* __restrict__ psi, const float* __restrict__ scan,
@@ -89,12 +93,13 @@ void ifft2_pass2_adjoint_kernel(
     float pnum_scale, cf* __restrict__ chi0, int nscan, int S, int H, int W, float inv_scale,
     int chunk) {
   constexpr int RB = N / 16;
-  constexpr int CW = 4 / MW;
+  constexpr int CW = 4 / (MW * PW);
   constexpr int NCB = N / (64 * CW);
   constexpr int NSLICE = 16 * NCB;
   constexpr bool REDUCE = MW > 1;
   constexpr int G = 8;  // rows whose operands are requested together
   static_assert(NCB >= 1 && NSLICE % 8 == 0, "slice layout");
+  static_assert(PW == 1 || MW == 1, "position-waves only without a sum over modes");
   static_assert(MW > 1 || MPW == 1, "a lone mode-wave writes objproj straight from one mode");
   // shared probe hoisted in registers when it fits beside one butterfly
   // (two modes per wave, or the numerator's accumulators: 64 more registers
@@ -116,7 +121,7 @@ void ifft2_pass2_adjoint_kernel(
   const int ya = slice / NCB, cb = slice % NCB;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const int mw = w % MW, cw = w / MW;
+  const int mw = w % MW, cw = (w / MW) % CW, pwi = w / (MW * CW);
   constexpr long ROW = 16 * N;
   const int x0 = (cb * CW + cw) * 64;  // first column of this wave
   const long slice0 = (long)ya * N + x0;
@@ -206,7 +211,7 @@ void ifft2_pass2_adjoint_kernel(
     if (b0 < b1) publish(b0, 0);
     __syncthreads();
   }
-  for (int n = b0; n < b1; ++n) {
+  for (int n = b0 + pwi; n < b1; n += PW) {
     unsigned lo = lb;
     asm volatile("" : "+v"(lo));
     const int obuf = (n - b0) & 1;
@@ -335,9 +340,10 @@ int tk_ifft2_pass2_products(cf* work, const cf* psi, const float* scan, const cf
                             cf* chi0, int out, int nscan, int S, int det, int H, int W,
                             float inv_scale, hipStream_t stream) {
   int MW = S >= 3 ? 4 : S;
-  if (det == 128 && MW == 1) MW = 2;  // a 128-wide tile has only two 64-column waves
   const int MPW = S > 4 ? 2 : 1;
-  const int nslice = 16 * (det / (64 * (4 / MW)));
+  // 128^2 x one mode: two column-waves x two position-waves (see the kernel)
+  const int PW = det == 128 && MW == 1 ? 2 : 1;
+  const int nslice = 16 * (det / (64 * (4 / (MW * PW))));
   // (slice, chunk) workgroups: about two rounds of the chip, but chunks of at
   // least 8 positions (a workgroup loads its slice of a shared probe once)
   int nchunk = (1536 + nslice - 1) / nslice;
@@ -348,9 +354,10 @@ int tk_ifft2_pass2_products(cf* work, const cf* psi, const float* scan, const cf
   nchunk = (nscan + chunk - 1) / chunk;
   const dim3 grid((unsigned)(nslice * nchunk)), block(256);
 #define TK_ADJ_O(N, MW_, MPW_, PP, OUT_)                                                       \
-  hipLaunchKernelGGL((ifft2_pass2_adjoint_kernel<N, MW_, MPW_, PP, OUT_>), grid, block, 0,     \
-                     stream, work, psi, scan, probe, objproj, pnum, pnum_scale, chi0, nscan, S, \
-                     H, W, inv_scale, chunk)
+  hipLaunchKernelGGL(                                                                          \
+      (ifft2_pass2_adjoint_kernel<N, MW_, MPW_, PP, OUT_, (N == 128 && MW_ == 1) ? 2 : 1>),    \
+      grid, block, 0, stream, work, psi, scan, probe, objproj, pnum, pnum_scale, chi0, nscan,  \
+      S, H, W, inv_scale, chunk)
 #define TK_ADJ(N, MW_, MPW_)                        \
   do {                                              \
     if (probe_per_scan && out == 0)                 \
@@ -369,7 +376,7 @@ int tk_ifft2_pass2_products(cf* work, const cf* psi, const float* scan, const cf
 #define TK_ADJ_N(N, A)               \
   do {                               \
     if (MW == 1)                     \
-      A(N < 256 ? 256 : N, 1, 1);    \
+      A(N, 1, 1);                    \
     else if (MW == 2)                \
       A(N, 2, 1);                    \
     else if (MPW == 1)               \

@@ -165,11 +165,16 @@ def main():
                  if k.startswith("tike_ptycho_adj:") or k == "tike_scatter_patches"]
         calls = max(1, doc["kernels"].get("tike_ptycho_adj:interleave",
                                           {}).get("launches", 1))
+        # (every sub-batch has one pass 1, one pass 2 and one scatter)
+        per_call = doc["kernels"].get("tike_ptycho_adj:pass2", {}).get("launches", 0)
+        count = lambda k: (per_call if k != "tike_ptycho_adj:interleave"
+                           else doc["kernels"][k]["launches"])
         doc["composite"] = {"tike_ptycho_adj": {
             "parts": parts,
+            "sub_batches_per_call": per_call / calls,
             "hbm_bytes_per_launch": sum(
-                doc["kernels"][k]["hbm_bytes_per_launch"] *
-                doc["kernels"][k]["launches"] for k in parts) / calls}}
+                doc["kernels"][k]["hbm_bytes_per_launch"] * count(k)
+                for k in parts) / calls}}
     doc["setup_kernels_excluded_from_step"] = list(setup)
     doc["hbm_bytes_per_step"] = sum(
         k["hbm_bytes_per_launch"] * k["launches"]
