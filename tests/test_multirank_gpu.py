@@ -322,3 +322,61 @@ def test_reconstruction_context_refuses_num_gpu_it_cannot_honour(monkeypatch):
     with pytest.warns(UserWarning, match="GPU"):
         r = tp.reconstruct(data, params, num_gpu=64)
     assert len(r.algorithm_options.costs) == 1
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("eigen,solver", [(False, "lstsq_grad"),
+                                          (True, "lstsq_grad"),
+                                          (True, "rpie"), (False, "cgrad")])
+def test_a_rank_with_an_empty_share_issues_the_same_collectives(monkeypatch,
+                                                                eigen, solver):
+    """Round-4 advisor finding: a minibatch of ONE position leaves rank 1 of
+    two with an empty share.  That rank never enters the chunk loop, where
+    the early probe-gradient all-reduce used to be started: it issued one sum
+    where rank 0 issued two (a hang under RCCL, an error under gloo).  The
+    order of the collectives now depends on rank-invariant facts only, and the
+    cached per-minibatch counts are keyed on the minibatch (two empty shares
+    have the same local bounds): the two-rank run completes and reproduces the
+    one-rank iterates."""
+    import tike_amd.ptycho as tp
+    import tike_amd.random
+    data, scan, probe, psi0, ep, ew = _problem(eigen)
+    N = 11
+    data, scan = data[:N], scan[:N]
+    if eigen:
+        ew = ew[:N]
+    order = np.arange(N)
+    sizes = [1, 1, 5, 4]  # two one-position minibatches: two empty shares
+    ends = np.cumsum(sizes)
+    batches = [np.arange(e - s, e) for s, e in zip(sizes, ends)]
+
+    def run(num_gpu):
+        np.random.seed(1)
+        tike_amd.random.randomizer_np = np.random.default_rng(2)
+        params = tp.PtychoParameters(
+            probe=probe.copy(), psi=psi0.copy(), scan=scan.copy(),
+            eigen_probe=None if ep is None else ep.copy(),
+            eigen_weights=None if ew is None else ew.copy(),
+            algorithm_options=dict(
+                lstsq_grad=lambda: tp.LstsqOptions(
+                    num_batch=len(sizes), num_iter=2,
+                    batch_method="wobbly_center"),
+                rpie=lambda: tp.RpieOptions(
+                    num_batch=len(sizes), num_iter=2, alpha=1.0,
+                    batch_method="wobbly_center"),
+                cgrad=lambda: tp.CgradOptions(num_batch=len(sizes), num_iter=2,
+                                              cg_iter=2))[solver](),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions())
+        return tp.reconstruct(data, params, num_gpu=num_gpu, order=order,
+                              batches=batches)
+
+    single = run(None)
+    monkeypatch.setenv("TIKE_AMD_OVERSUBSCRIBE", "1")
+    two = run(2)
+    np.testing.assert_allclose(np.array(two.algorithm_options.costs),
+                               np.array(single.algorithm_options.costs),
+                               rtol=1e-3)
+    assert_close(two.psi, single.psi, normwise=1e-3, maxabs=1e-2, what="psi")
+    assert_close(two.probe, single.probe, normwise=1e-3, maxabs=1e-2,
+                 what="probe")

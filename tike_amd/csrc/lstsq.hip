@@ -1596,12 +1596,14 @@ extern "C" int tike_eigen_pixel_update1(const void* patches, const void* chi0,
                                         void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && chi_modes >= 1 && weights_row >= 1);
-  TK_CHECK_ARG(!sums3 || (stats && costs));
-  TK_CHECK_ARG(!psi || (scan && H >= 1 && W >= 1));
+  // (an EMPTY share of a minibatch -- more ranks than positions -- comes with
+  // null per-position arrays: nothing to check, the sums are zero)
   if (nscan == 0) {
     if (sums3) return (int)hipMemsetAsync(sums3, 0, 3 * sizeof(float), (hipStream_t)stream);
     return TK_OK;
   }
+  TK_CHECK_ARG(!sums3 || (stats && costs));
+  TK_CHECK_ARG(!psi || (scan && H >= 1 && W >= 1));
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen0 && eigen_proj && weights_c && norm && update);
   const long P = (long)pw * pw;
   const int chunk = probe_chunk(nscan);
@@ -1621,8 +1623,8 @@ extern "C" int tike_eigen_position_sums1(const void* patches, const void* chi0,
                                          void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(nscan >= 0 && pw >= 1 && chi_modes >= 1);
-  TK_CHECK_ARG(!psi || (scan && H >= 1 && W >= 1));
   if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(!psi || (scan && H >= 1 && W >= 1));
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen0 && sums && dsum);
   const TkResidual R = make_residual(patches, chi0, mpu0, eigen0, nullptr, 1, 1, 0, pw, chi_modes);
   const bool det = tk_deterministic();

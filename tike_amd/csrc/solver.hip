@@ -512,6 +512,10 @@ extern "C" int tike_lstsq_tail_finish(const float* tail3, const float* sums3, do
   TK_ENTER();
   TK_CHECK_ARG(tail3 && sums3 && steps && count > 0 && B >= 0 && nprobe >= 0 && npix >= 0);
   TK_CHECK_ARG(!probe || mpu);
+  if (B == 0) {  // an empty share of the minibatch: no per-position rows to update
+    weights = nullptr;
+    sums5 = nullptr;
+  }
   TK_CHECK_ARG(!weights || (stats && weights_row >= 1 && S >= 1 && m >= 0 && m < S));
   TK_CHECK_ARG(!sums5 || (weights && weights_row >= 2L * S && npix >= 1));
   long work = 1;
