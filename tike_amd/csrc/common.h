@@ -90,6 +90,15 @@ __device__ __forceinline__ float tk_block_sum256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// The same for 512-thread blocks (`red`: >= 8 floats), a fixed tree.
+__device__ __forceinline__ float tk_block_sum512(float v, float* red) {
+  v = tk_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
 // Bilinear weights and integer corner of a scan position (y, x), as the
 // reference computes them (convolution.cu:101-134).
 struct TkCorner {

@@ -1035,21 +1035,19 @@ extern "C" int tike_probe_preconditioner(const float* scan, const void* psi, voi
 //                sum Re(conj(O_n P_0) chi_n,0), sum |O_n P_0|^2 }
 // (the last two feed _get_coefs_intensity, lstsq.py:721-738, which uses the
 // SHARED probe P_0).  eps terms (:641,661,667) are added by the solver.
+// the sums of work item (position n, part `part` of nsplit) -- the body of
+// step_stats_kernel, also the fall-back of step_stats_pair_kernel
 template <bool HAVE_PATCHES, bool HAVE_GOBJ>
-__global__ __launch_bounds__(256) void step_stats_kernel(
+__device__ __forceinline__ void step_stats_item(
     const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
-    const cf* __restrict__ gobj, const TkProbe probe, const cf* __restrict__ mpu,
-    const cf* __restrict__ patches, float* __restrict__ stats, int nscan, int chi_modes, int pw,
-    int H, int W, const cf* __restrict__ eigen0, float* __restrict__ eigen_proj, int nsplit) {
-  __shared__ float red[4];
+    const cf* __restrict__ gobj, const TkProbe& probe, const cf* __restrict__ mpu,
+    const cf* __restrict__ patches, float* __restrict__ stats, int chi_modes, int pw, int H,
+    int W, const cf* __restrict__ eigen0, float* __restrict__ eigen_proj, int nsplit, int n,
+    int part, float* red) {
   const long P = (long)pw * pw;
   const long total = (long)H * W;
-  // work item = (position, 1 / nsplit of its pixels): a minibatch of a few
-  // hundred positions would otherwise leave most of the chip idle; with
-  // nsplit > 1 the sums are accumulated into the (zeroed) tables by atomics
   const int plen = (int)(P / nsplit);
-  for (int v = blockIdx.x; v < nscan * nsplit; v += gridDim.x) {
-    const int n = v / nsplit, part = v % nsplit;
+  {
     const TkCorner c = tk_corner(scan, n);
     // the varying probe of mode 0 (probe.py:272-303): weights and bases are
     // per position, hoisted here (TkProbe::at re-read them for every pixel)
@@ -1231,6 +1229,200 @@ __global__ __launch_bounds__(256) void step_stats_kernel(
   }
 }
 
+template <bool HAVE_PATCHES, bool HAVE_GOBJ>
+__global__ __launch_bounds__(256) void step_stats_kernel(
+    const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
+    const cf* __restrict__ gobj, const TkProbe probe, const cf* __restrict__ mpu,
+    const cf* __restrict__ patches, float* __restrict__ stats, int nscan, int chi_modes, int pw,
+    int H, int W, const cf* __restrict__ eigen0, float* __restrict__ eigen_proj, int nsplit) {
+  __shared__ float red[4];
+  // work item = (position, 1 / nsplit of its pixels): a minibatch of a few
+  // hundred positions would otherwise leave most of the chip idle; with
+  // nsplit > 1 the sums are accumulated into the (zeroed) tables by atomics
+  for (int v = blockIdx.x; v < nscan * nsplit; v += gridDim.x)
+    step_stats_item<HAVE_PATCHES, HAVE_GOBJ>(chi, scan, psi, gobj, probe, mpu, patches, stats,
+                                             chi_modes, pw, H, W, eigen0, eigen_proj, nsplit,
+                                             v / nsplit, v % nsplit, red);
+}
+
+#ifndef TK_STATS_PAIRS
+#define TK_STATS_PAIRS 1  // build switch of the A/B (tools/build_variant.py)
+#endif
+static const bool g_stats_pairs = TK_STATS_PAIRS != 0;
+
+// Two positions per work item (the common configurations K = 2 / K = 3 of
+// step_stats_item, stored patches and the preconditioned update given): the
+// shared operands of a pixel -- P_0, the probe update and the eigen probe --
+// are loaded once for both positions, 11 loads per pixel pair instead of 14.
+// A pair with a position on the border falls back to step_stats_item.
+template <bool EIGEN>
+__global__ __launch_bounds__(256) void step_stats_pair_kernel(
+    const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
+    const cf* __restrict__ gobj, const TkProbe probe, const cf* __restrict__ mpu,
+    const cf* __restrict__ patches, float* __restrict__ stats, int nscan, int chi_modes, int pw,
+    int H, int W, const cf* __restrict__ eigen0, float* __restrict__ eigen_proj, int nsplit) {
+  __shared__ float red[4];
+  typedef float tk_v4f __attribute__((ext_vector_type(4)));
+  const long P = (long)pw * pw;
+  const int plen = (int)(P / nsplit);
+  const int npair = (nscan + 1) / 2;
+  for (int v = blockIdx.x; v < npair * nsplit; v += gridDim.x) {
+    const int n0 = 2 * (v / nsplit), part = v % nsplit;
+    const TkCorner c0 = tk_corner(scan, n0);
+    const bool two = n0 + 1 < nscan;
+    const TkCorner c1 = tk_corner(scan, two ? n0 + 1 : n0);
+    const bool in0 = c0.sy >= 0 && c0.sx >= 0 && c0.sy + pw < H && c0.sx + pw < W;
+    const bool in1 = c1.sy >= 0 && c1.sx >= 0 && c1.sy + pw < H && c1.sx + pw < W;
+    if (!(two && in0 && in1)) {  // uniform
+      step_stats_item<true, true>(chi, scan, psi, gobj, probe, mpu, patches, stats, chi_modes,
+                                  pw, H, W, eigen0, eigen_proj, nsplit, n0, part, red);
+      if (two)
+        step_stats_item<true, true>(chi, scan, psi, gobj, probe, mpu, patches, stats, chi_modes,
+                                    pw, H, W, eigen0, eigen_proj, nsplit, n0 + 1, part, red);
+      continue;
+    }
+    float s0 = 1.0f, s1 = 1.0f, t0 = 0.f, t1 = 0.f;  // weights of P_0 and of E_0
+    if (probe.weights != nullptr) {
+      const float* w = probe.weights + n0 * (long)(probe.C + 1) * probe.S;
+      s0 = w[0];
+      s1 = w[(long)(probe.C + 1) * probe.S];
+      if (EIGEN) {
+        t0 = w[probe.S];
+        t1 = w[(long)(probe.C + 1) * probe.S + probe.S];
+      }
+    }
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ea = 0.f, eb = 0.f;
+    const int qstep = (int)blockDim.x / pw, rstep = (int)blockDim.x % pw;
+    const int pbeg = part * plen + (int)threadIdx.x;
+    const int pend = part + 1 == nsplit ? (int)P : (part + 1) * plen;
+    int py = pbeg / pw, px = pbeg % pw;
+    const unsigned base0 = (unsigned)(c0.sy * W + c0.sx), base1 = (unsigned)(c1.sy * W + c1.sx);
+    const cf* __restrict__ chi_a = chi + ((long)n0 * chi_modes) * P;
+    const cf* __restrict__ chi_b = chi + ((long)(n0 + 1) * chi_modes) * P;
+    const cf* __restrict__ pat_a = patches + (long)n0 * P;
+    const cf* __restrict__ pat_b = pat_a + P;
+    auto tap = [](const tk_v4f u, const tk_v4f l, const TkCorner& c) {
+      cf g = mk(u.x * c.w00, u.y * c.w00);
+      g.x += u.z * c.w01;
+      g.y += u.w * c.w01;
+      g.x += l.x * c.w10;
+      g.y += l.y * c.w10;
+      g.x += l.z * c.w11;
+      g.y += l.w * c.w11;
+      return g;
+    };
+    auto sums = [](float* acc, float& e_acc, const cf g, const cf o, const cf x0, const cf p0,
+                   const cf pn, const cf m0, const cf e1) {
+      const cf dOP = g * pn;
+      const cf dPO = m0 * o;
+      const cf OP = o * p0;
+      acc[0] += norm2(dOP);
+      acc[1] += norm2(dPO);
+      const cf a2 = dOP * conjf(dPO);
+      acc[2] += a2.x;
+      acc[3] += a2.y;
+      acc[4] += dOP.x * x0.x + dOP.y * x0.y;
+      acc[5] += dPO.x * x0.x + dPO.y * x0.y;
+      acc[6] += OP.x * x0.x + OP.y * x0.y;
+      acc[7] += norm2(OP);
+      if (EIGEN) {
+        const cf r = conjf(o) * x0 - m0;
+        e_acc += r.x * e1.x + r.y * e1.y;
+      }
+    };
+    auto pixel = [&](const int p, const tk_v4f u0, const tk_v4f l0, const tk_v4f u1,
+                     const tk_v4f l1) {
+      const cf oa = pat_a[p], ob = pat_b[p];
+      const cf xa = chi_a[p], xb = chi_b[p];
+      const cf p0 = probe.probe[p];
+      const cf m0 = mpu[p];
+      cf e1 = mk(0.f, 0.f);
+      cf pa = p0 * s0, pb = p0 * s1;
+      if (EIGEN) {
+        e1 = probe.eigen[p];
+        pa.x += t0 * e1.x;
+        pa.y += t0 * e1.y;
+        pb.x += t1 * e1.x;
+        pb.y += t1 * e1.y;
+      }
+      sums(a, ea, tap(u0, l0, c0), oa, xa, p0, pa, m0, e1);
+      sums(b, eb, tap(u1, l1, c1), ob, xb, p0, pb, m0, e1);
+    };
+    auto taps16 = [&](const unsigned off) {
+      tk_v4f t;
+      __builtin_memcpy(&t, reinterpret_cast<const char*>(gobj) + off, sizeof(t));
+      return t;
+    };
+    // Row walk: a thread keeps its column and goes down the rows of its
+    // share, so the lower taps of one pixel are the upper taps of the next --
+    // one 16-byte load per pixel and position instead of two.  Windows of
+    // 256 k columns: the column blocks one after the other; narrower windows
+    // that divide 256: 256 / pw thread groups stacked over the rows.
+    const int cols = pw < 256 ? pw : 256, groups = 256 / cols;
+    const bool walk = (pw % 256 == 0 || 256 % pw == 0) && pw % (nsplit * groups) == 0;
+    if (walk) {
+      const int rows = pw / (nsplit * groups);
+      const int ybeg = (part * groups + (int)threadIdx.x / cols) * rows;
+      for (int x = (int)threadIdx.x % cols; x < pw; x += 256) {
+        unsigned rel = (unsigned)(ybeg * W + x);
+        tk_v4f u0 = taps16((base0 + rel) * 8u), u1 = taps16((base1 + rel) * 8u);
+        int p = ybeg * pw + x;
+#pragma unroll 2
+        for (int y = 0; y < rows; ++y) {
+          rel += (unsigned)W;
+          const tk_v4f l0 = taps16((base0 + rel) * 8u), l1 = taps16((base1 + rel) * 8u);
+          pixel(p, u0, l0, u1, l1);
+          u0 = l0;
+          u1 = l1;
+          p += pw;
+        }
+      }
+    } else {
+      for (int p = pbeg; p < pend; p += blockDim.x) {
+        const unsigned rel = (unsigned)(py * W + px);
+        const unsigned off0 = (base0 + rel) * 8u, off1 = (base1 + rel) * 8u;
+        pixel(p, taps16(off0), taps16(off0 + (unsigned)W * 8u), taps16(off1),
+              taps16(off1 + (unsigned)W * 8u));
+        py += qstep;
+        px += rstep;
+        if (px >= pw) {
+          px -= pw;
+          ++py;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float ta = tk_block_sum256(a[k], red);
+      const float tb = tk_block_sum256(b[k], red);
+      if (threadIdx.x == 0) {
+        if (nsplit > 1) {
+          unsafeAtomicAdd(&stats[(long)n0 * 8 + k], ta);
+          unsafeAtomicAdd(&stats[(long)n0 * 8 + 8 + k], tb);
+        } else {
+          stats[(long)n0 * 8 + k] = ta;
+          stats[(long)n0 * 8 + 8 + k] = tb;
+        }
+      }
+    }
+    if (EIGEN) {
+      const float ta = tk_block_sum256(ea, red);
+      const float tb = tk_block_sum256(eb, red);
+      if (threadIdx.x == 0) {
+        if (nsplit > 1) {
+          unsafeAtomicAdd(&eigen_proj[n0], ta);
+          unsafeAtomicAdd(&eigen_proj[n0 + 1], tb);
+        } else {
+          eigen_proj[n0] = ta;
+          eigen_proj[n0 + 1] = tb;
+        }
+      }
+    }
+  }
+}
+
 extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const void* psi,
                                      const void* object_update_precond, const void* probe,
                                      const void* eigen_probe, const float* eigen_weights,
@@ -1247,8 +1439,16 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
                                    S, pw, unique_probe);
   // split the pixels of a position over several workgroups until the launch
   // holds ~8192 of them (probe windows that are a multiple of 1024 pixels)
+  // two positions per work item where the common configurations allow it
+  const bool no_eigen = (eigen_probe == nullptr || eigen_modes == 0) && eigen_proj == nullptr;
+  const bool one_eigen = eigen_probe != nullptr && eigen_weights != nullptr && eigen_modes > 0 &&
+                         num_eigen == 1 && eigen_proj != nullptr && eigen0 == eigen_probe;
+  const bool pairs = g_stats_pairs && patches && object_update_precond && m_probe_update &&
+                     unique_probe == nullptr && (no_eigen || one_eigen) &&
+                     (long)H * W < (1L << 28) && nscan > 1;
+  const long nitem = pairs ? (nscan + 1) / 2 : nscan;
   int nsplit = 1;
-  while (nsplit < 16 && (long)nscan * nsplit * 2 <= 8192 && ((long)pw * pw) % (2048L * nsplit) == 0)
+  while (nsplit < 16 && nitem * nsplit * 2 <= 8192 && ((long)pw * pw) % (2048L * nsplit) == 0)
     nsplit *= 2;
   if (tk_deterministic()) nsplit = 1;  // one workgroup per position: no atomics
   if (nsplit > 1) {
@@ -1264,11 +1464,21 @@ extern "C" int tike_lstsq_step_stats(const void* chi, const float* scan, const v
                      (const cf*)object_update_precond, pr, (const cf*)m_probe_update,         \
                      (const cf*)patches, stats, nscan, chi_modes, pw, H, W, (const cf*)eigen0, \
                      eigen_proj, nsplit)
-  if (patches && object_update_precond) TK_SS(true, true);
+#define TK_SP(EIG)                                                                            \
+  hipLaunchKernelGGL((step_stats_pair_kernel<EIG>), dim3(tk_grid(nitem * nsplit, 16)),        \
+                     dim3(256), 0,                                                            \
+                     (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,               \
+                     (const cf*)object_update_precond, pr, (const cf*)m_probe_update,         \
+                     (const cf*)patches, stats, nscan, chi_modes, pw, H, W, (const cf*)eigen0, \
+                     eigen_proj, nsplit)
+  if (pairs && one_eigen) TK_SP(true);
+  else if (pairs) TK_SP(false);
+  else if (patches && object_update_precond) TK_SS(true, true);
   else if (patches) TK_SS(true, false);
   else if (object_update_precond) TK_SS(false, true);
   else TK_SS(false, false);
 #undef TK_SS
+#undef TK_SP
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -1523,6 +1733,105 @@ __global__ __launch_bounds__(256) void eigen_position_sums1_kernel(
   }
 }
 
+// Two positions per workgroup of 512 threads, row walk (see
+// step_stats_pair_kernel): E_0 and the probe update are loaded once for both
+// positions and every pixel costs one 16-byte tap load per position -- 6 loads
+// per pixel pair instead of 10.  cols = min(pw, 256) columns per thread group,
+// 512 / cols groups stacked over the rows; a pair with a position on the
+// border (or the odd last position) takes the strided per-position loop.
+__global__ __launch_bounds__(512) void eigen_position_sums1_pair_kernel(
+    const TkResidual R, float* __restrict__ sums, float* __restrict__ dsum, int nscan,
+    const cf* __restrict__ psi, const float* __restrict__ scan, int pw, int H, int W) {
+  __shared__ float red[8];
+  typedef float tk_v4f __attribute__((ext_vector_type(4)));
+  const cf* __restrict__ E = R.eigen;
+  const unsigned row_bytes = (unsigned)W * (unsigned)sizeof(cf);
+  const int cols = pw < 256 ? pw : 256, rows = pw / (512 / cols);
+  const int npair = (nscan + 1) / 2;
+  auto add = [](float* a, const cf o, const cf x, const cf e, const cf m0) {
+    const cf r = conjf(o) * x - m0;
+    const cf phi = o * e;
+    a[0] += r.x * e.x + r.y * e.y;
+    a[1] += x.x * phi.x + x.y * phi.y;
+    a[2] += norm2(phi);
+    const cf re = r * conjf(e);
+    a[3] += re.x;
+    a[4] += re.y;
+  };
+  auto finish = [&](const float* a, const int n) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float v = tk_block_sum512(a[k], red);
+      if (threadIdx.x == 0) {
+        sums[(long)n * 5 + k] = v;
+        if (k == 2 && dsum != nullptr) unsafeAtomicAdd(dsum, v / (float)R.P);
+      }
+    }
+  };
+  auto one = [&](const int n, const TkCorner& c, const bool gather) {
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned off0 = gather ? (unsigned)(c.sy * W + c.sx) * 8u : 0u;
+    for (long p = threadIdx.x; p < R.P; p += blockDim.x) {
+      const cf o = gather ? tk_patch_pixel(psi, off0 + (unsigned)(p / pw) * row_bytes +
+                                                    (unsigned)(p % pw) * 8u, row_bytes, c)
+                          : R.patches[n * R.P + p];
+      add(a, o, R.chi0[n * R.XS + p], E[p], R.mpu0[p]);
+    }
+    finish(a, n);
+  };
+  auto taps16 = [&](const unsigned off) {
+    tk_v4f t;
+    __builtin_memcpy(&t, reinterpret_cast<const char*>(psi) + off, sizeof(t));
+    return t;
+  };
+  auto tap = [](const tk_v4f u, const tk_v4f l, const TkCorner& c) {
+    cf o = mk(u.x * c.w00, u.y * c.w00);  // the order of tk_patch_pixel
+    o.x += u.z * c.w01;
+    o.y += u.w * c.w01;
+    o.x += l.x * c.w10;
+    o.y += l.y * c.w10;
+    o.x += l.z * c.w11;
+    o.y += l.w * c.w11;
+    return o;
+  };
+  for (int pair = blockIdx.x; pair < npair; pair += gridDim.x) {
+    const int n0 = 2 * pair;
+    const bool two = n0 + 1 < nscan;
+    const TkCorner c0 = tk_corner(scan, n0);
+    const TkCorner c1 = tk_corner(scan, two ? n0 + 1 : n0);
+    const bool in0 = tk_interior(c0, pw, H, W), in1 = tk_interior(c1, pw, H, W);
+    if (!(two && in0 && in1)) {  // uniform
+      one(n0, c0, in0);
+      if (two) one(n0 + 1, c1, in1);
+      continue;
+    }
+    float a[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, b[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned base0 = (unsigned)(c0.sy * W + c0.sx), base1 = (unsigned)(c1.sy * W + c1.sx);
+    const cf* __restrict__ chi_a = R.chi0 + (long)n0 * R.XS;
+    const cf* __restrict__ chi_b = chi_a + R.XS;
+    const int ybeg = ((int)threadIdx.x / cols) * rows;
+    for (int x = (int)threadIdx.x % cols; x < pw; x += 256) {
+      unsigned rel = (unsigned)(ybeg * W + x);
+      tk_v4f u0 = taps16((base0 + rel) * 8u), u1 = taps16((base1 + rel) * 8u);
+      int p = ybeg * pw + x;
+#pragma unroll 2
+      for (int y = 0; y < rows; ++y) {
+        rel += (unsigned)W;
+        const tk_v4f l0 = taps16((base0 + rel) * 8u), l1 = taps16((base1 + rel) * 8u);
+        const cf e = E[p], m0 = R.mpu0[p];
+        const cf xa = chi_a[p], xb = chi_b[p];
+        add(a, tap(u0, l0, c0), xa, e, m0);
+        add(b, tap(u1, l1, c1), xb, e, m0);
+        u0 = l0;
+        u1 = l1;
+        p += pw;
+      }
+    }
+    finish(a, n0);
+    finish(b, n0 + 1);
+  }
+}
+
 static TkResidual make_residual(const void* patches, const void* chi0, const void* mpu0,
                                 const void* eigen, const void* coefs, int C, int Sm, int c,
                                 int pw, int chi_modes) {
@@ -1628,9 +1937,18 @@ extern "C" int tike_eigen_position_sums1(const void* patches, const void* chi0,
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen0 && sums && dsum);
   const TkResidual R = make_residual(patches, chi0, mpu0, eigen0, nullptr, 1, 1, 0, pw, chi_modes);
   const bool det = tk_deterministic();
-  hipLaunchKernelGGL(eigen_position_sums1_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
-                     (hipStream_t)stream, R, sums, det ? nullptr : dsum, nscan, (const cf*)psi,
-                     scan, pw, H, W);
+  const int cols = pw < 256 ? pw : 256;
+  const bool pairs = g_stats_pairs && psi != nullptr && nscan > 1 &&
+                     (pw % 256 == 0 || 256 % pw == 0) && pw % (512 / cols) == 0 &&
+                     (long)H * W < (1L << 28);
+  if (pairs)
+    hipLaunchKernelGGL(eigen_position_sums1_pair_kernel, dim3(tk_grid((nscan + 1) / 2, 16)),
+                       dim3(512), 0, (hipStream_t)stream, R, sums, det ? nullptr : dsum, nscan,
+                       (const cf*)psi, scan, pw, H, W);
+  else
+    hipLaunchKernelGGL(eigen_position_sums1_kernel, dim3(tk_grid(nscan, 16)), dim3(256), 0,
+                       (hipStream_t)stream, R, sums, det ? nullptr : dsum, nscan, (const cf*)psi,
+                       scan, pw, H, W);
   if (det)  // dsum += sum_n sums[n][2] / P, one workgroup, a fixed order
     hipLaunchKernelGGL(column_sum_ordered_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums,
                        5, 2, nscan, 1.0f / (float)((long)pw * pw), dsum);

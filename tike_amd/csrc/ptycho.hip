@@ -2780,13 +2780,6 @@ __global__ __launch_bounds__(512, 2) void grad_ifft2_pass1_512_kernel(
 // 32) through the inverse's pass 1.  Against the two launches it replaces
 // (tike_fwd_gradient_scale + tike_grad_ifft2_pass1) the factor never goes
 // through memory and HBM sees the hand-off once.
-__device__ __forceinline__ float tk_block_sum512(float v, float* red) {
-  v = tk_wave_sum(v);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-}
 
 template <int MODEL, class DT>
 __global__ __launch_bounds__(512, 2) void fwd_grad_ifft2_pass1_512_kernel(

@@ -340,8 +340,14 @@ def lstsq_grad(parameters, data, batches, comm, *, op, epoch):
 EIGEN_PATCH_RECOMPUTE = True
 """The eigen pixel update of the packed tail gathers the object patches from
 psi (L2) instead of streaming the stored ones (HBM): 0.186 -> 0.160 ms per 1000
-positions at 256^2.  (The position sums can do the same -- the entry takes psi
--- but are bound by their L1 requests, not by HBM: 0.215 -> 0.221 ms.)"""
+positions at 256^2.  (With two 16-byte tap loads per pixel the position sums
+lost by it, 0.215 -> 0.221 ms; see EIGEN_SUMS_RECOMPUTE.)"""
+
+EIGEN_SUMS_RECOMPUTE = os.environ.get("TIKE_EIGEN_SUMS_GATHER", "1") == "1"
+"""The position sums gather too, through the two-positions-per-workgroup row
+walk of tike_eigen_position_sums1 (one 16-byte tap load per pixel and
+position, E_0 and the probe update loaded once per pair): 0.215 -> 0.176 ms
+per 1000 positions at 256^2."""
 
 STATS_PATCH_RECOMPUTE = os.environ.get("TIKE_STATS_GATHER", "0") == "1"
 """The step statistics gather O_n from the object with the two 16-byte tap
@@ -866,7 +872,9 @@ def _packed_tail(g, psi, scan, probe, eigen_probe, eigen_weights,
             lib.tike_eigen_position_sums1(
                 A.ptr(g["patches"]), A.ptr(g["chi0"]), A.ptr(mpu[0, 0, 0]),
                 A.ptr(E), A.ptr(sums5), tail3[2:].data_ptr(), B, pw,
-                g["chi_modes"], None, None, 0, 0, st), "eigen position sums")
+                g["chi_modes"], gpsi if EIGEN_SUMS_RECOMPUTE else None,
+                A.ptr(scan[lo:hi]), psi.shape[-2], psi.shape[-1], st),
+            "eigen position sums")
     if comm.collective:
         comm.Allreduce(tail3)
     check(
