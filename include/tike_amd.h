@@ -38,7 +38,7 @@ extern "C" {
  * A binding compares tike_abi_version() of the loaded library with the
  * TIKE_ABI_VERSION it was written against before its first call
  * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
-#define TIKE_ABI_VERSION 7
+#define TIKE_ABI_VERSION 8
 
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
@@ -226,6 +226,19 @@ int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, int data_u1
                               const unsigned char* measured, float* costs, void* work,
                               int nscan, int S, int det, float fwd_scale, int model,
                               float unmeasured_scaling, long num_measured, void* stream);
+/* The same for the LAST slice of a multislice object (ptycho/solvers/rpie.py:
+ * 444-472; det = 256, probe window = detector): the loop there hands
+ * diff = FresnelSpectProp.adj(diff) (fresnelspectprop.py:100-113) to the slice
+ * in front, b times for slice nslices - 1 - b.  With chi = IFFT2(G) that is
+ * IFFT2(conj(H) FFT2(IFFT2(G))) = IFFT2(conj(H)^b G): the step's forward
+ * transform cancels.  work (nslices,nscan,S,det,det): work[b] = the inverse's
+ * pass 1 of conj(propagator)^b x G, each finished by tike_ifft2_pass2_products
+ * of its slice; propagator (det,det) c64 in FFT order. */
+int tike_fwd_grad_ifft2_pass1_slices(const void* scratch, const void* data, int data_u16,
+                                     const unsigned char* measured, float* costs, void* work,
+                                     int nscan, int S, int det, float fwd_scale, int model,
+                                     float unmeasured_scaling, long num_measured,
+                                     const void* propagator, int nslices, void* stream);
 int tike_grad_ifft2_pass1(const void* colin, const float* gscale, const float* mode_scale,
                           const unsigned char* measured, int S, void* work, long ntile, int det,
                           float fwd_scale, void* stream);
@@ -469,6 +482,15 @@ int tike_fft2_pass1(const void* in, void* out, long ntile, int det, int inverse,
 /* pass 2 alone, in place, every element times `scale`. */
 int tike_fft2_pass2_inplace(void* tiles, long ntile, int det, int inverse, float scale,
                             void* stream);
+
+/* pass 2 of the S modes of every position with the illumination
+ * amplitude[n] = sum_s |wave[n][s] * scale|^2 formed from the registers
+ * (ptycho/solvers/_preconditioner.py:40-45,86-95: _probe_amp_sum of the probe
+ * propagated to a slice).  tiles (nscan,S,det,det) c64: the finished wave is
+ * written back in place iff `keep`, otherwise tiles is left half-transformed
+ * (scratch); amplitude (nscan,det,det) f32. */
+int tike_fft2_pass2_intensity(void* tiles, float* amplitude, long nscan, int S, int det,
+                              int inverse, float scale, int keep, void* stream);
 
 /* forward column pass -> x propagator (conj when `adjoint`) x scale -> inverse
  * pass 1 (fresnelspectprop.py:86-113): colin = output of a FORWARD pass 1,

@@ -416,6 +416,43 @@ def test_fresnel_step_in_three_launches_vs_oracle(oracle, adjoint):
         assert_close(b.cpu().numpy(), want, what=f"fresnel, {ntile} tiles")
 
 
+@pytest.mark.parametrize("det,S,N", [(256, 8, 5), (256, 1, 33), (128, 3, 7),
+                                     (512, 2, 3)])
+@pytest.mark.parametrize("inverse", [True, False])
+@pytest.mark.parametrize("keep", [True, False])
+def test_pass2_with_illumination_vs_oracle(det, S, N, inverse, keep):
+    """tike_fft2_pass2_intensity == the second pass of the transform followed
+    by sum_s |wave_s|^2 (_preconditioner.py:40-45,86-95); the wave is written
+    back iff keep."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    rng = np.random.default_rng(det + S + N)
+    x = rc(rng, N, S, det, det)
+    scale = 0.37 / det
+    # (the unnormalised transform either way, times `scale`)
+    f = np.fft.ifft2 if inverse else np.fft.fft2
+    want = f(x.astype(np.complex128),
+             norm="forward" if inverse else "backward") * scale
+    st = A.stream_ptr()
+    xd = A.to_device(x)
+    work = torch.empty_like(xd)
+    check(lib.tike_fft2_pass1(A.ptr(xd), A.ptr(work), N * S, det, int(inverse),
+                              st))
+    before = work.clone()
+    amp = torch.full((N, det, det), -1.0, dtype=torch.float32, device="cuda")
+    check(lib.tike_fft2_pass2_intensity(A.ptr(work), A.ptr(amp), N, S, det,
+                                        int(inverse), scale, int(keep), st))
+    np.testing.assert_allclose(amp.cpu().numpy(),
+                               (np.abs(want)**2).sum(axis=1),
+                               rtol=2e-4, atol=1e-5 * (np.abs(want)**2).max())
+    if keep:
+        assert_close(work.cpu().numpy(), want.astype(np.complex64),
+                     what="wave in place")
+    else:
+        assert torch.equal(work, before)  # never written
+
+
 @pytest.mark.parametrize("det,S,N,shared,keep", [
     (256, 8, 9, False, True), (256, 8, 9, True, False), (256, 3, 7, False, False),
     (256, 1, 11, False, True), (256, 2, 6, True, True), (128, 5, 10, False, True),

@@ -1466,17 +1466,22 @@ def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
                                    rtol=5e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("step_back", ["frequency", "as written"])
 @pytest.mark.parametrize("depth,S,N,eigen,u16", [(2, 8, 10, False, False),
                                                   (3, 2, 9, False, True),
                                                   (2, 1, 12, False, False),
-                                                  (2, 5, 7, True, False)])
-def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16):
+                                                  (2, 5, 7, True, False),
+                                                  (4, 6, 5, False, False)])
+def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16, step_back):
     """A multislice object at 256^2 on the fused kernels (`tike_fwd_pass1`
     with the incident probes -> `tike_fresnel_colpass` ->
     `tike_fft2_pass2_inplace`; `tike_ifft2_pass2_products` on the way back):
     two rpie epochs against the CPU oracle (rpie.py:367-495,
     multislice.py:69-92, fresnelspectprop.py:52-113) and against the
-    slice-by-slice composition of the general operators."""
+    slice-by-slice composition of the general operators.  step_back: the
+    steps back through the slices as extra outputs of the last slice's
+    gradient pass (`tike_fwd_grad_ifft2_pass1_slices`, the default) or as the
+    reference writes them (`tike_fft2_pass1` -> `tike_fresnel_colpass`)."""
     import importlib
     import tike_amd.random
     from oracle import operators as oops
@@ -1494,6 +1499,7 @@ def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16):
 
     def run(fused):
         R.FUSED_MULTISLICE = fused
+        R.STEP_BACK_IN_FREQUENCY = step_back == "frequency"
         params = tp.PtychoParameters(
             probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
             eigen_probe=None if ep is None else ep.copy(),
@@ -1515,6 +1521,7 @@ def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16):
                 return ctx.get_result()
         finally:
             R.FUSED_MULTISLICE = True
+            R.STEP_BACK_IN_FREQUENCY = True
 
     got, slow = run(True), run(False)
     np.testing.assert_allclose(np.array(got.algorithm_options.costs),

@@ -97,6 +97,76 @@ __global__ __launch_bounds__(256, N == 512 ? 2 : 4) void colpass_inplace_kernel(
   }
 }
 
+// Pass 2 of the S modes of a position with the illumination sum_s |wave_s|^2
+// formed from the registers (_preconditioner.py:40-45,86-95): the wave is read
+// once and, unless KEEP, never written -- tike_fft2_pass2_inplace followed by
+// tike_intensity moves 3 T + T / S per position, this T + T / S.
+// Work item = (position, k1, 256-column block), positions descending.
+template <int N, bool INV, bool KEEP>
+__global__ __launch_bounds__(256, N == 512 ? 2 : 4) void colpass_intensity_kernel(
+    cf* tiles, float* __restrict__ amp, long nscan, int S, float scale) {
+  constexpr int RB = N / 16, NH = N >= 256 ? N / 256 : 1, NT = N >= 256 ? 256 : N;
+  const long nitem = nscan * 16 * NH;
+  if ((int)threadIdx.x >= NT) return;
+  for (long v = blockIdx.x; v < nitem; v += gridDim.x) {
+    const int hb = (int)(v % NH);
+    const int k1 = (int)((v / NH) & 15);
+    const long n = nscan - 1 - v / (16 * NH);
+    const long lane = (long)k1 * N + hb * 256 + threadIdx.x;
+    float acc[RB];
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) acc[k2] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      cf* p = tiles + (n * S + s) * (long)N * N + lane;
+      cf u[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) u[r] = KEEP ? p[(long)(16 * r) * N] : tk_ld_stream(p + (long)(16 * r) * N);
+      Dft<RB, INV>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < RB; ++k2) {
+        const cf w = u[k2] * scale;
+        acc[k2] += w.x * w.x + w.y * w.y;
+        if (KEEP) tk_st_stream(p + (long)(16 * k2) * N, w);
+      }
+    }
+    float* __restrict__ a = amp + n * (long)N * N + lane;
+#pragma unroll
+    for (int k2 = 0; k2 < RB; ++k2) a[(long)(16 * k2) * N] = acc[k2];
+  }
+}
+
+extern "C" int tike_fft2_pass2_intensity(void* tiles, float* amplitude, long nscan, int S,
+                                         int det, int inverse, float scale, int keep,
+                                         void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(tiles != nullptr && amplitude != nullptr);
+  const long nitem = nscan * 16 * (det >= 256 ? det / 256 : 1);
+  const dim3 grid(tk_grid(nitem, 32)), block(256);
+#define TK_CI(N, INV, KEEP)                                                                  \
+  hipLaunchKernelGGL((colpass_intensity_kernel<N, INV, KEEP>), grid, block, 0, stream,       \
+                     (cf*)tiles, amplitude, nscan, S, scale)
+#define TK_CI_N(N)                          \
+  do {                                      \
+    if (inverse && keep) TK_CI(N, true, true);         \
+    else if (inverse) TK_CI(N, true, false);           \
+    else if (keep) TK_CI(N, false, true);              \
+    else TK_CI(N, false, false);                       \
+  } while (0)
+  switch (det) {
+    case 128: TK_CI_N(128); break;
+    case 256: TK_CI_N(256); break;
+    case 512: TK_CI_N(512); break;
+    default: return TK_ERR_UNSUPPORTED;
+  }
+#undef TK_CI_N
+#undef TK_CI
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
 extern "C" int tike_fft2_pass1(const void* in, void* out, long ntile, int det, int inverse,
                                void* stream) {
   TK_ENTER();

@@ -2433,12 +2433,22 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
 // 6 1.89 / 1.77, 7 1.86 / 1.78, 8 1.97 / 1.67 (two sweeps / resident)
 #define TK_FG_RESIDENT_MIN_MODES 6
 
-template <int MODEL, class DT>
-__global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
+//
+// BACK (the last slice of a multislice object, rpie.py:444-472): the wave the
+// slices in front receive is FresnelSpectProp.adj applied b times to chi =
+// IFFT2(G), i.e. IFFT2(conj(H) FFT2(IFFT2(G))) = IFFT2(conj(H)^b G) -- the
+// forward transform of the step back cancels against the inverse that formed
+// chi (probe window = detector).  G is in registers here, so the kernel also
+// emits the inverse's pass 1 of conj(H)^b G, b = 1 .. nback, into work + b *
+// back_stride: the steps back cost one more store each instead of a stored
+// chi, a forward pass 1 and a column pass.
+template <int MODEL, class DT, bool BACK = false>
+__global__ __launch_bounds__(256, BACK ? 2 : 3) void fwd_grad_ifft2_pass1_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
     long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
-    const cf* __restrict__ twtab) {
+    const cf* __restrict__ twtab, const cf* __restrict__ backprop = nullptr, int nback = 0,
+    long back_stride = 0) {
   constexpr int N = 256;
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
@@ -2504,11 +2514,30 @@ __global__ __launch_bounds__(256, 3) void fwd_grad_ifft2_pass1_kernel(
       Dft<16, false>::run(u);
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) u[k2] = u[k2] * I[k2];
+      cf g[BACK ? 16 : 1];
+      if (BACK) {
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) g[BACK ? k2 : 0] = u[k2];
+      }
       Dft<16, true>::run(u);
 #pragma unroll
       for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
       cf* mid = work + (n * S + s) * (long)N * N;
       fft2_rows_from_columns<N, true, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
+      if (BACK) {
+        for (int b = 1; b <= nback; ++b) {
+#pragma unroll
+          for (int k2 = 0; k2 < 16; ++k2) {
+            g[BACK ? k2 : 0] = g[BACK ? k2 : 0] * conjf(*tk_at_pinned(backprop + (k1 + 16 * k2) * N, (unsigned)t * 8u));
+            u[k2] = g[BACK ? k2 : 0];
+          }
+          Dft<16, true>::run(u);
+#pragma unroll
+          for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
+          fft2_rows_from_columns<N, true, true>(lds, tw, line, j, u,
+                                                mid + b * back_stride + (long)(16 * k1) * N);
+        }
+      }
     }
   }
 }
@@ -2597,15 +2626,18 @@ __device__ __forceinline__ void fft2_rows_from_columns_half(cf* __restrict__ lds
   __syncthreads();
 }
 
-template <int MH, int MODEL, class DT>
+// BACK: see fwd_grad_ifft2_pass1_kernel; G of the mode in hand is parked in
+// LDS (16 x 256 values per half) while its registers go through the inverse.
+template <int MH, int MODEL, class DT, bool BACK = false>
 __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
     long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
-    const cf* __restrict__ twtab) {
+    const cf* __restrict__ twtab, const cf* __restrict__ backprop = nullptr, int nback = 0,
+    long back_stride = 0) {
   constexpr int N = 256;
   using G2 = Fft2Geom<N>;
-  __shared__ cf lds[2 * G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  __shared__ cf lds[2 * G2::LDS_ELEMS + FftTwLds<N>::ELEMS + (BACK ? 2 * 16 * N : 0)];
   cf* twl = lds + 2 * G2::LDS_ELEMS;
   FftTwLds<N>::fill(twl, twtab);
   __syncthreads();
@@ -2680,12 +2712,39 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
     for (int m = 0; m < MH; ++m) {
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) F[m][k2] = F[m][k2] * I[k2];
+      // (a thread reads back only what it wrote: no barrier for the parking)
+      cf* const park = lds + 2 * G2::LDS_ELEMS + FftTwLds<N>::ELEMS + h * 16 * N + t;
+      if (BACK) {
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) park[k2 * N] = F[m][k2];
+      }
       Dft<16, true>::run(F[m]);
 #pragma unroll
       for (int ya = 1; ya < 16; ++ya) F[m][ya] = mul_tw<true>(F[m][ya], twtab[N + k1 * ya]);
       cf* mid = work + (n * S + m0 + m) * (long)N * N;
       fft2_rows_from_columns_half<N, true>(mylds, tw, t, line, j, F[m], mid + (long)(16 * k1) * N,
                                            m0 + m < S);
+      if (BACK) {
+        for (int b = 1; b <= nback; ++b) {
+          // (in quarters: sixteen propagator values in flight at once do
+          // not fit the registers next to the other modes)
+#pragma unroll
+          for (int q = 0; q < 16; q += 4) {
+#pragma unroll
+            for (int k2 = q; k2 < q + 4; ++k2) {
+              F[m][k2] = park[k2 * N] * conjf(*tk_at_pinned(backprop + (k1 + 16 * k2) * N, (unsigned)t * 8u));
+              park[k2 * N] = F[m][k2];
+            }
+            asm volatile("" ::: "memory");
+          }
+          Dft<16, true>::run(F[m]);
+#pragma unroll
+          for (int ya = 1; ya < 16; ++ya) F[m][ya] = mul_tw<true>(F[m][ya], twtab[N + k1 * ya]);
+          fft2_rows_from_columns_half<N, true>(mylds, tw, t, line, j, F[m],
+                                               mid + b * back_stride + (long)(16 * k1) * N,
+                                               m0 + m < S);
+        }
+      }
       if (vn < total) request(vn, m);
     }
   }
@@ -2904,18 +2963,17 @@ extern "C" int tike_grad_ifft2_crop(const void* colin, const float* gscale,
 // column pass (rows 16 k1 + ya), consumed by tike_ifft2_pass2_gradients.
 // scratch: from tike_fwd_pass1.  costs (may be NULL) must not need zeroing by
 // the caller (done here); work must not alias scratch.  det = 256 or 512.
-extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, int data_u16,
-                                         const unsigned char* measured, float* costs,
-                                         void* work, int nscan, int S, int det, float fwd_scale,
-                                         int model, float unmeasured_scaling, long num_measured,
-                                         void* stream_) {
-  TK_ENTER();
-  hipStream_t stream = (hipStream_t)stream_;
+static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, int data_u16,
+                                       const unsigned char* measured, float* costs, void* work,
+                                       int nscan, int S, int det, float fwd_scale, int model,
+                                       float unmeasured_scaling, long num_measured,
+                                       const cf* backprop, int nback, hipStream_t stream) {
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1 && (model == 0 || model == 1) &&
-               num_measured > 0);
+               num_measured > 0 && nback >= 0);
   if (nscan == 0) return TK_OK;
-  TK_CHECK_ARG(scratch && data && work && work != scratch);
-  if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
+  TK_CHECK_ARG(scratch && data && work && work != scratch && (nback == 0 || backprop));
+  if (det != 256 && (det != 512 || nback > 0)) return TK_ERR_UNSUPPORTED;
+  const long back_stride = (long)nscan * S * det * det;
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   if (det == 512) {
@@ -2952,9 +3010,17 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
     // one 512-thread workgroup per CU (it takes the whole register file)
     const dim3 grid(tk_grid((long)nscan * 16, 1)), block(512);
 #define TK_FGR(MH, M, DT)                                                                     \
-  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT>), grid, block, 0,       \
-                     stream, (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work, \
-                     (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
+  do {                                                                                        \
+    if (nback > 0)                                                                            \
+      hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT, true>), grid,       \
+                         block, 0, stream, (const cf*)scratch, (const DT*)data, measured,     \
+                         sink, (cf*)work, (long)nscan, S, fwd_scale, unmeasured_scaling, inv, \
+                         tw, backprop, nback, back_stride);                                   \
+    else                                                                                      \
+      hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT>), grid, block, 0,   \
+                         stream, (const cf*)scratch, (const DT*)data, measured, sink,         \
+                         (cf*)work, (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw);  \
+  } while (0)
 #define TK_FGR_M(MH)                                                                          \
   do {                                                                                        \
     if (model == 0 && data_u16)                                                               \
@@ -2976,6 +3042,24 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
     return tk_cost_finish(sink, nscan, stream);
   }
   const dim3 grid(tk_grid((long)nscan * 16, 12)), block(256);
+  if (nback > 0) {  // (one mode too: the two-sweep kernel reads it twice)
+#define TK_FGB(M, DT)                                                                         \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_kernel<M, DT, true>), grid, block, 0, stream,      \
+                     (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work,         \
+                     (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw, backprop, nback, \
+                     back_stride)
+    if (model == 0 && data_u16)
+      TK_FGB(0, unsigned short);
+    else if (model == 0)
+      TK_FGB(0, float);
+    else if (data_u16)
+      TK_FGB(1, unsigned short);
+    else
+      TK_FGB(1, float);
+#undef TK_FGB
+    TK_LAUNCH_CHECK();
+    return tk_cost_finish(sink, nscan, stream);
+  }
   if (S == 1) {
 #define TK_FG1(M, DT)                                                                         \
   hipLaunchKernelGGL((fwd_grad_ifft2_pass1_single_kernel<M, DT>), grid, block, 0, stream,     \
@@ -3008,6 +3092,34 @@ extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, 
 #undef TK_FG
   TK_LAUNCH_CHECK();
   return tk_cost_finish(sink, nscan, stream);
+}
+
+extern "C" int tike_fwd_grad_ifft2_pass1(const void* scratch, const void* data, int data_u16,
+                                         const unsigned char* measured, float* costs,
+                                         void* work, int nscan, int S, int det, float fwd_scale,
+                                         int model, float unmeasured_scaling, long num_measured,
+                                         void* stream) {
+  TK_ENTER();
+  return launch_fwd_grad_ifft2_pass1(scratch, data, data_u16, measured, costs, work, nscan, S,
+                                     det, fwd_scale, model, unmeasured_scaling, num_measured,
+                                     nullptr, 0, (hipStream_t)stream);
+}
+
+// The last slice of a multislice object: work (nslices, nscan, S, det, det);
+// work[b] = the inverse's pass 1 of conj(propagator)^b x (far-plane gradient)
+// -- what tike_ifft2_pass2_products of slice nslices - 1 - b finishes.
+extern "C" int tike_fwd_grad_ifft2_pass1_slices(const void* scratch, const void* data,
+                                                int data_u16, const unsigned char* measured,
+                                                float* costs, void* work, int nscan, int S,
+                                                int det, float fwd_scale, int model,
+                                                float unmeasured_scaling, long num_measured,
+                                                const void* propagator, int nslices,
+                                                void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nslices >= 1);
+  return launch_fwd_grad_ifft2_pass1(scratch, data, data_u16, measured, costs, work, nscan, S,
+                                     det, fwd_scale, model, unmeasured_scaling, num_measured,
+                                     (const cf*)propagator, nslices - 1, (hipStream_t)stream);
 }
 
 extern "C" int tike_grad_ifft2_pass1(const void* colin, const float* gscale,

@@ -24,7 +24,7 @@ def fused_slices(probe_shape, detector_shape, S):
 
 
 def next_incident_probe(psi_slice, scan, beam, scratch, out, propagator,
-                        scale, patches=None):
+                        scale, patches=None, amplitude=None, keep=True):
     """The probe incident on the NEXT slice, fused (multislice.py:86-91 =
     Convolution.fwd + FresnelSpectProp.fwd): `tike_fwd_pass1` forms patch x
     incident probe on the fly and runs the first pass of the transform,
@@ -32,7 +32,10 @@ def next_incident_probe(psi_slice, scan, beam, scratch, out, propagator,
     `tike_fft2_pass2_inplace` finishes in `out` (n, S, pw, pw).  beam
     (1|n, ..., S, pw, pw) device tensor; scratch: a workspace shaped like
     `out`; scale = forward x inverse normalisation; patches (n, pw, pw), if
-    given, receives the object patches of this slice."""
+    given, receives the object patches of this slice.  amplitude (n, pw, pw)
+    float32, if given, receives sum_s |out_s|^2 from the last pass
+    (`tike_fft2_pass2_intensity`); with keep=False that pass does not write
+    the wave and `out` is scratch."""
     from .._lib import check, lib
     n = scan.shape[0]
     S, pw = out.shape[-3], out.shape[-1]
@@ -47,8 +50,14 @@ def next_incident_probe(psi_slice, scan, beam, scratch, out, propagator,
         lib.tike_fresnel_colpass(A.ptr(scratch), A.ptr(propagator), 0,
                                  A.ptr(out), n * S, pw, scale, st),
         "Fresnel step: column passes")
-    check(lib.tike_fft2_pass2_inplace(A.ptr(out), n * S, pw, 1, 1.0, st),
-          "Fresnel step: pass 2")
+    if amplitude is None:
+        check(lib.tike_fft2_pass2_inplace(A.ptr(out), n * S, pw, 1, 1.0, st),
+              "Fresnel step: pass 2")
+    else:
+        check(
+            lib.tike_fft2_pass2_intensity(A.ptr(out), A.ptr(amplitude), n, S,
+                                          pw, 1, 1.0, int(keep), st),
+            "Fresnel step: pass 2 + illumination")
     return out
 
 

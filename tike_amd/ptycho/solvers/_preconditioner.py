@@ -6,12 +6,19 @@ position) and ``tike_probe_preconditioner``.  Unlike the reference (whose all-re
 commented out, :185,201, because every GPU owns a spatial stripe) positions
 are sharded across ranks here, so both preconditioners are summed over ranks.
 """
+import os
+
 import torch
 
 from ... import _arrays as A
 from ..._lib import check, lib
 from ...operators.multislice import fused_slices, next_incident_probe
 from ...operators.propagation import fft_scales
+
+
+MULTISLICE_CHUNK = int(os.environ.get("TIKE_PRECOND_CHUNK", "512"))
+"""Positions per launch of the fused multislice object preconditioner
+(c3rpie2 at 64 / 128 / 256 / 512: 49.1 / 49.5 / 50.2 / 50.6 k patterns/s)."""
 
 
 def _psi_preconditioner(parameters, operator):
@@ -54,7 +61,7 @@ def _psi_preconditioner_multislice(parameters, operator):
         fwd_scale, inv_scale = fft_scales(pw, operator.norm)
         prop = operator.diffraction.propagation._propagator((pw, pw),
                                                             psi.device)
-        chunk = max(1, min(N, 128))
+        chunk = max(1, min(N, MULTISLICE_CHUNK))
         bufs = [torch.empty((chunk, S, pw, pw), dtype=torch.complex64,
                             device=psi.device) for _ in range(3)]
         amp = torch.empty((chunk, pw, pw), dtype=torch.float32,
@@ -64,12 +71,11 @@ def _psi_preconditioner_multislice(parameters, operator):
             sc = scan[lo:lo + n]
             beam = probe1
             for i in range(1, D):
+                # (the illumination comes out of the step's last pass; the
+                # wave itself is only written when another slice follows)
                 beam = next_incident_probe(
                     psi[i - 1], sc, beam, bufs[2][:n], bufs[i % 2][:n], prop,
-                    fwd_scale * inv_scale)
-                check(
-                    lib.tike_intensity(A.ptr(beam), A.ptr(amp), n, S, pw * pw,
-                                       st), "illumination of a slice")
+                    fwd_scale * inv_scale, amplitude=amp, keep=i + 1 < D)
                 check(
                     lib.tike_scatter_amplitudes(A.ptr(amp), A.ptr(sc),
                                                 A.ptr(out[i]), n, pw, H, W,

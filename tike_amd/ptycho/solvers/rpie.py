@@ -18,6 +18,7 @@ max(preconditioner)`` alone (:271-280); position correction is commented out
 (:163-176, 521-563).
 """
 import logging
+import os
 
 import numpy as np
 import torch
@@ -197,6 +198,11 @@ composition of the general operators, which remains the path of every other
 configuration."""
 
 
+STEP_BACK_IN_FREQUENCY = os.environ.get("TIKE_MS_STEP_BACK", "1") == "1"
+"""The steps back through the slices of the fused multislice path as extra
+outputs of the last slice's gradient pass (see _gradients_multislice_fused)."""
+
+
 def _fused_multislice_shapes(op, S, pw, exitwave_options, recover_psi, data):
     return (FUSED_MULTISLICE and recover_psi
             and fused_slices(pw, op.detector_shape, S)
@@ -216,10 +222,16 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
     kept for the way back.  Last slice: `tike_fwd_pass1` ->
     `tike_fwd_grad_ifft2_pass1` (far field, cost, gradient factor and the
     inverse's first pass in one launch; the far plane is never stored).
-    Way back, per slice tt: `tike_ifft2_pass2_products` finishes the inverse
-    and forms both numerators of the slice (object: through the grouped
-    scatter), then `tike_fft2_pass1` -> `tike_fresnel_colpass` (conjugated
-    propagator) hand the wave to the slice in front."""
+    Way back: the reference hands `diff = propagation.adj(diff)` to the slice
+    in front (:470); with diff = IFFT2(G) that is IFFT2(conj(H) FFT2(IFFT2(G)))
+    = IFFT2(conj(H)^b G) -- the forward transform of every step back cancels
+    (probe window = detector).  `tike_fwd_grad_ifft2_pass1_slices` therefore
+    emits the inverse's first pass of conj(H)^b G for every slice while G is
+    in its registers, and `tike_ifft2_pass2_products` of slice D - 1 - b
+    finishes it and forms both numerators of the slice (object: through the
+    grouped scatter).  STEP_BACK_IN_FREQUENCY = False runs the step as the
+    reference writes it (`tike_fft2_pass1` -> `tike_fresnel_colpass` with the
+    conjugated propagator)."""
     dev = psi.device
     B = hi - lo
     D = psi.shape[0]
@@ -235,12 +247,16 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
     chi0 = torch.empty((max(B, 1), pw, pw), dtype=torch.complex64, device=dev)
     patches0 = (torch.empty_like(chi0) if eigen_weights is not None else None)
     # (a chunk holds far + mid + D - 1 sets of incident probes: 1.5 GiB per
-    # 256 positions at 8 modes and two slices; the launches of a 100-position
-    # chunk are too short to fill the chip more than twice)
-    chunk = L.chunk_positions(S, det)
+    # 256 positions at 8 modes and two slices)
+    # Measured (c3rpie2, same box): 64 / 128 / 256 / 512 / 1000 positions per
+    # chunk -> 45.2 / 47.4 / 49.5 / 51.2 / 52.4 k patterns/s: these stages
+    # hand nothing over through the Infinity Cache, longer launches win.
+    chunk = (L.chunk_positions(S, det) if L.CHUNK_POSITIONS_OVERRIDE else
+             max(64, (1 << 34) // (2 * D * S * det * det * 8)))  # 16 GiB
     nmax = max(1, min(chunk, B))
     far = ws.get("ms_far", (nmax, S, det, det), torch.complex64, dev)
-    mid = ws.get("ms_mid", (nmax, S, det, det), torch.complex64, dev)
+    nback = D if STEP_BACK_IN_FREQUENCY else 1
+    mids = ws.get("ms_mid", (nback, nmax, S, det, det), torch.complex64, dev)
     beams = ws.get("ms_beams", (max(D - 1, 1), nmax, S, pw, pw),
                    torch.complex64, dev)
     objproj = ws.get("ms_objproj", (nmax, pw, pw), torch.complex64, dev)
@@ -269,27 +285,34 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
             lib.tike_fwd_pass1(A.ptr(psi[D - 1]), A.ptr(sc), A.ptr(beam), per,
                                None, None, None, 0, 0, A.ptr(far), None, n, S,
                                pw, det, H, W, st), "last slice, pass 1")
+        # (the outputs of a chunk packed: (nback, n, S, det, det))
+        midv = mids.view(-1)[:nback * n * S * det * det].view(
+            nback, n, S, det, det)
         check(
-            lib.tike_fwd_grad_ifft2_pass1(
+            lib.tike_fwd_grad_ifft2_pass1_slices(
                 A.ptr(far), A.ptr(data[clo:chi_hi]), u16, A.ptr(mask_u8),
-                A.ptr(costs[blo:blo + n]), A.ptr(mid), n, S, det, fwd_scale,
-                0, unmeasured, nmeasured, st),
-            "far field + gradient + inverse pass 1")
+                A.ptr(costs[blo:blo + n]), A.ptr(midv), n, S, det, fwd_scale,
+                0, unmeasured, nmeasured, A.ptr(prop), nback, st),
+            "far field + gradient + inverse pass 1 (every slice)")
+        mid = midv[0]
         for tt in range(D - 1, -1, -1):
             beam, per = incident[tt]
+            if STEP_BACK_IN_FREQUENCY:
+                mid = midv[D - 1 - tt]
             check(
                 lib.tike_ifft2_pass2_products(
                     A.ptr(mid), A.ptr(psi[tt]), A.ptr(sc), A.ptr(beam), per,
                     A.ptr(objproj), A.ptr(pacc[tt]), 1.0,
                     A.ptr(chi0[blo:blo + n]) if tt == 0 else None,
-                    int(tt > 0), n, S, det, H, W, inv_scale, st),
+                    int(tt > 0 and not STEP_BACK_IN_FREQUENCY), n, S, det, H,
+                    W, inv_scale, st),
                 "inverse pass 2 + numerators")
             check(
                 lib.tike_scatter_patches(A.ptr(objproj), A.ptr(sc),
                                          A.ptr(acc[tt]), n, pw, H, W, st),
                 "object numerator")
-            if tt == 0:
-                break
+            if tt == 0 or STEP_BACK_IN_FREQUENCY:
+                continue
             check(lib.tike_fft2_pass1(A.ptr(mid), A.ptr(far), n * S, det, 0,
                                       st), "Fresnel step back: pass 1")
             # (the inverse transform's normalisation is applied by the pass
