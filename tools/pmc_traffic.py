@@ -29,6 +29,7 @@ KERNELS = {
     "void farplane_gradient_kernel": "tike_farplane_gradient",
     "eigen_pixel_update1_kernel": "tike_eigen_pixel_update1",
     "eigen_position_sums1_kernel": "tike_eigen_position_sums1",
+    "eigen_position_sums1_pair_kernel": "tike_eigen_position_sums1",
     "ls_trial_kernel": "tike_cgrad_line_search:trial",
     "ls_decide_kernel": "tike_cgrad_line_search:decide",
     "void ls_ksteps_colpass_kernel": "tike_cgrad_line_search_linear:costs",
@@ -52,6 +53,7 @@ KERNELS = {
     "void ifft2_crop_v2_kernel": "tike_ifft2_crop_scaled",
     "void probe_grad_kernel<true": "tike_lstsq_gradients",
     "void step_stats_kernel": "tike_lstsq_step_stats",
+    "void step_stats_pair_kernel": "tike_lstsq_step_stats",
     "scatter_patches_kernel": "tike_scatter_patches",
     "void gradient_scale_kernel": "tike_gradient_scale",
     "psi_precond_kernel": "tike_psi_preconditioner",
@@ -68,7 +70,8 @@ KERNELS = {
 SOLVER_ONLY = ("psi_precond_kernel", "void fwd_gradient_scale_kernel",
                "void fwd_grad_ifft2_pass1_kernel",
                "void fwd_grad_ifft2_pass1_resident_kernel",
-               "void step_stats_kernel", "void probe_grad_kernel",
+               "void step_stats_kernel", "void step_stats_pair_kernel",
+               "void probe_grad_kernel",
                "void gradient_scale_kernel", "void farplane_gradient_kernel",
                "void fwd_grad_ifft2_pass1_single_kernel", "ls_trial_kernel",
                "void fwd_grad_ifft2_pass1_512_kernel",
