@@ -136,6 +136,19 @@ def synthetic(N_total, S, det, lo, hi, seed=1234):
 # ------------------------------------------------------ per-kernel HIP events
 # entry -> index of the output argument whose absence marks a cost-only launch
 COST_ONLY_ARG = {"tike_fwd_pass1": 10, "tike_fwd_gradient_scale": 4}
+# entry -> index of its probe_per_scan argument: a launch whose probe is one
+# wave per position (the slices of a multislice object behind the first) reads
+# a far-plane-sized array more: own line (":incident")
+INCIDENT_ARG = {"tike_fwd_pass1": 3, "tike_ifft2_pass2_products": 4}
+# entry -> (index of its position / tile count, tiles per position or None):
+# launches of one entry differ in size in the multislice workload (the object
+# preconditioner's chunks, the gradient chunks), so the roofline of such an
+# entry is priced on the positions its launches really covered
+POSITIONS_ARG = {"tike_fwd_pass1": (11, None), "tike_ifft2_pass2_products": (10, None),
+                 "tike_fwd_grad_ifft2_pass1_slices": (6, None),
+                 "tike_fresnel_colpass": (4, "S"), "tike_fft2_pass2_inplace": (1, "S"),
+                 "tike_fft2_pass2_intensity": (2, None)}
+MULTISLICE_DEPTH = 1  # set by the workload (byte model of the sliced gradient pass)
 
 
 class KernelTimers:
@@ -149,6 +162,8 @@ class KernelTimers:
         self.enabled = False
         self.only = None  # bracket these entries only (None: all of them)
         self.label_cost_only = False  # (cgrad workloads: see COST_ONLY_ARG)
+        self.cost_only_suffix = ":cost_only"
+        self.modes = 1  # tiles per position of the entries counted in tiles
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
         self.next = 0
         for name in names:
@@ -168,9 +183,16 @@ class KernelTimers:
                 # cost-only launches (cgrad's line search: no patches / no
                 # gradient factor stored) move fewer bytes: own line
                 out = COST_ONLY_ARG.get(_name) if self.label_cost_only else None
-                if out is not None and args[out] is None:
-                    _name = _name + ":cost_only"
-                self.events[_name].append((e0, e1))
+                inc = INCIDENT_ARG.get(_name)
+                pos = POSITIONS_ARG.get(_name)
+                n = None
+                if pos is not None:
+                    n = int(args[pos[0]]) / (self.modes if pos[1] else 1)
+                if inc is not None and args[inc]:
+                    _name = _name + ":incident"
+                elif out is not None and args[out] is None:
+                    _name = _name + self.cost_only_suffix
+                self.events[_name].append((e0, e1, n))
                 return rc
 
             setattr(lib, name, wrapper)
@@ -198,7 +220,7 @@ class KernelTimers:
             out = fn(*args, **kw)
             e1.record()
             self.events[name(*args) if callable(name) else name].append(
-                (e0, e1))
+                (e0, e1, None))
             return out
 
         setattr(obj, method, wrapper)
@@ -210,9 +232,11 @@ class KernelTimers:
     def summary(self):
         out = {}
         for name, evs in self.events.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
             out[name] = dict(calls=len(ms), total_ms=float(np.sum(ms)),
                              avg_ms=float(np.mean(ms)))
+            if all(n is not None for _, _, n in evs):
+                out[name]["positions"] = float(sum(n for _, _, n in evs))
         return out
 
 
@@ -376,6 +400,21 @@ def algorithmic_bytes(name, n, S, det, pw, C):
         "tike_lstsq_gradients": n * (S * P + 2 * P),
         "tike_scatter_patches": n * (P + 8 * (pw + 1) * (pw + 1)),
         "tike_lstsq_step_stats": n * (3 * P + 32),
+        # ---- the stages of a multislice object (no patches stored there)
+        "tike_fwd_pass1:no_patches": n * (T + P + 8) + (S + C) * P,
+        # the probe incident on a slice behind the first: one wave per position in
+        "tike_fwd_pass1:incident": n * (2 * T + P + 8),
+        "tike_fresnel_colpass": n * 2 * T + D * 2,
+        "tike_fft2_pass2_inplace": n * 2 * T,
+        # last pass of a slice step + illumination (the wave itself not written)
+        "tike_fft2_pass2_intensity": n * (T + D),
+        # gradient pass of the last slice: hand-off + data in, one intermediate
+        # per slice out
+        "tike_fwd_grad_ifft2_pass1_slices": n * (T + D + MULTISLICE_DEPTH * T),
+        # inverse pass 2 + both numerators of a slice: intermediate in, object
+        # patch gathered, objproj (+ mode 0 of chi) out
+        "tike_ifft2_pass2_products": n * (T + 3 * P) + S * P,
+        "tike_ifft2_pass2_products:incident": n * (2 * T + 2 * P),
     }
     return table.get(name, 0)
 
@@ -671,7 +710,12 @@ def main():
     from tike_amd.ptycho.solvers.lstsq import chunk_positions
 
     timers = KernelTimers(lib, [n for n in _PROTOTYPES if n != "tike_init"])
-    timers.label_cost_only = a.workload in ("c1", "c2")
+    timers.label_cost_only = a.workload in ("c1", "c2", "c3rpie2")
+    if a.workload == "c3rpie2":
+        global MULTISLICE_DEPTH
+        MULTISLICE_DEPTH = 2
+        timers.cost_only_suffix = ":no_patches"
+        timers.modes = EPOCH_DEFAULTS["c3rpie2"][1]
     counts = dict(epoch=0, steps=0, in_minibatch=False)
     cpu = None
     cpu_job = None
@@ -887,6 +931,9 @@ def main():
         if dominant is None:
             dominant = dominant_entry(full, launch_n, S, det, C)
         k = summ.get(dominant) or full[dominant]
+        if k.get("positions"):
+            # launches of different sizes under one entry: the mean launch
+            launch_n = k["positions"] / k["calls"]
         nbytes = algorithmic_bytes(dominant, launch_n, S, det, pw, C)
         achieved = nbytes / (k["avg_ms"] * 1e-3) / 1e9
         ktot = sum(v["total_ms"] for v in kernels.values())

@@ -2065,6 +2065,125 @@ __global__ __launch_bounds__(256) void position_sums_kernel(
   }
 }
 
+// Radius 2, two positions per work item, row walk (see step_stats_pair_kernel):
+// a thread keeps its column of the central window and goes down the rows of
+// its share with the five vertical taps of each position in registers -- one
+// new 8-byte load per pixel instead of five -- the four horizontal neighbours
+// come as two 16-byte loads, and a shared probe is loaded once for the pair:
+// 9 loads per pixel pair instead of 24.  cols = min(w, 256) columns per thread
+// group, 256 / cols groups stacked over the rows.
+__global__ __launch_bounds__(256) void position_sums_pair_kernel(
+    const cf* __restrict__ patches, const cf* __restrict__ chi, int chi_modes,
+    const TkProbe probe, const TkTaps taps, float* __restrict__ num, float* __restrict__ den,
+    int pw, int nscan, int nsplit) {
+  __shared__ float red[4];
+  typedef float tk_v4f __attribute__((ext_vector_type(4)));
+  const long P = (long)pw * pw;
+  const int crop = pw / 4;
+  const int w = pw - 2 * crop;
+  const int cols = w < 256 ? w : 256, groups = 256 / cols, rows = w / (nsplit * groups);
+  const int npair = (nscan + 1) / 2;
+  const bool shared = probe.weights == nullptr && probe.pos_stride == 0;
+  const float t0 = taps.t[0], t1 = taps.t[1], t2 = taps.t[2], t3 = taps.t[3], t4 = taps.t[4];
+  auto ld16 = [](const cf* p) {
+    tk_v4f v;
+    __builtin_memcpy(&v, p, sizeof(v));
+    return v;
+  };
+  auto add = [&](float* a, const cf (&v)[5], const tk_v4f hl, const tk_v4f hr, const cf Pm,
+                 const cf c) {
+    cf gx = mk(t0 * v[0].x, t0 * v[0].y), gy = mk(t0 * hl.x, t0 * hl.y);
+    gx.x += t1 * v[1].x;
+    gx.y += t1 * v[1].y;
+    gy.x += t1 * hl.z;
+    gy.y += t1 * hl.w;
+    gx.x += t2 * v[2].x;
+    gx.y += t2 * v[2].y;
+    gy.x += t2 * v[2].x;
+    gy.y += t2 * v[2].y;
+    gx.x += t3 * v[3].x;
+    gx.y += t3 * v[3].y;
+    gy.x += t3 * hr.x;
+    gy.y += t3 * hr.y;
+    gx.x += t4 * v[4].x;
+    gx.y += t4 * v[4].y;
+    gy.x += t4 * hr.z;
+    gy.y += t4 * hr.w;
+    const cf px = gx * Pm, py = gy * Pm;
+    a[0] += px.x * c.x + px.y * c.y;
+    a[1] += py.x * c.x + py.y * c.y;
+    a[2] += norm2(px);
+    a[3] += norm2(py);
+  };
+  for (int item = blockIdx.x; item < npair * nsplit; item += gridDim.x) {
+    const long n0 = 2 * (item / nsplit);
+    const int part = item % nsplit;
+    const bool two = n0 + 1 < nscan;
+    const long n1 = two ? n0 + 1 : n0;
+    const cf* __restrict__ O0 = patches + n0 * P;
+    const cf* __restrict__ O1 = patches + n1 * P;
+    const cf* __restrict__ X0 = chi + n0 * chi_modes * P;
+    const cf* __restrict__ X1 = chi + n1 * chi_modes * P;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ybeg = crop + (part * groups + (int)threadIdx.x / cols) * rows;
+    for (int x = crop + (int)threadIdx.x % cols; x < crop + w; x += 256) {
+      cf u[5], v[5];  // rows y - 2 .. y + 2 of column x, positions n0 / n1
+#pragma unroll
+      for (int d = 1; d < 5; ++d) {
+        u[d] = O0[(ybeg - 3 + d) * pw + x];
+        v[d] = O1[(ybeg - 3 + d) * pw + x];
+      }
+      for (int y = ybeg; y < ybeg + rows; ++y) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          u[d] = u[d + 1];
+          v[d] = v[d + 1];
+        }
+        const int pix = y * pw + x;
+        u[4] = O0[pix + 2 * pw];
+        v[4] = O1[pix + 2 * pw];
+        const tk_v4f ul = ld16(O0 + pix - 2), ur = ld16(O0 + pix + 1);
+        const tk_v4f vl = ld16(O1 + pix - 2), vr = ld16(O1 + pix + 1);
+        const cf c0 = X0[pix], c1 = X1[pix];
+        const cf P0 = probe.at(n0, 0, pix);
+        const cf P1 = shared ? P0 : probe.at(n1, 0, pix);
+        add(a, u, ul, ur, P0, c0);
+        add(b, v, vl, vr, P1, c1);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = tk_block_sum256(a[k], red);
+      b[k] = tk_block_sum256(b[k], red);
+    }
+    if (threadIdx.x == 0) {
+      if (nsplit > 1) {
+        unsafeAtomicAdd(&num[2 * n0], a[0]);
+        unsafeAtomicAdd(&num[2 * n0 + 1], a[1]);
+        unsafeAtomicAdd(&den[2 * n0], a[2]);
+        unsafeAtomicAdd(&den[2 * n0 + 1], a[3]);
+        if (two) {
+          unsafeAtomicAdd(&num[2 * n1], b[0]);
+          unsafeAtomicAdd(&num[2 * n1 + 1], b[1]);
+          unsafeAtomicAdd(&den[2 * n1], b[2]);
+          unsafeAtomicAdd(&den[2 * n1 + 1], b[3]);
+        }
+      } else {
+        num[2 * n0] = a[0];
+        num[2 * n0 + 1] = a[1];
+        den[2 * n0] = a[2];
+        den[2 * n0 + 1] = a[3];
+        if (two) {
+          num[2 * n1] = b[0];
+          num[2 * n1 + 1] = b[1];
+          den[2 * n1] = b[2];
+          den[2 * n1 + 1] = b[3];
+        }
+      }
+    }
+  }
+}
+
 extern "C" int tike_position_sums(const void* patches, const void* chi, int chi_modes,
                                   const void* probe, const void* eigen_probe,
                                   const float* eigen_weights, int num_eigen, int eigen_modes,
@@ -2079,8 +2198,15 @@ extern "C" int tike_position_sums(const void* patches, const void* chi, int chi_
   for (int k = 0; k < 9; ++k) taps.t[k] = k <= 2 * radius ? taps_host[k] : 0.f;
   const TkProbe pr =
       tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes, S, pw);
+  // the pair kernel: radius 2, a window whose columns tile 256 threads
+  const int win = pw - 2 * (pw / 4), wcols = win < 256 ? win : 256;
+  const bool pairs = g_stats_pairs && radius == 2 && pw >= 16 && nscan > 1 &&
+                     (win % 256 == 0 || 256 % win == 0) && win % (256 / wcols) == 0;
+  const long nitem = pairs ? (nscan + 1) / 2 : nscan;
   int nsplit = 1;
-  while (nsplit < 16 && (long)nscan * nsplit * 2 <= 8192 && pw >= 64) nsplit *= 2;
+  while (nsplit < 16 && nitem * nsplit * 2 <= 8192 && pw >= 64 &&
+         (!pairs || win % (2 * nsplit * (256 / wcols)) == 0))
+    nsplit *= 2;
   if (tk_deterministic()) nsplit = 1;
   if (nsplit > 1) {
     hipError_t e = hipMemsetAsync(numerator, 0, sizeof(float) * 2 * (size_t)nscan,
@@ -2089,7 +2215,11 @@ extern "C" int tike_position_sums(const void* patches, const void* chi, int chi_
       e = hipMemsetAsync(denominator, 0, sizeof(float) * 2 * (size_t)nscan, (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
   }
-  if (radius == 2)  // position.py:779-810: sigma = 0.333, truncate 4 -> radius 2
+  if (pairs)
+    hipLaunchKernelGGL(position_sums_pair_kernel, dim3(tk_grid(nitem * nsplit, 16)), dim3(256), 0,
+                       (hipStream_t)stream, (const cf*)patches, (const cf*)chi, chi_modes, pr,
+                       taps, numerator, denominator, pw, nscan, nsplit);
+  else if (radius == 2)  // position.py:779-810: sigma = 0.333, truncate 4 -> radius 2
     hipLaunchKernelGGL(position_sums_kernel<2>, dim3((unsigned)nscan * nsplit), dim3(256), 0,
                        (hipStream_t)stream, (const cf*)patches, (const cf*)chi, chi_modes, pr,
                        taps, numerator, denominator, pw, nsplit);

@@ -2629,18 +2629,15 @@ __device__ __forceinline__ void fft2_rows_from_columns_half(cf* __restrict__ lds
   __syncthreads();
 }
 
-// BACK: see fwd_grad_ifft2_pass1_kernel; G of the mode in hand is parked in
-// LDS (16 x 256 values per half) while its registers go through the inverse.
-template <int MH, int MODEL, class DT, bool BACK = false>
+template <int MH, int MODEL, class DT>
 __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
     long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
-    const cf* __restrict__ twtab, const cf* __restrict__ backprop = nullptr, int nback = 0,
-    long back_stride = 0) {
+    const cf* __restrict__ twtab) {
   constexpr int N = 256;
   using G2 = Fft2Geom<N>;
-  __shared__ cf lds[2 * G2::LDS_ELEMS + FftTwLds<N>::ELEMS + (BACK ? 2 * 16 * N : 0)];
+  __shared__ cf lds[2 * G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
   cf* twl = lds + 2 * G2::LDS_ELEMS;
   FftTwLds<N>::fill(twl, twtab);
   __syncthreads();
@@ -2715,39 +2712,12 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
     for (int m = 0; m < MH; ++m) {
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) F[m][k2] = F[m][k2] * I[k2];
-      // (a thread reads back only what it wrote: no barrier for the parking)
-      cf* const park = lds + 2 * G2::LDS_ELEMS + FftTwLds<N>::ELEMS + h * 16 * N + t;
-      if (BACK) {
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) park[k2 * N] = F[m][k2];
-      }
       Dft<16, true>::run(F[m]);
 #pragma unroll
       for (int ya = 1; ya < 16; ++ya) F[m][ya] = mul_tw<true>(F[m][ya], twtab[N + k1 * ya]);
       cf* mid = work + (n * S + m0 + m) * (long)N * N;
       fft2_rows_from_columns_half<N, true>(mylds, tw, t, line, j, F[m], mid + (long)(16 * k1) * N,
                                            m0 + m < S);
-      if (BACK) {
-        for (int b = 1; b <= nback; ++b) {
-          // (in quarters: sixteen propagator values in flight at once do
-          // not fit the registers next to the other modes)
-#pragma unroll
-          for (int q = 0; q < 16; q += 4) {
-#pragma unroll
-            for (int k2 = q; k2 < q + 4; ++k2) {
-              F[m][k2] = park[k2 * N] * conjf(*tk_at_pinned(backprop + (k1 + 16 * k2) * N, (unsigned)t * 8u));
-              park[k2 * N] = F[m][k2];
-            }
-            asm volatile("" ::: "memory");
-          }
-          Dft<16, true>::run(F[m]);
-#pragma unroll
-          for (int ya = 1; ya < 16; ++ya) F[m][ya] = mul_tw<true>(F[m][ya], twtab[N + k1 * ya]);
-          fft2_rows_from_columns_half<N, true>(mylds, tw, t, line, j, F[m],
-                                               mid + b * back_stride + (long)(16 * k1) * N,
-                                               m0 + m < S);
-        }
-      }
       if (vn < total) request(vn, m);
     }
   }
@@ -3001,7 +2971,10 @@ static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, in
     TK_LAUNCH_CHECK();
     return tk_cost_finish(sink512, nscan, stream);
   }
-  const bool resident = S >= TK_FG_RESIDENT_MIN_MODES && S <= 8;
+  // (nback > 0: the two-sweep kernel for any number of modes -- a BACK form of
+  // the resident kernel, G of the mode in hand parked in LDS, was 10 % slower:
+  // 3.13 vs 2.81 ms per 1000 positions x 8 modes x 2 slices)
+  const bool resident = S >= TK_FG_RESIDENT_MIN_MODES && S <= 8 && nback == 0;
   // contributors per pattern: (k1, wave of the first half) / (k1)
   TkCostSink sink;
   {
@@ -3013,17 +2986,9 @@ static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, in
     // one 512-thread workgroup per CU (it takes the whole register file)
     const dim3 grid(tk_grid((long)nscan * 16, 1)), block(512);
 #define TK_FGR(MH, M, DT)                                                                     \
-  do {                                                                                        \
-    if (nback > 0)                                                                            \
-      hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT, true>), grid,       \
-                         block, 0, stream, (const cf*)scratch, (const DT*)data, measured,     \
-                         sink, (cf*)work, (long)nscan, S, fwd_scale, unmeasured_scaling, inv, \
-                         tw, backprop, nback, back_stride);                                   \
-    else                                                                                      \
-      hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT>), grid, block, 0,   \
-                         stream, (const cf*)scratch, (const DT*)data, measured, sink,         \
-                         (cf*)work, (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw);  \
-  } while (0)
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT>), grid, block, 0,       \
+                     stream, (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work, \
+                     (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
 #define TK_FGR_M(MH)                                                                          \
   do {                                                                                        \
     if (model == 0 && data_u16)                                                               \
