@@ -38,7 +38,7 @@ extern "C" {
  * A binding compares tike_abi_version() of the loaded library with the
  * TIKE_ABI_VERSION it was written against before its first call
  * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
-#define TIKE_ABI_VERSION 8
+#define TIKE_ABI_VERSION 9
 
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
@@ -482,6 +482,16 @@ int tike_fft2_pass1(const void* in, void* out, long ntile, int det, int inverse,
 /* pass 2 alone, in place, every element times `scale`. */
 int tike_fft2_pass2_inplace(void* tiles, long ntile, int det, int inverse, float scale,
                             void* stream);
+
+/* The last pass of a Fresnel step fused with the first pass of the next
+ * slice's transform (operators/cupy/multislice.py:86-91, then :79-85 of the
+ * slice behind; det = 256, probe window = detector): wave (nscan,S,det,det)
+ * in = tike_fresnel_colpass's output, out = the probe incident on the slice
+ * (x scale), in place; farplane1 (nscan,S,det,det) != wave receives pass 1 of
+ * FFT2(wave x patch_n(psi)) -- the input of the column pass kernels
+ * (tike_fresnel_colpass, tike_fwd_grad_ifft2_pass1[_slices]).  psi (H,W). */
+int tike_slice_step(void* wave, const void* psi, const float* scan, void* farplane1, int nscan,
+                    int S, int det, int H, int W, float scale, void* stream);
 
 /* pass 2 of the S modes of every position with the illumination
  * amplitude[n] = sum_s |wave[n][s] * scale|^2 formed from the registers

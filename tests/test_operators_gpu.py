@@ -416,6 +416,56 @@ def test_fresnel_step_in_three_launches_vs_oracle(oracle, adjoint):
         assert_close(b.cpu().numpy(), want, what=f"fresnel, {ntile} tiles")
 
 
+@pytest.mark.parametrize("S,N,inside", [(8, 5, True), (1, 33, True),
+                                        (3, 6, False)])
+def test_slice_step_vs_its_two_launches(oracle, S, N, inside):
+    """tike_slice_step == tike_fft2_pass2_inplace (the probe incident on the
+    slice) followed by tike_fwd_pass1 with those per-position probes
+    (multislice.py:86-91, :79-85), and both against NumPy; positions whose
+    window leaves the image take the general gather."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    rng = np.random.default_rng(S + N)
+    det, HW = 256, 300
+    scan = (rng.random((N, 2)) * 40 + 1.5).astype(np.float32)
+    if not inside:
+        scan[1] = (-3.25, 10.5)
+        scan[2] = (47.5, 60.75)
+    psi = rc(rng, HW, HW)
+    x = rc(rng, N, S, det, det)
+    scale = 0.81 / det
+    st = A.stream_ptr()
+    d = {k: A.to_device(v) for k, v in dict(x=x, psi=psi, scan=scan).items()}
+    work = torch.empty_like(d["x"])
+    check(lib.tike_fft2_pass1(A.ptr(d["x"]), A.ptr(work), N * S, det, 1, st))
+    # the two launches
+    wave2 = work.clone()
+    far2 = torch.empty_like(wave2)
+    check(lib.tike_fft2_pass2_inplace(A.ptr(wave2), N * S, det, 1, scale, st))
+    check(lib.tike_fwd_pass1(A.ptr(d["psi"]), A.ptr(d["scan"]), A.ptr(wave2), 1,
+                             None, None, None, 0, 0, A.ptr(far2), None, N, S,
+                             det, det, HW, HW, st))
+    # the one
+    wave1 = work.clone()
+    far1 = torch.empty_like(wave1)
+    check(lib.tike_slice_step(A.ptr(wave1), A.ptr(d["psi"]), A.ptr(d["scan"]),
+                              A.ptr(far1), N, S, det, HW, HW, scale, st))
+    want_wave = (np.fft.ifft2(x.astype(np.complex128), norm="forward")
+                 * scale).astype(np.complex64)
+    assert_close(wave1.cpu().numpy(), want_wave, what="incident probe")
+    assert_close(wave1.cpu().numpy(), wave2.cpu().numpy(), normwise=1e-6,
+                 what="incident probe vs pass 2 alone")
+    assert_close(far1.cpu().numpy(), far2.cpu().numpy(), normwise=2e-6,
+                 what="pass 1 vs tike_fwd_pass1")
+    # ... and finished by the column pass, against NumPy
+    check(lib.tike_fft2_pass2_inplace(A.ptr(far1), N * S, det, 0, 1.0, st))
+    patches = oracle.patch_fwd(psi, scan, patch_width=det)
+    want = np.fft.fft2(want_wave.astype(np.complex128) * patches[:, None])
+    assert_close(far1.cpu().numpy(), want.astype(np.complex64),
+                 what="FFT2(incident x patch)")
+
+
 @pytest.mark.parametrize("det,S,N", [(256, 8, 5), (256, 1, 33), (128, 3, 7),
                                      (512, 2, 3)])
 @pytest.mark.parametrize("inverse", [True, False])

@@ -1466,7 +1466,8 @@ def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
                                    rtol=5e-3, atol=1e-4)
 
 
-@pytest.mark.parametrize("step_back", ["frequency", "as written"])
+@pytest.mark.parametrize("step_back", ["frequency", "as written",
+                                       "frequency, separate slice passes"])
 @pytest.mark.parametrize("depth,S,N,eigen,u16", [(2, 8, 10, False, False),
                                                   (3, 2, 9, False, True),
                                                   (2, 1, 12, False, False),
@@ -1499,7 +1500,8 @@ def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16, step_back)
 
     def run(fused):
         R.FUSED_MULTISLICE = fused
-        R.STEP_BACK_IN_FREQUENCY = step_back == "frequency"
+        R.STEP_BACK_IN_FREQUENCY = step_back.startswith("frequency")
+        R.SLICE_STEP_FUSED = "separate" not in step_back
         params = tp.PtychoParameters(
             probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
             eigen_probe=None if ep is None else ep.copy(),
@@ -1522,6 +1524,7 @@ def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16, step_back)
         finally:
             R.FUSED_MULTISLICE = True
             R.STEP_BACK_IN_FREQUENCY = True
+            R.SLICE_STEP_FUSED = True
 
     got, slow = run(True), run(False)
     np.testing.assert_allclose(np.array(got.algorithm_options.costs),

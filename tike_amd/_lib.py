@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("TIKE_AMD_LIB") or os.path.join(
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
 # the header version this binding's prototypes were written against
-ABI_VERSION = 8
+ABI_VERSION = 9
 ERR_ARG = 1000001
 ERR_UNSUPPORTED = 1000002
 ERR_COMM = 2000000
@@ -54,6 +54,7 @@ _PROTOTYPES = {
     "tike_fresnel_spect_prop": [_p, _p, _p, _l, _i, _i, _f, _f, _p],
     "tike_fft2_pass1": [_p, _p, _l, _i, _i, _p],
     "tike_fft2_pass2_inplace": [_p, _l, _i, _i, _f, _p],
+    "tike_slice_step": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p],
     "tike_fft2_pass2_intensity": [_p, _p, _l, _i, _i, _i, _f, _i, _p],
     "tike_fresnel_colpass": [_p, _p, _i, _p, _l, _i, _f, _p],
     "tike_ifft2_pass2_products": [_p, _p, _p, _p, _i, _p, _p, _f, _p, _i, _i, _i,

@@ -74,6 +74,94 @@ __global__ __launch_bounds__(256, 4) void fresnel_colpass_kernel(
   }
 }
 
+// The last pass of a Fresnel step and the first pass of the next slice's
+// transform in one launch (multislice.py:86-91 followed by :79-85 of the next
+// slice): a work item = (position, k1) finishes the inverse on the rows
+// {16 r + k1} of every mode -- the probe incident on the slice, rows
+// {k1 + 16 k2}, written back in place for the way back -- multiplies by the
+// slice's object patch (gathered once per work item, 16 pixels per thread) and,
+// these being exactly the 16 rows of group r = k1 of a forward pass 1, starts
+// the next transform on the same registers: radix-16 over k2, twiddle, LDS
+// transpose, forward row transforms (the two directions commute).
+// tike_fft2_pass2_inplace + tike_fwd_pass1 with per-position probes read the
+// incident wave a second time; here it never leaves the registers.  N = 256.
+__global__ __launch_bounds__(256, 2) void slice_step_kernel(
+    cf* wave, const cf* __restrict__ psi, const float* __restrict__ scan, cf* __restrict__ far,
+    long nscan, int S, int H, int W, float scale, const cf* __restrict__ twtab) {
+  constexpr int N = 256;
+  using G2 = Fft2Geom<N>;
+  static_assert(G2::RB == 16, "one radix-16 per direction");
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int t = threadIdx.x;
+  const long total = (long)H * W;
+  for (long v = blockIdx.x; v < nscan * 16; v += gridDim.x) {
+    const int k1 = (int)(v & 15);
+    const long n = nscan - 1 - (v >> 4);  // descending: the column pass wrote ascending
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    const TkCorner c = tk_corner(scan, n);
+    // object patch at rows k1 + 16 k2, column t
+    cf O[16];
+    const bool interior = c.sy >= 0 && c.sx >= 0 && c.sy + N < H && c.sx + N < W &&
+                          total < (1L << 28);
+    if (interior) {  // uniform
+      typedef float tk_v4f __attribute__((ext_vector_type(4)));
+      const unsigned row_bytes = (unsigned)W * 8u;
+      const unsigned off0 = (unsigned)((c.sy + k1) * W + c.sx + t) * 8u;
+      tk_v4f u4[16], l4[16];
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const unsigned off = off0 + (unsigned)(16 * k2) * row_bytes;
+        __builtin_memcpy(&u4[k2], reinterpret_cast<const char*>(psi) + off, 16);
+        __builtin_memcpy(&l4[k2], reinterpret_cast<const char*>(psi) + off + row_bytes, 16);
+      }
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        cf o = mk(u4[k2].x * c.w00, u4[k2].y * c.w00);
+        o.x += u4[k2].z * c.w01;
+        o.y += u4[k2].w * c.w01;
+        o.x += l4[k2].x * c.w10;
+        o.y += l4[k2].y * c.w10;
+        o.x += l4[k2].z * c.w11;
+        o.y += l4[k2].w * c.w11;
+        O[k2] = o;
+      }
+    } else {
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const int y = c.sy + k1 + 16 * k2, x = c.sx + t;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+        const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+        const int xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+        const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
+        O[k2] = ok ? o : mk(0.f, 0.f);
+      }
+    }
+    for (int s = 0; s < S; ++s) {
+      cf* p = wave + (n * S + s) * (long)N * N + (long)k1 * N + t;
+      cf u[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = p[(long)(16 * r) * N];
+      Dft<16, true>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        u[k2] = u[k2] * scale;
+        p[(long)(16 * k2) * N] = u[k2];  // the incident probe, kept for the way back
+        u[k2] = u[k2] * O[k2];
+      }
+      Dft<16, false>::run(u);
+#pragma unroll
+      for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<false>(u[ya], twtab[N + k1 * ya]);
+      fft2_rows_from_columns<N, false, true>(lds, tw, line, j, u,
+                                             far + (n * S + s) * (long)N * N + (long)(16 * k1) * N);
+    }
+  }
+}
+
 // Pass 2 alone, in place: rows {k1 + 16 r} of a tile in, the same rows out.
 // Work item = (tile, k1, 256-column block), tiles in descending order.
 template <int N, bool INV>
@@ -202,6 +290,24 @@ extern "C" int tike_fft2_pass2_inplace(void* tiles, long ntile, int det, int inv
     default: return TK_ERR_UNSUPPORTED;
   }
 #undef TK_CP
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_slice_step(void* wave, const void* psi, const float* scan, void* farplane1,
+                               int nscan, int S, int det, int H, int W, float scale,
+                               void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1 && H >= 1 && W >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(wave && psi && scan && farplane1 && wave != farplane1);
+  if (det != 256) return TK_ERR_UNSUPPORTED;
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  hipLaunchKernelGGL(slice_step_kernel, dim3(tk_grid((long)nscan * 16, 8)), dim3(256), 0, stream,
+                     (cf*)wave, (const cf*)psi, scan, (cf*)farplane1, (long)nscan, S, H, W, scale,
+                     tw);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

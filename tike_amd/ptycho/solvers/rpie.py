@@ -198,6 +198,10 @@ composition of the general operators, which remains the path of every other
 configuration."""
 
 
+SLICE_STEP_FUSED = os.environ.get("TIKE_MS_SLICE_STEP", "1") == "1"
+"""The last pass of a Fresnel step and the first pass of the next slice's
+transform in one launch (`tike_slice_step`)."""
+
 STEP_BACK_IN_FREQUENCY = os.environ.get("TIKE_MS_STEP_BACK", "1") == "1"
 """The steps back through the slices of the fused multislice path as extra
 outputs of the last slice's gradient pass (see _gradients_multislice_fused)."""
@@ -219,7 +223,8 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
     incident probe, formed on the fly, through the first pass of the
     transform) -> `tike_fresnel_colpass` (column pass x propagator -> inverse
     pass 1) -> `tike_fft2_pass2_inplace`: the probe incident on slice d + 1,
-    kept for the way back.  Last slice: `tike_fwd_pass1` ->
+    kept for the way back -- or, SLICE_STEP_FUSED, that last pass together
+    with pass 1 of slice d + 1 (`tike_slice_step`).  Last slice: `tike_fwd_pass1` ->
     `tike_fwd_grad_ifft2_pass1` (far field, cost, gradient factor and the
     inverse's first pass in one launch; the far plane is never stored).
     Way back: the reference hands `diff = propagation.adj(diff)` to the slice
@@ -273,18 +278,42 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
         unique = get_varying_probe(probe, eigen_probe, w_c).contiguous()
         # the probe incident on slice d: (tensor, one per position?)
         incident = [(unique, int(unique.shape[0] != 1))]
-        for d in range(D - 1):
-            nxt = next_incident_probe(
-                psi[d], sc, incident[d][0], far[:n], beams[d, :n], prop,
-                fwd_scale * inv_scale,
-                patches=patches0[blo:blo + n]
-                if d == 0 and patches0 is not None else None)
-            incident.append((nxt, 1))
-        beam, per = incident[D - 1]
-        check(
-            lib.tike_fwd_pass1(A.ptr(psi[D - 1]), A.ptr(sc), A.ptr(beam), per,
-                               None, None, None, 0, 0, A.ptr(far), None, n, S,
-                               pw, det, H, W, st), "last slice, pass 1")
+        if SLICE_STEP_FUSED:
+            # pass 1 of slice 0, then per slice behind it: column passes of
+            # the Fresnel step -> `tike_slice_step` (the step's last pass,
+            # x the slice's patch, pass 1 of the next transform)
+            check(
+                lib.tike_fwd_pass1(
+                    A.ptr(psi[0]), A.ptr(sc), A.ptr(unique), incident[0][1],
+                    None, None, None, 0, 0, A.ptr(far),
+                    None if patches0 is None else A.ptr(patches0[blo:blo + n]),
+                    n, S, pw, det, H, W, st), "first slice, pass 1")
+            for d in range(1, D):
+                check(
+                    lib.tike_fresnel_colpass(
+                        A.ptr(far), A.ptr(prop), 0, A.ptr(beams[d - 1, :n]),
+                        n * S, det, fwd_scale * inv_scale, st),
+                    "Fresnel step: column passes")
+                check(
+                    lib.tike_slice_step(
+                        A.ptr(beams[d - 1, :n]), A.ptr(psi[d]), A.ptr(sc),
+                        A.ptr(far), n, S, det, H, W, 1.0, st),
+                    "Fresnel step: last pass + next slice, pass 1")
+                incident.append((beams[d - 1, :n], 1))
+        else:
+            for d in range(D - 1):
+                nxt = next_incident_probe(
+                    psi[d], sc, incident[d][0], far[:n], beams[d, :n], prop,
+                    fwd_scale * inv_scale,
+                    patches=patches0[blo:blo + n]
+                    if d == 0 and patches0 is not None else None)
+                incident.append((nxt, 1))
+            beam, per = incident[D - 1]
+            check(
+                lib.tike_fwd_pass1(A.ptr(psi[D - 1]), A.ptr(sc), A.ptr(beam),
+                                   per, None, None, None, 0, 0, A.ptr(far),
+                                   None, n, S, pw, det, H, W, st),
+                "last slice, pass 1")
         # (the outputs of a chunk packed: (nback, n, S, det, det))
         midv = mids.view(-1)[:nback * n * S * det * det].view(
             nback, n, S, det, det)
