@@ -1467,7 +1467,8 @@ def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
 
 
 @pytest.mark.parametrize("step_back", ["frequency", "as written",
-                                       "frequency, separate slice passes"])
+                                       "frequency, separate slice passes",
+                                       "frequency, first slice by products"])
 @pytest.mark.parametrize("depth,S,N,eigen,u16", [(2, 8, 10, False, False),
                                                   (3, 2, 9, False, True),
                                                   (2, 1, 12, False, False),
@@ -1502,6 +1503,7 @@ def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16, step_back)
         R.FUSED_MULTISLICE = fused
         R.STEP_BACK_IN_FREQUENCY = step_back.startswith("frequency")
         R.SLICE_STEP_FUSED = "separate" not in step_back
+        R.FIRST_SLICE_STORED_PATCHES = "products" not in step_back
         params = tp.PtychoParameters(
             probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
             eigen_probe=None if ep is None else ep.copy(),
@@ -1525,6 +1527,7 @@ def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16, step_back)
             R.FUSED_MULTISLICE = True
             R.STEP_BACK_IN_FREQUENCY = True
             R.SLICE_STEP_FUSED = True
+            R.FIRST_SLICE_STORED_PATCHES = True
 
     got, slow = run(True), run(False)
     np.testing.assert_allclose(np.array(got.algorithm_options.costs),
