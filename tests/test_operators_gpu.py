@@ -1202,3 +1202,147 @@ def test_extract_patches_and_probe_constraints_on_device(golden):
                                rtol=2e-6, atol=1e-7)
     out = tp.constrain_probe_sparsity(dev(g["sparse_in"]), 0.6)
     np.testing.assert_array_equal(out.cpu().numpy(), g["sparse_out_60"])
+
+
+def _patches(oracle, img, scan, pw):
+    return oracle.patch_fwd(img, scan, patch_width=pw)
+
+
+@pytest.mark.parametrize("pw,N,eigen,border", [(256, 7, True, False),
+                                                (256, 6, False, True),
+                                                (128, 9, True, True),
+                                                (64, 5, False, False),
+                                                (48, 4, True, False),
+                                                (512, 3, False, False)])
+def test_step_statistics_on_pairs_vs_numpy(oracle, pw, N, eigen, border):
+    """tike_lstsq_step_stats (lstsq.py:641-694, 721-738) straight against
+    NumPy: odd and even numbers of positions (the pair kernel's last, single
+    position), windows that tile 256 threads and one that does not (48: no row
+    walk), positions on the border of the image (the pair falls back)."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    rng = np.random.default_rng(pw + N)
+    HW = pw + 40
+    scan = (rng.random((N, 2)) * 30 + 2.25).astype(np.float32)
+    if border:
+        scan[1] = (HW - pw + 2.5, 3.5)  # the window leaves the image
+        scan[N - 2] = (-1.75, HW - pw + 1.25)
+    psi, gobj = rc(rng, HW, HW), rc(rng, HW, HW)
+    probe = rc(rng, 1, 1, 2, pw, pw)
+    mpu = rc(rng, 1, 1, 2, pw, pw)
+    chi0 = rc(rng, N, pw, pw)
+    E = rc(rng, 1, 1, 1, pw, pw) if eigen else None
+    w = np.ones((N, 2, 2), np.float32)
+    w[:, 1] = 0
+    if eigen:
+        w = (rng.standard_normal((N, 2, 2)) * 0.3 + 1).astype(np.float32)
+    O = _patches(oracle, psi, scan, pw)
+    G = _patches(oracle, gobj, scan, pw)
+    P0 = probe[0, 0, 0]
+    Pn = w[:, 0, 0, None, None] * P0
+    if eigen:
+        Pn = Pn + w[:, 1, 0, None, None] * E[0, 0, 0]
+    dOP, dPO, OP = G * Pn, mpu[0, 0, 0] * O, O * P0
+    tot = lambda a: a.reshape(N, -1).sum(axis=1)
+    a2 = tot(dOP * np.conj(dPO))
+    want = np.stack([tot(np.abs(dOP)**2), tot(np.abs(dPO)**2), a2.real, a2.imag,
+                     tot((np.conj(dOP) * chi0).real),
+                     tot((np.conj(dPO) * chi0).real),
+                     tot((np.conj(OP) * chi0).real), tot(np.abs(OP)**2)], 1)
+    d = {k: A.to_device(v) for k, v in dict(
+        psi=psi, gobj=gobj, probe=probe, mpu=mpu, chi0=chi0, scan=scan, O=O,
+        w=w).items()}
+    Ed = None if E is None else A.to_device(E)
+    stats = torch.full((N, 8), np.nan, dtype=torch.float32, device="cuda")
+    eproj = torch.full((N,), np.nan, dtype=torch.float32, device="cuda")
+    check(lib.tike_lstsq_step_stats(
+        A.ptr(d["chi0"]), A.ptr(d["scan"]), A.ptr(d["psi"]), A.ptr(d["gobj"]),
+        A.ptr(d["probe"]), A.ptr(Ed), A.ptr(d["w"]) if eigen else None,
+        1 if eigen else 0, 1 if eigen else 0, None, A.ptr(d["mpu"]),
+        A.ptr(d["O"]), A.ptr(stats), N, 2, 1, pw, HW, HW,
+        None if Ed is None else A.ptr(Ed[0, 0, 0]),
+        A.ptr(eproj) if eigen else None, A.stream_ptr()))
+    scale = np.abs(want).max(axis=0)
+    np.testing.assert_allclose(stats.cpu().numpy(), want, rtol=2e-4,
+                               atol=2e-5 * scale.max())
+    if eigen:
+        R = np.conj(O) * chi0 - mpu[0, 0, 0]
+        np.testing.assert_allclose(
+            eproj.cpu().numpy(), tot((np.conj(R) * E[0, 0, 0]).real),
+            rtol=2e-4, atol=2e-5 * np.abs(tot(np.abs(R))).max())
+
+
+@pytest.mark.parametrize("pw,N,border", [(256, 7, False), (256, 4, True),
+                                         (128, 5, False), (48, 3, False),
+                                         (512, 2, False)])
+def test_eigen_position_sums_on_pairs_vs_numpy(oracle, pw, N, border):
+    """tike_eigen_position_sums1 (probe.py:437-469 after the eigen probe's
+    update) gathering O_n from the object, against NumPy."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    rng = np.random.default_rng(pw + 3 * N)
+    HW = pw + 40
+    scan = (rng.random((N, 2)) * 30 + 2.25).astype(np.float32)
+    if border:
+        scan[0] = (HW - pw + 2.5, 3.5)  # the window leaves the image
+    psi = rc(rng, HW, HW)
+    chi0, mpu, E = rc(rng, N, pw, pw), rc(rng, pw, pw), rc(rng, pw, pw)
+    O = _patches(oracle, psi, scan, pw)
+    R = np.conj(O) * chi0 - mpu
+    phi = O * E
+    tot = lambda a: a.reshape(N, -1).sum(axis=1)
+    re = tot(R * np.conj(E))
+    want = np.stack([tot((np.conj(R) * E).real), tot((chi0 * np.conj(phi)).real),
+                     tot(np.abs(phi)**2), re.real, re.imag], 1)
+    d = {k: A.to_device(v) for k, v in dict(psi=psi, chi0=chi0, mpu=mpu, E=E,
+                                            scan=scan, O=O).items()}
+    sums = torch.full((N, 5), np.nan, dtype=torch.float32, device="cuda")
+    dsum = torch.zeros(1, dtype=torch.float32, device="cuda")
+    check(lib.tike_eigen_position_sums1(
+        A.ptr(d["O"]), A.ptr(d["chi0"]), A.ptr(d["mpu"]), A.ptr(d["E"]),
+        A.ptr(sums), A.ptr(dsum), N, pw, 1, A.ptr(d["psi"]), A.ptr(d["scan"]),
+        HW, HW, A.stream_ptr()))
+    np.testing.assert_allclose(sums.cpu().numpy(), want, rtol=2e-4,
+                               atol=2e-5 * np.abs(want).max())
+    np.testing.assert_allclose(float(dsum), want[:, 2].sum() / (pw * pw),
+                               rtol=2e-4)
+
+
+@pytest.mark.parametrize("pw,N,S", [(512, 3, 2), (256, 6, 1), (128, 7, 3),
+                                    (64, 2, 1), (40, 5, 1)])
+def test_position_sums_on_pairs_vs_numpy(pw, N, S):
+    """tike_position_sums (lstsq.py:545-579; position.py:779-810: gaussian
+    derivative of radius 2 along both axes of the patch, central window) against
+    NumPy for window widths that tile 256 threads and one that does not."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    from tike_amd.ptycho.position import gaussian_derivative_taps
+    rng = np.random.default_rng(pw + N + S)
+    O, chi = rc(rng, N, pw, pw), rc(rng, N, S, pw, pw)
+    probe = rc(rng, 1, 1, S, pw, pw)
+    # g[i] = sum_d t[d] x[i + d], d = -2 .. 2 (the taps themselves are pinned
+    # to scipy's gaussian_filter1d by the CPU tests of gaussian_gradient)
+    taps, radius = gaussian_derivative_taps(sigma=0.333)
+    assert radius == 2
+    crop = pw // 4
+    win = (slice(None), slice(crop, pw - crop), slice(crop, pw - crop))
+    gx = sum(taps[d + 2] * np.roll(O, -d, axis=1) for d in range(-2, 3))[win]
+    gy = sum(taps[d + 2] * np.roll(O, -d, axis=2) for d in range(-2, 3))[win]
+    P0, c = probe[0, 0, 0][win[1:]], chi[:, 0][win]
+    tot = lambda a: a.reshape(N, -1).sum(axis=1)
+    num = np.stack([tot((np.conj(gx * P0) * c).real),
+                    tot((np.conj(gy * P0) * c).real)], 1)
+    den = np.stack([tot(np.abs(gx * P0)**2), tot(np.abs(gy * P0)**2)], 1)
+    d = {k: A.to_device(v) for k, v in dict(O=O, chi=chi, probe=probe).items()}
+    got_n = torch.full((N, 2), np.nan, dtype=torch.float32, device="cuda")
+    got_d = torch.full((N, 2), np.nan, dtype=torch.float32, device="cuda")
+    check(lib.tike_position_sums(
+        A.ptr(d["O"]), A.ptr(d["chi"]), S, A.ptr(d["probe"]), None, None, 0, 1,
+        taps.ctypes.data, 2, A.ptr(got_n), A.ptr(got_d), N, S, pw,
+        A.stream_ptr()))
+    np.testing.assert_allclose(got_n.cpu().numpy(), num, rtol=2e-4,
+                               atol=2e-5 * np.abs(num).max())
+    np.testing.assert_allclose(got_d.cpu().numpy(), den, rtol=2e-4)
