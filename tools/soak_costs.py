@@ -15,7 +15,7 @@ import tike_amd.ptycho as tp  # noqa: E402
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 bad = 0
 for workload, positions in (("c1", 0), ("c2", 2000), ("c3", 2000),
-                            ("c3poisson", 2000), ("c3rpie", 2000),
+                            ("c3poisson", 2000), ("c3rpie", 2000), ("c3rpie2", 2000),
                             ("c5", 1000)):
     built = bench.epoch_problem(workload, positions, 1, 0, tp, A)
     ctx = built["ctx"]
