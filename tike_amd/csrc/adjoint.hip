@@ -91,7 +91,7 @@ void ifft2_pass2_adjoint_kernel(
     cf* work, const cf* __restrict__ psi, const float* __restrict__ scan,
     const cf* __restrict__ probe, cf* __restrict__ objproj, float* __restrict__ pnum,
     float pnum_scale, cf* __restrict__ chi0, int nscan, int S, int H, int W, float inv_scale,
-    int chunk) {
+    int chunk, float* __restrict__ pnum_part) {
   constexpr int RB = N / 16;
   constexpr int CW = 4 / (MW * PW);
   constexpr int NCB = N / (64 * CW);
@@ -286,6 +286,16 @@ void ifft2_pass2_adjoint_kernel(
       if (s < S) {
 #pragma unroll
         for (int yb = 0; yb < RB; ++yb) {
+          if (pnum_part != nullptr) {
+            // deterministic mode: the chunk's own row, summed in chunk order
+            // by tk_ordered_sum after the launch
+            // (position-waves keep separate sums: a row each)
+            const long ci = (long)((v >> 3) / per) * PW + pwi;
+            float* q = tk_at(pnum_part + 2 * ((ci * S + s) * P + slice0 + yb * ROW), lb);
+            q[0] = acc[m][yb].x * pnum_scale;
+            q[1] = acc[m][yb].y * pnum_scale;
+            continue;
+          }
           float* o = tk_at(pnum + 2 * ((long)s * P + slice0 + yb * ROW), lb);
           unsafeAtomicAdd(o, acc[m][yb].x * pnum_scale);
           unsafeAtomicAdd(o + 1, acc[m][yb].y * pnum_scale);
@@ -349,15 +359,25 @@ int tk_ifft2_pass2_products(cf* work, const cf* psi, const float* scan, const cf
   int nchunk = (1536 + nslice - 1) / nslice;
   int chunk = (nscan + nchunk - 1) / nchunk;
   if (chunk < 8) chunk = 8;
-  // deterministic mode: the probe numerator has one contributor per address
-  if (out != 0 && tk_deterministic()) chunk = nscan > 8 ? nscan : 8;
   nchunk = (nscan + chunk - 1) / chunk;
+  // deterministic mode: per-chunk partial sums of the probe numerator in the
+  // caller's scratch buffer; ONE chunk (a single contributor per address)
+  // when it is too small
+  float* pnum_part = nullptr;
+  const long pnum_len = 2L * S * det * det;
+  if (out != 0 && pnum != nullptr && tk_deterministic()) {
+    pnum_part = tk_det_scratch(sizeof(float) * (size_t)pnum_len * nchunk * PW);
+    if (pnum_part == nullptr) {
+      chunk = nscan > 8 ? nscan : 8;
+      nchunk = (nscan + chunk - 1) / chunk;
+    }
+  }
   const dim3 grid((unsigned)(nslice * nchunk)), block(256);
 #define TK_ADJ_O(N, MW_, MPW_, PP, OUT_)                                                       \
   hipLaunchKernelGGL(                                                                          \
       (ifft2_pass2_adjoint_kernel<N, MW_, MPW_, PP, OUT_, (N == 128 && MW_ == 1) ? 2 : 1>),    \
       grid, block, 0, stream, work, psi, scan, probe, objproj, pnum, pnum_scale, chi0, nscan,  \
-      S, H, W, inv_scale, chunk)
+      S, H, W, inv_scale, chunk, pnum_part)
 #define TK_ADJ(N, MW_, MPW_)                        \
   do {                                              \
     if (probe_per_scan && out == 0)                 \
@@ -404,6 +424,8 @@ int tk_ifft2_pass2_products(cf* work, const cf* psi, const float* scan, const cf
 #undef TK_ADJ
 #undef TK_ADJ_O
   TK_LAUNCH_CHECK();
+  if (pnum_part != nullptr)
+    return tk_ordered_sum(pnum, pnum_part, pnum_len, nchunk * PW, true, stream);
   return TK_OK;
 }
 

@@ -59,19 +59,20 @@ float* tk_det_scratch(size_t bytes) {
 
 __global__ __launch_bounds__(256) void ordered_sum_kernel(float* __restrict__ out,
                                                           const float* __restrict__ part,
-                                                          long n, int nparts, int accumulate) {
+                                                          long n, int nparts, int accumulate,
+                                                          int out_stride) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
-    float s = accumulate ? out[i] : 0.f;
+    float s = accumulate ? out[i * out_stride] : 0.f;
     for (int c = 0; c < nparts; ++c) s += part[(long)c * n + i];
-    out[i] = s;
+    out[i * out_stride] = s;
   }
 }
 
 int tk_ordered_sum(float* out, const float* part, long n, int nparts, bool accumulate,
-                   hipStream_t stream) {
+                   hipStream_t stream, int out_stride) {
   if (n <= 0) return TK_OK;
   hipLaunchKernelGGL(ordered_sum_kernel, dim3(tk_grid((n + 255) / 256, 8)), dim3(256), 0, stream,
-                     out, part, n, nparts, accumulate ? 1 : 0);
+                     out, part, n, nparts, accumulate ? 1 : 0, out_stride);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

@@ -52,4 +52,4 @@ int tk_cost_sink(float* costs, long nscan, int nslots, hipStream_t stream, TkCos
 int tk_cost_finish(const TkCostSink& sink, long nscan, hipStream_t stream);
 // out[i] (+)= sum_c part[c * n + i], c ascending
 int tk_ordered_sum(float* out, const float* part, long n, int nparts, bool accumulate,
-                   hipStream_t stream);
+                   hipStream_t stream, int out_stride = 1);

@@ -501,7 +501,8 @@ template <bool WITH_CHI, int SC>
 __global__ __launch_bounds__(256) void probe_grad_kernel(
     const cf* __restrict__ chi, const float* __restrict__ scan, const cf* __restrict__ psi,
     cf* __restrict__ patches, float* __restrict__ out, const TkProbe probe,
-    cf* __restrict__ objproj, int nscan, int S_rt, int pw, int H, int W, int chunk) {
+    cf* __restrict__ objproj, int nscan, int S_rt, int pw, int H, int W, int chunk,
+    float* __restrict__ part) {
   constexpr int SM = SC > 0 ? SC : TK_MAX_MODES;
   const int S = SC > 0 ? SC : S_rt;
   const long P = (long)pw * pw;
@@ -582,15 +583,25 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
       acc[0].x += norm2(o);
     }
   }
+  // deterministic mode: the chunk's sums go to its own row of `part`, added in
+  // a fixed order after the launch (tk_ordered_sum)
   if (WITH_CHI) {
     if (out) {
 #pragma unroll
       for (int s = 0; s < SM; ++s)
         if (SC > 0 || s < S) {
-          unsafeAtomicAdd(&out[2 * (s * P + p)], acc[s].x);
-          unsafeAtomicAdd(&out[2 * (s * P + p) + 1], acc[s].y);
+          if (part != nullptr) {
+            float* o = part + 2 * (((long)blockIdx.y * S + s) * P + p);
+            o[0] = acc[s].x;
+            o[1] = acc[s].y;
+          } else {
+            unsafeAtomicAdd(&out[2 * (s * P + p)], acc[s].x);
+            unsafeAtomicAdd(&out[2 * (s * P + p) + 1], acc[s].y);
+          }
         }
     }
+  } else if (part != nullptr) {
+    part[(long)blockIdx.y * P + p] = acc[0].x;
   } else {
     unsafeAtomicAdd(&out[2 * p], acc[0].x);
   }
@@ -599,10 +610,11 @@ __global__ __launch_bounds__(256) void probe_grad_kernel(
 template <bool WITH_CHI>
 static void launch_probe_grad(dim3 grid, hipStream_t stream, const cf* chi, const float* scan,
                               const cf* psi, cf* patches, float* out, const TkProbe& probe,
-                              cf* objproj, int nscan, int S, int pw, int H, int W, int chunk) {
+                              cf* objproj, int nscan, int S, int pw, int H, int W, int chunk,
+                              float* part = nullptr) {
 #define TK_PG(SC)                                                                              \
   hipLaunchKernelGGL((probe_grad_kernel<WITH_CHI, SC>), grid, dim3(256), 0, stream, chi, scan, \
-                     psi, patches, out, probe, objproj, nscan, S, pw, H, W, chunk)
+                     psi, patches, out, probe, objproj, nscan, S, pw, H, W, chunk, part)
   switch (WITH_CHI ? S : 1) {
     case 1: TK_PG(1); break;
     case 2: TK_PG(2); break;
@@ -616,14 +628,24 @@ static void launch_probe_grad(dim3 grid, hipStream_t stream, const cf* chi, cons
 #undef TK_PG
 }
 
-static int probe_chunk(int nscan) {
-  // deterministic mode: one chunk, so that every sum over the positions has a
-  // single contributor per address (its one atomic then only adds to what
-  // earlier, stream-ordered launches left there)
-  if (tk_deterministic()) return nscan > 8 ? nscan : 8;
+// Positions per chunk of the sums over positions, and -- deterministic mode --
+// where the chunks leave their partial sums (`len` floats each; *part stays
+// NULL otherwise).  When the caller's scratch buffer cannot hold them the
+// launch falls back to ONE chunk, so that every sum has a single contributor
+// per address (its one atomic then only adds to what earlier, stream-ordered
+// launches left there).
+static int probe_chunk(int nscan, long len = 0, float** part = nullptr) {
   // enough position chunks to fill the chip, at least 8 positions each
   int chunk = (nscan + 31) / 32;
-  return chunk < 8 ? 8 : chunk;
+  chunk = chunk < 8 ? 8 : chunk;
+  if (!tk_deterministic()) return chunk;
+  const int nchunk = (nscan + chunk - 1) / chunk;
+  float* p = len > 0 && part ? tk_det_scratch(sizeof(float) * (size_t)len * nchunk) : nullptr;
+  if (p != nullptr) {
+    *part = p;
+    return chunk;
+  }
+  return nscan > 8 ? nscan : 8;
 }
 
 extern "C" int tike_probe_grad(const void* chi, const float* scan, const void* psi,
@@ -634,13 +656,17 @@ extern "C" int tike_probe_grad(const void* chi, const float* scan, const void* p
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(chi && scan && psi && m_probe_update);
   const long P = (long)pw * pw;
-  const int chunk = probe_chunk(nscan);
+  float* part = nullptr;
+  const int chunk = probe_chunk(nscan, 2 * S * P, &part);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
   launch_probe_grad<true>(grid, (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,
                           (cf*)patches, (float*)m_probe_update,
                           tk_make_probe(psi, 0, nullptr, nullptr, 0, 0, S, pw), (cf*)nullptr,
-                          nscan, S, pw, H, W, chunk);
+                          nscan, S, pw, H, W, chunk, part);
   TK_LAUNCH_CHECK();
+  if (part != nullptr)
+    return tk_ordered_sum((float*)m_probe_update, part, 2 * S * P, (int)grid.y, true,
+                          (hipStream_t)stream);
   return TK_OK;
 }
 
@@ -659,14 +685,18 @@ extern "C" int tike_lstsq_gradients(const void* chi, const float* scan, const vo
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(chi && scan && psi && probe);
   const long P = (long)pw * pw;
-  const int chunk = probe_chunk(nscan);
+  float* part = nullptr;
+  const int chunk = probe_chunk(nscan, m_probe_update ? 2 * S * P : 0, &part);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
   launch_probe_grad<true>(grid, (hipStream_t)stream, (const cf*)chi, scan, (const cf*)psi,
                           (cf*)patches, (float*)m_probe_update,
                           tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen,
                                         eigen_modes, S, pw, unique_probe),
-                          (cf*)objproj, nscan, S, pw, H, W, chunk);
+                          (cf*)objproj, nscan, S, pw, H, W, chunk, part);
   TK_LAUNCH_CHECK();
+  if (part != nullptr)
+    return tk_ordered_sum((float*)m_probe_update, part, 2 * S * P, (int)grid.y, true,
+                          (hipStream_t)stream);
   return TK_OK;
 }
 
@@ -1016,13 +1046,16 @@ extern "C" int tike_probe_preconditioner(const float* scan, const void* psi, voi
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(scan && psi && out);
   const long P = (long)pw * pw;
-  const int chunk = probe_chunk(nscan);
+  float* part = nullptr;
+  const int chunk = probe_chunk(nscan, P, &part);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
   launch_probe_grad<false>(grid, (hipStream_t)stream, (const cf*)nullptr, scan,
                            (const cf*)psi, (cf*)nullptr, (float*)out,
                            tk_make_probe(psi, 0, nullptr, nullptr, 0, 0, 1, pw), (cf*)nullptr,
-                           nscan, 1, pw, H, W, chunk);
+                           nscan, 1, pw, H, W, chunk, part);
   TK_LAUNCH_CHECK();
+  if (part != nullptr)  // (the real parts of `out`)
+    return tk_ordered_sum((float*)out, part, P, (int)grid.y, true, (hipStream_t)stream, 2);
   return TK_OK;
 }
 
@@ -1546,7 +1579,8 @@ template <bool C0>
 __global__ __launch_bounds__(256) void eigen_pixel_update_kernel(const TkResidual R,
                                                                  const float* __restrict__ pm,
                                                                  float* __restrict__ update,
-                                                                 int nscan, int chunk) {
+                                                                 int nscan, int chunk,
+                                                                 float* __restrict__ part) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= R.P) return;
   const int b0 = blockIdx.y * chunk;
@@ -1558,6 +1592,11 @@ __global__ __launch_bounds__(256) void eigen_pixel_update_kernel(const TkResidua
     const float w = pm[n];
     acc.x += r.x * w;
     acc.y += r.y * w;
+  }
+  if (part != nullptr) {  // deterministic mode: see probe_grad_kernel
+    part[2 * ((long)blockIdx.y * R.P + p)] = acc.x;
+    part[2 * ((long)blockIdx.y * R.P + p) + 1] = acc.y;
+    return;
   }
   unsafeAtomicAdd(&update[2 * p], acc.x);
   unsafeAtomicAdd(&update[2 * p + 1], acc.y);
@@ -1599,7 +1638,7 @@ __global__ __launch_bounds__(256) void eigen_pixel_update1_kernel(
     long row, const float* __restrict__ norm, float inv_P, float* __restrict__ update, int nscan,
     int chunk, const float* __restrict__ stats, const float* __restrict__ costs, float eps,
     float* __restrict__ sums3, const cf* __restrict__ psi, const float* __restrict__ scan, int pw,
-    int H, int W) {
+    int H, int W, float* __restrict__ part) {
   if (blockIdx.x + 1 == gridDim.x) {
     if (blockIdx.y != 0 || sums3 == nullptr) return;
     __shared__ float red[4];
@@ -1655,6 +1694,11 @@ __global__ __launch_bounds__(256) void eigen_pixel_update1_kernel(
       acc.x += r.x * w;
       acc.y += r.y * w;
     }
+  }
+  if (part != nullptr) {  // deterministic mode: see probe_grad_kernel
+    part[2 * ((long)blockIdx.y * R.P + p)] = acc.x;
+    part[2 * ((long)blockIdx.y * R.P + p) + 1] = acc.y;
+    return;
   }
   unsafeAtomicAdd(&update[2 * p], acc.x);
   unsafeAtomicAdd(&update[2 * p + 1], acc.y);
@@ -1881,17 +1925,20 @@ extern "C" int tike_eigen_pixel_update(const void* patches, const void* chi0, co
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen_probe && pm && update && (c == 0 || coefs));
   const long P = (long)pw * pw;
-  const int chunk = probe_chunk(nscan);
+  float* part = nullptr;
+  const int chunk = probe_chunk(nscan, 2 * P, &part);
   dim3 grid((unsigned)((P + 255) / 256), (unsigned)((nscan + chunk - 1) / chunk));
   const TkResidual R = make_residual(patches, chi0, mpu0, eigen_probe, coefs, num_eigen,
                                      eigen_modes, c, pw, chi_modes);
   if (c == 0)
     hipLaunchKernelGGL(eigen_pixel_update_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream,
-                       R, pm, (float*)update, nscan, chunk);
+                       R, pm, (float*)update, nscan, chunk, part);
   else
     hipLaunchKernelGGL(eigen_pixel_update_kernel<false>, grid, dim3(256), 0,
-                       (hipStream_t)stream, R, pm, (float*)update, nscan, chunk);
+                       (hipStream_t)stream, R, pm, (float*)update, nscan, chunk, part);
   TK_LAUNCH_CHECK();
+  if (part != nullptr)
+    return tk_ordered_sum((float*)update, part, 2 * P, (int)grid.y, true, (hipStream_t)stream);
   return TK_OK;
 }
 
@@ -1915,13 +1962,17 @@ extern "C" int tike_eigen_pixel_update1(const void* patches, const void* chi0,
   TK_CHECK_ARG(!psi || (scan && H >= 1 && W >= 1));
   TK_CHECK_ARG(patches && chi0 && mpu0 && eigen0 && eigen_proj && weights_c && norm && update);
   const long P = (long)pw * pw;
-  const int chunk = probe_chunk(nscan);
+  float* part = nullptr;
+  const int chunk = probe_chunk(nscan, 2 * P, &part);
   dim3 grid((unsigned)((P + 255) / 256) + 1, (unsigned)((nscan + chunk - 1) / chunk));
   const TkResidual R = make_residual(patches, chi0, mpu0, eigen0, nullptr, 1, 1, 0, pw, chi_modes);
   hipLaunchKernelGGL(eigen_pixel_update1_kernel, grid, dim3(256), 0, (hipStream_t)stream, R,
                      eigen_proj, weights_c, weights_row, norm, 1.0f / (float)P, (float*)update,
-                     nscan, chunk, stats, costs, eps, sums3, (const cf*)psi, scan, pw, H, W);
+                     nscan, chunk, stats, costs, eps, sums3, (const cf*)psi, scan, pw, H, W,
+                     part);
   TK_LAUNCH_CHECK();
+  if (part != nullptr)
+    return tk_ordered_sum((float*)update, part, 2 * P, (int)grid.y, true, (hipStream_t)stream);
   return TK_OK;
 }
 

@@ -377,7 +377,8 @@ extern "C" int tike_eigen_weights(const float* sums, int B, long P, const float*
 __global__ __launch_bounds__(256) void lstsq_tail_mid_kernel(
     const cf* __restrict__ E, const cf* __restrict__ update, int npix, float* __restrict__ nacc,
     const float* __restrict__ stats, int B, float eps, const float* __restrict__ sums3,
-    float inv_count, int recover_psi, int recover_probe, float* __restrict__ tail3) {
+    float inv_count, int recover_psi, int recover_probe, float* __restrict__ tail3,
+    float* __restrict__ part) {
   __shared__ float red[4];
   if (blockIdx.x + 1 < gridDim.x) {
     float uu = 0.f, ee = 0.f, eu = 0.f;
@@ -391,9 +392,15 @@ __global__ __launch_bounds__(256) void lstsq_tail_mid_kernel(
     ee = tk_block_sum256(ee, red);
     eu = tk_block_sum256(eu, red);
     if (threadIdx.x == 0) {
-      unsafeAtomicAdd(&nacc[0], uu);
-      unsafeAtomicAdd(&nacc[1], ee);
-      unsafeAtomicAdd(&nacc[2], eu);
+      if (part != nullptr) {  // deterministic mode: added in workgroup order afterwards
+        part[3 * blockIdx.x] = uu;
+        part[3 * blockIdx.x + 1] = ee;
+        part[3 * blockIdx.x + 2] = eu;
+      } else {
+        unsafeAtomicAdd(&nacc[0], uu);
+        unsafeAtomicAdd(&nacc[1], ee);
+        unsafeAtomicAdd(&nacc[2], eu);
+      }
     }
     return;
   }
@@ -446,14 +453,22 @@ extern "C" int tike_lstsq_tail_mid(void* eigen0, const void* update, int npix, f
   TK_ENTER();
   TK_CHECK_ARG(B >= 0 && count > 0 && sums3 && tail3 && (B == 0 || stats));
   TK_CHECK_ARG(!eigen0 || (update && nacc && npix >= 1));
-  // (deterministic mode: ONE summing workgroup, so the three sums have one
-  // contributor each)
-  const int grid = !eigen0 ? 0
-                           : (tk_deterministic() ? 1
-                                                 : (npix >= 256 * 64 ? 64 : (npix + 255) / 256));
+  // (deterministic mode: the summing workgroups leave their three sums in the
+  // caller's scratch buffer, added in workgroup order by tk_ordered_sum; ONE
+  // summing workgroup when there is no room)
+  int grid = !eigen0 ? 0 : (npix >= 256 * 64 ? 64 : (npix + 255) / 256);
+  float* part = nullptr;
+  if (grid > 0 && tk_deterministic()) {
+    part = tk_det_scratch(sizeof(float) * 3 * (size_t)grid);
+    if (part == nullptr) grid = 1;
+  }
   hipLaunchKernelGGL(lstsq_tail_mid_kernel, dim3(grid + 1), dim3(256), 0, (hipStream_t)stream,
                      (const cf*)eigen0, (const cf*)update, npix, nacc, stats, B, eps, sums3,
-                     (float)(1.0 / count), recover_psi, recover_probe, tail3);
+                     (float)(1.0 / count), recover_psi, recover_probe, tail3, part);
+  if (part != nullptr) {
+    int rc = tk_ordered_sum(nacc, part, 3, grid, true, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   if (eigen0)
     hipLaunchKernelGGL(eigen_apply1_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        (cf*)eigen0, (const cf*)update, nacc, (float)(1.0 / count), beta_eigen,
