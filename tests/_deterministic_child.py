@@ -1,6 +1,7 @@
 """Child process of test_deterministic_mode: runs the reference's
 ReconstructTwice configuration (fixture lstsq_recon_compact) and a headline-shaped
-problem (256^2, 8 modes + eigen probe, the fused kernels) and prints one JSON
+problem (256^2, 8 modes + eigen probe, the fused kernels), then two rpie epochs
+on a two-slice object (the fused slice stages), and prints one JSON
 line with hashes of every result and the errors against the fixture.  The
 parent runs it twice under TIKE_DETERMINISTIC=1 and once without."""
 import hashlib
@@ -60,6 +61,30 @@ def main():
                              np.array(r.algorithm_options.costs))
     out["headline_cost"] = [float(c[0]) for c in r.algorithm_options.costs]
     out["headline_psi_norm"] = float(np.linalg.norm(r.psi))
+    # a two-slice object through rpie's fused slice stages (their probe
+    # numerators: per-chunk partial sums under the switch)
+    S, N = 3, 20
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=8, eigen=False)
+    psi0 = np.repeat(np.full_like(psi_true, 0.5), 2, axis=0)
+    psi0[1:] = 1.0
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=psi0, scan=scan.copy(),
+        algorithm_options=tp.RpieOptions(num_batch=2, num_iter=2,
+                                         batch_method="compact", alpha=1.0),
+        probe_options=tp.ProbeOptions(
+            force_orthogonality=True, probe_wavelength=1e-10,
+            probe_FOV_lengths=(2e-6, 2e-6)),
+        object_options=tp.ObjectOptions(multislice_propagation_distance=1e-6),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    with tp.Reconstruction(data, params, order=np.arange(N),
+                           batches=np.array_split(np.arange(N), 2)) as ctx:
+        ctx.iterate(2)
+        r = ctx.get_result()
+    out["multislice"] = digest(r.psi, r.probe,
+                               np.array(r.algorithm_options.costs))
+    out["multislice_cost"] = [float(c[0]) for c in r.algorithm_options.costs]
     print("RESULT " + json.dumps(out))
 
 

@@ -1978,8 +1978,9 @@ def test_deterministic_mode_gives_bit_identical_runs():
     bit-identical objects, probes, eigen probes, weights and costs -- on the
     general-shape kernels (the reference's ReconstructTwice run, fixture
     lstsq_recon_compact, both calls) and on the fused 256^2 kernels (8 modes +
-    eigen probe) -- and the SECOND call of the fixture, whose tolerance is
-    5e-3 with atomics, agrees with the reference's run to 1e-3."""
+    eigen probe; two rpie epochs on a two-slice object) -- and the SECOND call
+    of the fixture, whose tolerance is 5e-3 with atomics, agrees with the
+    reference's run to 1e-3."""
     import json
     import os
     import subprocess
@@ -2000,6 +2001,9 @@ def test_deterministic_mode_gives_bit_identical_runs():
     assert a["compact"] == b["compact"]
     assert a["headline"] == b["headline"]
     assert a["headline_cost"] == b["headline_cost"]
+    assert a["multislice"] == b["multislice"]
+    np.testing.assert_allclose(a["multislice_cost"], free["multislice_cost"],
+                               rtol=1e-4)
     # the same algorithm: the atomics run agrees to float32 round-off
     np.testing.assert_allclose(a["headline_cost"], free["headline_cost"],
                                rtol=1e-4)
