@@ -561,7 +561,7 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
                 eigen_weights=eigen_weights)
 
 
-LEG_EPOCHS = {"c1": 20, "c2": 3, "c5": 3}
+LEG_EPOCHS = {"c1": 20, "c2": 3, "c5": 3, "c3poisson": 3, "c3rpie": 3, "c3rpie2": 3}
 # untimed epochs in front (cgrad: at least two -- its line searches learn their
 # slot counts; c1's epochs are 3 ms: ten of them bring the clocks of a GPU
 # that idled during the set-up back up, profiles/r04_leg_probe.txt)
@@ -587,13 +587,15 @@ def epoch_leg(workload, tp, A, torch, positions=0, epochs=None):
     det, S, N = built["det"], built["S"], built["N"]
     b_iter, f_iter = iteration_bounds(S, det, det)
     rate = N * epochs / dt
-    return dict(workload=workload, positions=N, modes=S, detector=det,
-                solver=SOLVER_LABEL.get(workload, "lstsq_grad"),
-                num_batch=built["num_batch"],
-                position_correction=workload == "c5", epochs=epochs,
-                ms_per_epoch=dt / epochs * 1e3, value=rate, unit="patterns/s",
-                iteration_hbm_frac=b_iter * rate / 1e9 / HBM_PEAK_GBS,
-                iteration_fp32_frac=f_iter * rate / 1e12 / FP32_PEAK_TFLOPS)
+    leg = dict(workload=workload, positions=N, modes=S, detector=det,
+               solver=SOLVER_LABEL.get(workload, "lstsq_grad"),
+               num_batch=built["num_batch"],
+               position_correction=workload == "c5", epochs=epochs,
+               ms_per_epoch=dt / epochs * 1e3, value=rate, unit="patterns/s")
+    if workload != "c3rpie2":  # (SURVEY 8(d)'s bounds are a single slice's)
+        leg.update(iteration_hbm_frac=b_iter * rate / 1e9 / HBM_PEAK_GBS,
+                   iteration_fp32_frac=f_iter * rate / 1e12 / FP32_PEAK_TFLOPS)
+    return leg
 
 
 def forward_leg(ops, A, torch, det, S, N, iters=40, warm=8):
@@ -920,6 +922,10 @@ def main():
         torch.cuda.empty_cache()
         secondary += [guarded(w, epoch_leg, w, tp, A, torch)
                       for w in ("c1", "c2", "c5")]
+        # ... and SURVEY 8 rows f2 / f3 at the headline shapes: the Poisson
+        # model, rpie, rpie on a two-slice object
+        secondary += [guarded(w, epoch_leg, w, tp, A, torch)
+                      for w in ("c3poisson", "c3rpie", "c3rpie2")]
 
     if rank == 0:
         summ = timers.summary()  # the timed steps
