@@ -385,6 +385,12 @@ def algorithmic_bytes(name, n, S, det, pw, C):
         # hand-off and the data in, the intermediate out (it reads the
         # hand-off twice; the second read is not algorithmic)
         "tike_fwd_grad_ifft2_pass1": n * (2 * T + D),
+        # poisson, every pixel measured: first sweep of the step lengths (the
+        # hand-off and the data in), then second sweep + gradient + inverse
+        # pass 1 (both in again -- the sweeps are separated by a sum over the
+        # whole pattern -- the intermediate out)
+        "tike_poisson_steps_grad_ifft2_pass1": n * (3 * T + 2 * D),
+        "tike_ifft2_pass2_gradients_scaled": n * (T + 3 * P) + S * P,
         # inverse pass 2 + both gradients: intermediate + patches in,
         # objproj + chi0 out (+ the probe gradient, probe-sized)
         "tike_ifft2_pass2_gradients": n * (T + 3 * P) + S * P,

@@ -38,7 +38,7 @@ extern "C" {
  * A binding compares tike_abi_version() of the loaded library with the
  * TIKE_ABI_VERSION it was written against before its first call
  * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
-#define TIKE_ABI_VERSION 9
+#define TIKE_ABI_VERSION 10
 
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
@@ -265,6 +265,15 @@ int tike_ifft2_pass2_gradients(const void* work, const void* patches, const void
                                int num_eigen, int eigen_modes, void* objproj, void* chi0,
                                void* m_probe_update, float mpu_scale, int nscan, int S, int det,
                                float inv_scale, void* stream);
+/* ... with chi_n,s also times mode_scale[n][s] (nscan,S) f32: per-mode factors
+ * that became known only after pass 1 of the inverse was written (the poisson
+ * step lengths of tike_poisson_steps_grad_ifft2_pass1). */
+int tike_ifft2_pass2_gradients_scaled(const void* work, const void* patches, const void* probe,
+                                      const void* eigen_probe, const float* eigen_weights,
+                                      int num_eigen, int eigen_modes, void* objproj, void* chi0,
+                                      void* m_probe_update, float mpu_scale, int nscan, int S,
+                                      int det, float inv_scale, const float* mode_scale,
+                                      void* stream);
 
 /* ---- far-plane gradient factor from the intensity (objective.py:31-44,97-109;
  * lstsq.py:491-502): gscale[n][p] = -(1 - sqrt(d)/(sqrt(I)+1e-9)) (gaussian) or
@@ -303,6 +312,22 @@ int tike_poisson_steps_handoff(const void* scratch, const void* data, int data_u
                                float* steps, float* sums, int nscan, int S, int det, float scale,
                                float unmeasured_scaling, long num_measured, float step_start,
                                float weight, void* stream);
+
+/* The same step lengths AND the gradient pass, every pixel measured, det = 256,
+ * S <= 8 (TIKE_ERR_UNSUPPORTED otherwise; a mask with unmeasured pixels takes
+ * tike_poisson_steps_handoff + tike_grad_ifft2_pass1).  With no unmeasured
+ * pixels the far-plane gradient of mode s (exitwave.py:122-184, lstsq.py:
+ * 454-502) is steps[n][s] x (F_s x poisson factor) -- linear in the step
+ * length -- so the second sweep and the gradient pass are ONE launch: work
+ * (nscan,S,det,det) != scratch receives pass 1 of the inverse of F_s x factor
+ * x scale WITHOUT the step length, which tike_ifft2_pass2_gradients_scaled
+ * applies (mode_scale = steps).  costs (nscan) or NULL, steps (nscan,S) out,
+ * sums (nscan,S,2) workspace. */
+int tike_poisson_steps_grad_ifft2_pass1(const void* scratch, const void* data, int data_u16,
+                                        float* costs, float* steps, float* sums, void* work,
+                                        int nscan, int S, int det, float scale,
+                                        float unmeasured_scaling, float step_start,
+                                        float weight, void* stream);
 
 /* tike_ifft2_crop_scaled with the factor of mode s multiplied by
  * mode_scale[n][s] on measured pixels (lstsq.py:487-489: farplane[measured] =

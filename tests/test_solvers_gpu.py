@@ -752,6 +752,8 @@ def _oracle_state(g_psi, g_probe, scan, order):
     (256, 256, 8, 6, 1, False, "poisson:all_modes"),      # ... at the headline mode count
     (512, 512, 2, 5, 1, True, "poisson:all_modes"),       # ... and at 512^2
     (256, 256, 3, 8, 2, True, "poisson:all_modes:kept"),  # the stored-far-plane pipeline
+    (256, 256, 3, 9, 2, False, "poisson:all_modes"),      # every pixel measured: steps applied by pass 2
+    (256, 256, 5, 7, 1, False, "poisson:all_modes:sweeps"),  # ... and its three-read form
 ])
 def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
     """Two lstsq_grad epochs against the CPU oracle on seeded problems that
@@ -766,6 +768,14 @@ def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
         mp.setattr(L, "POISSON_FROM_HANDOFF", False)
         request_cleanup = mp.undo
         model = model[:-len(":kept")]
+    elif model.endswith(":sweeps"):
+        import importlib
+        import pytest as _pytest
+        L = importlib.import_module("tike_amd.ptycho.solvers.lstsq")
+        mp = _pytest.MonkeyPatch()
+        mp.setattr(L, "POISSON_STEPS_IN_PASS2", False)
+        request_cleanup = mp.undo
+        model = model[:-len(":sweeps")]
     else:
         request_cleanup = lambda: None
     rng = np.random.default_rng(det * 7 + N)

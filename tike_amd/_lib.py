@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("TIKE_AMD_LIB") or os.path.join(
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
 # the header version this binding's prototypes were written against
-ABI_VERSION = 9
+ABI_VERSION = 10
 ERR_ARG = 1000001
 ERR_UNSUPPORTED = 1000002
 ERR_COMM = 2000000
@@ -91,6 +91,10 @@ _PROTOTYPES = {
     "tike_ifft2_pass1_scaled": [_p, _p, _p, _p, _i, _p, _l, _i, _p],
     "tike_ifft2_pass2_gradients": [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _f,
                                    _i, _i, _i, _f, _p],
+    "tike_ifft2_pass2_gradients_scaled": [_p, _p, _p, _p, _p, _i, _i, _p, _p,
+                                          _p, _f, _i, _i, _i, _f, _p, _p],
+    "tike_poisson_steps_grad_ifft2_pass1": [_p, _p, _i, _p, _p, _p, _p, _i, _i,
+                                            _i, _f, _f, _f, _f, _p],
     "tike_object_update_precond": [_p, _p, _p, _f, _p, _p, _p, _l, _p],
     "tike_lstsq_step_sums": [_p, _p, _i, _f, _p, _p],
     "tike_lstsq_step_solve": [_p, _i, _f, _p, _d, _i, _i, _p, _p],

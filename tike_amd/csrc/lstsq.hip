@@ -733,7 +733,8 @@ template <int N, int MW, int MPW, bool HAVE_PROJ, bool EIG = true>
 __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
     const cf* __restrict__ mid, const cf* __restrict__ patches, const TkProbe probe,
     cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, float mpu_scale,
-    int nscan, int S, float inv_scale, int chunk, float* __restrict__ mpu_part) {
+    int nscan, int S, float inv_scale, int chunk, float* __restrict__ mpu_part,
+    const float* __restrict__ mode_scale) {
   constexpr int RB = N / 16;
   constexpr int CW = 4 / MW;            // column-waves per workgroup
   constexpr int NCB = N / (64 * CW);    // column blocks
@@ -828,11 +829,14 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
           for (int yb = 0; yb < RB; ++yb) O[yb] = *tk_at(On + yb * ROW, lo);
         }
         const float w0 = vary ? wn[s] : 1.0f;
+        // (poisson step lengths that became known after pass 1 was written:
+        // a uniform factor per position and mode)
+        const float sc = mode_scale ? inv_scale * mode_scale[(long)n * S + s] : inv_scale;
         Dft<RB, true>::run(u);
         if (HOIST) {
 #pragma unroll
           for (int yb = 0; yb < RB; ++yb) {
-            u[yb] = u[yb] * inv_scale;  // chi of row ya + 16 yb
+            u[yb] = u[yb] * sc;  // chi of row ya + 16 yb
             acc[m][yb] = acc[m][yb] + conjf(O[yb]) * u[yb];
           }
         } else {
@@ -843,7 +847,7 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
             for (int i = 0; i < 8; ++i) o[i] = *tk_at(On + (g + i) * ROW, lo);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-              u[g + i] = u[g + i] * inv_scale;
+              u[g + i] = u[g + i] * sc;
               acc[m][g + i] = acc[m][g + i] + conjf(o[i]) * u[g + i];
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -948,14 +952,12 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
 // (S,det,det, accumulated).  Probe window = detector; det in {128, 256, 512};
 // S <= 8 (TIKE_ERR_UNSUPPORTED otherwise: use tike_ifft2_crop* +
 // tike_lstsq_gradients).
-extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
-                                          const void* probe, const void* eigen_probe,
-                                          const float* eigen_weights, int num_eigen,
-                                          int eigen_modes, void* objproj, void* chi0,
-                                          void* m_probe_update, float mpu_scale, int nscan,
-                                          int S, int det, float inv_scale, void* stream_) {
-  TK_ENTER();
-  hipStream_t stream = (hipStream_t)stream_;
+static int launch_pass2_gradients(const void* work, const void* patches, const void* probe,
+                                  const void* eigen_probe, const float* eigen_weights,
+                                  int num_eigen, int eigen_modes, void* objproj, void* chi0,
+                                  void* m_probe_update, float mpu_scale, int nscan, int S,
+                                  int det, float inv_scale, const float* mode_scale,
+                                  hipStream_t stream) {
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(work && patches && (probe || !objproj));
@@ -1000,18 +1002,18 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
                          eig_lds,                                                            \
                          stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
                          (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
-                         chunk, mpu_part);                                                   \
+                         chunk, mpu_part, mode_scale);                                       \
     else if (objproj)                                                                        \
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true, false>), grid,    \
                          block, 0,                                                           \
                          stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
                          (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
-                         chunk, mpu_part);                                                   \
+                         chunk, mpu_part, mode_scale);                                       \
     else                                                                                     \
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, false>), grid, block,   \
                          0, stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,   \
                          (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
-                         chunk, mpu_part);                                                   \
+                         chunk, mpu_part, mode_scale);                                       \
   } while (0)
 #define TK_P2G_N(N)                     \
   do {                                  \
@@ -1035,6 +1037,35 @@ extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
   if (mpu_part != nullptr)
     return tk_ordered_sum((float*)m_probe_update, mpu_part, mpu_len, nchunk, true, stream);
   return TK_OK;
+}
+
+extern "C" int tike_ifft2_pass2_gradients(const void* work, const void* patches,
+                                          const void* probe, const void* eigen_probe,
+                                          const float* eigen_weights, int num_eigen,
+                                          int eigen_modes, void* objproj, void* chi0,
+                                          void* m_probe_update, float mpu_scale, int nscan,
+                                          int S, int det, float inv_scale, void* stream) {
+  TK_ENTER();
+  return launch_pass2_gradients(work, patches, probe, eigen_probe, eigen_weights, num_eigen,
+                                eigen_modes, objproj, chi0, m_probe_update, mpu_scale, nscan, S,
+                                det, inv_scale, nullptr, (hipStream_t)stream);
+}
+
+// ... with chi_n,s also times mode_scale[n][s] (nscan,S): the poisson step
+// lengths of tike_poisson_steps_grad_ifft2_pass1, known only after its pass 1
+// was written.
+extern "C" int tike_ifft2_pass2_gradients_scaled(const void* work, const void* patches,
+                                                 const void* probe, const void* eigen_probe,
+                                                 const float* eigen_weights, int num_eigen,
+                                                 int eigen_modes, void* objproj, void* chi0,
+                                                 void* m_probe_update, float mpu_scale,
+                                                 int nscan, int S, int det, float inv_scale,
+                                                 const float* mode_scale, void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(nscan == 0 || mode_scale != nullptr);
+  return launch_pass2_gradients(work, patches, probe, eigen_probe, eigen_weights, num_eigen,
+                                eigen_modes, objproj, chi0, m_probe_update, mpu_scale, nscan, S,
+                                det, inv_scale, mode_scale, (hipStream_t)stream);
 }
 
 // probe preconditioner: out (pw,pw) complex (imaginary part untouched) +=

@@ -3384,9 +3384,11 @@ __global__ __launch_bounds__(256, 2) void poisson_colpass_kernel(
     }
     if (FIRST) {
       float cost = tk_gradient_factor<1, RB>(I, raw, bits, unmeasured_scaling, 1.0f);
+      if (gscale != nullptr) {
 #pragma unroll
-      for (int k2 = 0; k2 < RB; ++k2)
-        gscale[n * (long)N * N + (long)(k1 + 16 * k2) * N + t] = I[k2];
+        for (int k2 = 0; k2 < RB; ++k2)
+          gscale[n * (long)N * N + (long)(k1 + 16 * k2) * N + t] = I[k2];
+      }
       if (costs) {
         cost = tk_block_sum256(cost, red);
         if (threadIdx.x == 0) unsafeAtomicAdd(&costs[n], cost * inv_nmeasured);
@@ -3411,6 +3413,108 @@ __global__ __launch_bounds__(256, 2) void poisson_colpass_kernel(
     const int q = threadIdx.x;  // q = 2 s + {0: denominator, 1: numerator}
     if (q < 2 * S && (FIRST || (q & 1)))
       unsafeAtomicAdd(&sums[n * 2 * S + q], wsum[0][q] + wsum[1][q] + wsum[2][q] + wsum[3][q]);
+  }
+}
+
+// ---- every pixel measured, 256^2: the SECOND sweep and the gradient pass in
+// one launch.  With no unmeasured pixels the far-plane gradient of mode s is
+// alpha_s x (F_s x poisson factor) -- linear in the step length -- so pass 1 of
+// the inverse can be written BEFORE alpha_s of the second sweep is known and
+// the factor applied by pass 2 (tike_ifft2_pass2_gradients_scaled).  The
+// structure is fwd_grad_ifft2_pass1_kernel's two sweeps: sweep A re-forms F_s
+// of every mode for |F_s|^2 (all S x 16 of them stay in registers) -> the
+// second sweep's numerators at the alpha of the first (one atomic per
+// workgroup and mode) and the gradient factor; sweep B re-reads the rows,
+// newest first, applies the factor and runs the inverse's pass 1.  Replaces
+// poisson_colpass_kernel<.., false> + tike_grad_ifft2_pass1 (the factor table
+// written and read, the hand-off read once more from HBM).
+template <class DT>
+__global__ __launch_bounds__(256, 2) void poisson_sweep2_grad_ifft2_pass1_kernel(
+    const cf* __restrict__ colin, const DT* __restrict__ data, const float* __restrict__ alpha,
+    float* __restrict__ sums, cf* __restrict__ work, long nscan, int S, float fwd_scale,
+    float unmeasured_scaling, const cf* __restrict__ twtab) {
+  constexpr int N = 256, MAXS = 8;
+  using G2 = Fft2Geom<N>;
+  __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  __shared__ float wsum[4][MAXS];
+  cf* twl = lds + G2::LDS_ELEMS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int t = threadIdx.x;
+  const float s2 = fwd_scale * fwd_scale;
+  for (long v = blockIdx.x; v < nscan * 16; v += gridDim.x) {
+    const int k1 = (int)(v & 15);
+    const long n = nscan - 1 - (v >> 4);  // descending: see fwd_gradient_scale_kernel
+    int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
+    asm volatile("" : "+v"(line), "+v"(j));
+    const FftTwLds<N> tw{twl, j};
+    // ---- sweep A: |F_s|^2 of rows k1 + 16 k2, every mode
+    float a[MAXS][16], I[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) I[k2] = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      if (s < S) {  // uniform
+        const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
+        cf u[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) u[r] = src[(long)(16 * r) * N];
+        Dft<16, false>::run(u);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+          a[s][k2] = norm2(u[k2]) * s2;
+          I[k2] += a[s][k2];
+        }
+      }
+    }
+    DT raw[16];
+    unsigned bits;
+    tk_request_data16(data, (const unsigned char*)nullptr, n, k1, t, raw, bits);
+    // ---- the second sweep's numerators (exitwave.py:160-172)
+    float num[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      num[s] = 0.f;
+      if (s < S) {
+        const float al = alpha[n * S + s];  // uniform
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+          const float dv = (float)raw[k2];
+          const float xi = 1.0f - dv / (I[k2] + 1e-9f);
+          const float xam1 = xi * al - 1.0f;
+          const float av = a[s][k2];
+          num[s] += xi * av * (1.0f + dv * xam1 / (av * xam1 * xam1 + I[k2] - av));
+        }
+        num[s] = tk_wave_sum(num[s]);
+      }
+    }
+    __syncthreads();  // the previous item's sums have been read
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int s = 0; s < MAXS; ++s) wsum[threadIdx.x >> 6][s] = num[s];
+    }
+    __syncthreads();
+    if (t < S)
+      unsafeAtomicAdd(&sums[n * 2 * S + 2 * t + 1],
+                      wsum[0][t] + wsum[1][t] + wsum[2][t] + wsum[3][t]);
+    // ---- the factor (times the forward scale the inverse applies to F)
+    tk_gradient_factor16<1>(I, raw, bits, unmeasured_scaling, fwd_scale);
+    // ---- sweep B: modes S - 1 .. 0, gradient (without its step length) and
+    // the inverse's pass 1
+    for (int s = S - 1; s >= 0; --s) {
+      const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
+      cf u[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(src + (long)(16 * r) * N);
+      Dft<16, false>::run(u);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) u[k2] = u[k2] * I[k2];
+      Dft<16, true>::run(u);
+#pragma unroll
+      for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
+      cf* mid = work + (n * S + s) * (long)N * N;
+      fft2_rows_from_columns<N, true, true>(lds, tw, line, j, u, mid + (long)(16 * k1) * N);
+    }
   }
 }
 
@@ -3469,6 +3573,58 @@ extern "C" int tike_poisson_steps_handoff(const void* scratch, const void* data,
                      step_start, weight, 0);
 #undef TK_PC_N
 #undef TK_PC
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+// Every pixel measured, det = 256: the step lengths AND pass 1 of the inverse
+// of F_s x factor (WITHOUT the step lengths: tike_ifft2_pass2_gradients_scaled
+// applies `steps`) -- sweep 1, alpha, sweep 2 + gradient pass, alpha.
+extern "C" int tike_poisson_steps_grad_ifft2_pass1(const void* scratch, const void* data,
+                                                   int data_u16, float* costs, float* steps,
+                                                   float* sums, void* work, int nscan, int S,
+                                                   int det, float scale,
+                                                   float unmeasured_scaling, float step_start,
+                                                   float weight, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(scratch && data && steps && sums && work && work != scratch);
+  if (det != 256 || S > 8) return TK_ERR_UNSUPPORTED;
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  const long ntile = (long)nscan * S;
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(float) * 2 * (size_t)ntile, stream);
+  if (e == hipSuccess && costs) e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
+  if (e != hipSuccess) return (int)e;
+  const long nitem = (long)nscan * 16;
+  const float inv = 1.0f / (float)(det * det);
+  const dim3 grid(tk_grid(nitem, 32)), block(256);
+  const dim3 agrid(tk_grid((ntile + 255) / 256, 4));
+  if (data_u16)
+    hipLaunchKernelGGL((poisson_colpass_kernel<256, unsigned short, true>), grid, block, 0, stream,
+                       (const cf*)scratch, (const unsigned short*)data,
+                       (const unsigned char*)nullptr, (float*)nullptr, costs, steps, step_start,
+                       sums, nitem, S, scale, unmeasured_scaling, inv);
+  else
+    hipLaunchKernelGGL((poisson_colpass_kernel<256, float, true>), grid, block, 0, stream,
+                       (const cf*)scratch, (const float*)data, (const unsigned char*)nullptr,
+                       (float*)nullptr, costs, steps, step_start, sums, nitem, S, scale,
+                       unmeasured_scaling, inv);
+  hipLaunchKernelGGL(poisson_alpha_kernel, agrid, dim3(256), 0, stream, sums, steps, ntile,
+                     step_start, weight, 1);
+  const dim3 ggrid(tk_grid(nitem, 8));
+  if (data_u16)
+    hipLaunchKernelGGL((poisson_sweep2_grad_ifft2_pass1_kernel<unsigned short>), ggrid, block, 0,
+                       stream, (const cf*)scratch, (const unsigned short*)data, steps, sums,
+                       (cf*)work, (long)nscan, S, scale, unmeasured_scaling, tw);
+  else
+    hipLaunchKernelGGL((poisson_sweep2_grad_ifft2_pass1_kernel<float>), ggrid, block, 0, stream,
+                       (const cf*)scratch, (const float*)data, steps, sums, (cf*)work,
+                       (long)nscan, S, scale, unmeasured_scaling, tw);
+  hipLaunchKernelGGL(poisson_alpha_kernel, agrid, dim3(256), 0, stream, sums, steps, ntile,
+                     step_start, weight, 0);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }

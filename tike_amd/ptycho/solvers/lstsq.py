@@ -80,6 +80,11 @@ POISSON_FROM_HANDOFF = True
 (tike_poisson_steps_handoff) instead of from a stored far plane; tests set
 this to False to compare the two pipelines."""
 
+POISSON_STEPS_IN_PASS2 = _os.environ.get("TIKE_POISSON_LINEAR", "1") == "1"
+"""Every pixel measured, 256^2: the second sweep of the per-mode poisson step
+lengths and the gradient pass in one launch, the steps applied by pass 2
+(tike_poisson_steps_grad_ifft2_pass1)."""
+
 CHUNK_POSITIONS_OVERRIDE = (int(_os.environ["TIKE_CHUNK_POSITIONS"])
                             if _os.environ.get("TIKE_CHUNK_POSITIONS") else None)
 """Tests set this to force small kernel chunks (several per minibatch);
@@ -485,6 +490,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         w_c = None if w_old is None else w_old[blo:blo + n]
         chi = chi_ws
         uq = None
+        steps_in_pass2 = False
         if w_c is not None and Sm > 0 and not no_farplane:
             # varying probe of the modes that own eigen probes, once per chunk
             # (the 256^2 kernels form it on the fly instead)
@@ -518,7 +524,24 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             # goes through memory)
             one_launch = (fused and not poisson
                           and det in ONE_LAUNCH_GRADIENT_SIZES)
-            if poisson and not dominant:
+            # every pixel measured: the gradient is linear in the step
+            # lengths, so their second sweep and the gradient pass are one
+            # launch and pass 2 applies them
+            steps_in_pass2 = (poisson and not dominant and fused
+                              and det == 256 and mask_u8 is None
+                              and POISSON_STEPS_IN_PASS2)
+            if steps_in_pass2:
+                sums = ws.get("poisson_sums", (min(chunk, max(B, 1)), S, 2),
+                              torch.float32, dev)
+                check(
+                    lib.tike_poisson_steps_grad_ifft2_pass1(
+                        A.ptr(far), A.ptr(data[clo:chi_hi]),
+                        int(data.dtype == torch.uint16),
+                        A.ptr(costs[blo:blo + n]), A.ptr(steps), A.ptr(sums),
+                        A.ptr(mid), n, S, det, fwd_scale, unmeasured,
+                        step_start, step_weight, st),
+                    "poisson step lengths + gradient + inverse pass 1")
+            elif poisson and not dominant:
                 # gradient factor, costs and the per-mode step lengths from
                 # the hand-off: three reads of it, no far plane stored
                 sums = ws.get("poisson_sums", (min(chunk, max(B, 1)), S, 2),
@@ -554,7 +577,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                         None, A.ptr(inten), A.ptr(dchunk),
                         A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
                         step_weight, 1, st), "poisson step lengths")
-            if one_launch:
+            if one_launch or steps_in_pass2:
                 pass
             elif fused:
                 check(
@@ -670,16 +693,18 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         if fused:
             # inverse column pass + both gradients + mode 0 of chi, one
             # pixel-major kernel (chi itself never exists in memory)
-            check(
-                lib.tike_ifft2_pass2_gradients(
-                    A.ptr(far if split_kept else mid),
-                    A.ptr(patches[blo:blo + n]), A.ptr(probe),
-                    A.ptr(ep), A.ptr(w_c), C, Sm,
-                    A.ptr(objproj) if recover_psi else None,
-                    A.ptr(chi0[blo:blo + n]) if need_chi0 else None,
-                    A.ptr(m_probe_update),
-                    1.0 / num_batch, n, S, det, inv_scale, st),
-                "inverse pass 2 + gradients")
+            p2 = (A.ptr(far if split_kept else mid),
+                  A.ptr(patches[blo:blo + n]), A.ptr(probe), A.ptr(ep),
+                  A.ptr(w_c), C, Sm, A.ptr(objproj) if recover_psi else None,
+                  A.ptr(chi0[blo:blo + n]) if need_chi0 else None,
+                  A.ptr(m_probe_update), 1.0 / num_batch, n, S, det, inv_scale)
+            if steps_in_pass2:
+                check(lib.tike_ifft2_pass2_gradients_scaled(*p2, A.ptr(steps),
+                                                            st),
+                      "inverse pass 2 + gradients (x poisson steps)")
+            else:
+                check(lib.tike_ifft2_pass2_gradients(*p2, st),
+                      "inverse pass 2 + gradients")
         else:
             # one pass over chi: probe gradient, object projection, patches
             check(

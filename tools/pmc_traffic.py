@@ -37,6 +37,8 @@ KERNELS = {
     "ls_pick_kernel": "tike_cgrad_line_search_linear:pick",
     "ls_apply_kernel": "tike_cgrad_line_search_linear:apply",
     "void fwd_grad_ifft2_pass1_resident_kernel": "tike_fwd_grad_ifft2_pass1",
+    "void poisson_sweep2_grad_ifft2_pass1_kernel": "tike_poisson_steps_grad_ifft2_pass1:sweep2",
+    "void poisson_colpass_kernel": "tike_poisson_steps:sweep",
     "void fwd_grad_ifft2_pass1_512_kernel": "tike_fwd_grad_ifft2_pass1",
     "void plain_pass1_kernel": "tike_ptycho_adj:pass1",
     "void ifft2_pass2_adjoint_kernel": "tike_ptycho_adj:pass2",
