@@ -3422,21 +3422,21 @@ __global__ __launch_bounds__(256, 2) void poisson_colpass_kernel(
 // the inverse can be written BEFORE alpha_s of the second sweep is known and
 // the factor applied by pass 2 (tike_ifft2_pass2_gradients_scaled).  The
 // structure is fwd_grad_ifft2_pass1_kernel's two sweeps: sweep A re-forms F_s
-// of every mode for |F_s|^2 (all S x 16 of them stay in registers) -> the
-// second sweep's numerators at the alpha of the first (one atomic per
-// workgroup and mode) and the gradient factor; sweep B re-reads the rows,
-// newest first, applies the factor and runs the inverse's pass 1.  Replaces
+// of every mode for the intensity; sweep B re-reads the rows, newest first,
+// re-forms F_s -- whose |F_s|^2 gives the mode's numerator of the second sweep
+// at the alpha of the first (a first version held |F_s|^2 of all modes across
+// sweep A for them: 256 VGPRs + scratch, 2.3 ms; this one 2.0) -- applies the
+// factor and runs the inverse's pass 1.  Replaces
 // poisson_colpass_kernel<.., false> + tike_grad_ifft2_pass1 (the factor table
 // written and read, the hand-off read once more from HBM).
 template <class DT>
-__global__ __launch_bounds__(256, 2) void poisson_sweep2_grad_ifft2_pass1_kernel(
+__global__ __launch_bounds__(256, 3) void poisson_sweep2_grad_ifft2_pass1_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data, const float* __restrict__ alpha,
     float* __restrict__ sums, cf* __restrict__ work, long nscan, int S, float fwd_scale,
     float unmeasured_scaling, const cf* __restrict__ twtab) {
-  constexpr int N = 256, MAXS = 8;
+  constexpr int N = 256;
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
-  __shared__ float wsum[4][MAXS];
   cf* twl = lds + G2::LDS_ELEMS;
   FftTwLds<N>::fill(twl, twtab);
   __syncthreads();
@@ -3448,67 +3448,48 @@ __global__ __launch_bounds__(256, 2) void poisson_sweep2_grad_ifft2_pass1_kernel
     int line = threadIdx.x / G2::T, j = threadIdx.x % G2::T;
     asm volatile("" : "+v"(line), "+v"(j));
     const FftTwLds<N> tw{twl, j};
-    // ---- sweep A: |F_s|^2 of rows k1 + 16 k2, every mode
-    float a[MAXS][16], I[16];
+    // ---- sweep A: the intensity of rows k1 + 16 k2 (F_s discarded)
+    float I[16];
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) I[k2] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N;  // uniform
+      cf u[16];
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
-      if (s < S) {  // uniform
-        const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
-        cf u[16];
+      for (int r = 0; r < 16; ++r) u[r] = *tk_at_pinned(src + (16 * r) * N, t * 8u);
+      Dft<16, false>::run(u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) u[r] = src[(long)(16 * r) * N];
-        Dft<16, false>::run(u);
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-          a[s][k2] = norm2(u[k2]) * s2;
-          I[k2] += a[s][k2];
-        }
-      }
+      for (int k2 = 0; k2 < 16; ++k2) I[k2] += norm2(u[k2]) * s2;
     }
     DT raw[16];
     unsigned bits;
     tk_request_data16(data, (const unsigned char*)nullptr, n, k1, t, raw, bits);
-    // ---- the second sweep's numerators (exitwave.py:160-172)
-    float num[MAXS];
+    // xi = 1 - d / (I + eps); the gradient factor is -xi (x the forward scale).
+    // (the counts are not kept: d = (1 - xi)(I + eps) where sweep B needs them)
+    float xi[16];
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
-      num[s] = 0.f;
-      if (s < S) {
-        const float al = alpha[n * S + s];  // uniform
-#pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-          const float dv = (float)raw[k2];
-          const float xi = 1.0f - dv / (I[k2] + 1e-9f);
-          const float xam1 = xi * al - 1.0f;
-          const float av = a[s][k2];
-          num[s] += xi * av * (1.0f + dv * xam1 / (av * xam1 * xam1 + I[k2] - av));
-        }
-        num[s] = tk_wave_sum(num[s]);
-      }
-    }
-    __syncthreads();  // the previous item's sums have been read
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-      for (int s = 0; s < MAXS; ++s) wsum[threadIdx.x >> 6][s] = num[s];
-    }
-    __syncthreads();
-    if (t < S)
-      unsafeAtomicAdd(&sums[n * 2 * S + 2 * t + 1],
-                      wsum[0][t] + wsum[1][t] + wsum[2][t] + wsum[3][t]);
-    // ---- the factor (times the forward scale the inverse applies to F)
-    tk_gradient_factor16<1>(I, raw, bits, unmeasured_scaling, fwd_scale);
-    // ---- sweep B: modes S - 1 .. 0, gradient (without its step length) and
-    // the inverse's pass 1
+    for (int k2 = 0; k2 < 16; ++k2) xi[k2] = 1.0f - (float)raw[k2] / (I[k2] + 1e-9f);
+    // ---- sweep B: modes S - 1 .. 0.  F_s re-formed: |F_s|^2 gives the mode's
+    // numerator of the second sweep (exitwave.py:160-172, one atomic per wave),
+    // F_s x factor goes through the inverse's pass 1 without its step length
     for (int s = S - 1; s >= 0; --s) {
-      const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N + t;
+      const cf* __restrict__ src = colin + (n * S + s) * (long)N * N + k1 * N;  // uniform
       cf u[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(src + (long)(16 * r) * N);
+      for (int r = 0; r < 16; ++r) u[r] = tk_ld_stream(tk_at_pinned(src + (16 * r) * N, t * 8u));
       Dft<16, false>::run(u);
+      const float al = alpha[n * S + s];  // uniform
+      float num = 0.f;
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) u[k2] = u[k2] * I[k2];
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const float av = norm2(u[k2]) * s2;
+        const float xam1 = xi[k2] * al - 1.0f;
+        const float dv = (1.0f - xi[k2]) * (I[k2] + 1e-9f);
+        num += xi[k2] * av * (1.0f + dv * xam1 / (av * xam1 * xam1 + I[k2] - av));
+        u[k2] = u[k2] * (-xi[k2] * fwd_scale);
+      }
+      num = tk_wave_sum(num);
+      if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&sums[n * 2 * S + 2 * s + 1], num);
       Dft<16, true>::run(u);
 #pragma unroll
       for (int ya = 1; ya < 16; ++ya) u[ya] = mul_tw<true>(u[ya], twtab[N + k1 * ya]);
