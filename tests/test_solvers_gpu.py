@@ -754,6 +754,8 @@ def _oracle_state(g_psi, g_probe, scan, order):
     (256, 256, 3, 8, 2, True, "poisson:all_modes:kept"),  # the stored-far-plane pipeline
     (256, 256, 3, 9, 2, False, "poisson:all_modes"),      # every pixel measured: steps applied by pass 2
     (256, 256, 5, 7, 1, False, "poisson:all_modes:sweeps"),  # ... and its three-read form
+    (256, 256, 6, 5, 1, False, "poisson:all_modes"),      # resident sweeps, three modes per half
+    (256, 256, 7, 4, 2, False, "poisson:all_modes"),      # ... four, the last one empty
 ])
 def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
     """Two lstsq_grad epochs against the CPU oracle on seeded problems that

@@ -2629,15 +2629,28 @@ __device__ __forceinline__ void fft2_rows_from_columns_half(cf* __restrict__ lds
   __syncthreads();
 }
 
-template <int MH, int MODEL, class DT>
+// STEPS (poisson model, every pixel measured; see
+// poisson_sweep2_grad_ifft2_pass1_kernel): with F of all modes in registers the
+// sweeps of the per-mode step lengths (exitwave.py:122-184) cost no re-read --
+//   1: the FIRST sweep alone: denominators and numerators at alpha = start, the
+//      costs; nothing is transformed back or written;
+//   2: the SECOND sweep's numerators at alpha[n][s], then the gradient pass as
+//      usual (pass 1 of the inverse WITHOUT the step length).
+// sums (nscan, S, 2) = { denominator, numerator }, one atomic per wave.
+template <int MH, int MODEL, class DT, int STEPS = 0>
 __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
     long nscan, int S, float fwd_scale, float unmeasured_scaling, float inv_nmeasured,
-    const cf* __restrict__ twtab) {
+    const cf* __restrict__ twtab, const float* __restrict__ alpha = nullptr, float start = 0.f,
+    float* __restrict__ sums = nullptr) {
   constexpr int N = 256;
   using G2 = Fft2Geom<N>;
   __shared__ cf lds[2 * G2::LDS_ELEMS + FftTwLds<N>::ELEMS];
+  // (STEPS: the counts of a work item wait in LDS, a private slot per thread
+  // and pixel, while the modes go through their registers)
+  __shared__ float dvp[STEPS != 0 ? 16 * 512 : 1];
+  __shared__ float ivp[STEPS == 2 ? 16 * 512 : 1];  // ... and, beside the inverse, the intensity
   cf* twl = lds + 2 * G2::LDS_ELEMS;
   FftTwLds<N>::fill(twl, twtab);
   __syncthreads();
@@ -2701,7 +2714,21 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
       }
       __syncthreads();
     }
-    float cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
+    float cost;
+    if (STEPS == 0) {
+      cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
+    } else {
+      // (I stays the intensity: the sweeps need it next to every mode; the
+      // factor -xi x scale is formed per mode below)
+      cost = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) {
+        const float dv = (float)raw[k2];
+        cost += I[k2] - dv * logf(I[k2] + 1e-9f);
+        dvp[k2 * 512 + threadIdx.x] = dv;
+        if (STEPS == 2) ivp[k2 * 512 + threadIdx.x] = I[k2];
+      }
+    }
     if (costs.costs && h == 0) {
       cost = tk_wave_sum(cost);
       if ((threadIdx.x & 63) == 0)
@@ -2710,14 +2737,49 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
     const long vn = v + gridDim.x;
 #pragma unroll
     for (int m = 0; m < MH; ++m) {
+      if (STEPS != 0) {
+        // the sweep's sums of this mode over this thread's 16 pixels
+        const float al = (STEPS == 1 || m0 + m >= S) ? start : alpha[n * S + m0 + m];  // uniform
+        float num = 0.f, den = 0.f;
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) F[m][k2] = F[m][k2] * I[k2];
-      Dft<16, true>::run(F[m]);
+        for (int k2 = 0; k2 < 16; ++k2) {
+          // (in quarters: all sixteen pairs of parked values in flight at once
+          // do not fit next to the other modes)
+          if (STEPS == 2 && (k2 & 3) == 0) asm volatile("" ::: "memory");
+          const float dv = dvp[k2 * 512 + threadIdx.x];
+          const float ie = STEPS == 2 ? ivp[k2 * 512 + threadIdx.x] : I[k2];
+          // (v_rcp_f32, 1 ulp: an IEEE division is a dozen instructions and
+          // five temporaries, twice per pixel and mode, next to 128 registers
+          // of F)
+          const float xi = 1.0f - dv * __builtin_amdgcn_rcpf(ie + 1e-9f);
+          const float av = norm2(F[m][k2]) * s2;
+          const float xam1 = xi * al - 1.0f;
+          num += xi * av *
+                 (1.0f + dv * xam1 * __builtin_amdgcn_rcpf(av * xam1 * xam1 + ie - av));
+          if (STEPS == 1) den += xi * xi * av;
+          if (STEPS == 2) F[m][k2] = F[m][k2] * (-xi * fwd_scale);
+        }
+        if (m0 + m < S) {  // uniform
+          num = tk_wave_sum(num);
+          if (STEPS == 1) den = tk_wave_sum(den);
+          if ((threadIdx.x & 63) == 0) {
+            unsafeAtomicAdd(&sums[(n * S + m0 + m) * 2 + 1], num);
+            if (STEPS == 1) unsafeAtomicAdd(&sums[(n * S + m0 + m) * 2], den);
+          }
+        }
+      } else {
 #pragma unroll
-      for (int ya = 1; ya < 16; ++ya) F[m][ya] = mul_tw<true>(F[m][ya], twtab[N + k1 * ya]);
-      cf* mid = work + (n * S + m0 + m) * (long)N * N;
-      fft2_rows_from_columns_half<N, true>(mylds, tw, t, line, j, F[m], mid + (long)(16 * k1) * N,
-                                           m0 + m < S);
+        for (int k2 = 0; k2 < 16; ++k2) F[m][k2] = F[m][k2] * I[k2];
+      }
+      if (STEPS != 1) {
+        Dft<16, true>::run(F[m]);
+#pragma unroll
+        for (int ya = 1; ya < 16; ++ya)
+          F[m][ya] = mul_tw<true>(F[m][ya], twtab[N + k1 * ya]);
+        cf* mid = work + (n * S + m0 + m) * (long)N * N;
+        fft2_rows_from_columns_half<N, true>(mylds, tw, t, line, j, F[m],
+                                             mid + (long)(16 * k1) * N, m0 + m < S);
+      }
       if (vn < total) request(vn, m);
     }
   }
@@ -3583,6 +3645,41 @@ extern "C" int tike_poisson_steps_grad_ifft2_pass1(const void* scratch, const vo
   const float inv = 1.0f / (float)(det * det);
   const dim3 grid(tk_grid(nitem, 32)), block(256);
   const dim3 agrid(tk_grid((ntile + 255) / 256, 4));
+  if (S >= TK_FG_RESIDENT_MIN_MODES) {
+    // F of all modes in registers (fwd_grad_ifft2_pass1_resident_kernel): each
+    // sweep reads the hand-off once
+    TkCostSink sink;
+    int rc = tk_cost_sink(costs, nscan, 64, stream, &sink);
+    if (rc) return rc;
+    const TkCostSink none = {nullptr, nullptr, 0};
+    const dim3 rgrid(tk_grid(nitem, 1)), rblock(512);
+#define TK_PR(MH, DT, ST, SINK, AL)                                                           \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, 1, DT, ST>), rgrid, rblock, 0, \
+                     stream, (const cf*)scratch, (const DT*)data,                             \
+                     (const unsigned char*)nullptr, SINK, (cf*)work, (long)nscan, S, scale,   \
+                     unmeasured_scaling, inv, tw, AL, step_start, sums)
+#define TK_PR_S(ST, SINK, AL)                      \
+  do {                                             \
+    if (S == 6 && data_u16)                        \
+      TK_PR(3, unsigned short, ST, SINK, AL);      \
+    else if (S == 6)                               \
+      TK_PR(3, float, ST, SINK, AL);               \
+    else if (data_u16)                             \
+      TK_PR(4, unsigned short, ST, SINK, AL);      \
+    else                                           \
+      TK_PR(4, float, ST, SINK, AL);               \
+  } while (0)
+    TK_PR_S(1, sink, (const float*)nullptr);
+    hipLaunchKernelGGL(poisson_alpha_kernel, agrid, dim3(256), 0, stream, sums, steps, ntile,
+                       step_start, weight, 1);
+    TK_PR_S(2, none, (const float*)steps);
+    hipLaunchKernelGGL(poisson_alpha_kernel, agrid, dim3(256), 0, stream, sums, steps, ntile,
+                       step_start, weight, 0);
+#undef TK_PR_S
+#undef TK_PR
+    TK_LAUNCH_CHECK();
+    return tk_cost_finish(sink, nscan, stream);
+  }
   if (data_u16)
     hipLaunchKernelGGL((poisson_colpass_kernel<256, unsigned short, true>), grid, block, 0, stream,
                        (const cf*)scratch, (const unsigned short*)data,
