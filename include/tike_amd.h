@@ -313,21 +313,25 @@ int tike_poisson_steps_handoff(const void* scratch, const void* data, int data_u
                                float unmeasured_scaling, long num_measured, float step_start,
                                float weight, void* stream);
 
-/* The same step lengths AND the gradient pass, every pixel measured, det = 256,
- * S <= 8 (TIKE_ERR_UNSUPPORTED otherwise; a mask with unmeasured pixels takes
- * tike_poisson_steps_handoff + tike_grad_ifft2_pass1).  With no unmeasured
- * pixels the far-plane gradient of mode s (exitwave.py:122-184, lstsq.py:
- * 454-502) is steps[n][s] x (F_s x poisson factor) -- linear in the step
- * length -- so the second sweep and the gradient pass are ONE launch: work
- * (nscan,S,det,det) != scratch receives pass 1 of the inverse of F_s x factor
- * x scale WITHOUT the step length, which tike_ifft2_pass2_gradients_scaled
- * applies (mode_scale = steps).  costs (nscan) or NULL, steps (nscan,S) out,
- * sums (nscan,S,2) workspace. */
+/* The same step lengths AND the gradient pass, det = 256, S <= 8, for data
+ * whose unmeasured pixels carry no gradient: `measured` NULL (every pixel
+ * measured) or unmeasured_scaling == 1, the reference's default
+ * (TIKE_ERR_UNSUPPORTED otherwise: tike_poisson_steps_handoff +
+ * tike_grad_ifft2_pass1).  The far-plane gradient of mode s (exitwave.py:
+ * 122-184, lstsq.py:454-502) is then steps[n][s] x (F_s x poisson factor) --
+ * linear in the step length -- so the second sweep and the gradient pass are
+ * ONE launch: work (nscan,S,det,det) != scratch receives pass 1 of the inverse
+ * of F_s x factor x scale WITHOUT the step length, which
+ * tike_ifft2_pass2_gradients_scaled applies (mode_scale = steps).  With 6-8
+ * modes both sweeps run inside the resident gradient kernel (the hand-off is
+ * read once per sweep).  costs (nscan) or NULL, steps (nscan,S) out, sums
+ * (nscan,S,2) workspace; counts at unmeasured pixels may be NaN. */
 int tike_poisson_steps_grad_ifft2_pass1(const void* scratch, const void* data, int data_u16,
-                                        float* costs, float* steps, float* sums, void* work,
-                                        int nscan, int S, int det, float scale,
-                                        float unmeasured_scaling, float step_start,
-                                        float weight, void* stream);
+                                        const unsigned char* measured, float* costs,
+                                        float* steps, float* sums, void* work, int nscan, int S,
+                                        int det, float scale, float unmeasured_scaling,
+                                        long num_measured, float step_start, float weight,
+                                        void* stream);
 
 /* tike_ifft2_crop_scaled with the factor of mode s multiplied by
  * mode_scale[n][s] on measured pixels (lstsq.py:487-489: farplane[measured] =

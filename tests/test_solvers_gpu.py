@@ -756,30 +756,34 @@ def _oracle_state(g_psi, g_probe, scan, order):
     (256, 256, 5, 7, 1, False, "poisson:all_modes:sweeps"),  # ... and its three-read form
     (256, 256, 6, 5, 1, False, "poisson:all_modes"),      # resident sweeps, three modes per half
     (256, 256, 7, 4, 2, False, "poisson:all_modes"),      # ... four, the last one empty
+    (256, 256, 8, 5, 1, True, "poisson:all_modes:unit"),  # a mask with the default unmeasured scaling 1:
+    (256, 256, 3, 7, 2, True, "poisson:all_modes:unit"),  # still linear in the steps (resident / two sweeps)
 ])
 def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
     """Two lstsq_grad epochs against the CPU oracle on seeded problems that
     exercise ragged minibatches, unmeasured pixels holding NaN (reference
     tests/ptycho/test_ptycho.py:334,553), pw < det and every FFT path."""
     from oracle import solvers as osol
-    if model.endswith(":kept"):
-        import importlib
-        import pytest as _pytest
-        L = importlib.import_module("tike_amd.ptycho.solvers.lstsq")
-        mp = _pytest.MonkeyPatch()
-        mp.setattr(L, "POISSON_FROM_HANDOFF", False)
-        request_cleanup = mp.undo
-        model = model[:-len(":kept")]
-    elif model.endswith(":sweeps"):
-        import importlib
-        import pytest as _pytest
-        L = importlib.import_module("tike_amd.ptycho.solvers.lstsq")
-        mp = _pytest.MonkeyPatch()
-        mp.setattr(L, "POISSON_STEPS_IN_PASS2", False)
-        request_cleanup = mp.undo
-        model = model[:-len(":sweeps")]
-    else:
-        request_cleanup = lambda: None
+    import importlib
+    import pytest as _pytest
+    L = importlib.import_module("tike_amd.ptycho.solvers.lstsq")
+    mp = _pytest.MonkeyPatch()
+    request_cleanup = mp.undo
+    # tags behind the model: the pipeline to force / the unmeasured scaling
+    unmeasured_scaling = 0.9
+    model, *tags = model.split(":")[0:1] + model.split(":")[1:]
+    usemodes = tags.pop(0) if tags and tags[0] in ("all_modes",
+                                                   "dominant_mode") else None
+    for tag in tags:
+        if tag == "kept":
+            mp.setattr(L, "POISSON_FROM_HANDOFF", False)
+        elif tag == "sweeps":
+            mp.setattr(L, "POISSON_STEPS_IN_PASS2", False)
+        elif tag == "unit":
+            unmeasured_scaling = 1.0
+        else:
+            raise AssertionError(tag)
+    model = model if usemodes is None else f"{model}:{usemodes}"
     rng = np.random.default_rng(det * 7 + N)
     side = int(np.ceil(np.sqrt(N)))
     ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
@@ -808,7 +812,8 @@ def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
         probe_options=tp.ProbeOptions(force_orthogonality=True),
         object_options=tp.ObjectOptions(),
         exitwave_options=tp.ExitWaveOptions(
-            measured_pixels=mask, unmeasured_pixels_scaling=0.9,
+            measured_pixels=mask,
+            unmeasured_pixels_scaling=unmeasured_scaling,
             noise_model=model.split(":")[0],
             step_length_usemodes=(model.split(":") + ["all_modes"])[1]))
     import warnings
@@ -826,7 +831,8 @@ def test_lstsq_epochs_vs_oracle(tp, det, pw, S, N, num_batch, masked, model):
     state = osol.rescale_probe(state, odata, det, measured_pixels=mask)
     state = osol.iterate(state, odata, batches, 2, detector_shape=det,
                          batch_method="compact", force_orthogonality=True,
-                         measured_pixels=mask, unmeasured_pixels_scaling=0.9,
+                         measured_pixels=mask,
+                         unmeasured_pixels_scaling=unmeasured_scaling,
                          noise_model=model.split(":")[0],
                          step_length_usemodes=(model.split(":") +
                                                ["all_modes"])[1])

@@ -2723,8 +2723,12 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
       cost = 0.f;
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) {
-        const float dv = (float)raw[k2];
-        cost += I[k2] - dv * logf(I[k2] + 1e-9f);
+        // an unmeasured pixel (its count may be NaN: selected, never used in
+        // arithmetic) is parked as -1: no term in any sum, factor 0
+        // (unmeasured_pixels_scaling = 1, the only value this path serves)
+        const bool meas = (bits >> k2) & 1u;
+        const float dv = meas ? (float)raw[k2] : -1.0f;
+        cost += meas ? I[k2] - dv * logf(I[k2] + 1e-9f) : 0.f;
         dvp[k2 * 512 + threadIdx.x] = dv;
         if (STEPS == 2) ivp[k2 * 512 + threadIdx.x] = I[k2];
       }
@@ -2751,13 +2755,15 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
           // (v_rcp_f32, 1 ulp: an IEEE division is a dozen instructions and
           // five temporaries, twice per pixel and mode, next to 128 registers
           // of F)
+          const bool meas = dv >= 0.f;
           const float xi = 1.0f - dv * __builtin_amdgcn_rcpf(ie + 1e-9f);
           const float av = norm2(F[m][k2]) * s2;
           const float xam1 = xi * al - 1.0f;
-          num += xi * av *
-                 (1.0f + dv * xam1 * __builtin_amdgcn_rcpf(av * xam1 * xam1 + ie - av));
-          if (STEPS == 1) den += xi * xi * av;
-          if (STEPS == 2) F[m][k2] = F[m][k2] * (-xi * fwd_scale);
+          const float tn =
+              xi * av * (1.0f + dv * xam1 * __builtin_amdgcn_rcpf(av * xam1 * xam1 + ie - av));
+          num += meas ? tn : 0.f;
+          if (STEPS == 1) den += meas ? xi * xi * av : 0.f;
+          if (STEPS == 2) F[m][k2] = F[m][k2] * (meas ? -xi * fwd_scale : 0.f);
         }
         if (m0 + m < S) {  // uniform
           num = tk_wave_sum(num);
@@ -3493,7 +3499,8 @@ __global__ __launch_bounds__(256, 2) void poisson_colpass_kernel(
 // written and read, the hand-off read once more from HBM).
 template <class DT>
 __global__ __launch_bounds__(256, 3) void poisson_sweep2_grad_ifft2_pass1_kernel(
-    const cf* __restrict__ colin, const DT* __restrict__ data, const float* __restrict__ alpha,
+    const cf* __restrict__ colin, const DT* __restrict__ data,
+    const unsigned char* __restrict__ mask, const float* __restrict__ alpha,
     float* __restrict__ sums, cf* __restrict__ work, long nscan, int S, float fwd_scale,
     float unmeasured_scaling, const cf* __restrict__ twtab) {
   constexpr int N = 256;
@@ -3525,12 +3532,16 @@ __global__ __launch_bounds__(256, 3) void poisson_sweep2_grad_ifft2_pass1_kernel
     }
     DT raw[16];
     unsigned bits;
-    tk_request_data16(data, (const unsigned char*)nullptr, n, k1, t, raw, bits);
+    tk_request_data16(data, mask, n, k1, t, raw, bits);
     // xi = 1 - d / (I + eps); the gradient factor is -xi (x the forward scale).
-    // (the counts are not kept: d = (1 - xi)(I + eps) where sweep B needs them)
+    // (the counts are not kept: d = (1 - xi)(I + eps) where sweep B needs them;
+    // an unmeasured pixel -- its count may be NaN: selected, never used -- has
+    // xi = 0 here: no term in the sums, factor 0, what
+    // unmeasured_pixels_scaling = 1 asks for)
     float xi[16];
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) xi[k2] = 1.0f - (float)raw[k2] / (I[k2] + 1e-9f);
+    for (int k2 = 0; k2 < 16; ++k2)
+      xi[k2] = ((bits >> k2) & 1u) ? 1.0f - (float)raw[k2] / (I[k2] + 1e-9f) : 0.f;
     // ---- sweep B: modes S - 1 .. 0.  F_s re-formed: |F_s|^2 gives the mode's
     // numerator of the second sweep (exitwave.py:160-172, one atomic per wave),
     // F_s x factor goes through the inverse's pass 1 without its step length
@@ -3547,7 +3558,8 @@ __global__ __launch_bounds__(256, 3) void poisson_sweep2_grad_ifft2_pass1_kernel
         const float av = norm2(u[k2]) * s2;
         const float xam1 = xi[k2] * al - 1.0f;
         const float dv = (1.0f - xi[k2]) * (I[k2] + 1e-9f);
-        num += xi[k2] * av * (1.0f + dv * xam1 / (av * xam1 * xam1 + I[k2] - av));
+        const float tn = xi[k2] * av * (1.0f + dv * xam1 / (av * xam1 * xam1 + I[k2] - av));
+        num += xi[k2] != 0.f ? tn : 0.f;  // (0 x NaN of a dark unmeasured pixel)
         u[k2] = u[k2] * (-xi[k2] * fwd_scale);
       }
       num = tk_wave_sum(num);
@@ -3624,17 +3636,21 @@ extern "C" int tike_poisson_steps_handoff(const void* scratch, const void* data,
 // of F_s x factor (WITHOUT the step lengths: tike_ifft2_pass2_gradients_scaled
 // applies `steps`) -- sweep 1, alpha, sweep 2 + gradient pass, alpha.
 extern "C" int tike_poisson_steps_grad_ifft2_pass1(const void* scratch, const void* data,
-                                                   int data_u16, float* costs, float* steps,
-                                                   float* sums, void* work, int nscan, int S,
-                                                   int det, float scale,
-                                                   float unmeasured_scaling, float step_start,
+                                                   int data_u16, const unsigned char* measured,
+                                                   float* costs, float* steps, float* sums,
+                                                   void* work, int nscan, int S, int det,
+                                                   float scale, float unmeasured_scaling,
+                                                   long num_measured, float step_start,
                                                    float weight, void* stream_) {
   TK_ENTER();
   hipStream_t stream = (hipStream_t)stream_;
-  TK_CHECK_ARG(nscan >= 0 && S >= 1);
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && num_measured > 0);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(scratch && data && steps && sums && work && work != scratch);
-  if (det != 256 || S > 8) return TK_ERR_UNSUPPORTED;
+  // (unmeasured pixels keep F x (unmeasured_scaling - 1), which no step length
+  // multiplies: linear in the steps only when that is zero)
+  if (det != 256 || S > 8 || (measured != nullptr && unmeasured_scaling != 1.0f))
+    return TK_ERR_UNSUPPORTED;
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   const long ntile = (long)nscan * S;
@@ -3642,7 +3658,7 @@ extern "C" int tike_poisson_steps_grad_ifft2_pass1(const void* scratch, const vo
   if (e == hipSuccess && costs) e = hipMemsetAsync(costs, 0, sizeof(float) * (size_t)nscan, stream);
   if (e != hipSuccess) return (int)e;
   const long nitem = (long)nscan * 16;
-  const float inv = 1.0f / (float)(det * det);
+  const float inv = 1.0f / (float)num_measured;
   const dim3 grid(tk_grid(nitem, 32)), block(256);
   const dim3 agrid(tk_grid((ntile + 255) / 256, 4));
   if (S >= TK_FG_RESIDENT_MIN_MODES) {
@@ -3655,9 +3671,8 @@ extern "C" int tike_poisson_steps_grad_ifft2_pass1(const void* scratch, const vo
     const dim3 rgrid(tk_grid(nitem, 1)), rblock(512);
 #define TK_PR(MH, DT, ST, SINK, AL)                                                           \
   hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, 1, DT, ST>), rgrid, rblock, 0, \
-                     stream, (const cf*)scratch, (const DT*)data,                             \
-                     (const unsigned char*)nullptr, SINK, (cf*)work, (long)nscan, S, scale,   \
-                     unmeasured_scaling, inv, tw, AL, step_start, sums)
+                     stream, (const cf*)scratch, (const DT*)data, measured, SINK, (cf*)work,  \
+                     (long)nscan, S, scale, unmeasured_scaling, inv, tw, AL, step_start, sums)
 #define TK_PR_S(ST, SINK, AL)                      \
   do {                                             \
     if (S == 6 && data_u16)                        \
@@ -3682,24 +3697,23 @@ extern "C" int tike_poisson_steps_grad_ifft2_pass1(const void* scratch, const vo
   }
   if (data_u16)
     hipLaunchKernelGGL((poisson_colpass_kernel<256, unsigned short, true>), grid, block, 0, stream,
-                       (const cf*)scratch, (const unsigned short*)data,
-                       (const unsigned char*)nullptr, (float*)nullptr, costs, steps, step_start,
-                       sums, nitem, S, scale, unmeasured_scaling, inv);
-  else
-    hipLaunchKernelGGL((poisson_colpass_kernel<256, float, true>), grid, block, 0, stream,
-                       (const cf*)scratch, (const float*)data, (const unsigned char*)nullptr,
+                       (const cf*)scratch, (const unsigned short*)data, measured,
                        (float*)nullptr, costs, steps, step_start, sums, nitem, S, scale,
                        unmeasured_scaling, inv);
+  else
+    hipLaunchKernelGGL((poisson_colpass_kernel<256, float, true>), grid, block, 0, stream,
+                       (const cf*)scratch, (const float*)data, measured, (float*)nullptr, costs,
+                       steps, step_start, sums, nitem, S, scale, unmeasured_scaling, inv);
   hipLaunchKernelGGL(poisson_alpha_kernel, agrid, dim3(256), 0, stream, sums, steps, ntile,
                      step_start, weight, 1);
   const dim3 ggrid(tk_grid(nitem, 8));
   if (data_u16)
     hipLaunchKernelGGL((poisson_sweep2_grad_ifft2_pass1_kernel<unsigned short>), ggrid, block, 0,
-                       stream, (const cf*)scratch, (const unsigned short*)data, steps, sums,
-                       (cf*)work, (long)nscan, S, scale, unmeasured_scaling, tw);
+                       stream, (const cf*)scratch, (const unsigned short*)data, measured, steps,
+                       sums, (cf*)work, (long)nscan, S, scale, unmeasured_scaling, tw);
   else
     hipLaunchKernelGGL((poisson_sweep2_grad_ifft2_pass1_kernel<float>), ggrid, block, 0, stream,
-                       (const cf*)scratch, (const float*)data, steps, sums, (cf*)work,
+                       (const cf*)scratch, (const float*)data, measured, steps, sums, (cf*)work,
                        (long)nscan, S, scale, unmeasured_scaling, tw);
   hipLaunchKernelGGL(poisson_alpha_kernel, agrid, dim3(256), 0, stream, sums, steps, ntile,
                      step_start, weight, 0);

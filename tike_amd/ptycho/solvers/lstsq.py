@@ -524,11 +524,13 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             # goes through memory)
             one_launch = (fused and not poisson
                           and det in ONE_LAUNCH_GRADIENT_SIZES)
-            # every pixel measured: the gradient is linear in the step
-            # lengths, so their second sweep and the gradient pass are one
-            # launch and pass 2 applies them
+            # no gradient at unmeasured pixels (none of them, or the default
+            # unmeasured_pixels_scaling = 1): the gradient is linear in the
+            # step lengths, so their second sweep and the gradient pass are
+            # one launch and pass 2 applies them
             steps_in_pass2 = (poisson and not dominant and fused
-                              and det == 256 and mask_u8 is None
+                              and det == 256
+                              and (mask_u8 is None or unmeasured == 1.0)
                               and POISSON_STEPS_IN_PASS2)
             if steps_in_pass2:
                 sums = ws.get("poisson_sums", (min(chunk, max(B, 1)), S, 2),
@@ -536,10 +538,10 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                 check(
                     lib.tike_poisson_steps_grad_ifft2_pass1(
                         A.ptr(far), A.ptr(data[clo:chi_hi]),
-                        int(data.dtype == torch.uint16),
+                        int(data.dtype == torch.uint16), A.ptr(mask_u8),
                         A.ptr(costs[blo:blo + n]), A.ptr(steps), A.ptr(sums),
                         A.ptr(mid), n, S, det, fwd_scale, unmeasured,
-                        step_start, step_weight, st),
+                        nmeasured, step_start, step_weight, st),
                     "poisson step lengths + gradient + inverse pass 1")
             elif poisson and not dominant:
                 # gradient factor, costs and the per-mode step lengths from
