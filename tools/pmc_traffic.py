@@ -17,6 +17,11 @@ import sys
 
 # kernel-name prefix -> C-ABI entry whose launch it is
 KERNELS = {
+    # (the poisson sweeps inside the resident gradient kernel: before its plain form)
+    "void fwd_grad_ifft2_pass1_resident_kernel<4, 1, float, 1>": "tike_poisson_steps_grad_ifft2_pass1:sweep1",
+    "void fwd_grad_ifft2_pass1_resident_kernel<4, 1, float, 2>": "tike_poisson_steps_grad_ifft2_pass1:sweep2",
+    "void fwd_grad_ifft2_pass1_resident_kernel<3, 1, float, 1>": "tike_poisson_steps_grad_ifft2_pass1:sweep1",
+    "void fwd_grad_ifft2_pass1_resident_kernel<3, 1, float, 2>": "tike_poisson_steps_grad_ifft2_pass1:sweep2",
     "void ptycho_fwd_pos_kernel<256, false>": "tike_ptycho_fwd_gradient_scale",
     "void ptycho_fwd_pos_kernel<256, true>": "tike_ptycho_fwd_intensity",
     "void ptycho_fwd_pos_kernel<512": "tike_ptycho_fwd_intensity",
@@ -72,6 +77,7 @@ KERNELS = {
 SOLVER_ONLY = ("psi_precond_kernel", "void fwd_gradient_scale_kernel",
                "void fwd_grad_ifft2_pass1_kernel",
                "void fwd_grad_ifft2_pass1_resident_kernel",
+               "void poisson_colpass_kernel",
                "void step_stats_kernel", "void step_stats_pair_kernel",
                "void probe_grad_kernel",
                "void gradient_scale_kernel", "void farplane_gradient_kernel",
@@ -158,6 +164,15 @@ def main():
                  "tike_ifft2_pass2_gradients", "tike_scatter_patches")
         if all(k in doc["kernels"] for k in parts):
             doc["composite"] = {"tike_lstsq_chunk_gradients": {
+                "parts": list(parts),
+                "hbm_bytes_per_launch": sum(
+                    doc["kernels"][k]["hbm_bytes_per_launch"] for k in parts)}}
+    if workload == "c3poisson":
+        # one call = first sweep + (second sweep + gradient pass)
+        parts = ("tike_poisson_steps_grad_ifft2_pass1:sweep1",
+                 "tike_poisson_steps_grad_ifft2_pass1:sweep2")
+        if all(k in doc["kernels"] for k in parts):
+            doc["composite"] = {"tike_poisson_steps_grad_ifft2_pass1": {
                 "parts": list(parts),
                 "hbm_bytes_per_launch": sum(
                     doc["kernels"][k]["hbm_bytes_per_launch"] for k in parts)}}
