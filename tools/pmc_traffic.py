@@ -18,10 +18,10 @@ import sys
 # kernel-name prefix -> C-ABI entry whose launch it is
 KERNELS = {
     # (the poisson sweeps inside the resident gradient kernel: before its plain form)
-    "void fwd_grad_ifft2_pass1_resident_kernel<4, 1, float, 1>": "tike_poisson_steps_grad_ifft2_pass1:sweep1",
-    "void fwd_grad_ifft2_pass1_resident_kernel<4, 1, float, 2>": "tike_poisson_steps_grad_ifft2_pass1:sweep2",
-    "void fwd_grad_ifft2_pass1_resident_kernel<3, 1, float, 1>": "tike_poisson_steps_grad_ifft2_pass1:sweep1",
-    "void fwd_grad_ifft2_pass1_resident_kernel<3, 1, float, 2>": "tike_poisson_steps_grad_ifft2_pass1:sweep2",
+    "void fwd_grad_ifft2_pass1_resident_kernel<4, 1, float, 1,": "tike_poisson_steps_grad_ifft2_pass1:sweep1",
+    "void fwd_grad_ifft2_pass1_resident_kernel<4, 1, float, 2,": "tike_poisson_steps_grad_ifft2_pass1:sweep2",
+    "void fwd_grad_ifft2_pass1_resident_kernel<3, 1, float, 1,": "tike_poisson_steps_grad_ifft2_pass1:sweep1",
+    "void fwd_grad_ifft2_pass1_resident_kernel<3, 1, float, 2,": "tike_poisson_steps_grad_ifft2_pass1:sweep2",
     "void ptycho_fwd_pos_kernel<256, false>": "tike_ptycho_fwd_gradient_scale",
     "void ptycho_fwd_pos_kernel<256, true>": "tike_ptycho_fwd_intensity",
     "void ptycho_fwd_pos_kernel<512": "tike_ptycho_fwd_intensity",
