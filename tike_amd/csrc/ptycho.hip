@@ -2196,6 +2196,7 @@ static int tk_farplane_gradient(void* farplane, const float* data, const unsigne
   if (model == 1 && apply_gradient) TK_FG(1, true);
   if (model == 1 && !apply_gradient) TK_FG(1, false);
 #undef TK_FG
+#undef TK_FG_K
   TK_LAUNCH_CHECK();
   return tk_cost_finish(sink, nscan, stream);
 }
@@ -2445,7 +2446,7 @@ __global__ __launch_bounds__(N, TK_GINV_WAVES) void grad_ifft2_crop_kernel(
 // emits the inverse's pass 1 of conj(H)^b G, b = 1 .. nback, into work + b *
 // back_stride: the steps back cost one more store each instead of a stored
 // chi, a forward pass 1 and a column pass.
-template <int MODEL, class DT, bool BACK = false>
+template <int MODEL, class DT, bool BACK = false, bool MK = true>
 __global__ __launch_bounds__(256, BACK ? 2 : 3) void fwd_grad_ifft2_pass1_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
@@ -2497,7 +2498,7 @@ __global__ __launch_bounds__(256, BACK ? 2 : 3) void fwd_grad_ifft2_pass1_kernel
     {
       DT raw[16];
       unsigned bits;
-      tk_request_data16(data, mask, n, k1, t, raw, bits);
+      tk_request_data16(data, !MK ? (const unsigned char*)nullptr : mask, n, k1, t, raw, bits);
       cost = tk_gradient_factor16<MODEL>(I, raw, bits, unmeasured_scaling, fwd_scale);
     }
     if (costs.costs) {
@@ -2547,7 +2548,7 @@ __global__ __launch_bounds__(256, BACK ? 2 : 3) void fwd_grad_ifft2_pass1_kernel
 
 // ---- one mode: the column-pass values of the work item are 16 registers per
 // thread, so there is no second sweep at all (cgrad's gradient pass, S = 1)
-template <int MODEL, class DT>
+template <int MODEL, class DT, bool MK = true>
 __global__ __launch_bounds__(256, 4) void fwd_grad_ifft2_pass1_single_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
@@ -2576,7 +2577,7 @@ __global__ __launch_bounds__(256, 4) void fwd_grad_ifft2_pass1_single_kernel(
     }
     DT raw[16];
     unsigned bits;
-    tk_request_data16(data, mask, n, k1, t, raw, bits);
+    tk_request_data16(data, !MK ? (const unsigned char*)nullptr : mask, n, k1, t, raw, bits);
     Dft<16, false>::run(u);
     float I[16];
 #pragma unroll
@@ -2698,8 +2699,7 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
       // the counts: requested behind the last hand-off rows, used after the
       // last butterfly and the exchange
       if (m == MH - 1)
-        tk_request_data16(data, (STEPS != 0 && !MK) ? (const unsigned char*)nullptr : mask, n, k1,
-                          t, raw, bits);
+        tk_request_data16(data, !MK ? (const unsigned char*)nullptr : mask, n, k1, t, raw, bits);
       Dft<16, false>::run(F[m]);
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) I[k2] += norm2(F[m][k2]) * s2;
@@ -2886,7 +2886,7 @@ __global__ __launch_bounds__(512, 2) void grad_ifft2_pass1_512_kernel(
 // (tike_fwd_gradient_scale + tike_grad_ifft2_pass1) the factor never goes
 // through memory and HBM sees the hand-off once.
 
-template <int MODEL, class DT>
+template <int MODEL, class DT, bool MK = true>
 __global__ __launch_bounds__(512, 2) void fwd_grad_ifft2_pass1_512_kernel(
     const cf* __restrict__ colin, const DT* __restrict__ data,
     const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ work,
@@ -2925,7 +2925,7 @@ __global__ __launch_bounds__(512, 2) void fwd_grad_ifft2_pass1_512_kernel(
     {
       DT raw[32];
       unsigned bits;
-      tk_request_data<N, 32>(data, mask, n, k1, t, raw, bits);
+      tk_request_data<N, 32>(data, !MK ? (const unsigned char*)nullptr : mask, n, k1, t, raw, bits);
       cost = tk_gradient_factor<MODEL, 32>(I, raw, bits, unmeasured_scaling, fwd_scale);
     }
     if (costs.costs) {
@@ -3028,10 +3028,17 @@ static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, in
     if (rc) return rc;
     const float inv512 = 1.0f / (float)num_measured;
     const dim3 grid(tk_grid((long)nscan * 16, 2)), block(512);
-#define TK_FG512(M, DT)                                                                       \
-  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_512_kernel<M, DT>), grid, block, 0, stream,        \
+#define TK_FG512_K(M, DT, MK_)                                                                \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_512_kernel<M, DT, MK_>), grid, block, 0, stream,   \
                      (const cf*)scratch, (const DT*)data, measured, sink512, (cf*)work,       \
                      (long)nscan, S, fwd_scale, unmeasured_scaling, inv512, tw)
+#define TK_FG512(M, DT)           \
+  do {                            \
+    if (measured != nullptr)      \
+      TK_FG512_K(M, DT, true);    \
+    else                          \
+      TK_FG512_K(M, DT, false);   \
+  } while (0)
     if (model == 0 && data_u16)
       TK_FG512(0, unsigned short);
     else if (model == 0)
@@ -3041,6 +3048,7 @@ static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, in
     else
       TK_FG512(1, float);
 #undef TK_FG512
+#undef TK_FG512_K
     TK_LAUNCH_CHECK();
     return tk_cost_finish(sink512, nscan, stream);
   }
@@ -3058,10 +3066,17 @@ static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, in
   if (resident) {
     // one 512-thread workgroup per CU (it takes the whole register file)
     const dim3 grid(tk_grid((long)nscan * 16, 1)), block(512);
-#define TK_FGR(MH, M, DT)                                                                     \
-  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT>), grid, block, 0,       \
-                     stream, (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work, \
-                     (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
+#define TK_FGR_K(MH, M, DT, MK_)                                                              \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_resident_kernel<MH, M, DT, 0, MK_>), grid, block,  \
+                     0, stream, (const cf*)scratch, (const DT*)data, measured, sink,          \
+                     (cf*)work, (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
+#define TK_FGR(MH, M, DT)          \
+  do {                             \
+    if (measured != nullptr)       \
+      TK_FGR_K(MH, M, DT, true);   \
+    else                           \
+      TK_FGR_K(MH, M, DT, false);  \
+  } while (0)
 #define TK_FGR_M(MH)                                                                          \
   do {                                                                                        \
     if (model == 0 && data_u16)                                                               \
@@ -3079,6 +3094,7 @@ static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, in
       TK_FGR_M(4);
 #undef TK_FGR_M
 #undef TK_FGR
+#undef TK_FGR_K
     TK_LAUNCH_CHECK();
     return tk_cost_finish(sink, nscan, stream);
   }
@@ -3102,10 +3118,17 @@ static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, in
     return tk_cost_finish(sink, nscan, stream);
   }
   if (S == 1) {
-#define TK_FG1(M, DT)                                                                         \
-  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_single_kernel<M, DT>), grid, block, 0, stream,     \
+#define TK_FG1_K(M, DT, MK_)                                                                  \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_single_kernel<M, DT, MK_>), grid, block, 0, stream, \
                      (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work,         \
                      (long)nscan, fwd_scale, unmeasured_scaling, inv, tw)
+#define TK_FG1(M, DT)           \
+  do {                          \
+    if (measured != nullptr)    \
+      TK_FG1_K(M, DT, true);    \
+    else                        \
+      TK_FG1_K(M, DT, false);   \
+  } while (0)
     if (model == 0 && data_u16)
       TK_FG1(0, unsigned short);
     else if (model == 0)
@@ -3115,13 +3138,21 @@ static int launch_fwd_grad_ifft2_pass1(const void* scratch, const void* data, in
     else
       TK_FG1(1, float);
 #undef TK_FG1
+#undef TK_FG1_K
     TK_LAUNCH_CHECK();
     return tk_cost_finish(sink, nscan, stream);
   }
-#define TK_FG(M, DT)                                                                          \
-  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_kernel<M, DT>), grid, block, 0, stream,            \
+#define TK_FG_K(M, DT, MK_)                                                                   \
+  hipLaunchKernelGGL((fwd_grad_ifft2_pass1_kernel<M, DT, false, MK_>), grid, block, 0, stream, \
                      (const cf*)scratch, (const DT*)data, measured, sink, (cf*)work,         \
                      (long)nscan, S, fwd_scale, unmeasured_scaling, inv, tw)
+#define TK_FG(M, DT)           \
+  do {                         \
+    if (measured != nullptr)   \
+      TK_FG_K(M, DT, true);    \
+    else                       \
+      TK_FG_K(M, DT, false);   \
+  } while (0)
   if (model == 0 && data_u16)
     TK_FG(0, unsigned short);
   else if (model == 0)
