@@ -1346,3 +1346,32 @@ def test_position_sums_on_pairs_vs_numpy(pw, N, S):
     np.testing.assert_allclose(got_n.cpu().numpy(), num, rtol=2e-4,
                                atol=2e-5 * np.abs(num).max())
     np.testing.assert_allclose(got_d.cpu().numpy(), den, rtol=2e-4)
+
+
+@pytest.mark.parametrize("pw,N,border", [(256, 70, False), (256, 9, True),
+                                         (128, 33, False), (64, 5, True),
+                                         (48, 7, False), (512, 4, False)])
+def test_probe_preconditioner_vs_numpy(oracle, pw, N, border):
+    """tike_probe_preconditioner (_preconditioner.py:106-160): sum_n
+    |patch_n(psi)|^2 into the real parts of `out`, for window widths with and
+    without the shared-tap-row kernel, several position chunks, windows that
+    leave the image."""
+    import torch
+    import tike_amd._arrays as A
+    from tike_amd._lib import check, lib
+    rng = np.random.default_rng(pw + N)
+    HW = pw + 40
+    scan = (rng.random((N, 2)) * 30 + 2.25).astype(np.float32)
+    if border:
+        scan[1] = (HW - pw + 2.5, 3.5)
+        scan[N - 1] = (-1.75, HW - pw + 1.25)
+    psi = rc(rng, HW, HW)
+    want = (np.abs(_patches(oracle, psi, scan, pw))**2).sum(axis=0)
+    out = torch.full((pw, pw), 0.0 + 2.0j, dtype=torch.complex64, device="cuda")
+    scan_d, psi_d = A.to_device(scan), A.to_device(psi)  # (kept alive)
+    check(lib.tike_probe_preconditioner(A.ptr(scan_d), A.ptr(psi_d), A.ptr(out),
+                                        N, pw, HW, HW, A.stream_ptr()))
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(got.real, want, rtol=1e-4,
+                               atol=1e-5 * want.max())
+    assert np.all(got.imag == 2.0)  # untouched
