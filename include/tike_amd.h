@@ -38,7 +38,7 @@ extern "C" {
  * A binding compares tike_abi_version() of the loaded library with the
  * TIKE_ABI_VERSION it was written against before its first call
  * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
-#define TIKE_ABI_VERSION 10
+#define TIKE_ABI_VERSION 11
 
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
@@ -92,9 +92,27 @@ int tike_conv_adj_probe(const void* nearplane, const float* scan, const void* ps
 /* ---- Propagation: replaces cuFFT behind CachedFFT._fft2/_ifft2
  * (operators/cupy/propagation.py:43-73, cache.py:66-82).
  * ntile tiles of n x n c64; out may alias in (overwrite); every element is
- * multiplied by `scale` (norm='ortho' -> 1/n both ways). n <= 1024. */
+ * multiplied by `scale` (norm='ortho' -> 1/n both ways).
+ * Any n cuFFT would be handed by a detector: powers of two 32..1024 on the
+ * register engines; every other n = 2^a 3^b 5^c 7^d 11^e 13^f <= 4096 (96,
+ * 192, 320, 384, 640, 768, 2048 ...) by mixed-radix lines in LDS; any other
+ * n <= 2048 (45 * 23, 127, primes) by Bluestein's chirp-z over that engine.
+ * TIKE_ERR_UNSUPPORTED only beyond those bounds (tike_fft2_supported). */
 int tike_fft2(const void* in, void* out, long ntile, int n, int inverse, float scale,
               void* stream);
+
+/* 1 when tike_fft2 takes tiles of n x n, else 0 (host only; the plan tables
+ * of a size -- twiddles, chirp -- are built at its first transform and kept
+ * per (n, device), as the reference keeps its cuFFT plans, cache.py:32-46). */
+int tike_fft2_supported(int n);
+
+/* The shape-general engine of tike_fft2 called directly, for EVERY n it
+ * supports (powers of two included: the cross-check of the two engines), with
+ * its grouping as arguments: lines (rows / columns) a workgroup transforms
+ * together, rounded down to a power of two that fits LDS; 0 = the planner's
+ * choice.  Same contract as tike_fft2 otherwise. */
+int tike_fft2_general(const void* in, void* out, long ntile, int n, int inverse, float scale,
+                      int lines_per_group_rows, int lines_per_group_cols, void* stream);
 
 /* ---- Ptycho.fwd fused (operators/cupy/ptycho.py:114-129):
  * farplane[n][s] = scale * FFT2( pad( patch_n(psi) * probe_n[s] ) ).

@@ -36,6 +36,16 @@ int main() {
   e = std::fmax(e, check<8, true>());
   e = std::fmax(e, check<16, false>());
   e = std::fmax(e, check<16, true>());
+  e = std::fmax(e, check<3, false>());
+  e = std::fmax(e, check<3, true>());
+  e = std::fmax(e, check<5, false>());
+  e = std::fmax(e, check<5, true>());
+  e = std::fmax(e, check<7, false>());
+  e = std::fmax(e, check<7, true>());
+  e = std::fmax(e, check<11, false>());
+  e = std::fmax(e, check<11, true>());
+  e = std::fmax(e, check<13, false>());
+  e = std::fmax(e, check<13, true>());
   e = std::fmax(e, check<32, false>());
   e = std::fmax(e, check<32, true>());
   printf("max err %.3e\n", e);

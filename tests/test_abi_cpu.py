@@ -87,17 +87,24 @@ def test_binding_refuses_a_library_of_another_abi_version(monkeypatch):
         L._check_abi_version()
 
 
-def test_fft_radix_host_unit_test_builds_and_passes(tmp_path):
-    """csrc/fft_radix.h says "host-unit-tested": this is the harness that runs
-    tests/csrc/test_fft_radix.cpp (plain g++, no GPU)."""
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("harness", ["test_fft_radix", "test_fft_mixed"])
+def test_fft_radix_host_unit_test_builds_and_passes(tmp_path, harness):
+    """csrc/fft_radix.h and csrc/fft_mixed.h say "host-unit-tested": this is
+    the harness that runs tests/csrc/test_fft_radix.cpp (every butterfly,
+    radices 2..32 incl. 3, 5, 7, 11, 13) and tests/csrc/test_fft_mixed.cpp (the
+    planner and the stage arithmetic of the shape-general engine for 35 sizes
+    up to 4096) with plain g++, no GPU."""
     import shutil
     import subprocess
     if shutil.which("g++") is None:
         import pytest
         pytest.skip("no g++")
     here = os.path.dirname(os.path.abspath(__file__))
-    src = os.path.join(here, "csrc", "test_fft_radix.cpp")
-    exe = str(tmp_path / "test_fft_radix")
+    src = os.path.join(here, "csrc", harness + ".cpp")
+    exe = str(tmp_path / harness)
     cmd = ["g++", "-O2", "-std=c++17", "-I",
            os.path.join(os.path.dirname(here), "tike_amd", "csrc"), src, "-o",
            exe]

@@ -157,11 +157,19 @@ def test_convolution_adjoint_identities(ops, oracle):
 
 
 # ---------------------------------------------------------- Propagation
-@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 127, 45, 24, 7])
+@pytest.mark.parametrize("n", [32, 64, 128, 256, 512, 1024, 127, 45, 24, 7,
+                               # round 6, the shape-general engine: mixed
+                               # radix (2, 3, 5, 7, 11, 13) ...
+                               96, 160, 192, 320, 384, 640, 768, 1000, 1536,
+                               2048, 3072, 4096, 15, 77, 143, 1, 2, 3,
+                               # ... and Bluestein (a prime factor > 13)
+                               17, 34, 129, 323, 1023, 1234, 2047, 2048 - 31])
 @pytest.mark.parametrize("norm", ["ortho", "forward", "backward"])
 def test_propagation_vs_numpy(ops, n, norm):
     rng = np.random.default_rng(n)
-    batch = 3 if n >= 512 else 13
+    batch = 2 if n >= 2000 else 3 if n >= 512 else 13
+    if norm != "ortho" and n in (3072, 4096, 1536, 2047, 1234):
+        pytest.skip("large sizes: one normalisation")
     x = rc(rng, batch, n, n)
     with ops.Propagation(detector_shape=n, norm=norm) as op:
         f = op.fwd(nearplane=x)
@@ -172,7 +180,53 @@ def test_propagation_vs_numpy(ops, n, norm):
                  normwise=2e-6, maxabs=2e-5, what=f"ifft2 n={n}")
 
 
-@pytest.mark.parametrize("n", [127, 64])
+@pytest.mark.parametrize("n", [16, 32, 64, 128, 256, 512, 1024])
+@pytest.mark.parametrize("groups", [(0, 0), (1, 1), (2, 8), (5, 3), (64, 64)])
+def test_general_fft_engine_at_the_register_engines_sizes(ops, n, groups):
+    """tike_fft2_general (mixed-radix lines in LDS) at the powers of two the
+    register engines serve, against float64 NumPy and at every grouping of the
+    lines (1 line per workgroup, unequal row / column groups, a request that
+    does not fit and is cut down, groups that straddle tiles: 5 tiles of n
+    lines in groups of 2..64), out of place and in place."""
+    import torch
+    from tike_amd import _arrays as A
+    from tike_amd._lib import check, lib
+    rng = np.random.default_rng(n)
+    x = rc(rng, 5, n, n)
+    xt = A.to_device(x, np.complex64)
+    out = torch.empty_like(xt)
+    for inverse, ref in ((0, np.fft.fft2), (1, np.fft.ifft2)):
+        check(lib.tike_fft2_general(A.ptr(xt), A.ptr(out), 5, n, inverse,
+                                    1.0 / n, groups[0], groups[1],
+                                    A.stream_ptr()), "general fft2")
+        assert_close(out.cpu().numpy(),
+                     ref(x.astype(np.complex128), norm="ortho"),
+                     normwise=2e-6, maxabs=2e-5, what=f"general n={n}")
+    inplace = xt.clone()
+    check(lib.tike_fft2_general(A.ptr(inplace), A.ptr(inplace), 5, n, 0,
+                                1.0 / n, groups[0], groups[1],
+                                A.stream_ptr()), "general fft2 in place")
+    assert_close(inplace.cpu().numpy(),
+                 np.fft.fft2(x.astype(np.complex128), norm="ortho"),
+                 normwise=2e-6, maxabs=2e-5, what=f"general in place n={n}")
+
+
+def test_fft_sizes_supported_and_refused(ops):
+    """Every size a detector crop can have has a plan; beyond the engine's
+    bounds (a prime factor > 13 above 2048; anything above 4096) the entry
+    says so and Propagation raises -- never a wrong answer."""
+    from tike_amd._lib import lib
+    for n in (1, 7, 45, 96, 127, 384, 1000, 2047, 2048, 3072, 4096, 4095):
+        # 4095 = 3^2 5 7 13
+        assert lib.tike_fft2_supported(n) == 1, n
+    for n in (0, -3, 2049, 4097, 8192, 2053):
+        assert lib.tike_fft2_supported(n) == 0, n
+    with ops.Propagation(detector_shape=2049) as op:
+        with pytest.raises(ValueError, match="unsupported size"):
+            op.fwd(nearplane=np.zeros((1, 2049, 2049), np.complex64))
+
+
+@pytest.mark.parametrize("n", [127, 64, 384])
 def test_propagation_adjoint_and_scaled(ops, n):
     """reference tests/operators/test_propagation.py:16-36 (13 waves of 127^2):
     <F m, d> = <m, F* d> and |F* F m| = |m| (rtol 1e-3)."""

@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("TIKE_AMD_LIB") or os.path.join(
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tike_amd.h")
 
 # the header version this binding's prototypes were written against
-ABI_VERSION = 10
+ABI_VERSION = 11
 ERR_ARG = 1000001
 ERR_UNSUPPORTED = 1000002
 ERR_COMM = 2000000
@@ -51,6 +51,8 @@ _PROTOTYPES = {
     "tike_conv_adj": [_p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p],
     "tike_conv_adj_probe": [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "tike_fft2": [_p, _p, _l, _i, _i, _f, _p],
+    "tike_fft2_supported": [_i],
+    "tike_fft2_general": [_p, _p, _l, _i, _i, _f, _i, _i, _p],
     "tike_fresnel_spect_prop": [_p, _p, _p, _l, _i, _i, _f, _f, _p],
     "tike_fft2_pass1": [_p, _p, _l, _i, _i, _p],
     "tike_fft2_pass2_inplace": [_p, _l, _i, _i, _f, _p],

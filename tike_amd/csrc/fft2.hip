@@ -3,8 +3,9 @@
 //
 // Power-of-two n in [32, 1024]: one workgroup owns one n x n tile and runs
 // both passes (rows, then columns in place on the output tile) through the
-// register/LDS engine of fft_engine.h.  Any other n <= 1024: direct O(n^2)
-// DFT per line (correctness path for the reference's 45/127-sized tests).
+// register/LDS engine of fft_engine.h.  Every other n: the shape-general
+// engine of fft_mixed.hip (mixed radix 2/3/5/7/11/13 up to 4096, Bluestein for
+// the rest up to 2048; until round 5 a direct O(n^2) DFT per line).
 #include <cmath>
 #include <mutex>
 
@@ -185,62 +186,6 @@ static int launch_v2(const cf* in, cf* out, long ntile, int inverse, float scale
   return TK_OK;
 }
 
-// --------------------------------------------------------- generic kernel
-// One workgroup per tile, n <= 1024.  LDS: twiddle table (n) + one line (n).
-template <bool INV>
-__global__ __launch_bounds__(256) void dft2_generic_kernel(const cf* in, cf* out, int n,
-                                                           long ntile, float scale) {
-  __shared__ cf tw[1024];
-  __shared__ cf line[1024];
-  for (int k = threadIdx.x; k < n; k += blockDim.x) {
-    double s, c;
-    sincospi(2.0 * (double)k / (double)n, &s, &c);
-    tw[k] = mk((float)c, INV ? (float)s : (float)-s);
-  }
-  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const cf* src = in + tile * (long)n * n;
-    cf* dst = out + tile * (long)n * n;
-    for (int pass = 0; pass < 2; ++pass) {
-      for (int l = 0; l < n; ++l) {
-        __syncthreads();
-        for (int e = threadIdx.x; e < n; e += blockDim.x)
-          line[e] = pass == 0 ? src[(long)l * n + e] : dst[(long)e * n + l];
-        __syncthreads();
-        for (int k = threadIdx.x; k < n; k += blockDim.x) {
-          float ax = 0.f, ay = 0.f, bx = 0.f, by = 0.f;
-          int m = 0;  // (j * k) mod n
-          int j = 0;
-          for (; j + 1 < n; j += 2) {
-            cf w0 = tw[m];
-            m += k;
-            if (m >= n) m -= n;
-            cf w1 = tw[m];
-            m += k;
-            if (m >= n) m -= n;
-            cf x0 = line[j], x1 = line[j + 1];
-            ax += x0.x * w0.x - x0.y * w0.y;
-            ay += x0.x * w0.y + x0.y * w0.x;
-            bx += x1.x * w1.x - x1.y * w1.y;
-            by += x1.x * w1.y + x1.y * w1.x;
-          }
-          if (j < n) {
-            cf w0 = tw[m];
-            cf x0 = line[j];
-            ax += x0.x * w0.x - x0.y * w0.y;
-            ay += x0.x * w0.y + x0.y * w0.x;
-          }
-          cf r = mk(ax + bx, ay + by);
-          if (pass == 0)
-            dst[(long)l * n + k] = r;
-          else
-            dst[(long)k * n + l] = r * scale;
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
 template <int N>
 static int launch_pow2(const cf* in, cf* out, long ntile, int inverse, float scale,
                        hipStream_t stream) {
@@ -278,16 +223,9 @@ int tk_fft2(const cf* in, cf* out, long ntile, int n, int inverse, float scale,
     case 1024: return launch_pow2<1024>(in, out, ntile, inverse, scale, stream);
     default: break;
   }
-  if (n > 1024) return TK_ERR_UNSUPPORTED;
-  const int grid = tk_grid(ntile, 8);
-  if (inverse)
-    hipLaunchKernelGGL((dft2_generic_kernel<true>), dim3(grid), dim3(256), 0, stream, in, out, n,
-                       ntile, scale);
-  else
-    hipLaunchKernelGGL((dft2_generic_kernel<false>), dim3(grid), dim3(256), 0, stream, in, out,
-                       n, ntile, scale);
-  TK_LAUNCH_CHECK();
-  return TK_OK;
+  // every other size: mixed-radix lines in LDS, or Bluestein over them
+  // (fft_mixed.hip) -- the reference's cuFFT takes any shape
+  return tk_fft2_general(in, out, ntile, n, inverse, scale, 0, 0, stream);
 }
 
 extern "C" int tike_fft2(const void* in, void* out, long ntile, int n, int inverse, float scale,

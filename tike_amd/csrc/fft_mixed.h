@@ -1,0 +1,165 @@
+// Shape-general line-FFT engine for gfx950 (round 6): mixed-radix Stockham
+// autosort in LDS, line length n = product of radices from {2,3,4,5,7,8,11,13,16}
+// chosen at run time by a host plan (MixPlan).  It is what serves every
+// detector size the register engines (fft_engine.h / fft_engine2.h: powers of
+// two, 32..1024) do not -- the reference hands any shape to cuFFT
+// (operators/cupy/cache.py:32-82, propagation.py:43-73).
+//
+// A workgroup holds `nlines` lines in LDS (two buffers, line stride p.ls).  One
+// stage = every butterfly of every line: thread t takes butterflies t, t + NT,
+// ...; a butterfly reads its R inputs from buffer a (stride n / R: consecutive
+// lanes read consecutive elements), multiplies by the twiddles w_n^(k r step)
+// from an LDS table of the n-th roots of unity, runs the radix-R DFT in
+// registers (fft_radix.h) and writes natural (autosorted) positions of buffer
+// b.  One barrier per stage.  Loads and stores of the lines go through caller
+// functors, so producers (patch gather x probe) and consumers (intensity,
+// crop, products) fuse into the transform, as with the register engines.
+//
+// Index arithmetic by float reciprocals (exact for the ranges asserted by the
+// planner: quotients < 2^8, divisors <= 4096): gfx950 has no integer divide.
+//
+// mix_butterfly / MixPlan are plain C++: tests/csrc/test_fft_mixed.cpp runs the
+// stages on the host against a float64 DFT for every planned size.
+#pragma once
+
+#if defined(__HIPCC__)
+#include "common.h"  // hip_runtime.h in front of fft_radix.h
+#else
+#include "fft_radix.h"
+#endif
+
+#define TK_MIX_MAX_STAGES 12
+#define TK_MIX_MAX_N 4096
+
+struct MixPlan {
+  int n;    // line length
+  int nst;  // number of stages
+  int ls;   // LDS line stride in elements (padded)
+  int radix[TK_MIX_MAX_STAGES];
+};
+
+// LDS position of element i of a line: one slot of padding per 16 elements, so
+// that the stride-R writes of the early stages spread over the banks.
+TK_HD int mix_pad(int i) { return i + (i >> 4); }
+TK_HD int mix_line_stride(int n) { return n + (n >> 4) + 1; }
+
+// q = a / d for 0 <= a < 2^16, 1 <= d <= 4096, a / d < 2^8 (see header)
+TK_HD int mix_div(int a, float rcp_d) { return (int)(((float)a + 0.5f) * rcp_d); }
+
+// Plan for n (host).  Returns false when n has a prime factor above 13 (the
+// caller then takes Bluestein's route over a power of two).
+static inline bool mix_make_plan(int n, MixPlan* p) {
+  if (n < 1 || n > TK_MIX_MAX_N) return false;
+  p->n = n;
+  p->ls = mix_line_stride(n);
+  p->nst = 0;
+  int m = n;
+  const int odd[5] = {13, 11, 7, 5, 3};
+  for (int f : odd)
+    while (m % f == 0) {
+      if (p->nst == TK_MIX_MAX_STAGES) return false;
+      p->radix[p->nst++] = f;
+      m /= f;
+    }
+  int a = 0;
+  while (m % 2 == 0) {
+    m /= 2;
+    ++a;
+  }
+  if (m != 1) return false;
+  // 2^a as ceil(a / 4) stages of nearly equal size (2048 = 16 * 16 * 8)
+  const int st = (a + 3) / 4;
+  for (int i = 0; i < st; ++i) {
+    const int e = (a + st - 1 - i) / st;  // larger radices first
+    if (p->nst == TK_MIX_MAX_STAGES) return false;
+    p->radix[p->nst++] = 1 << e;
+  }
+  if (p->nst == 0) p->radix[p->nst++] = 1;  // n == 1
+  return true;
+}
+
+// One radix-R butterfly of a line: a, b = the line's two LDS buffers, tw = n-th
+// roots of unity (forward values), nb = n / R, Ns = product of the radices of
+// the stages in front, step = n / (Ns * R).
+template <int R, bool INV>
+TK_HD void mix_butterfly(const cf* __restrict__ a, cf* __restrict__ b, const cf* __restrict__ tw,
+                         int nb, int Ns, int step, float rcp_ns, int jj) {
+  const int q = mix_div(jj, rcp_ns), k = jj - q * Ns;
+  cf u[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) u[r] = a[mix_pad(jj + r * nb)];
+  if (Ns > 1) {
+    const int ks = k * step;
+#pragma unroll
+    for (int r = 1; r < R; ++r) u[r] = mul_tw<INV>(u[r], tw[ks * r]);
+  }
+  Dft<R, INV>::run(u);
+  const int j0 = q * Ns * R + k;
+#pragma unroll
+  for (int r = 0; r < R; ++r) b[mix_pad(j0 + r * Ns)] = u[r];
+}
+
+template <bool INV>
+struct Dft<1, INV> {
+  static TK_HD void run(cf*) {}
+};
+
+#if defined(__HIPCC__)
+// Every butterfly of stage (R, Ns) over `nlines` lines; no barrier inside.
+template <int R, bool INV>
+__device__ __forceinline__ void mix_stage(const cf* __restrict__ a, cf* __restrict__ b,
+                                          const cf* __restrict__ tw, int n, int ls, int Ns,
+                                          int nlines) {
+  const int nb = n / R, step = n / (Ns * R);
+  const float rcp_nb = 1.0f / (float)nb, rcp_ns = 1.0f / (float)Ns;
+  const int total = nlines * nb;
+  for (int t = threadIdx.x; t < total; t += blockDim.x) {
+    const int line = mix_div(t, rcp_nb), jj = t - line * nb;
+    mix_butterfly<R, INV>(a + line * ls, b + line * ls, tw, nb, Ns, step, rcp_ns, jj);
+  }
+}
+
+// All stages of the plan over `nlines` lines held in buffer a (line stride
+// p.ls).  Every thread of the workgroup must call this (a barrier closes every
+// stage; the caller's loads must be visible on entry: barrier before).
+// Returns the buffer that holds the natural-order result (a or b).
+template <bool INV>
+__device__ __forceinline__ cf* mix_stages(cf* a, cf* b, const cf* __restrict__ tw,
+                                          const MixPlan& p, int nlines) {
+  int Ns = 1;
+  for (int s = 0; s < p.nst; ++s) {
+    const int R = p.radix[s];
+    switch (R) {
+      case 2: mix_stage<2, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 3: mix_stage<3, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 4: mix_stage<4, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 5: mix_stage<5, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 7: mix_stage<7, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 8: mix_stage<8, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 11: mix_stage<11, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 13: mix_stage<13, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 16: mix_stage<16, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      default: mix_stage<1, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+    }
+    __syncthreads();
+    cf* t = a;
+    a = b;
+    b = t;
+    Ns *= R;
+  }
+  return a;
+}
+
+// Host side of the engine (fft2.hip): plans and their device tables, cached per
+// (n, device) like the reference's cuFFT plans (cache.py:32-46).
+struct MixTables {
+  MixPlan plan;      // stages of the transform of length plan.n (= n, or the
+                     // Bluestein length M when n has a large prime factor)
+  int n;             // the caller's line length
+  bool bluestein;
+  const cf* tw;      // plan.n-th roots of unity, forward values
+  const cf* chirp;   // Bluestein: exp(-i pi j^2 / n), j < n
+  const cf* bhat;    // Bluestein: FFT_M of the wrapped conjugate chirp, / M
+};
+const MixTables* tk_mix_tables(int n);  // nullptr: unsupported size
+#endif

@@ -189,3 +189,95 @@ struct Dft<32, INV> {
     }
   }
 };
+
+// ---- odd radices (round 6: detector sizes with factors 3, 5, 7, 11, 13 --
+// 96, 192, 320, 384, 640, 768 ... -- through fft_mixed.h)
+template <bool INV>
+struct Dft<3, INV> {
+  static TK_HD void run(cf* v) {
+    const float s = 0.86602540378443864676f;  // sin(2 pi / 3)
+    const cf t1 = v[1] + v[2];
+    const cf t2 = mk(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
+    const cf t3 = (v[1] - v[2]) * s;
+    v[0] = v[0] + t1;
+    addsub_mi<INV>(t2, t3, v[1], v[2]);
+  }
+};
+
+template <bool INV>
+struct Dft<5, INV> {
+  static TK_HD void run(cf* v) {
+    const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+    const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+    const cf a1 = v[1] + v[4], a2 = v[2] + v[3];
+    const cf b1 = v[1] - v[4], b2 = v[2] - v[3];
+    const cf r1 = mk(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+    const cf r2 = mk(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+    const cf i1 = mk(s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y);
+    const cf i2 = mk(s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y);
+    v[0] = v[0] + a1 + a2;
+    addsub_mi<INV>(r1, i1, v[1], v[4]);
+    addsub_mi<INV>(r2, i2, v[2], v[3]);
+  }
+};
+
+// cos / sin of 2 pi k / P
+template <int P>
+struct PrimeTab;
+template <>
+struct PrimeTab<7> {
+  static constexpr float c[7] = {1.f, 0.62348980185873359f, -0.22252093395631434f, -0.90096886790241903f, -0.90096886790241915f, -0.22252093395631459f, 0.62348980185873337f};
+  static constexpr float s[7] = {0.f, 0.7818314824680298f, 0.97492791218182362f, 0.43388373911755823f, -0.43388373911755801f, -0.97492791218182362f, -0.78183148246802991f};
+};
+template <>
+struct PrimeTab<11> {
+  static constexpr float c[11] = {1.f, 0.84125353283118121f, 0.41541501300188644f, -0.142314838273285f, -0.65486073394528499f, -0.95949297361449737f, -0.95949297361449748f, -0.65486073394528521f, -0.14231483827328523f, 0.41541501300188605f, 0.84125353283118121f};
+  static constexpr float s[11] = {0.f, 0.54064081745559756f, 0.90963199535451833f, 0.9898214418809328f, 0.75574957435425827f, 0.28173255684142967f, -0.28173255684142939f, -0.75574957435425816f, -0.98982144188093268f, -0.90963199535451855f, -0.54064081745559744f};
+};
+template <>
+struct PrimeTab<13> {
+  static constexpr float c[13] = {1.f, 0.88545602565320991f, 0.56806474673115592f, 0.12053668025532301f, -0.35460488704253545f, -0.74851074817110119f, -0.97094181742605201f, -0.97094181742605212f, -0.7485107481711013f, -0.3546048870425359f, 0.1205366802553232f, 0.56806474673115481f, 0.88545602565321002f};
+  static constexpr float s[13] = {0.f, 0.46472317204376851f, 0.82298386589365635f, 0.99270887409805397f, 0.93501624268541483f, 0.66312265824079519f, 0.23931566428755768f, -0.23931566428755743f, -0.66312265824079497f, -0.93501624268541472f, -0.99270887409805397f, -0.82298386589365702f, -0.4647231720437684f};
+};
+
+// Odd prime P by the symmetric form: with a_r = v_r + v_{P-r}, b_r = v_r - v_{P-r},
+// X_q = v_0 + sum_r cos(2 pi r q / P) a_r  -+ i sum_r sin(2 pi r q / P) b_r,
+// X_{P-q} the same with the other sign: (P-1)^2 / 2 real multiplies per component.
+template <int P, bool INV>
+struct DftPrime {
+  static TK_HD void run(cf* v) {
+    constexpr int H = (P - 1) / 2;
+    cf a[H], b[H];
+#pragma unroll
+    for (int r = 1; r <= H; ++r) {
+      a[r - 1] = v[r] + v[P - r];
+      b[r - 1] = v[r] - v[P - r];
+    }
+    cf x0 = v[0];
+#pragma unroll
+    for (int r = 0; r < H; ++r) x0 = x0 + a[r];
+    cf out[P];
+    out[0] = x0;
+#pragma unroll
+    for (int q = 1; q <= H; ++q) {
+      cf re = v[0], im = mk(0.f, 0.f);
+#pragma unroll
+      for (int r = 1; r <= H; ++r) {
+        const float c = PrimeTab<P>::c[(r * q) % P], s = PrimeTab<P>::s[(r * q) % P];
+        re.x += c * a[r - 1].x;
+        re.y += c * a[r - 1].y;
+        im.x += s * b[r - 1].x;
+        im.y += s * b[r - 1].y;
+      }
+      addsub_mi<INV>(re, im, out[q], out[P - q]);
+    }
+#pragma unroll
+    for (int k = 0; k < P; ++k) v[k] = out[k];
+  }
+};
+template <bool INV>
+struct Dft<7, INV> : DftPrime<7, INV> {};
+template <bool INV>
+struct Dft<11, INV> : DftPrime<11, INV> {};
+template <bool INV>
+struct Dft<13, INV> : DftPrime<13, INV> {};

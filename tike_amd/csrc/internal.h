@@ -4,6 +4,10 @@
 
 int tk_fft2(const cf* in, cf* out, long ntile, int n, int inverse, float scale,
             hipStream_t stream);
+// csrc/fft_mixed.hip: the shape-general engine (any n it supports; l_rows /
+// l_cols = lines per workgroup group, 0 = planner's choice)
+int tk_fft2_general(const cf* in, cf* out, long ntile, int n, int inverse, float scale,
+                    int l_rows, int l_cols, hipStream_t stream);
 int tk_conv_fwd(const cf* psi, const float* scan, const TkProbe& probe, cf* nearplane, int nscan,
                 int S, int pw, int det, int H, int W, hipStream_t stream);
 int tk_conv_adj(const cf* nearplane, const float* scan, const TkProbe& probe, cf* psi, int nscan,
