@@ -93,9 +93,11 @@ def launch_ranks(a):
 
 
 # ------------------------------------------------------------ synthetic input
-def synthetic(N_total, S, det, lo, hi, seed=1234):
+def synthetic(N_total, S, det, lo, hi, seed=1234, pw=None):
     """SURVEY 8(d) generator (the build's own code).  Raster at 8 px pitch +
-    U[0,1) jitter, shuffled once; pw = det; psi amplitude 0.75+0.25U, phase
+    U[0,1) jitter, shuffled once; pw = det (unless given: the off-grid
+    workload c3pad has a probe window half the detector, as the reference's
+    own test generator does); psi amplitude 0.75+0.25U, phase
     pi(U-0.5); probe mode 0 = flat-top radial amplitude (rin 0.8, rout 1.0)
     x exp(i pi U) with U smoothed by a 5x5 box; mode m > 0 = mode 0 x a
     random linear phase ramp (tilts of up to half a period across the
@@ -103,7 +105,7 @@ def synthetic(N_total, S, det, lo, hi, seed=1234):
     keeps positions [lo, hi) of the shuffled order."""
     import scipy.ndimage
     rng = np.random.default_rng(seed)
-    pw = det
+    pw = pw or det
     side = int(np.ceil(np.sqrt(N_total)))
     ij = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"),
                   -1).reshape(-1, 2)[:N_total]
@@ -478,6 +480,12 @@ EPOCH_DEFAULTS = {
     "c3rpie": (256, 8, 10000, 10),
     # ... and by rpie on a two-slice object (row f3, multislice part)
     "c3rpie2": (256, 8, 10000, 10),
+    # off-grid shapes (round 6; not BASELINE configurations): what the
+    # reference's cuFFT path serves at one speed and the fused pow-2 kernels
+    # do not -- a probe window of half the detector, 12 modes, a 384^2 crop
+    "c3pad": (256, 8, 10000, 10),
+    "c3m12": (256, 12, 10000, 10),
+    "c384": (384, 4, 10000, 10),
 }
 # The minibatches are contiguous chunks of the ONCE-SHUFFLED scan (SURVEY
 # 8(d)): each spans the whole field of view, like the batches the reference's
@@ -511,7 +519,7 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
         np.arange(b * per + rank * share, b * per + (rank + 1) * share)
         for b in range(num_batch)
     ])
-    full = synthetic(Ng, S, det, 0, Ng)
+    full = synthetic(Ng, S, det, 0, Ng, pw=PROBE_WIDTH.get(workload))
     p = dict(full, scan=full["scan"][idx])
     N = len(idx)
     np.random.seed(1234 + rank)
@@ -567,6 +575,8 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
                 eigen_weights=eigen_weights)
 
 
+PROBE_WIDTH = {"c3pad": 128}  # probe window narrower than the detector
+
 LEG_EPOCHS = {"c1": 20, "c2": 3, "c5": 3, "c3poisson": 3, "c3rpie": 3, "c3rpie2": 3}
 # untimed epochs in front (cgrad: at least two -- its line searches learn their
 # slot counts; c1's epochs are 3 ms: ten of them bring the clocks of a GPU
@@ -591,9 +601,11 @@ def epoch_leg(workload, tp, A, torch, positions=0, epochs=None):
     finally:
         ctx.__exit__(None, None, None)
     det, S, N = built["det"], built["S"], built["N"]
-    b_iter, f_iter = iteration_bounds(S, det, det)
+    pw = built["p"]["pw"]
+    b_iter, f_iter = iteration_bounds(S, det, pw)
     rate = N * epochs / dt
     leg = dict(workload=workload, positions=N, modes=S, detector=det,
+               probe_width=pw,
                solver=SOLVER_LABEL.get(workload, "lstsq_grad"),
                num_batch=built["num_batch"],
                position_correction=workload == "c5", epochs=epochs,

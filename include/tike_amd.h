@@ -511,6 +511,58 @@ int tike_position_sums(const void* patches, const void* chi, int chi_modes, cons
                        int eigen_modes, const float* taps, int radius, float* numerator,
                        float* denominator, int nscan, int S, int pw, void* stream);
 
+/* ---- the chunk body of _get_nearplane_gradients for ANY shape (round 6;
+ * ptycho/solvers/lstsq.py:422-579 = operators/cupy/ptycho.py:114-176 around
+ * objective.py:31-44): probe window pw <= det, any number of modes S, any
+ * detector size with a mixed-radix plan (det = 2^a 3^b 5^c 7^d 11^e 13^f <=
+ * 4096).  Three launches on the LDS line engine; the zero padding, the far
+ * plane and chi never exist in memory.  tike_gen_supported(S, pw, det) = 1
+ * where the three entries run (lines of all S modes fit LDS), else 0 and they
+ * return TIKE_ERR_UNSUPPORTED.
+ *   hand1, hand2 (nscan, S, pw, det) c64: the rows of the probe window after
+ *   the forward row transforms / before the inverse row transforms (unscaled).
+ * The probe at position n as in tike_ptycho_fwd (shared; one per position;
+ * shared + eigen probes x weights; `unique` (nscan, eigen_modes, pw, pw): the
+ * varying modes already synthesised by tike_varying_probe). */
+int tike_gen_supported(int S, int pw, int det);
+
+/* K1 (convolution.py:58-101 + the row half of propagation.py:43-57):
+ * hand1[n][s][y][:] = FFT_row( pad( patch_n(psi)[y][:] * probe_n[s][y][:] ) ),
+ * patches (nscan, pw, pw) = patch_n(psi) if not NULL (gathered once per
+ * position for all modes; pixels outside the image are zero). */
+int tike_gen_fwd_rows(const void* psi, const float* scan, const void* probe, int probe_per_scan,
+                      const void* unique, const void* eigen_probe, const float* eigen_weights,
+                      int num_eigen, int eigen_modes, void* hand1, void* patches, int nscan, int S,
+                      int pw, int det, int H, int W, void* stream);
+
+/* K2 (the column half of propagation.py:43-73 around objective.py:11-124 and
+ * lstsq.py:444-502): far plane F = fwd_scale * FFT_col(hand1 zero-padded),
+ * intensity = sum_s |F_s|^2, costs[n] = mean over measured pixels of the
+ * per-pixel cost (model 0 gaussian, 1 poisson), gradient factor g (measured
+ * pixels; unmeasured_scaling - 1 elsewhere; counts at unmeasured pixels may be
+ * NaN), hand2 = rows [pad, pad + pw) of IFFT_col(F * g), unscaled.  data
+ * (nscan, det, det) f32; measured (det, det) u8 or NULL; hand2 NULL = costs
+ * only. */
+int tike_gen_cols_gradient(const void* hand1, const float* data, const unsigned char* measured,
+                           float* costs, void* hand2, int nscan, int S, int pw, int det,
+                           float fwd_scale, int model, float unmeasured_scaling,
+                           long num_measured, void* stream);
+
+/* K3 (the row half of propagation.py:59-73, convolution.py:103-154,
+ * lstsq.py:504-539): chi[n][s] = inv_scale * crop(IFFT_row(hand2)) is formed
+ * in LDS; objproj[n] = sum_s conj(probe_n[s]) chi[n][s] (input of
+ * tike_scatter_patches), chi0[n] = chi[n][0], m_probe_update[s] +=
+ * probe_update_scale * sum_n conj(patches[n]) chi[n][s] -- each NULL to skip.
+ * objproj, chi0, patches (nscan, pw, pw) c64; m_probe_update (S, pw, pw) c64,
+ * accumulated (one float atomic per pixel, mode and chunk of positions; under
+ * tike_set_deterministic per-chunk partial sums added in order). */
+int tike_gen_inv_rows_gradients(const void* hand2, const void* patches, const void* probe,
+                                int probe_per_scan, const void* unique, const void* eigen_probe,
+                                const float* eigen_weights, int num_eigen, int eigen_modes,
+                                void* objproj, void* chi0, void* m_probe_update,
+                                float probe_update_scale, int nscan, int S, int pw, int det,
+                                float inv_scale, void* stream);
+
 /* ---- the stages of a multislice object, fused (operators/cupy/multislice.py:
  * 69-92,144-194 = Convolution + FresnelSpectProp slice by slice;
  * fresnelspectprop.py:52-113; ptycho/solvers/rpie.py:367-495).  A Fresnel

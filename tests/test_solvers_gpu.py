@@ -911,11 +911,13 @@ def test_reconstruct_multigrid_vs_reference(tp, golden):
                  what="probe")
 
 
-def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0, margin=8):
-    """Small problem with the shapes of BASELINE configs[2] / [4]."""
+def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0, margin=8,
+                      pw=None):
+    """Small problem with the shapes of BASELINE configs[2] / [4] (pw: a
+    probe window narrower than the detector)."""
     import tike_amd.random
     rng = np.random.default_rng(seed)
-    pw = det
+    pw = pw or det
     side = int(np.ceil(np.sqrt(N)))
     ij = np.stack(np.meshgrid(np.arange(side), np.arange(side),
                               indexing="ij"), -1).reshape(-1, 2)[:N]
@@ -1078,13 +1080,94 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
     specialisation on the number of modes the bench runs: S = 8 at 256^2,
     S = 4 at 512^2) against the oracle's _get_nearplane_gradients /
     _precondition_nearplane_gradients / _update_nearplane."""
+    _minibatch_vs_oracle(tp, det, S, N, eigen)
+
+
+@pytest.mark.parametrize("det,pw,S,N,eigen", [
+    (256, 128, 8, 9, True),    # bench c3pad: probe window = half the detector
+    (256, 256, 12, 7, True),   # bench c3m12: more modes than the fused kernels take
+    (384, 384, 4, 5, False),   # bench c384: a detector size with a factor 3
+    (384, 192, 3, 5, True),
+    (96, 64, 2, 11, True), (160, 100, 3, 6, False),  # radix 5; odd padding
+    (45, 31, 2, 13, True),     # 3 * 3 * 5, odd window, odd padding
+    (64, 64, 16, 6, True),     # a power of two the fused kernels do not serve
+    (1024, 1024, 1, 2, False), (640, 512, 2, 3, False),
+])
+def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen):
+    """The three shape-general launches (csrc/general.hip: tike_gen_fwd_rows ->
+    tike_gen_cols_gradient -> tike_gen_inv_rows_gradients) on shapes the fused
+    power-of-two kernels refuse -- probe window < detector, 12 and 16 modes,
+    detector sizes with factors 3 and 5, odd windows -- against the oracle's
+    minibatch (gradients, chi0, patches, costs, position sums, step lengths,
+    eigen update, packed tail).  The reference runs all of them through cuFFT
+    at one speed (ptycho/solvers/lstsq.py:422-579)."""
+    from tike_amd.ptycho.solvers import lstsq as L
+    assert not L.fused_gradients(S, pw, det)
+    assert L.general_gradients(S, pw, det)
+    _minibatch_vs_oracle(tp, det, S, N, eigen, pw=pw)
+
+
+def test_general_shape_launches_equal_the_unfused_kernels(tp):
+    """... and equal the unfused round-1 kernels they replace (stored far
+    plane, generic transforms, per-tap gradients) on a masked problem with
+    NaN counts at the unmeasured pixels."""
+    import tike_amd._arrays as A
+    from tike_amd.communicators import Comm
+    from tike_amd.operators import Ptycho
+    from tike_amd.ptycho.solvers import lstsq as L
+    det, pw, S, N = 96, 64, 3, 9
+    scan, psi_true, probe0, ep, ew, data = _headline_problem(
+        tp, det, S, N, seed=11, eigen=True, pw=pw)
+    rng = np.random.default_rng(3)
+    mask = rng.random((det, det)) > 0.1
+    data = data.copy()
+    data[:, ~mask] = np.nan
+    params = tp.PtychoParameters(
+        probe=probe0, psi=psi_true, scan=scan, eigen_probe=ep,
+        eigen_weights=ew, algorithm_options=tp.LstsqOptions(num_batch=2),
+        exitwave_options=tp.ExitWaveOptions(measured_pixels=mask,
+                                            unmeasured_pixels_scaling=0.9))
+    d = {k: A.to_device(v) for k, v in dict(psi=psi_true, probe=probe0,
+                                            scan=scan, ep=ep, ew=ew).items()}
+    data_d = A.to_device(data, np.float32)
+    HW = psi_true.shape[-1]
+    outs = []
+    for general in (True, False):
+        saved = L.GENERAL_FUSED
+        L.GENERAL_FUSED = general
+        try:
+            with Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
+                out = L._get_nearplane_gradients(
+                    data_d, d["psi"], d["scan"], d["probe"], d["ep"], d["ew"],
+                    0, N, Comm(), num_batch=2,
+                    exitwave_options=params.exitwave_options, op=op,
+                    recover_psi=True, recover_probe=True)
+                chi0 = out["chi0"]
+                if out["chi_modes"] > 1:
+                    chi0 = chi0[:N, 0, 0]
+                outs.append(dict(
+                    obj=L.object_upd_sum(out).cpu().numpy(),
+                    mpu=out["m_probe_update"].cpu().numpy(),
+                    chi0=chi0.cpu().numpy().copy(),
+                    costs=out["costs"].cpu().numpy().copy()))
+        finally:
+            L.GENERAL_FUSED = saved
+    for k in ("obj", "mpu", "chi0"):
+        assert np.isfinite(outs[0][k]).all()
+        assert_close(outs[0][k], outs[1][k], normwise=2e-5, what=k)
+    np.testing.assert_allclose(outs[0]["costs"], outs[1]["costs"],
+                               rtol=COST_RTOL)
+
+
+def _minibatch_vs_oracle(tp, det, S, N, eigen, pw=None):
+    pw = pw or det
     import tike_amd._arrays as A
     from tike_amd.communicators import Comm
     from tike_amd.operators import Ptycho
     from tike_amd.ptycho.solvers import lstsq as L
     from oracle import solvers as osol
     scan, psi_true, probe0, ep, ew, data = _headline_problem(
-        tp, det, S, N, seed=3 * det + S, eigen=eigen)
+        tp, det, S, N, seed=3 * det + S, eigen=eigen, pw=pw)
     rng = np.random.default_rng(5)
     psi0 = (psi_true * (1 + 0.1 * rng.standard_normal(psi_true.shape))
             ).astype(np.complex64)
@@ -1101,7 +1184,7 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
         exitwave_options=tp.ExitWaveOptions(measured_pixels=mask))
     comm = Comm()
     HW = psi0.shape[-1]
-    with Ptycho(probe_shape=det, detector_shape=det, nz=HW, n=HW) as op:
+    with Ptycho(probe_shape=pw, detector_shape=det, nz=HW, n=HW) as op:
         pos_terms = (A.to_device(np.zeros_like(scan)),
                      A.to_device(np.zeros_like(scan)))
         out = L._get_nearplane_gradients(
@@ -1139,7 +1222,7 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
         stats = L._step_stats(out, d["psi"], d["scan"], d["probe"], d["ep"],
                               precond, 0, N, op=op)
         bo, bp, cost = L._solve_steps(stats, out["costs"], out["count"], comm,
-                                      pw=det, recover_psi=True,
+                                      pw=pw, recover_psi=True,
                                       recover_probe=True)
         np.testing.assert_allclose(float(cost), o["costs"].mean(),
                                    rtol=COST_RTOL)

@@ -53,6 +53,13 @@ _PROTOTYPES = {
     "tike_fft2": [_p, _p, _l, _i, _i, _f, _p],
     "tike_fft2_supported": [_i],
     "tike_fft2_general": [_p, _p, _l, _i, _i, _f, _i, _i, _p],
+    "tike_gen_supported": [_i, _i, _i],
+    "tike_gen_fwd_rows": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i,
+                          _i, _i, _i, _p],
+    "tike_gen_cols_gradient": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _i, _f,
+                               _l, _p],
+    "tike_gen_inv_rows_gradients": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p,
+                                    _p, _f, _i, _i, _i, _i, _f, _p],
     "tike_fresnel_spect_prop": [_p, _p, _p, _l, _i, _i, _f, _f, _p],
     "tike_fft2_pass1": [_p, _p, _l, _i, _i, _p],
     "tike_fft2_pass2_inplace": [_p, _l, _i, _i, _f, _p],

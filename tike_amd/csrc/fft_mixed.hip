@@ -104,6 +104,39 @@ const MixTables* tk_mix_tables(int n) {
 // consecutive lines (L a power of two): rows are then one contiguous run of
 // L * n elements, columns L * 8-byte segments per tile row.
 // LDS: [twiddles plan.n][buffer a: L * ls][buffer b: L * ls][line bases: L longs]
+//
+// Memory phases: every thread requests MIX_U elements before it uses the first
+// (a run-time loop around one load is one request in flight per thread: 2 us of
+// latency per element; 384^2: 0.36 -> 0.54 M tiles/s), and the first MIX_U x
+// 256 elements of the NEXT group are requested before the butterflies of the
+// group in hand; 3-5 workgroups per CU so that one group's butterflies run
+// under the others' loads and stores (profiles/r06_experiments.md: occupancy
+// counts for more than the depth of the request queue -- 8 requests at 4
+// waves/SIMD with 92 B/lane of scratch lose 12 % against 4 requests at 3).
+// Groups are dealt to the XCDs in contiguous ranges (workgroup b runs on XCD
+// b % 8): the column groups that split a 128-byte line are neighbours in time
+// AND share an L2.
+#define MIX_U 4
+
+struct MixGroups {
+  long first, end, step;  // this workgroup's groups: first, first + step, ... < end
+};
+__device__ __forceinline__ MixGroups mix_groups(long ngroup) {
+  const long nb = gridDim.x;
+  MixGroups g;
+  if (nb % 8 != 0 || ngroup < 64) {
+    g.first = blockIdx.x;
+    g.end = ngroup;
+    g.step = nb;
+  } else {
+    const long per = (ngroup + 7) / 8, xcd = blockIdx.x & 7;
+    g.first = xcd * per + (blockIdx.x >> 3);
+    g.end = (xcd + 1) * per < ngroup ? (xcd + 1) * per : ngroup;
+    g.step = nb >> 3;
+  }
+  return g;
+}
+
 template <bool INV, bool BLU, bool COLS>
 __global__ __launch_bounds__(256) void mix_pass_kernel(const cf* in, cf* out, MixPlan p, int n,
                                                        long nlines, int L, int logL,
@@ -115,41 +148,86 @@ __global__ __launch_bounds__(256) void mix_pass_kernel(const cf* in, cf* out, Mi
   cf* twl = reinterpret_cast<cf*>(lds_raw);
   cf* bufa = twl + p.n;
   cf* bufb = bufa + (long)L * p.ls;
-  long* lbase = reinterpret_cast<long*>(bufb + (long)L * p.ls);
+  long* lbase2 = reinterpret_cast<long*>(bufb + (long)L * p.ls);  // two sets of L
   for (int k = threadIdx.x; k < p.n; k += blockDim.x) twl[k] = twg[k];
   const float rcp_n = 1.0f / (float)n;
-  const long ngroup = (nlines + L - 1) / L;
-  for (long grp = blockIdx.x; grp < ngroup; grp += gridDim.x) {
+  const MixGroups mg = mix_groups((nlines + L - 1) / L);
+  // element idx of group grp -> (line, e, address or -1); COLS: the lines a
+  // short last group does not have are -1
+  auto where = [&](long grp, const long* lbase, int idx, int& line, int& e, long& off) {
     const long g0 = grp * L;
     const int nl = (int)(nlines - g0 < L ? nlines - g0 : L);
     if (COLS) {
-      if (threadIdx.x < nl) {
-        const long g = g0 + threadIdx.x, tile = g / n;
-        lbase[threadIdx.x] = tile * (long)n * n + (g - tile * n);
-      }
-      __syncthreads();
+      line = idx & (L - 1);
+      e = idx >> logL;
+      off = line < nl && e < n ? lbase[line] + (long)e * n : -1;
+    } else {
+      line = mix_div(idx, rcp_n);
+      e = idx - line * n;
+      off = idx < nl * n ? g0 * n + idx : -1;
     }
-    // ---- load (BLU: x * chirp -- the conjugate of x for the inverse --, zero fill)
-    const int total = COLS ? (n << logL) : nl * n;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+  };
+  auto bases = [&](long grp, long* lbase) {
+    if (COLS && threadIdx.x < L) {
+      const long g = grp * L + threadIdx.x, tile = g / n;
+      lbase[threadIdx.x] = tile * (long)n * n + (g - tile * n);
+    }
+  };
+  // the first MIX_U * 256 elements of a group travel in registers: requested
+  // one group AHEAD, while the butterflies of the group in hand run
+  cf pre[MIX_U];
+  auto request = [&](long grp, const long* lbase) {
+#pragma unroll
+    for (int u = 0; u < MIX_U; ++u) {
       int line, e;
-      long src;
-      if (COLS) {
-        line = idx & (L - 1);
-        e = idx >> logL;
-        if (line >= nl) continue;
-        src = lbase[line] + (long)e * n;
-      } else {
-        line = mix_div(idx, rcp_n);
-        e = idx - line * n;
-        src = g0 * n + idx;
-      }
-      cf v = in[src];
+      long off;
+      where(grp, lbase, threadIdx.x + u * 256, line, e, off);
+      // (unconditionally -- a load behind a condition is a branch around the
+      // load --: what the group does not have reads element 0)
+      pre[u] = in[off >= 0 ? off : 0];
+    }
+  };
+  int cur = 0;
+  if (mg.first < mg.end) {
+    bases(mg.first, lbase2);
+    if (COLS) __syncthreads();
+    request(mg.first, lbase2);
+  }
+  for (long grp = mg.first; grp < mg.end; grp += mg.step) {
+    const long* lbase = lbase2 + cur * L;
+    const long g0 = grp * L;
+    const int nl = (int)(nlines - g0 < L ? nlines - g0 : L);
+    const int total = COLS ? (n << logL) : nl * n;
+    auto put = [&](int line, int e, cf x) {
       if (BLU) {
-        if (INV) v = conjf(v);
-        v = v * chirp[e];
+        if (INV) x = conjf(x);
+        x = x * chirp[e];
       }
-      bufa[line * p.ls + mix_pad(e)] = v;
+      bufa[line * p.ls + mix_pad(e)] = x;
+    };
+    // ---- the group's samples into LDS (BLU: x * chirp -- the conjugate of x
+    // for the inverse --, zero fill up to M)
+    asm volatile("" : "+v"(pre[0].x), "+v"(pre[1].x), "+v"(pre[2].x), "+v"(pre[3].x));
+#pragma unroll
+    for (int u = 0; u < MIX_U; ++u) {
+      int line, e;
+      long off;
+      where(grp, lbase, threadIdx.x + u * 256, line, e, off);
+      if (off >= 0) put(line, e, pre[u]);
+    }
+    for (int base = threadIdx.x + 256 * MIX_U; base < total; base += 256 * MIX_U) {
+      cf v[MIX_U];
+      int line[MIX_U], e[MIX_U];
+      long off[MIX_U];
+#pragma unroll
+      for (int u = 0; u < MIX_U; ++u) {
+        where(grp, lbase, base + u * 256, line[u], e[u], off[u]);
+        v[u] = in[off[u] >= 0 ? off[u] : 0];
+      }
+      asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x));
+#pragma unroll
+      for (int u = 0; u < MIX_U; ++u)
+        if (off[u] >= 0) put(line[u], e[u], v[u]);
     }
     if (BLU) {
       const int padn = p.n - n;  // zeros behind the n samples, up to M
@@ -159,7 +237,14 @@ __global__ __launch_bounds__(256) void mix_pass_kernel(const cf* in, cf* out, Mi
         bufa[line * p.ls + mix_pad(e)] = mk(0.f, 0.f);
       }
     }
+    // ---- the next group's request goes out before this group's butterflies
+    // (in place: this group's samples have been read above -- program order on
+    // the same addresses only when in == out AND the groups coincide, which
+    // they never do)
+    const long nxt = grp + mg.step;
+    if (nxt < mg.end) bases(nxt, lbase2 + (cur ^ 1) * L);
     __syncthreads();
+    if (nxt < mg.end) request(nxt, lbase2 + (cur ^ 1) * L);
     cf* res;
     if (BLU) {
       res = mix_stages<false>(bufa, bufb, twl, p, nl);
@@ -176,34 +261,28 @@ __global__ __launch_bounds__(256) void mix_pass_kernel(const cf* in, cf* out, Mi
       res = mix_stages<INV>(bufa, bufb, twl, p, nl);
     }
     // ---- store
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    for (int idx = threadIdx.x; idx < total; idx += 256) {
       int line, e;
-      long dst;
-      if (COLS) {
-        line = idx & (L - 1);
-        e = idx >> logL;
-        if (line >= nl) continue;
-        dst = lbase[line] + (long)e * n;
-      } else {
-        line = mix_div(idx, rcp_n);
-        e = idx - line * n;
-        dst = g0 * n + idx;
-      }
+      long off;
+      where(grp, lbase, idx, line, e, off);
+      if (off < 0) continue;
       cf v = res[line * p.ls + mix_pad(e)];
       if (BLU) {
         v = v * chirp[e];
         if (INV) v = conjf(v);
       }
-      out[dst] = v * scale;
+      out[off] = v * scale;
     }
     __syncthreads();
+    cur ^= 1;
   }
 }
 
 // Lines per group: as many as fit `budget` bytes of LDS beside the twiddles, a
 // power of two, at most `cap`.
 static int mix_lines_per_group(const MixPlan& p, size_t budget, int cap) {
-  const size_t tw = sizeof(cf) * (size_t)p.n, per = 2 * sizeof(cf) * (size_t)p.ls + sizeof(long);
+  const size_t tw = sizeof(cf) * (size_t)p.n,
+               per = 2 * sizeof(cf) * (size_t)p.ls + 2 * sizeof(long);
   if (budget <= tw + per) return 0;
   size_t fit = (budget - tw) / per;
   int L = 1;
@@ -217,7 +296,7 @@ static int launch_mix_pass(const cf* in, cf* out, const MixTables* t, long nline
   int logL = 0;
   while ((1 << logL) < L) ++logL;
   const size_t lds = sizeof(cf) * (size_t)t->plan.n +
-                     (2 * sizeof(cf) * (size_t)t->plan.ls + sizeof(long)) * (size_t)L;
+                     (2 * sizeof(cf) * (size_t)t->plan.ls + 2 * sizeof(long)) * (size_t)L;
   auto kern = mix_pass_kernel<INV, BLU, COLS>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern,
@@ -235,22 +314,35 @@ template <bool INV, bool BLU>
 static int mix_fft2(const cf* in, cf* out, const MixTables* t, long ntile, float scale,
                     int l_rows, int l_cols, hipStream_t stream) {
   const long nlines = ntile * t->n;
-  // two workgroups per CU where the lines allow it (64 KiB each), else one
-  auto pick = [&](int want, int cap) {
-    if (want > 0) {  // the caller's grouping (tests, tuning): a power of two that fits
-      int L = 1;
-      while (2 * L <= want) L *= 2;
-      const int fit = mix_lines_per_group(t->plan, 150 * 1024, 1 << 20);
-      return L < fit ? L : fit;
-    }
-    int L = mix_lines_per_group(t->plan, 64 * 1024, cap);
-    if (L < 4) L = mix_lines_per_group(t->plan, 150 * 1024, cap < 4 ? cap : 4);
-    return L;
+  // the caller's grouping (tests, tuning): a power of two that fits; else
+  // rows: a group is one contiguous run of memory whatever L is, so L only has
+  // to give the workgroup enough butterflies per stage (>= 2 per thread) --
+  // small groups, five workgroups per CU; columns: L sets the width of every
+  // access (L * 8 bytes): 64-byte segments where three workgroups still fit a
+  // CU, 32-byte ones else (the other half of the line: same XCD, same time)
+  auto fits = [&](size_t budget, int cap) { return mix_lines_per_group(t->plan, budget, cap); };
+  auto forced = [&](int want) {
+    int L = 1;
+    while (2 * L <= want) L *= 2;
+    const int fit = fits(150 * 1024, 1 << 20);
+    return L < fit ? L : fit;
   };
-  // rows: a group is one contiguous run of memory whatever L is; columns: L
-  // sets the width of every access (L * 8 bytes)
-  const int cap = t->plan.n <= 64 ? 64 : 16;
-  const int Lr = pick(l_rows, cap), Lc = pick(l_cols, cap);
+  int Lr, Lc;
+  if (l_rows > 0) {
+    Lr = forced(l_rows);
+  } else {
+    int want = 1;
+    while (want * t->plan.n < 2048 && want < 64) want *= 2;
+    Lr = fits(30 * 1024, want);
+    if (Lr < 1) Lr = fits(150 * 1024, 1);
+  }
+  if (l_cols > 0) {
+    Lc = forced(l_cols);
+  } else {
+    Lc = fits(52 * 1024, t->plan.n <= 64 ? 64 : 8);
+    if (Lc < 4) Lc = fits(76 * 1024, 4);
+    if (Lc < 2) Lc = fits(150 * 1024, 2);
+  }
   if (Lr < 1 || Lc < 1) return TK_ERR_UNSUPPORTED;
   int rc = launch_mix_pass<INV, BLU, false>(in, out, t, nlines, Lr, 1.0f, stream);
   if (rc) return rc;

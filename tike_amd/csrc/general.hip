@@ -1,0 +1,491 @@
+// The lstsq_grad / rpie chunk body for ANY shape (round 6): probe window
+// narrower than the detector, any number of modes, any detector size the
+// mixed-radix engine plans (n = 2^a 3^b 5^c 7^d 11^e 13^f <= 4096) -- what the
+// reference runs at one speed through cuFFT (ptycho/solvers/lstsq.py:422-579)
+// and the fused power-of-two kernels of ptycho.hip / lstsq.hip do not serve.
+// Until round 5 these shapes took the unfused round-1 path: patch x probe
+// stored zero-padded, two generic transforms in place, a gradient pass over
+// the stored far plane, two more transforms, a crop, then chi read back by the
+// gradient kernel: ~14 T of traffic per position (T = 8 S det^2).
+//
+// Three launches on the LDS line engine (fft_mixed.h), zero padding never
+// stored, the far plane and chi never stored:
+//
+//   K1 tike_gen_fwd_rows           (position, group of probe rows):
+//        bilinear patch rows gathered ONCE for all modes (-> patches), x probe
+//        (shared, per position, or eigen probes on the fly), zero-padded to
+//        det IN LDS, row transforms -> hand1 (nscan, S, pw, det)
+//   K2 tike_gen_cols_gradient      (position, group of L detector columns):
+//        sweep 1 over the modes: columns of hand1 (rows outside the probe
+//        window are zeros made in LDS) -> forward column transform -> the
+//        intensity of the group's pixels accumulates in LDS; gradient factor
+//        and cost from the counts; sweep 2: transform again, x factor, inverse
+//        column transform, rows of the probe window only -> hand2 (nscan, S,
+//        pw, det)
+//   K3 tike_gen_inv_rows_gradients (probe row y, chunk of positions):
+//        the S lines of row y of one position -> inverse row transforms ->
+//        crop -> chi in LDS: objproj = sum_s conj(P_s) chi_s, chi0, and the
+//        probe gradient of the row accumulates in LDS over the chunk (one
+//        atomic per pixel, mode and chunk)
+//
+// then tike_scatter_patches and the packed tail as on the fused path.  Traffic
+// per position: 5 T pw/det + D + 5 P (hand1 written once and read twice, hand2
+// written and read once).
+#include "fft_mixed.h"
+#include "internal.h"
+#include "tike_amd.h"
+
+#define GEN_NT 256
+
+static size_t gen_lds_limit() { return 150 * 1024; }
+
+// ------------------------------------------------------------------- K1
+__global__ __launch_bounds__(GEN_NT) void gen_fwd_rows_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    cf* __restrict__ hand1, cf* __restrict__ patches, MixPlan p, const cf* __restrict__ twg,
+    int nscan, int S, int pw, int det, int H, int W, int RG) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  cf* twl = reinterpret_cast<cf*>(lds_raw);
+  cf* bufa = twl + det;
+  cf* bufb = bufa + (long)S * RG * p.ls;
+  cf* prow = bufb + (long)S * RG * p.ls;  // RG rows of the patch
+  for (int k = threadIdx.x; k < det; k += GEN_NT) twl[k] = twg[k];
+  const int pad = (det - pw) / 2;
+  const long total = (long)H * W;
+  const int ngrp = (pw + RG - 1) / RG;
+  const long nitem = (long)nscan * ngrp;
+  const float rcp_pw = 1.0f / (float)pw, rcp_det = 1.0f / (float)det;
+  for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
+    const long n = item / ngrp;
+    const int y0 = (int)(item - n * ngrp) * RG;
+    const int nr = pw - y0 < RG ? pw - y0 : RG;
+    const TkCorner c = tk_corner(scan, n);
+    // ---- the nr patch rows, once for all modes (four pixels = 16 taps
+    // requested together)
+    for (int base = threadIdx.x; base < nr * pw; base += GEN_NT * 4) {
+      cf v[4];
+      int idx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        idx[u] = base + u * GEN_NT;
+        const int i = idx[u] < nr * pw ? idx[u] : 0;
+        const int r = mix_div(i, rcp_pw), px = i - r * pw;
+        const int y = c.sy + y0 + r, x = c.sx + px;
+        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
+        // (outside the image: pixel 0 is requested and selected away -- a
+        // load behind a condition is a branch around the load)
+        const cf g = tk_gather(psi, ok ? (long)y * W + x : 0L, W, total, c);
+        v[u] = ok ? g : mk(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (idx[u] < nr * pw) {
+          prow[idx[u]] = v[u];
+          if (patches) patches[(n * pw + y0) * (long)pw + idx[u]] = v[u];
+        }
+    }
+    __syncthreads();
+    // ---- lines (s, r): patch row x probe, zero-padded to det
+    const int nl = S * nr;
+    const float rcp_nr = 1.0f / (float)nr;
+    for (int base = threadIdx.x; base < nl * det; base += GEN_NT * 4) {
+      cf w[4];
+      int line[4], e[4], r[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * GEN_NT;
+        const int i = idx < nl * det ? idx : 0;
+        line[u] = mix_div(i, rcp_det);
+        e[u] = i - line[u] * det;
+        const int s = mix_div(line[u], rcp_nr);
+        r[u] = line[u] - s * nr;
+        const int px = e[u] - pad;
+        in[u] = idx < nl * det && px >= 0 && px < pw;
+        w[u] = probe.at(n, s, in[u] ? (long)(y0 + r[u]) * pw + px : 0L);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (base + u * GEN_NT < nl * det)
+          bufa[line[u] * p.ls + mix_pad(e[u])] =
+              in[u] ? prow[r[u] * pw + e[u] - pad] * w[u] : mk(0.f, 0.f);
+    }
+    __syncthreads();
+    cf* res = mix_stages<false>(bufa, bufb, twl, p, nl);
+    for (int idx = threadIdx.x; idx < nl * det; idx += GEN_NT) {
+      const int line = mix_div(idx, rcp_det), e = idx - line * det;
+      const int s = mix_div(line, rcp_nr), r = line - s * nr;
+      hand1[(((n * S + s) * pw) + y0 + r) * (long)det + e] = res[line * p.ls + mix_pad(e)];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------- K2
+template <int MODEL>
+__global__ __launch_bounds__(GEN_NT) void gen_cols_gradient_kernel(
+    const cf* __restrict__ hand1, const float* __restrict__ data,
+    const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ hand2,
+    MixPlan p, const cf* __restrict__ twg, int nscan, int S, int pw, int det, int L, int logL,
+    float fwd_scale, float unmeasured_scaling, float inv_nmeasured) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  cf* twl = reinterpret_cast<cf*>(lds_raw);
+  cf* bufa = twl + det;
+  cf* bufb = bufa + (long)L * p.ls;
+  float* inten = reinterpret_cast<float*>(bufb + (long)L * p.ls);  // L x det
+  __shared__ float red[4];
+  for (int k = threadIdx.x; k < det; k += GEN_NT) twl[k] = twg[k];
+  const int pad = (det - pw) / 2;
+  const int ngrp = (det + L - 1) / L;
+  const long nitem = (long)nscan * ngrp;
+  const float rcp_pad = 1.0f / (float)(det - pw > 0 ? det - pw : 1);
+  for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
+    const long n = item / ngrp;
+    const int grp = (int)(item - n * ngrp);
+    const int x0 = grp * L;
+    const int nc = det - x0 < L ? det - x0 : L;
+    // columns x0 .. x0 + nc of mode s into buffer a: rows of the probe window
+    // from hand1, zeros above and below
+    auto load = [&](int s) {
+      const cf* src = hand1 + (n * S + s) * (long)pw * det + x0;
+      for (int base = threadIdx.x; base < (pw << logL); base += GEN_NT * 8) {
+        cf v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * GEN_NT;
+          const int l = idx & (L - 1), r = idx >> logL;
+          const bool ok = r < pw && l < nc;
+          v[u] = src[ok ? (long)r * det + l : 0L];
+        }
+        asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x),
+                     "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * GEN_NT;
+          const int l = idx & (L - 1), r = idx >> logL;
+          if (r < pw && l < nc) bufa[l * p.ls + mix_pad(pad + r)] = v[u];
+        }
+      }
+      for (int idx = threadIdx.x; idx < nc * (det - pw); idx += GEN_NT) {
+        const int l = mix_div(idx, rcp_pad), q = idx - l * (det - pw);
+        bufa[l * p.ls + mix_pad(q < pad ? q : q + pw)] = mk(0.f, 0.f);
+      }
+    };
+    for (int idx = threadIdx.x; idx < nc * det; idx += GEN_NT) inten[idx] = 0.f;
+    __syncthreads();
+    // ---- sweep 1: intensity of the group's pixels
+    for (int s = 0; s < S; ++s) {
+      load(s);
+      __syncthreads();
+      const cf* res = mix_stages<false>(bufa, bufb, twl, p, nc);
+      for (int idx = threadIdx.x; idx < (det << logL); idx += GEN_NT) {
+        const int l = idx & (L - 1), k = idx >> logL;
+        if (l < nc) inten[l * det + k] += norm2(res[l * p.ls + mix_pad(k)] * fwd_scale);
+      }
+      __syncthreads();
+    }
+    // ---- gradient factor (objective.py:31-44,97-109; lstsq.py:491-502) and
+    // cost; counts of unmeasured pixels may be NaN: selected away, never used
+    float cost = 0.f;
+    for (int idx = threadIdx.x; idx < (det << logL); idx += GEN_NT) {
+      const int l = idx & (L - 1), k = idx >> logL;
+      const long pix = (long)k * det + x0 + (l < nc ? l : 0);
+      const float dv = data[n * (long)det * det + pix];
+      const bool measured = mask ? mask[pix] != 0 : true;
+      if (l >= nc) continue;
+      const float I = inten[l * det + k];
+      float g, term;
+      if (MODEL == 0) {
+        const float sI = sqrtf(I), sd = sqrtf(dv);
+        const float diff = sI - sd;
+        term = diff * diff;
+        g = -(1.0f - sd / (sI + 1e-9f));
+      } else {
+        term = I - dv * logf(I + 1e-9f);
+        g = -(1.0f - dv / (I + 1e-9f));
+      }
+      cost += measured ? term : 0.f;
+      inten[l * det + k] = (measured ? g : unmeasured_scaling - 1.0f) * fwd_scale;
+    }
+    if (costs.costs) {
+      cost = tk_block_sum256(cost, red);
+      if (threadIdx.x == 0) tk_cost_add(costs, n, grp, cost * inv_nmeasured);
+    }
+    __syncthreads();
+    if (hand2 == nullptr) continue;  // cost only
+    // ---- sweep 2: transform again, x factor, inverse column transform, the
+    // rows of the probe window out
+    for (int s = 0; s < S; ++s) {
+      load(s);
+      __syncthreads();
+      cf* res = mix_stages<false>(bufa, bufb, twl, p, nc);
+      for (int idx = threadIdx.x; idx < (det << logL); idx += GEN_NT) {
+        const int l = idx & (L - 1), k = idx >> logL;
+        if (l < nc) {
+          cf* q = res + l * p.ls + mix_pad(k);
+          *q = *q * inten[l * det + k];
+        }
+      }
+      __syncthreads();
+      const cf* back = mix_stages<true>(res, res == bufa ? bufb : bufa, twl, p, nc);
+      cf* dst = hand2 + (n * S + s) * (long)pw * det + x0;
+      for (int idx = threadIdx.x; idx < (pw << logL); idx += GEN_NT) {
+        const int l = idx & (L - 1), r = idx >> logL;
+        if (l < nc) dst[(long)r * det + l] = back[l * p.ls + mix_pad(pad + r)];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------- K3
+// mpu: S x pw x pw complex as float pairs; with `part` != nullptr (deterministic
+// mode) chunk c leaves its sums in part[c] instead of adding them atomically
+__global__ __launch_bounds__(GEN_NT) void gen_inv_rows_gradients_kernel(
+    const cf* __restrict__ hand2, const cf* __restrict__ patches, const TkProbe probe,
+    cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, float mpu_scale,
+    float* __restrict__ part, MixPlan p, const cf* __restrict__ twg, int nscan, int S, int pw,
+    int det, int chunk, float inv_scale) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  cf* twl = reinterpret_cast<cf*>(lds_raw);
+  cf* bufa = twl + det;
+  cf* bufb = bufa + (long)S * p.ls;
+  cf* acc = bufb + (long)S * p.ls;  // S x pw
+  for (int k = threadIdx.x; k < det; k += GEN_NT) twl[k] = twg[k];
+  const int pad = (det - pw) / 2;
+  const int nchunk = (nscan + chunk - 1) / chunk;
+  const long nitem = (long)pw * nchunk;
+  const float rcp_det = 1.0f / (float)det;
+  const bool grad = mpu != nullptr || part != nullptr;
+  for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
+    // (rows fastest: the workgroups of one chunk run together and share the
+    // chunk's probe / patch lines in L2)
+    const int y = (int)(item % pw);
+    const long c = item / pw;
+    const long n0 = c * chunk, n1 = n0 + chunk < nscan ? n0 + chunk : nscan;
+    if (grad)
+      for (int idx = threadIdx.x; idx < S * pw; idx += GEN_NT) acc[idx] = mk(0.f, 0.f);
+    for (long n = n0; n < n1; ++n) {
+      // ---- row y of every mode of position n
+      const cf* src = hand2 + (n * S * pw + y) * (long)det;
+      for (int base = threadIdx.x; base < S * det; base += GEN_NT * 8) {
+        cf v[8];
+        int line[8], e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int idx = base + u * GEN_NT;
+          const int i = idx < S * det ? idx : 0;
+          line[u] = mix_div(i, rcp_det);
+          e[u] = i - line[u] * det;
+          v[u] = src[(long)line[u] * pw * det + e[u]];
+        }
+        asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x),
+                     "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (base + u * GEN_NT < S * det) bufa[line[u] * p.ls + mix_pad(e[u])] = v[u];
+      }
+      __syncthreads();
+      const cf* res = mix_stages<true>(bufa, bufb, twl, p, S);
+      // ---- chi = crop(res) / scale: both products, mode 0
+      const long rowpix = (long)y * pw;
+      for (int x = threadIdx.x; x < pw; x += GEN_NT) {
+        const cf O = conjf(patches[(n * pw + y) * (long)pw + x]);
+        cf op = mk(0.f, 0.f);
+        for (int s = 0; s < S; ++s) {
+          const cf chi = res[s * p.ls + mix_pad(pad + x)] * inv_scale;
+          op = op + conjf(probe.at(n, s, rowpix + x)) * chi;
+          if (grad) acc[s * pw + x] = acc[s * pw + x] + O * chi;
+          if (s == 0 && chi0) chi0[(n * pw + y) * (long)pw + x] = chi;
+        }
+        if (objproj) objproj[(n * pw + y) * (long)pw + x] = op;
+      }
+      __syncthreads();
+    }
+    if (grad) {
+      for (int idx = threadIdx.x; idx < S * pw; idx += GEN_NT) {
+        const int s = idx / pw, x = idx - s * pw;
+        const long o = 2 * (((long)s * pw + y) * pw + x);
+        const cf v = acc[idx] * mpu_scale;
+        if (part) {
+          float* q = part + c * 2L * S * pw * pw + o;
+          q[0] = v.x;
+          q[1] = v.y;
+        } else {
+          unsafeAtomicAdd(mpu + o, v.x);
+          unsafeAtomicAdd(mpu + o + 1, v.y);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host side
+static int log2_floor(int v) {
+  int l = 0;
+  while ((2 << l) <= v) ++l;
+  return l;
+}
+
+// Row groups of K1 (rows per work item) and column groups of K2 for a shape,
+// chosen for three workgroups per CU where the lines allow it; 0: no fit.
+static int gen_rows_per_item(const MixPlan& p, int S, int pw) {
+  const size_t tw = sizeof(cf) * (size_t)p.n;
+  for (int rg = 8; rg >= 1; rg /= 2) {
+    const size_t need = tw + 2 * sizeof(cf) * (size_t)p.ls * S * rg + sizeof(cf) * (size_t)rg * pw;
+    if (need <= (rg > 1 ? 50 * 1024 : gen_lds_limit())) return rg;
+  }
+  return 0;
+}
+static int gen_cols_per_item(const MixPlan& p) {
+  const size_t tw = sizeof(cf) * (size_t)p.n;
+  for (int L = 8; L >= 1; L /= 2) {
+    const size_t need = tw + (2 * sizeof(cf) * (size_t)p.ls + sizeof(float) * (size_t)p.n) * L;
+    if (need <= (L > 2 ? 50 * 1024 : gen_lds_limit())) return L;
+  }
+  return 0;
+}
+static size_t gen_k3_lds(const MixPlan& p, int S, int pw) {
+  return sizeof(cf) * ((size_t)p.n + 2 * (size_t)p.ls * S + (size_t)S * pw);
+}
+
+extern "C" int tike_gen_supported(int S, int pw, int det) {
+  if (S < 1 || pw < 1 || det < pw || det > TK_MIX_MAX_N) return 0;
+  MixPlan p;
+  if (!mix_make_plan(det, &p)) return 0;  // (Bluestein sizes: the unfused path)
+  return gen_rows_per_item(p, S, pw) > 0 && gen_cols_per_item(p) > 0 &&
+                 gen_k3_lds(p, S, pw) <= gen_lds_limit()
+             ? 1
+             : 0;
+}
+
+template <class K>
+static int gen_lds_attr(K kern, size_t lds) {
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  return TK_OK;
+}
+
+extern "C" int tike_gen_fwd_rows(const void* psi, const float* scan, const void* probe,
+                                 int probe_per_scan, const void* unique,
+                                 const void* eigen_probe, const float* eigen_weights,
+                                 int num_eigen, int eigen_modes, void* hand1, void* patches,
+                                 int nscan, int S, int pw, int det, int H, int W, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(psi && scan && probe && hand1);
+  if (!tike_gen_supported(S, pw, det)) return TK_ERR_UNSUPPORTED;
+  const MixTables* t = tk_mix_tables(det);
+  if (!t || t->bluestein) return TK_ERR_UNSUPPORTED;
+  const int RG = gen_rows_per_item(t->plan, S, pw);
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw, unique);
+  const size_t lds = sizeof(cf) * ((size_t)det + 2 * (size_t)t->plan.ls * S * RG +
+                                   (size_t)RG * pw);
+  int rc = gen_lds_attr(gen_fwd_rows_kernel, lds);
+  if (rc) return rc;
+  const long nitem = (long)nscan * ((pw + RG - 1) / RG);
+  hipLaunchKernelGGL(gen_fwd_rows_kernel, dim3(tk_grid(nitem, 8)), dim3(GEN_NT), lds, stream,
+                     (const cf*)psi, scan, P, (cf*)hand1, (cf*)patches, t->plan, t->tw, nscan, S,
+                     pw, det, H, W, RG);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_gen_cols_gradient(const void* hand1, const float* data,
+                                      const unsigned char* measured, float* costs, void* hand2,
+                                      int nscan, int S, int pw, int det, float fwd_scale,
+                                      int model, float unmeasured_scaling, long num_measured,
+                                      void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw);
+  TK_CHECK_ARG((model == 0 || model == 1) && num_measured > 0);
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(hand1 && data);
+  if (!tike_gen_supported(S, pw, det)) return TK_ERR_UNSUPPORTED;
+  const MixTables* t = tk_mix_tables(det);
+  if (!t || t->bluestein) return TK_ERR_UNSUPPORTED;
+  const int L = gen_cols_per_item(t->plan), logL = log2_floor(L);
+  const int ngrp = (det + L - 1) / L;
+  TkCostSink sink;
+  int rc = tk_cost_sink(costs, nscan, ngrp, stream, &sink);
+  if (rc) return rc;
+  const size_t lds = sizeof(cf) * (size_t)det +
+                     (2 * sizeof(cf) * (size_t)t->plan.ls + sizeof(float) * (size_t)det) * L;
+  const long nitem = (long)nscan * ngrp;
+  const float inv = 1.0f / (float)num_measured;
+#define TK_GEN_K2(M)                                                                           \
+  do {                                                                                         \
+    rc = gen_lds_attr(gen_cols_gradient_kernel<M>, lds);                                       \
+    if (rc) return rc;                                                                         \
+    hipLaunchKernelGGL((gen_cols_gradient_kernel<M>), dim3(tk_grid(nitem, 8)), dim3(GEN_NT),   \
+                       lds, stream, (const cf*)hand1, data, measured, sink, (cf*)hand2,        \
+                       t->plan, t->tw, nscan, S, pw, det, L, logL, fwd_scale,                  \
+                       unmeasured_scaling, inv);                                               \
+  } while (0)
+  if (model == 0)
+    TK_GEN_K2(0);
+  else
+    TK_GEN_K2(1);
+#undef TK_GEN_K2
+  TK_LAUNCH_CHECK();
+  return tk_cost_finish(sink, nscan, stream);
+}
+
+extern "C" int tike_gen_inv_rows_gradients(const void* hand2, const void* patches,
+                                           const void* probe, int probe_per_scan,
+                                           const void* unique, const void* eigen_probe,
+                                           const float* eigen_weights, int num_eigen,
+                                           int eigen_modes, void* objproj, void* chi0,
+                                           void* m_probe_update, float probe_update_scale,
+                                           int nscan, int S, int pw, int det, float inv_scale,
+                                           void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(hand2 && patches && probe);
+  if (!tike_gen_supported(S, pw, det)) return TK_ERR_UNSUPPORTED;
+  const MixTables* t = tk_mix_tables(det);
+  if (!t || t->bluestein) return TK_ERR_UNSUPPORTED;
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw, unique);
+  const size_t lds = gen_k3_lds(t->plan, S, pw);
+  int rc = gen_lds_attr(gen_inv_rows_gradients_kernel, lds);
+  if (rc) return rc;
+  // chunks: pw x nchunk work items, about eight per CU; at least 8 positions
+  // per chunk (one atomic per pixel, mode and chunk)
+  int nchunk = (int)((2048 + pw - 1) / pw);
+  if (nchunk > (nscan + 7) / 8) nchunk = (nscan + 7) / 8;
+  if (nchunk < 1) nchunk = 1;
+  int chunk = (nscan + nchunk - 1) / nchunk;
+  nchunk = (nscan + chunk - 1) / chunk;
+  float* part = nullptr;
+  const long nmpu = 2L * S * pw * pw;
+  if (m_probe_update && tk_deterministic()) {
+    part = tk_det_scratch(sizeof(float) * (size_t)nmpu * nchunk);
+    if (!part) {  // scratch too small: one chunk, one contributor per address
+      nchunk = 1;
+      chunk = nscan;
+      part = tk_det_scratch(sizeof(float) * (size_t)nmpu);
+      if (!part) return TK_ERR_ARG;
+    }
+  }
+  hipLaunchKernelGGL(gen_inv_rows_gradients_kernel, dim3(tk_grid((long)pw * nchunk, 8)),
+                     dim3(GEN_NT), lds, stream, (const cf*)hand2, (const cf*)patches, P,
+                     (cf*)objproj, (cf*)chi0, (float*)m_probe_update, probe_update_scale, part,
+                     t->plan, t->tw, nscan, S, pw, det, chunk, inv_scale);
+  TK_LAUNCH_CHECK();
+  if (part)
+    return tk_ordered_sum((float*)m_probe_update, part, nmpu, nchunk, true, stream);
+  return TK_OK;
+}

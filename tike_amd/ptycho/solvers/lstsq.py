@@ -91,6 +91,20 @@ CHUNK_POSITIONS_OVERRIDE = (int(_os.environ["TIKE_CHUNK_POSITIONS"])
 TIKE_CHUNK_POSITIONS does the same for A/B runs of the bench."""
 
 
+GENERAL_FUSED = True
+"""Shapes outside `fused_gradients` (probe window < detector, more than 8
+modes, detector sizes with factors 3 / 5 / 7 ...) run the three general
+launches of csrc/general.hip (tike_gen_*; gaussian model) instead of the
+unfused round-1 kernels; tests set this to False to compare the two."""
+
+
+def general_gradients(S, pw, det):
+    """True where the shape-general fused launches serve (csrc/general.hip):
+    the detector size has a mixed-radix plan and the S lines of a row fit
+    LDS."""
+    return bool(GENERAL_FUSED and lib.tike_gen_supported(S, pw, det))
+
+
 def fused_gradients(S, pw, det):
     """True where tike_ifft2_pass2_gradients serves (probe window = detector,
     a v2-engine size, at most 8 modes -- 4 at 512^2)."""
@@ -424,12 +438,20 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # inverse pass 2 fused with both gradients (chi never stored): probe
     # window = detector, at most 8 modes (4 at 512^2)
     fused = fused_gradients(S, pw, det)
-    if (recover_probe and eigen_weights is not None) or position_terms or fused:
+    # every other shape, gaussian model: the three shape-general launches
+    # (zero padding, far plane and chi never stored); downstream it looks
+    # like the fused route (patches and chi0 stored, 1/num_batch applied)
+    general = (not fused and exitwave_options.noise_model == "gaussian"
+               and general_gradients(S, pw, det))
+    if general:
+        pos_major = False
+    if ((recover_probe and eigen_weights is not None) or position_terms
+            or fused or general):
         patches = ws.get("patches", (max(B, 1), pw, pw), torch.complex64, dev)
     if position_terms:
         taps, taps_r = gaussian_derivative_taps(sigma=0.333)
     costs = ws.get("costs", (max(B, 1),), torch.float32, dev)
-    chunk = chunk_positions(S, det, pos_major)
+    chunk = chunk_positions(S, det, pos_major or general)
     poisson = exitwave_options.noise_model == "poisson"
     inten = gscale = steps = None
     if pos_major or poisson:
@@ -461,16 +483,17 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     objproj = ws.get("objproj", (min(chunk, max(B, 1)), pw, pw),
                      torch.complex64, dev)
     unique = None
-    if w_old is not None and Sm > 0:
+    if w_old is not None and Sm > 0 and not general:
         unique = ws.get("unique", (min(chunk, max(B, 1)), Sm, pw, pw),
                         torch.complex64, dev)
-    far = ws.get("far", (min(chunk, max(B, 1)), 1, S, det, det),
-                 torch.complex64, dev)
+    # (general: the two hand-offs hold the pw rows of the probe window only)
+    far = ws.get("far", (min(chunk, max(B, 1)), 1, S, pw if general else det,
+                         det), torch.complex64, dev)
     # the inverse transform is out of place (far -> mid); chi is the cropped
     # result and aliases mid when the probe fills the detector
     mid = ws.get("mid", tuple(far.shape), torch.complex64, dev)
     chi_ws = mid
-    if pw != det:
+    if pw != det and not general:
         chi_ws = ws.get("chi", (min(chunk, max(B, 1)), 1, S, pw, pw),
                         torch.complex64, dev)
 
@@ -480,7 +503,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # 256^2 / 512^2 with the far plane kept: split forward, intermediate in `far`
     split_kept = (pos_major and fused and not no_farplane
                   and det in SPLIT_FORWARD_SIZES)
-    single_chunk = B <= chunk and not fused
+    single_chunk = B <= chunk and not fused and not general
     if not single_chunk:
         chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
     for clo in range(lo, hi, chunk):
@@ -491,7 +514,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         chi = chi_ws
         uq = None
         steps_in_pass2 = False
-        if w_c is not None and Sm > 0 and not no_farplane:
+        if w_c is not None and Sm > 0 and not no_farplane and not general:
             # varying probe of the modes that own eigen probes, once per chunk
             # (the 256^2 kernels form it on the fly instead)
             uq = unique[:n]
@@ -506,7 +529,22 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         dchunk = None
         if not (pos_major and no_farplane and not (poisson and dominant)):
             dchunk = A.data_f32(data, clo, chi_hi)
-        if pos_major and no_farplane:
+        if general:
+            # K1 rows (patch x probe, zero padding made in LDS) -> K2 columns
+            # (intensity, cost, gradient factor, inverse columns) -> K3 below
+            check(
+                lib.tike_gen_fwd_rows(
+                    A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0, None,
+                    A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(far),
+                    A.ptr(patches[blo:blo + n]), n, S, pw, det, H, W, st),
+                "general forward rows")
+            check(
+                lib.tike_gen_cols_gradient(
+                    A.ptr(far), A.ptr(dchunk), A.ptr(mask_u8),
+                    A.ptr(costs[blo:blo + n]), A.ptr(mid), n, S, pw, det,
+                    fwd_scale, model, unmeasured, nmeasured, st),
+                "general columns + gradient")
+        elif pos_major and no_farplane:
             # the far-plane waves never reach memory: the forward kernel forms
             # them in registers for the intensity and leaves the input of its
             # column pass in `far`; the inverse kernel re-forms them from
@@ -692,7 +730,16 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             check(
                 lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S,
                                     det, pw, inv_scale, st), "ifft2 + crop")
-        if fused:
+        if general:
+            check(
+                lib.tike_gen_inv_rows_gradients(
+                    A.ptr(mid), A.ptr(patches[blo:blo + n]), A.ptr(probe), 0,
+                    None, A.ptr(ep), A.ptr(w_c), C, Sm,
+                    A.ptr(objproj) if recover_psi else None,
+                    A.ptr(chi0[blo:blo + n]) if need_chi0 else None,
+                    A.ptr(m_probe_update), 1.0 / num_batch, n, S, pw, det,
+                    inv_scale, st), "general inverse rows + gradients")
+        elif fused:
             # inverse column pass + both gradients + mode 0 of chi, one
             # pixel-major kernel (chi itself never exists in memory)
             p2 = (A.ptr(far if split_kept else mid),
@@ -719,7 +766,8 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                     A.ptr(objproj) if recover_psi else None, n, S, pw, H, W,
                     st), "probe gradient + object projection")
         if position_terms:
-            chi_m, chi_modes = (chi0[blo:blo + n], 1) if fused else (chi, S)
+            chi_m, chi_modes = ((chi0[blo:blo + n], 1) if fused or general
+                                else (chi, S))
             check(
                 lib.tike_position_sums(
                     A.ptr(patches[blo:blo + n]), A.ptr(chi_m), chi_modes,
@@ -738,7 +786,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                                          A.ptr(scan[clo:chi_hi]),
                                          A.ptr(obj_acc), n, pw, H, W, st),
                 "object scatter")
-        if not single_chunk and not fused:
+        if not single_chunk and not fused and not general:
             chi0[blo:blo + n] = chi[:n, 0, 0]
 
     # complete the sums over positions across ranks.  Which collectives are
@@ -755,7 +803,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         else:
             comm.Allreduce(grads)
     count = global_count(comm, op, lo, hi)
-    if recover_probe and not fused:
+    if recover_probe and not fused and not general:
         m_probe_update = m_probe_update / num_batch  # (fused: in the kernel)
     return dict(chi0=chi_ws if single_chunk else chi0[:B],
                 chi_modes=S if single_chunk else 1, w_old=w_old,

@@ -32,6 +32,8 @@ det = int(os.environ.get("DIAG_DET", "256"))
 S = int(os.environ.get("DIAG_MODES", "8"))
 
 p, ep, ew, data = c3_problem(N, det=det, S=S, eigen=eigen)
+if os.environ.get("DIAG_TP_SIMULATE") == "1":  # the product's simulate
+    data = tp.simulate(det, p["probe"], p["scan"], p["psi"])
 cp = lambda x: None if x is None else x.copy()
 psi0 = np.full_like(p["psi"], 0.5 + 0j)
 batches = np.array_split(np.arange(N), num_batch)
@@ -70,8 +72,11 @@ def product_states():
     with tp.Reconstruction(A.to_device(data, np.float32), params,
                            presharded=True, order=np.arange(N),
                            batches=batches) as ctx:
+        if os.environ.get("DIAG_AT_ONCE") == "1":  # one call for all epochs
+            ctx.iterate(epochs)
         for _ in range(epochs):
-            ctx.iterate(1)
+            if os.environ.get("DIAG_AT_ONCE") != "1":
+                ctx.iterate(1)
             got = ctx.get_result()
             out.append(dict(psi=got.psi.copy(), probe=got.probe.copy(),
                             eigen_probe=cp(got.eigen_probe),
@@ -82,6 +87,10 @@ def product_states():
 
 print(f"c3 problem N {N} {det}x{det} S {S} batches {num_batch} rule {rule} "
       f"eigen {eigen}", flush=True)
+if os.environ.get("DIAG_PRODUCT_FIRST") == "1":
+    _, costs = product_states()
+    print("[product before the oracle] costs: " +
+          " ".join(f"{c:.4e}" for c in costs), flush=True)
 ostates, ocosts = oracle_states()
 print("oracle costs: " + " ".join(f"{c:.4e}" for c in ocosts), flush=True)
 
@@ -106,7 +115,7 @@ def report(tag):
 
 
 report("default")
-for name, setter in (
+for name, setter in () if os.environ.get("DIAG_LEVERS", "1") != "1" else (
         ("PACKED_TAIL=False", lambda: setattr(L, "PACKED_TAIL", False)),
         ("EIGEN_PATCH_RECOMPUTE=False",
          lambda: setattr(L, "EIGEN_PATCH_RECOMPUTE", False)),

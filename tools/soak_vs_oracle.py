@@ -103,5 +103,5 @@ def bench_c3(N, num_batch, S=8, det=256, eigen="init", jitter=True):
 
 
 if os.environ.get("SOAK_BENCH_C3", "1") == "1":
-    for eigen in ("none", "large", "init"):
-        bench_c3(160, 10, eigen=eigen)
+    for eigen in os.environ.get("SOAK_KINDS", "none,large,init").split(","):
+        bench_c3(int(os.environ.get("SOAK_N", "160")), 10, eigen=eigen)
