@@ -556,7 +556,11 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
                                            batch_method=BATCH_RULE)),
         exitwave_options=tp.ExitWaveOptions(
             measured_pixels=np.ones((det, det), dtype=bool),
-            noise_model="poisson") if workload == "c3poisson" else None,
+            noise_model="poisson") if workload == "c3poisson" else
+        # (the default mask has the probe's shape, options.py:168: a probe
+        # window narrower than the detector must bring its own)
+        tp.ExitWaveOptions(measured_pixels=np.ones((det, det), dtype=bool))
+        if workload in PROBE_WIDTH else None,
         probe_options=tp.ProbeOptions(force_orthogonality=True, **multislice),
         object_options=tp.ObjectOptions(
             **(dict(multislice_propagation_distance=1e-6)

@@ -20,6 +20,11 @@ static void stage(int R, const cf* a, cf* b, const cf* tw, int n, int Ns) {
       case 3: mix_butterfly<3, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
       case 4: mix_butterfly<4, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
       case 5: mix_butterfly<5, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
+      case 6: mix_butterfly<6, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
+      case 10: mix_butterfly<10, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
+      case 12: mix_butterfly<12, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
+      case 20: mix_butterfly<20, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
+      case 24: mix_butterfly<24, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
       case 7: mix_butterfly<7, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
       case 8: mix_butterfly<8, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
       case 11: mix_butterfly<11, INV>(a, b, tw, nb, Ns, step, rcp_ns, jj); break;
@@ -71,6 +76,13 @@ int main() {
                        160, 169, 192, 320, 384, 640, 768, 1000, 1536, 2048, 2187, 3072, 4096,
                        11 * 13 * 7, 32, 64, 128, 256, 1024, 675, 3125};
   double worst = 0;
+  for (int n : {96, 192, 384, 768, 320, 640, 1000, 2048, 4096, 1536}) {
+    MixPlan q;
+    mix_make_plan(n, &q);
+    printf("plan %d:", n);
+    for (int s = 0; s < q.nst; ++s) printf(" %d", q.radix[s]);
+    printf("\n");
+  }
   for (int n : sizes) {
     const double e = std::fmax(check<false>(n), check<true>(n));
     if (e > 1.5e-6) printf("n %d: normwise error %.3e\n", n, e);

@@ -46,6 +46,16 @@ int main() {
   e = std::fmax(e, check<11, true>());
   e = std::fmax(e, check<13, false>());
   e = std::fmax(e, check<13, true>());
+  e = std::fmax(e, check<6, false>());
+  e = std::fmax(e, check<6, true>());
+  e = std::fmax(e, check<10, false>());
+  e = std::fmax(e, check<10, true>());
+  e = std::fmax(e, check<12, false>());
+  e = std::fmax(e, check<12, true>());
+  e = std::fmax(e, check<20, false>());
+  e = std::fmax(e, check<20, true>());
+  e = std::fmax(e, check<24, false>());
+  e = std::fmax(e, check<24, true>());
   e = std::fmax(e, check<32, false>());
   e = std::fmax(e, check<32, true>());
   printf("max err %.3e\n", e);

@@ -1104,7 +1104,12 @@ def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen):
     from tike_amd.ptycho.solvers import lstsq as L
     assert not L.fused_gradients(S, pw, det)
     assert L.general_gradients(S, pw, det)
-    _minibatch_vs_oracle(tp, det, S, N, eigen, pw=pw)
+    saved = L.GENERAL_FUSED
+    L.GENERAL_FUSED = "always"  # also where position-major kernels exist
+    try:
+        _minibatch_vs_oracle(tp, det, S, N, eigen, pw=pw)
+    finally:
+        L.GENERAL_FUSED = saved
 
 
 def test_general_shape_launches_equal_the_unfused_kernels(tp):
@@ -1132,7 +1137,7 @@ def test_general_shape_launches_equal_the_unfused_kernels(tp):
     data_d = A.to_device(data, np.float32)
     HW = psi_true.shape[-1]
     outs = []
-    for general in (True, False):
+    for general in ("always", False):
         saved = L.GENERAL_FUSED
         L.GENERAL_FUSED = general
         try:
@@ -1161,6 +1166,13 @@ def test_general_shape_launches_equal_the_unfused_kernels(tp):
 
 def _minibatch_vs_oracle(tp, det, S, N, eigen, pw=None):
     pw = pw or det
+    # the cost of these nearly fitted patterns (psi0 = truth x (1 + 10 %
+    # noise)) is a mean of squared DIFFERENCES of nearly equal amplitudes,
+    # sqrt(I) - sqrt(d) ~ 2 % of sqrt(I): a float32 transform error of 2e-7
+    # sqrt(log2 n) in I (product and oracle alike, tools/debug/fft_bias.py) is
+    # 1e-5 ... 1e-4 of such a cost and grows with the line length -- 1.5e-4 at
+    # 640, 5.5e-4 at 1024 (gradients, chi and step lengths agree to 2e-5 there)
+    cost_rtol = COST_RTOL if det <= 512 else 1e-3
     import tike_amd._arrays as A
     from tike_amd.communicators import Comm
     from tike_amd.operators import Ptycho
@@ -1202,7 +1214,7 @@ def _minibatch_vs_oracle(tp, det, S, N, eigen, pw=None):
         assert_close(chi0.cpu().numpy(), o["chi"][:, 0, 0], normwise=2e-5,
                      what="chi mode 0")
         np.testing.assert_allclose(out["costs"].cpu().numpy(),
-                                   np.ravel(o["costs"]), rtol=COST_RTOL)
+                                   np.ravel(o["costs"]), rtol=cost_rtol)
         assert_close(out["patches"].cpu().numpy(), o["patches"][:, 0, 0],
                      what="patches")
         np.testing.assert_allclose(pos_terms[0].cpu().numpy(),
@@ -1225,7 +1237,7 @@ def _minibatch_vs_oracle(tp, det, S, N, eigen, pw=None):
                                       pw=pw, recover_psi=True,
                                       recover_probe=True)
         np.testing.assert_allclose(float(cost), o["costs"].mean(),
-                                   rtol=COST_RTOL)
+                                   rtol=cost_rtol)
         np.testing.assert_allclose(float(bo), np.ravel(bo_o)[0], rtol=1e-3)
         np.testing.assert_allclose(float(bp), np.ravel(bp_o)[0], rtol=1e-3)
         if eigen:
@@ -1258,7 +1270,7 @@ def _minibatch_vs_oracle(tp, det, S, N, eigen, pw=None):
         np.testing.assert_allclose(float(bo3), np.ravel(bo_o)[0], rtol=1e-3)
         np.testing.assert_allclose(float(bp3), np.ravel(bp_o)[0], rtol=1e-3)
         np.testing.assert_allclose(float(steps_row[4]), o["costs"].mean(),
-                                   rtol=COST_RTOL)
+                                   rtol=cost_rtol)
         want_probe = probe0 + np.ravel(bp_o)[0] * o["m_probe_update"]
         assert_close(probe3.cpu().numpy(), want_probe, normwise=2e-5,
                      what="probe after the packed tail")

@@ -155,6 +155,9 @@ __global__ __launch_bounds__(256) void mix_pass_kernel(const cf* in, cf* out, Mi
   // element idx of group grp -> (line, e, address or -1); COLS: the lines a
   // short last group does not have are -1
   auto where = [&](long grp, const long* lbase, int idx, int& line, int& e, long& off) {
+    // (opaque: (line, e) of a prefetch slot do not depend on the group; hoisted
+    // out of the group loop they would stay alive across the butterflies)
+    asm volatile("" : "+v"(idx));
     const long g0 = grp * L;
     const int nl = (int)(nlines - g0 < L ? nlines - g0 : L);
     if (COLS) {
@@ -207,7 +210,8 @@ __global__ __launch_bounds__(256) void mix_pass_kernel(const cf* in, cf* out, Mi
     };
     // ---- the group's samples into LDS (BLU: x * chirp -- the conjugate of x
     // for the inverse --, zero fill up to M)
-    asm volatile("" : "+v"(pre[0].x), "+v"(pre[1].x), "+v"(pre[2].x), "+v"(pre[3].x));
+#pragma unroll
+    for (int u = 0; u < MIX_U; ++u) asm volatile("" : "+v"(pre[u].x));
 #pragma unroll
     for (int u = 0; u < MIX_U; ++u) {
       int line, e;
@@ -224,7 +228,8 @@ __global__ __launch_bounds__(256) void mix_pass_kernel(const cf* in, cf* out, Mi
         where(grp, lbase, base + u * 256, line[u], e[u], off[u]);
         v[u] = in[off[u] >= 0 ? off[u] : 0];
       }
-      asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x));
+#pragma unroll
+      for (int u = 0; u < MIX_U; ++u) asm volatile("" : "+v"(v[u].x));
 #pragma unroll
       for (int u = 0; u < MIX_U; ++u)
         if (off[u] >= 0) put(line[u], e[u], v[u]);

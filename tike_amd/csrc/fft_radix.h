@@ -281,3 +281,77 @@ template <bool INV>
 struct Dft<11, INV> : DftPrime<11, INV> {};
 template <bool INV>
 struct Dft<13, INV> : DftPrime<13, INV> {};
+
+// ---- composite radices 6, 10, 12, 20, 24 (round 6): one Cooley-Tukey step in
+// registers, R = R1 * R2 with input n = R2 n1 + n2 and output k = k1 + R1 k2:
+// R2 DFTs of length R1, the twiddles w_R^(n2 k1) from a literal table, R1 DFTs
+// of length R2.  A 384-point line is two LDS stages (24 x 16) instead of three
+// (3 x 8 x 16): fewer barriers, and the index arithmetic of a butterfly is
+// shared by 24 elements.
+template <int R>
+struct UnitTab;
+template <>
+struct UnitTab<6> {
+  static constexpr float c[6] = {1.0f, 0.5f, -0.5f, -1.0f, -0.5f, 0.5f};
+  static constexpr float s[6] = {0.0f, 0.8660254037844386f, 0.86602540378443871f, 0.0f, -0.86602540378443837f, -0.8660254037844386f};
+};
+template <>
+struct UnitTab<10> {
+  static constexpr float c[10] = {1.0f, 0.80901699437494745f, 0.30901699437494745f, -0.30901699437494734f, -0.80901699437494734f, -1.0f, -0.80901699437494756f, -0.30901699437494756f, 0.30901699437494723f, 0.80901699437494734f};
+  static constexpr float s[10] = {0.0f, 0.58778525229247314f, 0.95105651629515353f, 0.95105651629515364f, 0.58778525229247325f, 0.0f, -0.58778525229247303f, -0.95105651629515353f, -0.95105651629515364f, -0.58778525229247336f};
+};
+template <>
+struct UnitTab<12> {
+  static constexpr float c[12] = {1.0f, 0.86602540378443871f, 0.5f, 0.0f, -0.5f, -0.86602540378443871f, -1.0f, -0.86602540378443882f, -0.5f, 0.0f, 0.5f, 0.86602540378443837f};
+  static constexpr float s[12] = {0.0f, 0.5f, 0.8660254037844386f, 1.0f, 0.86602540378443871f, 0.5f, 0.0f, -0.5f, -0.86602540378443837f, -1.0f, -0.8660254037844386f, -0.5f};
+};
+template <>
+struct UnitTab<20> {
+  static constexpr float c[20] = {1.0f, 0.95105651629515353f, 0.80901699437494745f, 0.58778525229247314f, 0.30901699437494745f, 0.0f, -0.30901699437494734f, -0.58778525229247303f, -0.80901699437494734f, -0.95105651629515353f, -1.0f, -0.95105651629515375f, -0.80901699437494756f, -0.58778525229247325f, -0.30901699437494756f, 0.0f, 0.30901699437494723f, 0.58778525229247292f, 0.80901699437494734f, 0.95105651629515353f};
+  static constexpr float s[20] = {0.0f, 0.3090169943749474f, 0.58778525229247314f, 0.80901699437494745f, 0.95105651629515353f, 1.0f, 0.95105651629515364f, 0.80901699437494745f, 0.58778525229247325f, 0.30901699437494751f, 0.0f, -0.3090169943749469f, -0.58778525229247303f, -0.80901699437494734f, -0.95105651629515353f, -1.0f, -0.95105651629515364f, -0.80901699437494756f, -0.58778525229247336f, -0.30901699437494762f};
+};
+template <>
+struct UnitTab<24> {
+  static constexpr float c[24] = {1.0f, 0.96592582628906831f, 0.86602540378443871f, 0.70710678118654757f, 0.5f, 0.25881904510252074f, 0.0f, -0.25881904510252063f, -0.5f, -0.70710678118654746f, -0.86602540378443871f, -0.9659258262890682f, -1.0f, -0.96592582628906831f, -0.86602540378443882f, -0.70710678118654791f, -0.5f, -0.25881904510252063f, 0.0f, 0.2588190451025203f, 0.5f, 0.70710678118654735f, 0.86602540378443837f, 0.96592582628906809f};
+  static constexpr float s[24] = {0.0f, 0.25881904510252074f, 0.5f, 0.70710678118654746f, 0.8660254037844386f, 0.96592582628906831f, 1.0f, 0.96592582628906831f, 0.86602540378443871f, 0.70710678118654757f, 0.5f, 0.25881904510252102f, 0.0f, -0.25881904510252079f, -0.5f, -0.70710678118654713f, -0.86602540378443837f, -0.96592582628906831f, -1.0f, -0.96592582628906842f, -0.8660254037844386f, -0.70710678118654768f, -0.5f, -0.25881904510252157f};
+};
+
+template <int R1, int R2, bool INV>
+struct DftCT {
+  static TK_HD void run(cf* v) {
+    constexpr int R = R1 * R2;
+    cf a[R2][R1];
+#pragma unroll
+    for (int n2 = 0; n2 < R2; ++n2) {
+      cf t[R1];
+#pragma unroll
+      for (int n1 = 0; n1 < R1; ++n1) t[n1] = v[R2 * n1 + n2];
+      Dft<R1, INV>::run(t);
+#pragma unroll
+      for (int k1 = 0; k1 < R1; ++k1)
+        a[n2][k1] = (n2 * k1) % R == 0
+                        ? t[k1]
+                        : mul_tw<INV>(t[k1], mk(UnitTab<R>::c[(n2 * k1) % R],
+                                                -UnitTab<R>::s[(n2 * k1) % R]));
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+      cf t[R2];
+#pragma unroll
+      for (int n2 = 0; n2 < R2; ++n2) t[n2] = a[n2][k1];
+      Dft<R2, INV>::run(t);
+#pragma unroll
+      for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
+    }
+  }
+};
+template <bool INV>
+struct Dft<6, INV> : DftCT<2, 3, INV> {};
+template <bool INV>
+struct Dft<10, INV> : DftCT<2, 5, INV> {};
+template <bool INV>
+struct Dft<12, INV> : DftCT<4, 3, INV> {};
+template <bool INV>
+struct Dft<20, INV> : DftCT<4, 5, INV> {};
+template <bool INV>
+struct Dft<24, INV> : DftCT<8, 3, INV> {};

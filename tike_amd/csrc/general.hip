@@ -40,6 +40,14 @@
 static size_t gen_lds_limit() { return 150 * 1024; }
 
 // ------------------------------------------------------------------- K1
+// Index arithmetic is kept out of the element loops (profiles/r06_experiments.md:
+// the first version spent 4.2 wave instructions per element, 5x the
+// butterflies, on float-reciprocal divisions, 64-bit offsets and TkProbe::at):
+// a line's base is uniform (scalar), a lane adds e.
+__device__ __forceinline__ const cf* gen_probe_row(const TkProbe& probe, long n, int s, int y) {
+  return probe.probe + n * probe.pos_stride + ((long)s * probe.pw + y) * probe.pw;
+}
+
 __global__ __launch_bounds__(GEN_NT) void gen_fwd_rows_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ hand1, cf* __restrict__ patches, MixPlan p, const cf* __restrict__ twg,
@@ -47,75 +55,69 @@ __global__ __launch_bounds__(GEN_NT) void gen_fwd_rows_kernel(
   extern __shared__ __align__(16) unsigned char lds_raw[];
   cf* twl = reinterpret_cast<cf*>(lds_raw);
   cf* bufa = twl + det;
-  cf* bufb = bufa + (long)S * RG * p.ls;
-  cf* prow = bufb + (long)S * RG * p.ls;  // RG rows of the patch
+  cf* bufb = bufa + S * RG * p.ls;
+  cf* prow = bufb + S * RG * p.ls;  // RG rows of the patch
   for (int k = threadIdx.x; k < det; k += GEN_NT) twl[k] = twg[k];
   const int pad = (det - pw) / 2;
   const long total = (long)H * W;
   const int ngrp = (pw + RG - 1) / RG;
   const long nitem = (long)nscan * ngrp;
-  const float rcp_pw = 1.0f / (float)pw, rcp_det = 1.0f / (float)det;
+  const bool plain = probe.weights == nullptr;  // an explicit array, no eigen probes
   for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
     const long n = item / ngrp;
     const int y0 = (int)(item - n * ngrp) * RG;
     const int nr = pw - y0 < RG ? pw - y0 : RG;
     const TkCorner c = tk_corner(scan, n);
-    // ---- the nr patch rows, once for all modes (four pixels = 16 taps
-    // requested together)
-    for (int base = threadIdx.x; base < nr * pw; base += GEN_NT * 4) {
-      cf v[4];
-      int idx[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        idx[u] = base + u * GEN_NT;
-        const int i = idx[u] < nr * pw ? idx[u] : 0;
-        const int r = mix_div(i, rcp_pw), px = i - r * pw;
-        const int y = c.sy + y0 + r, x = c.sx + px;
-        const bool ok = y >= 0 && y < H && x >= 0 && x < W;
-        // (outside the image: pixel 0 is requested and selected away -- a
-        // load behind a condition is a branch around the load)
+    // ---- the nr patch rows, once for all modes
+    for (int r = 0; r < nr; ++r) {
+      const int y = c.sy + y0 + r;
+      const bool row_ok = y >= 0 && y < H;
+      cf* out = patches ? patches + (n * pw + y0 + r) * (long)pw : nullptr;
+      for (int px = threadIdx.x; px < pw; px += GEN_NT) {
+        const int x = c.sx + px;
+        const bool ok = row_ok && x >= 0 && x < W;
+        // (outside the image: pixel 0 is requested and selected away -- a load
+        // behind a condition is a branch around the load)
         const cf g = tk_gather(psi, ok ? (long)y * W + x : 0L, W, total, c);
-        v[u] = ok ? g : mk(0.f, 0.f);
+        const cf v = ok ? g : mk(0.f, 0.f);
+        prow[r * pw + px] = v;
+        if (out) out[px] = v;
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (idx[u] < nr * pw) {
-          prow[idx[u]] = v[u];
-          if (patches) patches[(n * pw + y0) * (long)pw + idx[u]] = v[u];
-        }
     }
     __syncthreads();
-    // ---- lines (s, r): patch row x probe, zero-padded to det
+    // ---- lines (s, r): patch row x probe, zero-padded to det; the probe
+    // values of four lines are requested together
     const int nl = S * nr;
-    const float rcp_nr = 1.0f / (float)nr;
-    for (int base = threadIdx.x; base < nl * det; base += GEN_NT * 4) {
-      cf w[4];
-      int line[4], e[4], r[4];
-      bool in[4];
+    for (int e = threadIdx.x; e < det; e += GEN_NT) {
+      const int px = e - pad;
+      const bool in = px >= 0 && px < pw;
+      const int pe = mix_pad(e);
+      for (int l0 = 0; l0 < nl; l0 += 4) {
+        cf w[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = base + u * GEN_NT;
-        const int i = idx < nl * det ? idx : 0;
-        line[u] = mix_div(i, rcp_det);
-        e[u] = i - line[u] * det;
-        const int s = mix_div(line[u], rcp_nr);
-        r[u] = line[u] - s * nr;
-        const int px = e[u] - pad;
-        in[u] = idx < nl * det && px >= 0 && px < pw;
-        w[u] = probe.at(n, s, in[u] ? (long)(y0 + r[u]) * pw + px : 0L);
+        for (int u = 0; u < 4; ++u) {
+          const int line = l0 + u < nl ? l0 + u : nl - 1;
+          const int sm = line / nr, r = line - sm * nr;
+          w[u] = plain ? gen_probe_row(probe, n, sm, y0 + r)[in ? px : 0]
+                       : probe.at(n, sm, in ? (long)(y0 + r) * pw + px : 0L);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int line = l0 + u;
+          if (line < nl) {
+            const int r = line % nr;
+            bufa[line * p.ls + pe] = in ? prow[r * pw + px] * w[u] : mk(0.f, 0.f);
+          }
+        }
       }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (base + u * GEN_NT < nl * det)
-          bufa[line[u] * p.ls + mix_pad(e[u])] =
-              in[u] ? prow[r[u] * pw + e[u] - pad] * w[u] : mk(0.f, 0.f);
     }
     __syncthreads();
     cf* res = mix_stages<false>(bufa, bufb, twl, p, nl);
-    for (int idx = threadIdx.x; idx < nl * det; idx += GEN_NT) {
-      const int line = mix_div(idx, rcp_det), e = idx - line * det;
-      const int s = mix_div(line, rcp_nr), r = line - s * nr;
-      hand1[(((n * S + s) * pw) + y0 + r) * (long)det + e] = res[line * p.ls + mix_pad(e)];
+    for (int line = 0; line < nl; ++line) {
+      const int sm = line / nr, r = line - sm * nr;
+      cf* dst = hand1 + ((n * S + sm) * pw + y0 + r) * (long)det;
+      const cf* src = res + line * p.ls;
+      for (int e = threadIdx.x; e < det; e += GEN_NT) dst[e] = src[mix_pad(e)];
     }
     __syncthreads();
   }
@@ -240,23 +242,30 @@ __global__ __launch_bounds__(GEN_NT) void gen_cols_gradient_kernel(
 
 // ------------------------------------------------------------------- K3
 // mpu: S x pw x pw complex as float pairs; with `part` != nullptr (deterministic
-// mode) chunk c leaves its sums in part[c] instead of adding them atomically
+// mode) chunk c leaves its sums in part[c] instead of adding them atomically.
+// The S rows of the NEXT position are requested (GEN_K3_PRE elements per
+// thread, (mode, e) decoded with e padded to a power of two: no division)
+// before the butterflies of the position in hand.
+#define GEN_K3_PRE 8
 __global__ __launch_bounds__(GEN_NT) void gen_inv_rows_gradients_kernel(
     const cf* __restrict__ hand2, const cf* __restrict__ patches, const TkProbe probe,
     cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, float mpu_scale,
     float* __restrict__ part, MixPlan p, const cf* __restrict__ twg, int nscan, int S, int pw,
-    int det, int chunk, float inv_scale) {
+    int det, int logD, int chunk, float inv_scale) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   cf* twl = reinterpret_cast<cf*>(lds_raw);
   cf* bufa = twl + det;
-  cf* bufb = bufa + (long)S * p.ls;
-  cf* acc = bufb + (long)S * p.ls;  // S x pw
+  cf* bufb = bufa + S * p.ls;
+  cf* acc = bufb + S * p.ls;  // S x pw
   for (int k = threadIdx.x; k < det; k += GEN_NT) twl[k] = twg[k];
   const int pad = (det - pw) / 2;
   const int nchunk = (nscan + chunk - 1) / chunk;
   const long nitem = (long)pw * nchunk;
-  const float rcp_det = 1.0f / (float)det;
   const bool grad = mpu != nullptr || part != nullptr;
+  const bool plain = probe.weights == nullptr;
+  const int D = 1 << logD;  // >= det
+  const int mode_stride = pw * det;  // elements between the rows y of two modes
+  const int slots = S << logD;       // (mode, e) slots of one position
   for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
     // (rows fastest: the workgroups of one chunk run together and share the
     // chunk's probe / patch lines in L2)
@@ -265,55 +274,86 @@ __global__ __launch_bounds__(GEN_NT) void gen_inv_rows_gradients_kernel(
     const long n0 = c * chunk, n1 = n0 + chunk < nscan ? n0 + chunk : nscan;
     if (grad)
       for (int idx = threadIdx.x; idx < S * pw; idx += GEN_NT) acc[idx] = mk(0.f, 0.f);
-    for (long n = n0; n < n1; ++n) {
-      // ---- row y of every mode of position n
+    cf pre[GEN_K3_PRE];
+    auto request = [&](long n) {
       const cf* src = hand2 + (n * S * pw + y) * (long)det;
-      for (int base = threadIdx.x; base < S * det; base += GEN_NT * 8) {
-        cf v[8];
-        int line[8], e[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + u * GEN_NT;
-          const int i = idx < S * det ? idx : 0;
-          line[u] = mix_div(i, rcp_det);
-          e[u] = i - line[u] * det;
-          v[u] = src[(long)line[u] * pw * det + e[u]];
-        }
-        asm volatile("" : "+v"(v[0].x), "+v"(v[1].x), "+v"(v[2].x), "+v"(v[3].x), "+v"(v[4].x),
-                     "+v"(v[5].x), "+v"(v[6].x), "+v"(v[7].x));
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (base + u * GEN_NT < S * det) bufa[line[u] * p.ls + mix_pad(e[u])] = v[u];
+      for (int u = 0; u < GEN_K3_PRE; ++u) {
+        int idx = threadIdx.x + u * GEN_NT;
+        asm volatile("" : "+v"(idx));  // (not hoisted out of the position loop)
+        const int sm = idx >> logD, e = idx & (D - 1);
+        pre[u] = src[idx < slots && e < det ? sm * mode_stride + e : 0];
       }
-      __syncthreads();
-      const cf* res = mix_stages<true>(bufa, bufb, twl, p, S);
-      // ---- chi = crop(res) / scale: both products, mode 0
-      const long rowpix = (long)y * pw;
-      for (int x = threadIdx.x; x < pw; x += GEN_NT) {
-        const cf O = conjf(patches[(n * pw + y) * (long)pw + x]);
-        cf op = mk(0.f, 0.f);
-        for (int s = 0; s < S; ++s) {
-          const cf chi = res[s * p.ls + mix_pad(pad + x)] * inv_scale;
-          op = op + conjf(probe.at(n, s, rowpix + x)) * chi;
-          if (grad) acc[s * pw + x] = acc[s * pw + x] + O * chi;
-          if (s == 0 && chi0) chi0[(n * pw + y) * (long)pw + x] = chi;
+    };
+    request(n0);
+    for (long n = n0; n < n1; ++n) {
+      // ---- row y of every mode of position n into LDS
+#pragma unroll
+      for (int u = 0; u < GEN_K3_PRE; ++u) asm volatile("" : "+v"(pre[u].x));
+#pragma unroll
+      for (int u = 0; u < GEN_K3_PRE; ++u) {
+        int idx = threadIdx.x + u * GEN_NT;
+        asm volatile("" : "+v"(idx));
+        const int sm = idx >> logD, e = idx & (D - 1);
+        if (idx < slots && e < det) bufa[sm * p.ls + mix_pad(e)] = pre[u];
+      }
+      if (slots > GEN_K3_PRE * GEN_NT) {  // (more modes than the registers take)
+        const cf* src = hand2 + (n * S * pw + y) * (long)det;
+        for (int idx = threadIdx.x + GEN_K3_PRE * GEN_NT; idx < slots; idx += GEN_NT) {
+          const int sm = idx >> logD, e = idx & (D - 1);
+          if (e < det) bufa[sm * p.ls + mix_pad(e)] = src[sm * mode_stride + e];
         }
-        if (objproj) objproj[(n * pw + y) * (long)pw + x] = op;
+      }
+      // the object patch row of this position (needed after the butterflies)
+      const cf* orow = patches + (n * pw + y) * (long)pw;
+      // (requested before the butterflies, used after them)
+      const cf O0 = conjf(orow[threadIdx.x < pw ? threadIdx.x : 0]);
+      __syncthreads();
+      if (n + 1 < n1) request(n + 1);
+      const cf* res = mix_stages<true>(bufa, bufb, twl, p, S);
+      // ---- chi = crop(res) * scale: both products, mode 0
+      cf* oproj = objproj ? objproj + (n * pw + y) * (long)pw : nullptr;
+      cf* c0 = chi0 ? chi0 + (n * pw + y) * (long)pw : nullptr;
+      for (int x = threadIdx.x; x < pw; x += GEN_NT) {
+        const cf Ox = x == (int)threadIdx.x ? O0 : conjf(orow[x]);
+        const cf* q = res + mix_pad(pad + x);
+        cf op = mk(0.f, 0.f);
+        for (int s0 = 0; s0 < S; s0 += 4) {
+          cf P[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int sm = s0 + u < S ? s0 + u : S - 1;
+            P[u] = plain ? gen_probe_row(probe, n, sm, y)[x]
+                         : probe.at(n, sm, (long)y * pw + x);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int sm = s0 + u;
+            if (sm < S) {
+              const cf chi = q[sm * p.ls] * inv_scale;
+              op = op + conjf(P[u]) * chi;
+              if (grad) acc[sm * pw + x] = acc[sm * pw + x] + Ox * chi;
+              if (sm == 0 && c0) c0[x] = chi;
+            }
+          }
+        }
+        if (oproj) oproj[x] = op;
       }
       __syncthreads();
     }
     if (grad) {
-      for (int idx = threadIdx.x; idx < S * pw; idx += GEN_NT) {
-        const int s = idx / pw, x = idx - s * pw;
-        const long o = 2 * (((long)s * pw + y) * pw + x);
-        const cf v = acc[idx] * mpu_scale;
-        if (part) {
-          float* q = part + c * 2L * S * pw * pw + o;
-          q[0] = v.x;
-          q[1] = v.y;
-        } else {
-          unsafeAtomicAdd(mpu + o, v.x);
-          unsafeAtomicAdd(mpu + o + 1, v.y);
+      for (int sm = 0; sm < S; ++sm) {
+        const long o = 2 * (((long)sm * pw + y) * pw);
+        float* dst = part ? part + c * 2L * S * pw * pw + o : mpu + o;
+        for (int x = threadIdx.x; x < pw; x += GEN_NT) {
+          const cf v = acc[sm * pw + x] * mpu_scale;
+          if (part) {
+            dst[2 * x] = v.x;
+            dst[2 * x + 1] = v.y;
+          } else {
+            unsafeAtomicAdd(dst + 2 * x, v.x);
+            unsafeAtomicAdd(dst + 2 * x + 1, v.y);
+          }
         }
       }
       __syncthreads();
@@ -321,7 +361,165 @@ __global__ __launch_bounds__(GEN_NT) void gen_inv_rows_gradients_kernel(
   }
 }
 
+// ------------------------------------------------- K2, one sweep (resident)
+// Where all S modes of a column group fit LDS beside each other (S x L lines,
+// two buffers): hand1 is read ONCE -- the forward column transforms of every
+// mode are in LDS when the intensity is formed, the factor is applied in
+// place and the inverse runs on the same lines.  One 1024-thread workgroup
+// per CU; the columns of the NEXT work item are requested into registers
+// before the butterflies of the one in hand (GEN_PF elements per thread), the
+// counts of the item before its forward transform.
+#define GEN_BIG 1024
+#ifndef GEN_K2_NT
+#define GEN_K2_NT 512
+#endif
+
+__device__ __forceinline__ float gen_block_sum(float v, float* red) {
+  v = tk_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+  return s;
+}
+
+template <int MODEL, int NT>
+__global__ __launch_bounds__(NT) void gen_cols_resident_kernel(
+    const cf* __restrict__ hand1, const float* __restrict__ data,
+    const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ hand2,
+    MixPlan p, const cf* __restrict__ twg, int nscan, int S, int pw, int det, int L, int logL,
+    float fwd_scale, float unmeasured_scaling, float inv_nmeasured) {
+  constexpr int PF = 8192 / NT, DV = 4096 / NT;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  cf* twl = reinterpret_cast<cf*>(lds_raw);
+  cf* bufa = twl + det;
+  cf* bufb = bufa + (long)S * L * p.ls;
+  __shared__ float red[16];
+  for (int k = threadIdx.x; k < det; k += NT) twl[k] = twg[k];
+  const int pad = (det - pw) / 2;
+  const int ngrp = (det + L - 1) / L;
+  const long nitem = (long)nscan * ngrp;
+  const int nl = S * L, tot = pw * nl;
+  const float rcp_pw = 1.0f / (float)pw;
+  const float rcp_pad = 1.0f / (float)(det - pw > 0 ? det - pw : 1);
+  // element idx of an item: column l of row r of mode s -> (line, r, offset in
+  // hand1 / hand2 or -1 for the columns a short last group does not have)
+  // (idx is made opaque at every use: (line, r) of an element do not depend on
+  // the item, so the compiler would hoist them -- for every prefetch slot --
+  // out of the item loop and keep them alive across the butterflies: 256
+  // VGPRs and 344 B/lane of scratch instead of 110 and none)
+  auto where = [&](long n, int x0, int idx, int& line, int& r) -> long {
+    asm volatile("" : "+v"(idx));
+    const int l = idx & (L - 1), q = idx >> logL;
+    const int s = mix_div(q, rcp_pw);
+    r = q - s * pw;
+    line = s * L + l;
+    return idx < tot && x0 + l < det ? ((n * S + s) * pw + r) * (long)det + x0 + l : -1L;
+  };
+  cf pre[PF];
+  auto request = [&](long item) {
+    const long n = item / ngrp;
+    const int x0 = (int)(item - n * ngrp) * L;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      int line, r;
+      const long off = where(n, x0, threadIdx.x + u * NT, line, r);
+      pre[u] = hand1[off >= 0 ? off : 0];
+    }
+  };
+  if (blockIdx.x < nitem) request(blockIdx.x);
+  for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
+    const long n = item / ngrp;
+    const int grp = (int)(item - n * ngrp), x0 = grp * L;
+#pragma unroll
+    for (int u = 0; u < PF; ++u) asm volatile("" : "+v"(pre[u].x));
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int idx = threadIdx.x + u * NT;
+      int line, r;
+      const long off = where(n, x0, idx, line, r);
+      // (columns the group does not have: zeros, so that the arithmetic on
+      // their lines stays finite)
+      if (idx < tot) bufa[line * p.ls + mix_pad(pad + r)] = off >= 0 ? pre[u] : mk(0.f, 0.f);
+    }
+    for (int idx = threadIdx.x; idx < nl * (det - pw); idx += NT) {
+      const int line = mix_div(idx, rcp_pad), q = idx - line * (det - pw);
+      bufa[line * p.ls + mix_pad(q < pad ? q : q + pw)] = mk(0.f, 0.f);
+    }
+    // the counts of the item's det x L pixels (requested with everything else,
+    // never behind the mask test; NaN at unmeasured pixels is selected away)
+    float dv[DV];
+    unsigned measured = 0;
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+      const int idx = threadIdx.x + j * NT;
+      const int l = idx & (L - 1), k = idx >> logL;
+      const bool ok = k < det && x0 + l < det;
+      const long pix = ok ? (long)k * det + x0 + l : 0L;
+      dv[j] = data[n * (long)det * det + pix];
+      measured |= (mask ? mask[pix] != 0 : true) ? 1u << j : 0u;
+    }
+    __syncthreads();
+    if (item + gridDim.x < nitem) request(item + gridDim.x);
+    cf* res = mix_stages<false>(bufa, bufb, twl, p, nl);
+    float cost = 0.f;
+#pragma unroll
+    for (int j = 0; j < DV; ++j) {
+      const int idx = threadIdx.x + j * NT;
+      const int l = idx & (L - 1), k = idx >> logL;
+      if (!(k < det && x0 + l < det)) continue;
+      const bool m = (measured >> j) & 1u;
+      cf* q = res + l * p.ls + mix_pad(k);
+      float I = 0.f;
+      for (int s = 0; s < S; ++s) I += norm2(q[(long)s * L * p.ls] * fwd_scale);
+      float g, term;
+      if (MODEL == 0) {
+        const float sI = sqrtf(I), sd = sqrtf(dv[j]);
+        const float diff = sI - sd;
+        term = diff * diff;
+        g = -(1.0f - sd / (sI + 1e-9f));
+      } else {
+        term = I - dv[j] * logf(I + 1e-9f);
+        g = -(1.0f - dv[j] / (I + 1e-9f));
+      }
+      cost += m ? term : 0.f;
+      const float gg = (m ? g : unmeasured_scaling - 1.0f) * fwd_scale;
+      for (int s = 0; s < S; ++s) q[(long)s * L * p.ls] = q[(long)s * L * p.ls] * gg;
+    }
+    if (costs.costs) {
+      cost = gen_block_sum(cost, red);
+      if (threadIdx.x == 0) tk_cost_add(costs, n, grp, cost * inv_nmeasured);
+    }
+    __syncthreads();
+    if (hand2) {
+      const cf* back = mix_stages<true>(res, res == bufa ? bufb : bufa, twl, p, nl);
+      for (int idx = threadIdx.x; idx < tot; idx += NT) {
+        int line, r;
+        const long off = where(n, x0, idx, line, r);
+        if (off >= 0) hand2[off] = back[line * p.ls + mix_pad(pad + r)];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// columns per item of the resident K2 (0: it does not fit, two sweeps)
+static int gen_cols_resident(const MixPlan& p, int S, int pw) {
+  for (int L = 8; L >= 2; L /= 2) {
+    const size_t need = sizeof(cf) * ((size_t)p.n + 2 * (size_t)p.ls * S * L);
+    if (need <= gen_lds_limit() && (long)p.n * L <= 4096 && (long)pw * S * L <= 8192)
+      return L;
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- host side
+static int log2_ceil(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
 static int log2_floor(int v) {
   int l = 0;
   while ((2 << l) <= v) ++l;
@@ -413,28 +611,34 @@ extern "C" int tike_gen_cols_gradient(const void* hand1, const float* data,
   if (!tike_gen_supported(S, pw, det)) return TK_ERR_UNSUPPORTED;
   const MixTables* t = tk_mix_tables(det);
   if (!t || t->bluestein) return TK_ERR_UNSUPPORTED;
-  const int L = gen_cols_per_item(t->plan), logL = log2_floor(L);
+  const int LR = gen_cols_resident(t->plan, S, pw);
+  const int L = LR ? LR : gen_cols_per_item(t->plan), logL = log2_floor(L);
   const int ngrp = (det + L - 1) / L;
   TkCostSink sink;
   int rc = tk_cost_sink(costs, nscan, ngrp, stream, &sink);
   if (rc) return rc;
-  const size_t lds = sizeof(cf) * (size_t)det +
-                     (2 * sizeof(cf) * (size_t)t->plan.ls + sizeof(float) * (size_t)det) * L;
+  const size_t lds =
+      LR ? sizeof(cf) * ((size_t)det + 2 * (size_t)t->plan.ls * S * L)
+         : sizeof(cf) * (size_t)det +
+               (2 * sizeof(cf) * (size_t)t->plan.ls + sizeof(float) * (size_t)det) * L;
   const long nitem = (long)nscan * ngrp;
   const float inv = 1.0f / (float)num_measured;
-#define TK_GEN_K2(M)                                                                           \
-  do {                                                                                         \
-    rc = gen_lds_attr(gen_cols_gradient_kernel<M>, lds);                                       \
-    if (rc) return rc;                                                                         \
-    hipLaunchKernelGGL((gen_cols_gradient_kernel<M>), dim3(tk_grid(nitem, 8)), dim3(GEN_NT),   \
-                       lds, stream, (const cf*)hand1, data, measured, sink, (cf*)hand2,        \
-                       t->plan, t->tw, nscan, S, pw, det, L, logL, fwd_scale,                  \
-                       unmeasured_scaling, inv);                                               \
+#define TK_GEN_K2(KERN, NT, PER_CU)                                                             \
+  do {                                                                                          \
+    rc = gen_lds_attr(KERN, lds);                                                               \
+    if (rc) return rc;                                                                          \
+    hipLaunchKernelGGL(KERN, dim3(tk_grid(nitem, PER_CU)), dim3(NT), lds, stream,               \
+                       (const cf*)hand1, data, measured, sink, (cf*)hand2, t->plan, t->tw,      \
+                       nscan, S, pw, det, L, logL, fwd_scale, unmeasured_scaling, inv);         \
   } while (0)
-  if (model == 0)
-    TK_GEN_K2(0);
+  if (LR && model == 0)
+    TK_GEN_K2((gen_cols_resident_kernel<0, GEN_K2_NT>), GEN_K2_NT, 1);
+  else if (LR)
+    TK_GEN_K2((gen_cols_resident_kernel<1, GEN_K2_NT>), GEN_K2_NT, 1);
+  else if (model == 0)
+    TK_GEN_K2(gen_cols_gradient_kernel<0>, GEN_NT, 8);
   else
-    TK_GEN_K2(1);
+    TK_GEN_K2(gen_cols_gradient_kernel<1>, GEN_NT, 8);
 #undef TK_GEN_K2
   TK_LAUNCH_CHECK();
   return tk_cost_finish(sink, nscan, stream);
@@ -483,7 +687,7 @@ extern "C" int tike_gen_inv_rows_gradients(const void* hand2, const void* patche
   hipLaunchKernelGGL(gen_inv_rows_gradients_kernel, dim3(tk_grid((long)pw * nchunk, 8)),
                      dim3(GEN_NT), lds, stream, (const cf*)hand2, (const cf*)patches, P,
                      (cf*)objproj, (cf*)chi0, (float*)m_probe_update, probe_update_scale, part,
-                     t->plan, t->tw, nscan, S, pw, det, chunk, inv_scale);
+                     t->plan, t->tw, nscan, S, pw, det, log2_ceil(det), chunk, inv_scale);
   TK_LAUNCH_CHECK();
   if (part)
     return tk_ordered_sum((float*)m_probe_update, part, nmpu, nchunk, true, stream);

@@ -441,7 +441,11 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # every other shape, gaussian model: the three shape-general launches
     # (zero padding, far plane and chi never stored); downstream it looks
     # like the fused route (patches and chi0 stored, 1/num_batch applied)
-    general = (not fused and exitwave_options.noise_model == "gaussian"
+    # (detector sizes with position-major kernels -- 128, 256, 512 -- keep
+    # those for pw < det or many modes: measured faster, c3pad 160 vs 88 k
+    # patterns/s, c3m12 69 vs 41 k, profiles/r06_experiments.md)
+    general = (not fused and (not pos_major or GENERAL_FUSED == "always")
+               and exitwave_options.noise_model == "gaussian"
                and general_gradients(S, pw, det))
     if general:
         pos_major = False
