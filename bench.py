@@ -62,6 +62,10 @@ def parse():
     p.add_argument("--data-on-host", action="store_true",
                    help="stream the patterns from pinned host memory (the "
                         "PCIe-inclusive rate; never the headline value)")
+    p.add_argument("--allreduce-probe", action="store_true",
+                   help="after the timed steps, time the object-gradient-sized "
+                        "all-reduce alone (100 calls): link time apart from "
+                        "compute in a multi-GPU line")
     p.add_argument("--breakdown", action="store_true",
                    help="print the per-kernel time breakdown to stderr")
     a = p.parse_args()
@@ -459,6 +463,12 @@ def measured_traffic(workload, launch_n):
             continue
         if doc.get("positions_per_launch") != launch_n:
             continue
+        # the counters belong to the kernels they were collected on: a file
+        # whose build id is not the loaded library's is not quoted
+        from tike_amd._lib import build_id
+        if doc.get("build_id") != build_id():
+            return {}, None, os.path.basename(f) + " (STALE: collected on "
+            "another build of csrc/; re-run tools/profile_round.sh)"
         per = {k: v.get("hbm_bytes_per_launch")
                for k, v in doc.get("kernels", {}).items()}
         per.update({k: v.get("hbm_bytes_per_launch")
@@ -620,6 +630,17 @@ def epoch_leg(workload, tp, A, torch, positions=0, epochs=None):
     return leg
 
 
+def leg_traffic(workload, entry, N, ms):
+    """PMC bytes of one operator call from profiles/ (None while no file of
+    this build exists) and the rate they crossed the HBM interface at."""
+    per_call, _, source = measured_traffic(workload, N)
+    moved = per_call.get(entry)
+    out = dict(traffic=moved, traffic_source=source)
+    if moved:
+        out["traffic_frac"] = moved / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return out
+
+
 def forward_leg(ops, A, torch, det, S, N, iters=40, warm=8):
     """One short leg of the forward operator alone (hip-event timed).  The
     GPU has idled while the host generated the inputs: `warm` untimed calls
@@ -645,7 +666,8 @@ def forward_leg(ops, A, torch, det, S, N, iters=40, warm=8):
     return dict(workload=f"fwd{det}x{S}", positions=N, ms_per_launch=ms,
                 value=N / (ms * 1e-3), unit="patterns/s",
                 achieved_GBs=nbytes / (ms * 1e-3) / 1e9,
-                frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                **leg_traffic(f"fwd{det}x{S}", "tike_ptycho_fwd", N, ms))
 
 
 def adjoint_problem(ops, A, torch, det, S, N, lo=0, hi=None, total=None):
@@ -689,7 +711,66 @@ def adjoint_leg(ops, A, torch, det, S, N, iters=40, warm=8):
     return dict(workload=f"adj{det}x{S}", positions=N, ms_per_launch=ms,
                 value=N / (ms * 1e-3), unit="patterns/s",
                 achieved_GBs=nbytes / (ms * 1e-3) / 1e9,
-                frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                **leg_traffic(f"adj{det}x{S}", "tike_ptycho_adj", N, ms))
+
+
+def ranks_agreement(ctx, world, torch, dist):
+    """Float64 checksums of the replicated state of every rank, gathered:
+    `ranks_agree` = the largest relative spread of any checksum over the
+    ranks (0.0: bit-identical sums), `rccl_ranks` = what an all-reduce of 1.0
+    over the live backend returns (the ranks the collectives really span),
+    `collective_backend` its name."""
+    prm = ctx.parameters
+    psi, probe = prm.psi.to(torch.complex128), prm.probe.to(torch.complex128)
+    costs = prm.algorithm_options.costs
+    sums = torch.stack([
+        psi.abs().square().sum(), psi.real.sum(), psi.imag.sum(),
+        probe.abs().square().sum(), probe.real.sum(), probe.imag.sum(),
+        torch.tensor(float(costs[-1][0]) if costs else 0.0,
+                     dtype=torch.float64, device=psi.device)]).to(torch.float64)
+    one = torch.ones(1, dtype=torch.float32, device=psi.device)
+    if dist.is_initialized() and dist.get_backend() != "nccl":
+        sums, one = sums.cpu(), one.cpu()  # (gloo gathers host tensors)
+    if dist.is_initialized():
+        gathered = [torch.empty_like(sums) for _ in range(world)]
+        dist.all_gather(gathered, sums)
+        dist.all_reduce(one)
+        backend = dist.get_backend()
+    else:
+        gathered, backend = [sums], "none"
+    table = torch.stack(gathered)  # (world, 7)
+    scale = table.abs().amax(dim=0).clamp_min(1e-300)
+    spread = ((table.amax(dim=0) - table.amin(dim=0)) / scale).max()
+    return dict(ranks_agree=float(spread.item()),
+                rccl_ranks=int(round(float(one.item()))),
+                collective_backend=backend,
+                checksums="sum |psi|^2, Re psi, Im psi, |probe|^2, Re probe, "
+                "Im probe, last cost (float64), all-gathered")
+
+
+def allreduce_probe(nbytes, world, torch, dist, calls=100):
+    """The object-gradient-sized sum all-reduce alone, `calls` times back to
+    back (HIP events): what a minibatch pays for the link."""
+    buf = torch.zeros(nbytes // 4, dtype=torch.float32, device="cuda")
+    for _ in range(5):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+    e0.record()
+    for _ in range(calls):
+        dist.all_reduce(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / calls
+    t = torch.tensor([ms], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())
+    return dict(bytes=nbytes, calls=calls, avg_ms=ms,
+                algbw_GBs=nbytes / (ms * 1e-3) / 1e9,
+                busbw_GBs=(2 * (world - 1) / max(world, 1)) * nbytes /
+                (ms * 1e-3) / 1e9, backend=dist.get_backend())
 
 
 def main():
@@ -910,6 +991,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    # ---- a multi-rank line has to prove itself: the replicated state (object,
+    # probe, last cost) must be the SAME on every rank after the timed steps
+    # (all-reduced gradients -> identical updates, reference comm.py:96-136),
+    # and the collective backend must really span `world` ranks
+    agreement = None
+    if (world > 1 or forced) and ctx is not None:
+        agreement = ranks_agreement(ctx, world, torch, dist)
+        if agreement["ranks_agree"] > 1e-6:
+            sys.exit(f"bench.py: the ranks hold different states after the "
+                     f"timed steps (max relative spread of the checksums "
+                     f"{agreement['ranks_agree']:.3e} > 1e-6): no value is "
+                     f"reported for a job whose ranks disagree\n{agreement}")
+    probe_line = None
+    if a.allreduce_probe and (world > 1 or forced):
+        probe_line = allreduce_probe(8 * p["HW"]**2, world, torch, dist)
+
     secondary = None
     if (rank == 0 and world == 1 and a.workload == "c3"
             and not a.no_secondary):
@@ -1084,6 +1181,10 @@ def main():
                     algbw_GBs=nbytes / (big["avg_ms"] * 1e-3) / 1e9,
                     busbw_GBs=(2 * (world - 1) / max(world, 1)) * nbytes /
                     (big["avg_ms"] * 1e-3) / 1e9)
+        if agreement is not None:
+            line.update(agreement)
+        if probe_line is not None:
+            line["allreduce_probe"] = probe_line
         if secondary is not None:
             line["secondary"] = secondary
         if cpu_job is not None:

@@ -40,6 +40,11 @@ extern "C" {
  * (tike_amd/_lib.py does; INTEGRATION.md shows the check). */
 #define TIKE_ABI_VERSION 11
 
+/* sha256 (64 hex digits) of the sources the library was built from: the PMC
+ * traffic files under profiles/ carry it, and bench.py withholds a traffic
+ * figure whose kernels are no longer the ones loaded.  Host only. */
+const char* tike_build_id(void);
+
 /* The TIKE_ABI_VERSION the library was built from.  No device, no allocation. */
 int tike_abi_version(void);
 

@@ -145,3 +145,19 @@ def test_cluster_entries_on_the_host():
     assert lib.tike_cluster_swap_sweep(ptr(dist), 0, 2, ptr(label), ptr(best),
                                        ptr(order), ptr(regret),
                                        ctypes.byref(moved)) == 1000001
+
+
+def test_build_id_is_the_hash_of_the_sources_in_the_tree():
+    """`tike_build_id()` = sha256 over the sources in the Makefile's order: the
+    loaded library was built from THIS tree (profiles/*_pmc_traffic_*.json
+    carry the id; bench.py quotes a traffic figure only for the same build)."""
+    import hashlib
+    import re
+    csrc = os.path.join(os.path.dirname(L.LIB_PATH))
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = re.search(r"^SRCS = (.*)$", mk, flags=re.M).group(1).split()
+    hdrs = re.search(r"^HDRS = (.*)$", mk, flags=re.M).group(1).split()
+    h = hashlib.sha256()
+    for name in srcs + hdrs + ["cluster_host.cpp"]:
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    assert L.build_id() == h.hexdigest()

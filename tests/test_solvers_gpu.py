@@ -1402,13 +1402,24 @@ def test_bench_whole_job_line_of_two_ranks():
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
          "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
          "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus",
-         "2", "--steps", "2", "--warmup", "1", "--positions", "160"],
+         "2", "--steps", "2", "--warmup", "1", "--positions", "160",
+         "--allreduce-probe"],
         env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    # the line proves itself: every rank holds the same object, probe and
+    # cost after the timed steps (float64 checksums, all-gathered), and an
+    # all-reduce of 1.0 over the live backend counts both ranks
+    assert line["ranks_agree"] <= 1e-6, line["ranks_agree"]
+    assert line["rccl_ranks"] == 2 and line["collective_backend"] == "gloo"
+    # the object-gradient-sized all-reduce timed on its own
+    assert line["allreduce_probe"]["bytes"] == line["allreduce"][
+        "object_slice"]["bytes"]
+    assert line["allreduce_probe"]["calls"] == 100
+    assert line["allreduce_probe"]["avg_ms"] > 0
     assert line["config"]["positions_per_gpu"] == 160
     # whole-job value = all ranks' positions over the slowest rank's time
     np.testing.assert_allclose(
@@ -1486,6 +1497,9 @@ def test_bench_rccl_path_through_the_launcher():
     big = line["allreduce"]["object_slice"]
     assert 10 <= big["calls_per_step"] <= 11 and big["bytes"] > 0
     assert big["avg_ms"] > 0 and big["busbw_GBs"] == 0  # one rank: no traffic
+    # the self-checks of a multi-rank line, through RCCL itself (one rank)
+    assert line["collective_backend"] == "nccl" and line["rccl_ranks"] == 1
+    assert line["ranks_agree"] == 0.0
     assert 0 < line["roofline"]["iteration_hbm_frac"] < 1
 
 

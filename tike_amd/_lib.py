@@ -163,6 +163,18 @@ _PROTOTYPES = {
 }
 
 
+def build_id():
+    """sha256 of the sources the loaded library was built from
+    (`tike_build_id`; '' for a library older than round 6)."""
+    try:
+        fn = lib.tike_build_id
+    except AttributeError:
+        return ""
+    fn.restype = ctypes.c_char_p
+    fn.argtypes = []
+    return fn().decode()
+
+
 def declared_symbols():
     """Names of every function declared in include/tike_amd.h."""
     with open(HEADER_PATH) as f:
@@ -220,13 +232,25 @@ _det_scratch = None
 
 
 def ensure_deterministic():
-    """Hand the library its scratch buffer once (no-op unless
-    TIKE_DETERMINISTIC=1)."""
+    """Hand the library its scratch buffer (no-op unless TIKE_DETERMINISTIC=1).
+    The buffer lives on ONE device -- the library's pointer is process-wide --
+    and its users are ordered by ONE stream: when the current device is no
+    longer the buffer's (torch.cuda.set_device, a second Reconstruction on
+    another GPU) the buffer is re-allocated there and registered again, after
+    the work in flight on the old one has finished.  Two devices driven
+    concurrently from one process are not supported in this mode (one process
+    per GPU is the design)."""
     global _det_scratch
-    if not DETERMINISTIC or _det_scratch is not None:
+    if not DETERMINISTIC:
         return
+    current = torch.cuda.current_device()
+    if _det_scratch is not None and _det_scratch.device.index == current:
+        return
+    if _det_scratch is not None:
+        torch.cuda.synchronize(_det_scratch.device)
     _det_scratch = torch.empty(DETERMINISTIC_SCRATCH_MIB << 20,
-                               dtype=torch.uint8, device="cuda")
+                               dtype=torch.uint8,
+                               device=torch.device("cuda", current))
     check(lib.tike_set_deterministic(1, _det_scratch.data_ptr(),
                                      _det_scratch.numel()),
           "tike_set_deterministic")

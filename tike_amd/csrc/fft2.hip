@@ -37,6 +37,9 @@ const cf* tk_twiddles() {
 
 extern "C" int tike_abi_version(void) { return TIKE_ABI_VERSION; }
 
+#include "build_id.h"
+extern "C" const char* tike_build_id(void) { return TIKE_BUILD_ID; }
+
 extern "C" int tike_init(void) { return tk_twiddles() ? TK_OK : (int)hipErrorNotInitialized; }
 
 // ------------------------------------------------------- deterministic mode

@@ -240,8 +240,12 @@ def reconstruct_spawned(data, parameters, devices, **kwargs):
     kwargs = dict(kwargs, order=order, batches=batches)
     small = A.is_small_integer(host.dtype)
     frame_bytes = int(np.prod(host.shape[1:])) * (2 if small else 4)
-    step = max(1, UPLOAD_BLOCK_BYTES // max(frame_bytes, 1))
-    _check_shm(2 * min(step, max(len(r) for r in rows)) * frame_bytes)
+    # one block PER RANK is in shared memory at a time (a round of the upload
+    # loop cuts `size` blocks before it waits for any of them): the blocks
+    # shrink with the number of ranks so that a round never holds more than
+    # two default blocks, and /dev/shm is checked for exactly that
+    step = max(1, 2 * UPLOAD_BLOCK_BYTES // (max(frame_bytes, 1) * max(size, 2)))
+    _check_shm(size * min(step, max(len(r) for r in rows)) * frame_bytes)
     # (drawn AFTER the clustering: the ranks continue the caller's sequences)
     blob = pickle.dumps((parameters, kwargs, np.random.get_state(),
                          tike_amd.random.randomizer_np))
@@ -249,9 +253,10 @@ def reconstruct_spawned(data, parameters, devices, **kwargs):
     ctx = mp.get_context("spawn")
     results = ctx.Queue()
     inboxes = [ctx.JoinableQueue() for _ in range(size)]
-    handle, store_path = tempfile.mkstemp(prefix="tike_amd_rendezvous_")
-    os.close(handle)
-    os.unlink(store_path)  # FileStore creates it; the name is ours
+    # a directory only this user can enter: nobody else can plant the store
+    # file between its naming here and its creation by FileStore
+    store_dir = tempfile.mkdtemp(prefix="tike_amd_rendezvous_")
+    store_path = os.path.join(store_dir, "store")
     env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update({k: v for k, v in env.items() if saved[k] is None})
@@ -292,12 +297,21 @@ def reconstruct_spawned(data, parameters, devices, **kwargs):
         # every rank's rows, a block at a time, round robin over the ranks so
         # that their uploads overlap; a block is released once it is uploaded
         cursor = [0] * size
+        warned = False
         while any(cursor[r] < len(rows[r]) for r in range(size)):
             for r in range(size):
                 lo = cursor[r]
                 if lo >= len(rows[r]):
                     continue
-                block = _as_resident(host[rows[r][lo:lo + step]])
+                raw = host[rows[r][lo:lo + step]]
+                # the check a one-rank call makes on the host (reference
+                # ptycho.py:392-397) BEFORE negative counts are clipped away
+                if not warned and (not np.all(np.isfinite(raw))
+                                   or np.any(raw < 0)):
+                    from .ptycho import _warn_invalid_data
+                    _warn_invalid_data()
+                    warned = True
+                block = _as_resident(raw)
                 shared, _ = _share(block)
                 inboxes[r].put(("rows", lo, shared))
                 cursor[r] = lo + len(block)
@@ -339,10 +353,8 @@ def reconstruct_spawned(data, parameters, devices, **kwargs):
     finally:
         for p in procs:
             p.join(60)
-        try:
-            os.unlink(store_path)
-        except OSError:
-            pass
+        import shutil
+        shutil.rmtree(store_dir, ignore_errors=True)
     result, legacy, rng = pickle.loads(message[1])
     # the generators advance as they would have in an in-process call
     np.random.set_state(legacy)

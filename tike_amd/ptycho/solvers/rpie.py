@@ -260,8 +260,16 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
     # Measured (c3rpie2, same box): 64 / 128 / 256 / 512 / 1000 positions per
     # chunk -> 45.2 / 47.4 / 49.5 / 51.2 / 52.4 k patterns/s: these stages
     # hand nothing over through the Infinity Cache, longer launches win.
+    # ... within HALF the HBM that is free right now (ranks that share a GPU,
+    # smaller parts, a resident dataset), at most 16 GiB, at least 64 positions
+    budget = 1 << 34
+    if dev.type == "cuda":
+        free = torch.cuda.mem_get_info(dev)[0]
+        held = sum(t.numel() * t.element_size() for name, t in
+                   getattr(ws, "buffers", {}).items() if name.startswith("ms_"))
+        budget = min(budget, (free + held) // 2)
     chunk = (L.chunk_positions(S, det) if L.CHUNK_POSITIONS_OVERRIDE else
-             max(64, (1 << 34) // (2 * D * S * det * det * 8)))  # 16 GiB
+             max(64, budget // (2 * D * S * det * det * 8)))
     nmax = max(1, min(chunk, B))
     far = ws.get("ms_far", (nmax, S, det, det), torch.complex64, dev)
     nback = D if STEP_BACK_IN_FREQUENCY else 1

@@ -26,6 +26,10 @@ KERNELS = {
     "void ptycho_fwd_pos_kernel<256, true>": "tike_ptycho_fwd_intensity",
     "void ptycho_fwd_pos_kernel<512": "tike_ptycho_fwd_intensity",
     "void fwd_pass1_kernel": "tike_fwd_pass1",
+    "gen_fwd_rows_kernel": "tike_gen_fwd_rows",
+    "void gen_cols_resident_kernel": "tike_gen_cols_gradient",
+    "void gen_cols_gradient_kernel": "tike_gen_cols_gradient",
+    "gen_inv_rows_gradients_kernel": "tike_gen_inv_rows_gradients",
     "void fwd_colpass_inplace_kernel": "tike_ptycho_fwd",
     "void fwd_gradient_scale_kernel": "tike_fwd_gradient_scale",
     "void fwd_grad_ifft2_pass1_kernel": "tike_fwd_grad_ifft2_pass1",
@@ -131,9 +135,16 @@ def main():
     cgrad = workload in ("c1", "c2")
     fetch = collect(fetch_dir, "FETCH_SIZE", cgrad)
     write = collect(write_dir, "WRITE_SIZE", cgrad)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tike_amd._lib import ABI_VERSION, build_id
     doc = {
         "workload": workload,
         "positions_per_launch": int(n),
+        # the kernels these counters belong to (bench.measured_traffic quotes
+        # the file only while the loaded library is this build)
+        "build_id": build_id(),
+        "abi_version": ABI_VERSION,
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on "
                 "`python3 bench.py --no-cpu-baseline --steps 1 --warmup 0`, "
                 "averaged over the launches with the largest grid (the timed "
@@ -176,6 +187,17 @@ def main():
                 "parts": list(parts),
                 "hbm_bytes_per_launch": sum(
                     doc["kernels"][k]["hbm_bytes_per_launch"] for k in parts)}}
+    if workload.startswith("fwd"):
+        # one Ptycho.fwd call = forward pass 1 + the column pass in place per
+        # sub-batch (256^2 / 512^2), or the one whole-tile launch (128^2)
+        parts = [k for k in ("tike_fwd_pass1", "tike_ptycho_fwd")
+                 if k in doc["kernels"]]
+        # (`--steps 1 --warmup 0` under the counters: one call)
+        doc["composite"] = {"tike_ptycho_fwd": {
+            "parts": parts,
+            "hbm_bytes_per_launch": sum(
+                doc["kernels"][k]["hbm_bytes_per_launch"] *
+                doc["kernels"][k]["launches"] for k in parts)}}
     if workload.startswith("adj"):
         # one Ptycho.adj call = the launches of all its sub-batches: inverse
         # pass 1, pass 2 with both products, the grouped scatter, one
