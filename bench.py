@@ -363,80 +363,24 @@ def adj_bytes(n, S, det, pw, per_position_probe=False):
 
 
 def algorithmic_bytes(name, n, S, det, pw, C):
-    """HBM bytes one launch must move for n positions."""
-    T = 8 * S * det * det  # one position's far-plane, bytes
-    P = 8 * pw * pw
-    D = 4 * det * det
-    table = {
-        "tike_ptycho_fwd": fwd_bytes(n, S, det, pw, C),
-        "tike_ptycho_adj": adj_bytes(n, S, det, pw),
-        # forward pass 1 hands a far-plane-sized array to the next kernel and
-        # stores the object patches
-        "tike_fwd_pass1": n * (T + 2 * P + 8) + (S + C) * P,
-        # column pass -> intensity -> gradient factor: reads the hand-off and
-        # the data, writes the factor
-        "tike_fwd_gradient_scale": n * (T + 2 * D),
-        # line-search probes: no patches / no gradient factor stored
-        "tike_fwd_pass1:cost_only": n * (T + P + 8) + (S + C) * P,
-        "tike_fwd_gradient_scale:cost_only": n * (T + D + 4),
-        "tike_ptycho_fwd_gradient_scale":
-        n * (T + P + 2 * D + 8) + (S + C) * P,
-        "tike_ptycho_fwd_intensity": n * (T + P + D + 8) + (S + C) * P,
-        "tike_ptycho_fwd_intensity_only": n * (T + P + D + 8) + (S + C) * P,
-        "tike_ifft2_crop_scaled": n * (T + S * P + D),
-        "tike_grad_ifft2_crop": n * (T + S * P + D),
-        # gradient + inverse pass 1: hand-off in, intermediate out
-        "tike_grad_ifft2_pass1": n * (2 * T + D),
-        # column pass + gradient factor + inverse pass 1 in one launch: the
-        # hand-off and the data in, the intermediate out (it reads the
-        # hand-off twice; the second read is not algorithmic)
-        "tike_fwd_grad_ifft2_pass1": n * (2 * T + D),
-        # poisson, every pixel measured: first sweep of the step lengths (the
-        # hand-off and the data in), then second sweep + gradient + inverse
-        # pass 1 (both in again -- the sweeps are separated by a sum over the
-        # whole pattern -- the intermediate out)
-        "tike_poisson_steps_grad_ifft2_pass1": n * (3 * T + 2 * D),
-        "tike_ifft2_pass2_gradients_scaled": n * (T + 3 * P) + S * P,
-        # inverse pass 2 + both gradients: intermediate + patches in,
-        # objproj + chi0 out (+ the probe gradient, probe-sized)
-        "tike_ifft2_pass2_gradients": n * (T + 3 * P) + S * P,
-        # the five far-plane-free stages in one call (cgrad's gradient pass:
-        # no chi0 stored)
-        "tike_lstsq_chunk_gradients":
-        (n * (T + 2 * P + 8) + (S + C) * P)
-        + (n * (2 * T + D) if det == 256 else n * (T + 2 * D) + n * (2 * T + D))
-        + (n * (T + 2 * P) + S * P) + n * (P + 8 * (pw + 1) * (pw + 1)),
-        "tike_gradient_scale": n * 3 * D,
-        "tike_farplane_gradient": n * (2 * T + D + 4),
-        "tike_ifft2_crop": n * (T + S * P),
-        "tike_lstsq_gradients": n * (S * P + 2 * P),
-        "tike_scatter_patches": n * (P + 8 * (pw + 1) * (pw + 1)),
-        "tike_lstsq_step_stats": n * (3 * P + 32),
-        # ---- the stages of a multislice object (no patches stored there)
-        "tike_fwd_pass1:no_patches": n * (T + P + 8) + (S + C) * P,
-        # the probe incident on a slice behind the first: one wave per position in
-        "tike_fwd_pass1:incident": n * (2 * T + P + 8),
-        "tike_fresnel_colpass": n * 2 * T + D * 2,
-        "tike_fft2_pass2_inplace": n * 2 * T,
-        # last pass of a slice step + illumination (the wave itself not written)
-        "tike_fft2_pass2_intensity": n * (T + D),
-        # gradient pass of the last slice: hand-off + data in, one intermediate
-        # per slice out
-        "tike_fwd_grad_ifft2_pass1_slices": n * (T + D + MULTISLICE_DEPTH * T),
-        # inverse pass 2 + both numerators of a slice: intermediate in, object
-        # patch gathered, objproj (+ mode 0 of chi) out
-        "tike_ifft2_pass2_products": n * (T + 3 * P) + S * P,
-        "tike_ifft2_pass2_products:incident": n * (2 * T + 2 * P),
-    }
-    return table.get(name, 0)
+    """HBM bytes one launch must move for n positions:
+    the operator entries here, every stage entry of a chunk from the byte
+    models the GradientPlan carries (tike_amd/ptycho/solvers/_plan.py)."""
+    from tike_amd.ptycho.solvers._plan import algorithmic_bytes as stage_bytes
+    if name == "tike_ptycho_fwd":
+        return fwd_bytes(n, S, det, pw, C)
+    if name == "tike_ptycho_adj":
+        return adj_bytes(n, S, det, pw)
+    return stage_bytes(name, n, S, det, pw, C, depth=MULTISLICE_DEPTH)
 
 
-def dominant_entry(summary, n, S, det, C):
+def dominant_entry(summary, n, S, det, C, pw=None):
     """The tike_* entry with the most time among those with a byte model (a
     composite such as tike_cgrad_line_search -- many small launches under one
     name -- has none and cannot carry a roofline)."""
     ks = {k: v for k, v in summary.items() if k.startswith("tike_")}
-    modelled = [k for k in ks if algorithmic_bytes(k, n, S, det, det, C)]
+    modelled = [k for k in ks
+                if algorithmic_bytes(k, n, S, det, pw or det, C)]
     return max(modelled or ks, key=lambda k: ks[k]["total_ms"])
 
 
@@ -922,6 +866,8 @@ def main():
                         solver=SOLVER_LABEL.get(a.workload, "lstsq_grad"),
                         num_batch=num_batch, chunk_positions=launch_n,
                         position_correction=a.workload == "c5")
+        if p["pw"] != det:
+            workload["probe_width"] = p["pw"]
         if a.workload not in ("c1", "c2"):
             workload["object_update"] = (
                 "after every minibatch (batch_method wobbly_center)"
@@ -991,6 +937,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    plans = list(getattr(getattr(ctx, "operator", None), "_tike_amd_plans",
+                         {}).values()) if ctx is not None else []
     # ---- a multi-rank line has to prove itself: the replicated state (object,
     # probe, last cost) must be the SAME on every rank after the timed steps
     # (all-reduced gradients -> identical updates, reference comm.py:96-136),
@@ -1052,9 +1000,9 @@ def main():
         # timed steps themselves
         full, full_wall = profile if profile is not None else (summ, wall)
         kernels = {k: v for k, v in full.items() if k.startswith("tike_")}
-        pw = det
+        pw = p.get("pw", det) if isinstance(p, dict) else det
         if dominant is None:
-            dominant = dominant_entry(full, launch_n, S, det, C)
+            dominant = dominant_entry(full, launch_n, S, det, C, pw)
         k = summ.get(dominant) or full[dominant]
         if k.get("positions"):
             # launches of different sizes under one entry: the mean launch
@@ -1185,6 +1133,11 @@ def main():
             line.update(agreement)
         if probe_line is not None:
             line["allreduce_probe"] = probe_line
+        # the route the chunks took and the launches it names (GradientPlan,
+        # cached on the operator by the first minibatch)
+        if plans:
+            line["config"]["route"] = plans[-1].route
+            line["config"]["launches"] = list(plans[-1].launches)
         if secondary is not None:
             line["secondary"] = secondary
         if cpu_job is not None:

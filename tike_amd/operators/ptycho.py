@@ -6,11 +6,11 @@ for the adjoint, the two-pass inverse transform whose second pass forms both
 products in place (``tike_ptycho_adj``; other shapes: ``tike_ifft2_crop``
 followed by the unfused object scatter-add and probe product).
 """
-import os
 
 import numpy as np
 import torch
 
+from .. import _tuning
 from .. import _arrays as A
 from .._lib import check, lib
 from . import objective
@@ -23,9 +23,10 @@ def sub_batch_positions(S, det, mib=None):
     """Positions per sub-batch of the two-kernel 256^2 / 512^2 operators: the
     ``sub_batch`` argument of ``tike_ptycho_fwd`` / ``tike_ptycho_adj``
     (0 = the library's default of 256 MiB of far plane, -1 = one batch).
-    ``TIKE_FWD_SUB_MIB`` is read HERE, on the host side of the C ABI."""
+    ``TIKE_FWD_SUB_MIB`` (`tike_amd._tuning`) is read on the host side of
+    the C ABI, never inside the library."""
     if mib is None:
-        mib = os.environ.get("TIKE_FWD_SUB_MIB")
+        mib = _tuning.fwd_sub_mib
     if mib is None:
         return 0
     mib = float(mib)

@@ -6,17 +6,17 @@ position) and ``tike_probe_preconditioner``.  Unlike the reference (whose all-re
 commented out, :185,201, because every GPU owns a spatial stripe) positions
 are sharded across ranks here, so both preconditioners are summed over ranks.
 """
-import os
 
 import torch
 
+from ... import _tuning
 from ... import _arrays as A
 from ..._lib import check, lib
 from ...operators.multislice import fused_slices, next_incident_probe
 from ...operators.propagation import fft_scales
 
 
-MULTISLICE_CHUNK = int(os.environ.get("TIKE_PRECOND_CHUNK", "512"))
+MULTISLICE_CHUNK = _tuning.precond_chunk
 """Positions per launch of the fused multislice object preconditioner
 (c3rpie2 at 64 / 128 / 256 / 512: 49.1 / 49.5 / 50.2 / 50.6 k patterns/s)."""
 

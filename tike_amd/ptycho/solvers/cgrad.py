@@ -9,11 +9,11 @@ following the multi-GPU pattern of lamino/solvers/cgrad.py:58-92: the cost and
 the gradient are summed over ranks, every rank then takes the same step.
 """
 import logging
-import os
 
 import numpy as np
 import torch
 
+from ... import _tuning
 from ... import _arrays as A
 from ... import opt
 from ..._lib import check, lib
@@ -400,7 +400,7 @@ def _cg_device(plan, op, comm, psi, probe, variable, num_iter, step_length,
         bufs, linear=linear))
 
 
-USE_GRAPHS = os.environ.get("TIKE_CGRAD_GRAPHS", "0") == "1"
+USE_GRAPHS = _tuning.cgrad_graphs
 """A conjugate-gradient call is a fixed sequence of ~10 launches per trial
 slot whose only data-dependent control flow lives on the device (the `skip`
 word), so it can be captured once and replayed as a HIP graph from its second

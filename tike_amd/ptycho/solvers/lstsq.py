@@ -18,18 +18,20 @@ Differences from the reference that do not change the mathematics:
     iterates up to summation order.
 """
 import logging
-import os
+from types import SimpleNamespace
 
 import numpy as np
 import torch
 
 from ... import _arrays as A
+from ... import _tuning
 from ... import linalg
 from ... import opt
 from ... import random as trandom
 from ..._lib import check, lib
 from ...operators.propagation import fft_scales
 from ..position import gaussian_derivative_taps
+from ._plan import GradientPlan
 
 logger = logging.getLogger(__name__)
 
@@ -66,13 +68,11 @@ SPLIT_FORWARD_SIZES = (256, 512)
 (tike_ptycho_fwd_intensity) and the gradient-scaled inverse."""
 
 
-import os as _os
-
 ONE_LAUNCH_GRADIENT_SIZES = (256, 512)
 """Detector sizes whose forward column pass, gradient factor and inverse pass
 1 are one launch (tike_fwd_grad_ifft2_pass1; 512^2 since round 5); A/B runs
 and tests shorten it to fall back to the two launches."""
-if _os.environ.get("TIKE_ONE_LAUNCH_512", "1") == "0":
+if not _tuning.one_launch_512:
     ONE_LAUNCH_GRADIENT_SIZES = (256,)
 
 POISSON_FROM_HANDOFF = True
@@ -80,13 +80,12 @@ POISSON_FROM_HANDOFF = True
 (tike_poisson_steps_handoff) instead of from a stored far plane; tests set
 this to False to compare the two pipelines."""
 
-POISSON_STEPS_IN_PASS2 = _os.environ.get("TIKE_POISSON_LINEAR", "1") == "1"
+POISSON_STEPS_IN_PASS2 = _tuning.poisson_steps_in_pass2
 """Every pixel measured, 256^2: the second sweep of the per-mode poisson step
 lengths and the gradient pass in one launch, the steps applied by pass 2
 (tike_poisson_steps_grad_ifft2_pass1)."""
 
-CHUNK_POSITIONS_OVERRIDE = (int(_os.environ["TIKE_CHUNK_POSITIONS"])
-                            if _os.environ.get("TIKE_CHUNK_POSITIONS") else None)
+CHUNK_POSITIONS_OVERRIDE = _tuning.chunk_positions
 """Tests set this to force small kernel chunks (several per minibatch);
 TIKE_CHUNK_POSITIONS does the same for A/B runs of the bench."""
 
@@ -362,13 +361,13 @@ psi (L2) instead of streaming the stored ones (HBM): 0.186 -> 0.160 ms per 1000
 positions at 256^2.  (With two 16-byte tap loads per pixel the position sums
 lost by it, 0.215 -> 0.221 ms; see EIGEN_SUMS_RECOMPUTE.)"""
 
-EIGEN_SUMS_RECOMPUTE = os.environ.get("TIKE_EIGEN_SUMS_GATHER", "1") == "1"
+EIGEN_SUMS_RECOMPUTE = _tuning.eigen_sums_gather
 """The position sums gather too, through the two-positions-per-workgroup row
 walk of tike_eigen_position_sums1 (one 16-byte tap load per pixel and
 position, E_0 and the probe update loaded once per pair): 0.215 -> 0.176 ms
 per 1000 positions at 256^2."""
 
-STATS_PATCH_RECOMPUTE = os.environ.get("TIKE_STATS_GATHER", "0") == "1"
+STATS_PATCH_RECOMPUTE = _tuning.stats_gather
 """The step statistics gather O_n from the object with the two 16-byte tap
 loads they already issue for the preconditioned update (same offsets)."""
 
@@ -394,11 +393,26 @@ def _eigen_args(eigen_probe, weights):
     return eigen_probe, weights, C, Sm
 
 
+def _once(make):
+    """`make()` evaluated at the first call, the same value afterwards."""
+    box = []
+
+    def get():
+        if not box:
+            box.append(make())
+        return box[0]
+
+    return get
+
+
 def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
                              eigen_weights, lo, hi, comm, *, num_batch,
                              exitwave_options, op, recover_psi, recover_probe,
                              position_terms=None, need_chi0=True):
-    """Object / probe gradients of one minibatch (lstsq.py:367-602).
+    """Object / probe gradients of one minibatch (lstsq.py:367-602).  Which
+    kernels a chunk runs is the GradientPlan of the shape (`_plan.py`, cached
+    on the operator like the reference's FFT plan, cache.py:32-46); this
+    function walks the chunks and completes the sums over the ranks.
     need_chi0=False (cgrad: no step statistics follow) skips the store of
     mode 0 of chi where the fused pass 2 would be its only producer."""
     dev = psi.device
@@ -406,16 +420,16 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     S, pw = probe.shape[-3], probe.shape[-1]
     det = op.detector_shape
     H, W = psi.shape[-2:]
-    ws = _workspace(op)
-    st = A.stream_ptr()
-    fwd_scale, inv_scale = fft_scales(det, op.norm)
+    if exitwave_options.noise_model not in _MODELS:
+        raise ValueError(
+            f"unknown noise model {exitwave_options.noise_model!r}")
     nmeasured, mask_u8 = mask_info(exitwave_options, det)
+    plan = GradientPlan.for_(op, S, pw, det, exitwave_options, mask_u8)
+    fwd_scale, inv_scale = fft_scales(det, op.norm)
 
     # the weights this gradient uses; every consumer (forward, gradients, step
     # statistics) runs before _update_nearplane changes them in place
-    w_old = None
-    if eigen_weights is not None:
-        w_old = eigen_weights[lo:hi]
+    w_old = None if eigen_weights is None else eigen_weights[lo:hi]
     ep, _, C, Sm = _eigen_args(eigen_probe, w_old)
 
     # planar (real plane, imaginary plane) float32 accumulator of the object
@@ -432,353 +446,56 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     # ... started as soon as pass 2 has finished that slice; decided from what
     # every rank knows alike (never from this rank's share of the positions)
     early = bool(comm.collective and recover_psi and recover_probe)
-    chi0 = None  # allocated below unless chi itself can be handed on
-    patches = None
-    pos_major = det in POSITION_MAJOR_SIZES
-    # inverse pass 2 fused with both gradients (chi never stored): probe
-    # window = detector, at most 8 modes (4 at 512^2)
-    fused = fused_gradients(S, pw, det)
-    # every other shape, gaussian model: the three shape-general launches
-    # (zero padding, far plane and chi never stored); downstream it looks
-    # like the fused route (patches and chi0 stored, 1/num_batch applied)
-    # (detector sizes with position-major kernels -- 128, 256, 512 -- keep
-    # those for pw < det or many modes: measured faster, c3pad 160 vs 88 k
-    # patterns/s, c3m12 69 vs 41 k, profiles/r06_experiments.md)
-    general = (not fused and (not pos_major or GENERAL_FUSED == "always")
-               and exitwave_options.noise_model == "gaussian"
-               and general_gradients(S, pw, det))
-    if general:
-        pos_major = False
-    if ((recover_probe and eigen_weights is not None) or position_terms
-            or fused or general):
-        patches = ws.get("patches", (max(B, 1), pw, pw), torch.complex64, dev)
+    buf = plan.buffers(
+        _workspace(op), B, dev, varying=Sm if w_old is not None else 0,
+        want_patches=bool((recover_probe and eigen_weights is not None)
+                          or position_terms))
     if position_terms:
         taps, taps_r = gaussian_derivative_taps(sigma=0.333)
-    costs = ws.get("costs", (max(B, 1),), torch.float32, dev)
-    chunk = chunk_positions(S, det, pos_major or general)
-    poisson = exitwave_options.noise_model == "poisson"
-    inten = gscale = steps = None
-    if pos_major or poisson:
-        inten = ws.get("intensity", (min(chunk, max(B, 1)), det, det),
-                       torch.float32, dev)
-    if pos_major:
-        gscale = ws.get("gscale", (min(chunk, max(B, 1)), det, det),
-                        torch.float32, dev)
-    # detector sizes with the far-plane-free pipeline (the per-mode poisson
-    # steps of 'all_modes' need |F_s|^2 and keep the stored far plane)
-    # (512^2: only together with the fused pass 2, the generic gradient +
-    # inverse + crop kernel exists at 256^2 only)
-    # (round 4: with the fused pass 2 the per-mode steps come from two more
-    # column passes over the forward hand-off, tike_poisson_steps_handoff, and
-    # the far plane is not kept either)
-    all_modes = (poisson and exitwave_options.step_length_usemodes
-                 != "dominant_mode")
-    no_farplane = (pos_major
-                   and (det in NO_FARPLANE_SIZES or (det == 512 and fused))
-                   and not (all_modes and not (fused and POISSON_FROM_HANDOFF)))
-    if poisson:
-        # per-(position, mode) step lengths (exitwave.py:122-234)
-        steps = ws.get("steps", (min(chunk, max(B, 1)), S), torch.float32,
-                       dev)
-        dominant = int(
-            exitwave_options.step_length_usemodes == "dominant_mode")
-        step_start = float(exitwave_options.step_length_start)
-        step_weight = float(exitwave_options.step_length_weight)
-    objproj = ws.get("objproj", (min(chunk, max(B, 1)), pw, pw),
-                     torch.complex64, dev)
-    unique = None
-    if w_old is not None and Sm > 0 and not general:
-        unique = ws.get("unique", (min(chunk, max(B, 1)), Sm, pw, pw),
-                        torch.complex64, dev)
-    # (general: the two hand-offs hold the pw rows of the probe window only)
-    far = ws.get("far", (min(chunk, max(B, 1)), 1, S, pw if general else det,
-                         det), torch.complex64, dev)
-    # the inverse transform is out of place (far -> mid); chi is the cropped
-    # result and aliases mid when the probe fills the detector
-    mid = ws.get("mid", tuple(far.shape), torch.complex64, dev)
-    chi_ws = mid
-    if pw != det and not general:
-        chi_ws = ws.get("chi", (min(chunk, max(B, 1)), 1, S, pw, pw),
-                        torch.complex64, dev)
-
-    # mode 0 of chi is read again after the whole minibatch (step sizes,
-    # eigen probes).  When the minibatch is one chunk, chi is still intact
-    # then and is handed on with a mode stride; otherwise mode 0 is packed.
-    # 256^2 / 512^2 with the far plane kept: split forward, intermediate in `far`
-    split_kept = (pos_major and fused and not no_farplane
-                  and det in SPLIT_FORWARD_SIZES)
-    single_chunk = B <= chunk and not fused and not general
-    if not single_chunk:
-        chi0 = ws.get("chi0", (max(B, 1), pw, pw), torch.complex64, dev)
+    # what every chunk shares
+    c = SimpleNamespace(
+        op=op, data=data, psi=psi, probe=probe, ep=ep, eigen_probe=eigen_probe,
+        C=C, Sm=Sm, H=H, W=W, st=A.stream_ptr(), fwd_scale=fwd_scale,
+        inv_scale=inv_scale, nmeasured=nmeasured, mask_u8=mask_u8,
+        unmeasured=float(exitwave_options.unmeasured_pixels_scaling),
+        step_start=float(exitwave_options.step_length_start),
+        step_weight=float(exitwave_options.step_length_weight), buf=buf,
+        m_probe_update=m_probe_update, num_batch=num_batch,
+        recover_psi=recover_psi, need_chi0=need_chi0)
+    chunk = plan.chunk
     for clo in range(lo, hi, chunk):
         chi_hi = min(hi, clo + chunk)
-        n = chi_hi - clo
-        blo = clo - lo
-        w_c = None if w_old is None else w_old[blo:blo + n]
-        chi = chi_ws
-        uq = None
-        steps_in_pass2 = False
-        if w_c is not None and Sm > 0 and not no_farplane and not general:
-            # varying probe of the modes that own eigen probes, once per chunk
-            # (the 256^2 kernels form it on the fly instead)
-            uq = unique[:n]
-            check(
-                lib.tike_varying_probe(A.ptr(probe), A.ptr(ep), A.ptr(w_c), C,
-                                       Sm, A.ptr(uq), n, S, pw, st),
-                "varying probe")
-        model = _MODELS[exitwave_options.noise_model]
-        unmeasured = float(exitwave_options.unmeasured_pixels_scaling)
+        n, blo = chi_hi - clo, clo - lo
+        rows = slice(blo, blo + n)
+        k = SimpleNamespace(
+            n=n, scan=scan[clo:chi_hi], data=data[clo:chi_hi],
+            w=None if w_old is None else w_old[rows], uq=None,
+            costs=buf.costs[rows],
+            patches=None if buf.patches is None else buf.patches[rows],
+            chi0=None if buf.chi0 is None else buf.chi0[rows])
         # float32 view of the chunk for the kernels without a 16-bit loader
-        # (the 256^2 gaussian hot path reads uint16 directly)
-        dchunk = None
-        if not (pos_major and no_farplane and not (poisson and dominant)):
-            dchunk = A.data_f32(data, clo, chi_hi)
-        if general:
-            # K1 rows (patch x probe, zero padding made in LDS) -> K2 columns
-            # (intensity, cost, gradient factor, inverse columns) -> K3 below
+        # (the 256^2 gaussian hot path reads uint16 directly), made on demand
+        k.data_f32 = _once(lambda a=clo, b=chi_hi: A.data_f32(data, a, b))
+        if k.w is not None and Sm > 0 and buf.unique is not None and (
+                not plan.no_farplane):
+            # varying probe of the modes that own eigen probes, once per chunk
+            # (the 256^2 and the shape-general kernels form it on the fly)
+            k.uq = buf.unique[:n]
             check(
-                lib.tike_gen_fwd_rows(
-                    A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0, None,
-                    A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(far),
-                    A.ptr(patches[blo:blo + n]), n, S, pw, det, H, W, st),
-                "general forward rows")
-            check(
-                lib.tike_gen_cols_gradient(
-                    A.ptr(far), A.ptr(dchunk), A.ptr(mask_u8),
-                    A.ptr(costs[blo:blo + n]), A.ptr(mid), n, S, pw, det,
-                    fwd_scale, model, unmeasured, nmeasured, st),
-                "general columns + gradient")
-        elif pos_major and no_farplane:
-            # the far-plane waves never reach memory: the forward kernel forms
-            # them in registers for the intensity and leaves the input of its
-            # column pass in `far`; the inverse kernel re-forms them from
-            # there, applies the gradient factor and transforms back
-            # (the gradient factor and the costs come out of the same launch;
-            # the intensity itself is stored only for the poisson steps)
-            check(
-                lib.tike_fwd_pass1(
-                    A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
-                    None, A.ptr(ep), A.ptr(w_c), C, Sm, A.ptr(far),
-                    A.ptr(patches[blo:blo + n]) if fused else None, n, S, pw,
-                    det, H, W, st), "forward pass 1")
-            # 256^2 without poisson step lengths: the column pass, the gradient
-            # factor and the inverse's pass 1 are ONE launch (the factor never
-            # goes through memory)
-            one_launch = (fused and not poisson
-                          and det in ONE_LAUNCH_GRADIENT_SIZES)
-            # no gradient at unmeasured pixels (none of them, or the default
-            # unmeasured_pixels_scaling = 1): the gradient is linear in the
-            # step lengths, so their second sweep and the gradient pass are
-            # one launch and pass 2 applies them
-            steps_in_pass2 = (poisson and not dominant and fused
-                              and det == 256
-                              and (mask_u8 is None or unmeasured == 1.0)
-                              and POISSON_STEPS_IN_PASS2)
-            if steps_in_pass2:
-                sums = ws.get("poisson_sums", (min(chunk, max(B, 1)), S, 2),
-                              torch.float32, dev)
-                check(
-                    lib.tike_poisson_steps_grad_ifft2_pass1(
-                        A.ptr(far), A.ptr(data[clo:chi_hi]),
-                        int(data.dtype == torch.uint16), A.ptr(mask_u8),
-                        A.ptr(costs[blo:blo + n]), A.ptr(steps), A.ptr(sums),
-                        A.ptr(mid), n, S, det, fwd_scale, unmeasured,
-                        nmeasured, step_start, step_weight, st),
-                    "poisson step lengths + gradient + inverse pass 1")
-            elif poisson and not dominant:
-                # gradient factor, costs and the per-mode step lengths from
-                # the hand-off: three reads of it, no far plane stored
-                sums = ws.get("poisson_sums", (min(chunk, max(B, 1)), S, 2),
-                              torch.float32, dev)
-                check(
-                    lib.tike_poisson_steps_handoff(
-                        A.ptr(far), A.ptr(data[clo:chi_hi]),
-                        int(data.dtype == torch.uint16), A.ptr(mask_u8),
-                        A.ptr(gscale), A.ptr(costs[blo:blo + n]),
-                        A.ptr(steps), A.ptr(sums), n, S, det, fwd_scale,
-                        unmeasured, nmeasured, step_start, step_weight, st),
-                    "forward pass 2 + poisson factor and step lengths")
-            elif one_launch:
-                check(
-                    lib.tike_fwd_grad_ifft2_pass1(
-                        A.ptr(far), A.ptr(data[clo:chi_hi]),
-                        int(data.dtype == torch.uint16), A.ptr(mask_u8),
-                        A.ptr(costs[blo:blo + n]), A.ptr(mid), n, S, det,
-                        fwd_scale, model, unmeasured, nmeasured, st),
-                    "column pass + gradient + inverse pass 1")
-            else:
-                check(
-                    lib.tike_fwd_gradient_scale(
-                        A.ptr(far), A.ptr(data[clo:chi_hi]),
-                        int(data.dtype == torch.uint16), A.ptr(mask_u8),
-                        A.ptr(gscale), A.ptr(inten) if poisson else None,
-                        A.ptr(costs[blo:blo + n]), None, n, S, det, fwd_scale,
-                        model, unmeasured, nmeasured, st),
-                    "forward pass 2 + gradient scale")
-            if poisson and dominant:  # the steps need no far-plane waves
-                check(
-                    lib.tike_poisson_steps(
-                        None, A.ptr(inten), A.ptr(dchunk),
-                        A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
-                        step_weight, 1, st), "poisson step lengths")
-            if one_launch or steps_in_pass2:
-                pass
-            elif fused:
-                check(
-                    lib.tike_grad_ifft2_pass1(
-                        A.ptr(far), A.ptr(gscale),
-                        A.ptr(steps) if poisson else None,
-                        A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
-                        n * S, det, fwd_scale, st),
-                    "gradient + inverse pass 1")
-            else:
-                check(
-                    lib.tike_grad_ifft2_crop(
-                        A.ptr(far), A.ptr(gscale),
-                        A.ptr(steps) if poisson else None,
-                        A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
-                        A.ptr(chi), n * S, det, pw, fwd_scale, inv_scale, st),
-                    "gradient + ifft2 + crop")
-        elif pos_major and fused and det in SPLIT_FORWARD_SIZES:
-            # the far plane is kept (512^2; per-mode poisson steps at 256^2):
-            # forward pass 1 -> streamed column pass that stores the far-plane
-            # waves (in `mid`) next to the gradient factor -> inverse pass 1
-            # back into `far` -> pass 2 + gradients
-            check(
-                lib.tike_fwd_pass1(
-                    A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
-                    A.ptr(uq), None, A.ptr(w_c), C, Sm, A.ptr(far),
-                    A.ptr(patches[blo:blo + n]), n, S, pw, det, H, W, st),
-                "forward pass 1")
-            check(
-                lib.tike_fwd_gradient_scale(
-                    A.ptr(far), A.ptr(dchunk), 0, A.ptr(mask_u8),
-                    A.ptr(gscale), A.ptr(inten) if poisson else None,
-                    A.ptr(costs[blo:blo + n]), A.ptr(mid), n, S, det,
-                    fwd_scale, model, unmeasured, nmeasured, st),
-                "forward pass 2 + gradient scale")
-            if poisson:
-                check(
-                    lib.tike_poisson_steps(
-                        A.ptr(mid), A.ptr(inten), A.ptr(dchunk),
-                        A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
-                        step_weight, dominant, st), "poisson step lengths")
-            check(
-                lib.tike_ifft2_pass1_scaled(
-                    A.ptr(mid), A.ptr(gscale),
-                    A.ptr(steps) if poisson else None,
-                    A.ptr(mask_u8) if poisson else None, S, A.ptr(far),
-                    n * S, det, st), "scaled inverse pass 1")
-        elif pos_major:
-            # forward + intensity in one kernel; the gradient factor is a
-            # per-pixel table applied while the inverse transform loads rows
-            check(
-                lib.tike_ptycho_fwd_intensity(
-                    A.ptr(psi), A.ptr(scan[clo:chi_hi]), A.ptr(probe), 0,
-                    A.ptr(uq), A.ptr(w_c), C, Sm, A.ptr(far), A.ptr(inten),
-                    A.ptr(patches[blo:blo + n]) if fused else None, n, S, pw,
-                    det, H, W, fwd_scale, st), "forward + intensity")
-            check(
-                lib.tike_gradient_scale(A.ptr(inten), A.ptr(dchunk),
-                                        A.ptr(mask_u8), A.ptr(gscale),
-                                        A.ptr(costs[blo:blo + n]), n, det,
-                                        model, unmeasured, nmeasured, st),
-                "gradient scale")
-            if poisson:
-                check(
-                    lib.tike_poisson_steps(
-                        A.ptr(far), A.ptr(inten), A.ptr(dchunk),
-                        A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
-                        step_weight, dominant, st), "poisson step lengths")
-            if fused:
-                check(
-                    lib.tike_ifft2_pass1_scaled(
-                        A.ptr(far), A.ptr(gscale),
-                        A.ptr(steps) if poisson else None,
-                        A.ptr(mask_u8) if poisson else None, S, A.ptr(mid),
-                        n * S, det, st), "scaled inverse pass 1")
-            elif poisson:
-                check(
-                    lib.tike_ifft2_crop_scaled_modes(
-                        A.ptr(far), A.ptr(gscale), A.ptr(steps),
-                        A.ptr(mask_u8), S, A.ptr(mid), A.ptr(chi), n * S, det,
-                        pw, inv_scale, st), "scaled ifft2 + crop (poisson)")
-            else:
-                check(
-                    lib.tike_ifft2_crop_scaled(A.ptr(far), A.ptr(gscale), S,
-                                               A.ptr(mid), A.ptr(chi), n * S,
-                                               det, pw, inv_scale, st),
-                    "scaled ifft2 + crop")
-        else:
-            op.fwd_device(probe, scan[clo:chi_hi], psi, eigen_probe, w_c,
-                          out=far[:n])
-            if poisson:
-                check(
-                    lib.tike_intensity(A.ptr(far), A.ptr(inten), n, S,
-                                       det * det, st), "intensity")
-                check(
-                    lib.tike_poisson_steps(
-                        A.ptr(far), A.ptr(inten), A.ptr(dchunk),
-                        A.ptr(mask_u8), A.ptr(steps), n, S, det, step_start,
-                        step_weight, dominant, st), "poisson step lengths")
-            check(
-                lib.tike_farplane_gradient(
-                    A.ptr(far), A.ptr(dchunk), A.ptr(mask_u8), None,
-                    A.ptr(costs[blo:blo + n]), n, S, det, model, 1, unmeasured,
-                    nmeasured, st), "farplane gradient")
-            if poisson:
-                check(
-                    lib.tike_scale_modes(A.ptr(far), A.ptr(steps),
-                                         A.ptr(mask_u8), n * S, det, st),
-                    "poisson step scaling")
-            check(
-                lib.tike_ifft2_crop(A.ptr(far), A.ptr(mid), A.ptr(chi), n * S,
-                                    det, pw, inv_scale, st), "ifft2 + crop")
-        if general:
-            check(
-                lib.tike_gen_inv_rows_gradients(
-                    A.ptr(mid), A.ptr(patches[blo:blo + n]), A.ptr(probe), 0,
-                    None, A.ptr(ep), A.ptr(w_c), C, Sm,
-                    A.ptr(objproj) if recover_psi else None,
-                    A.ptr(chi0[blo:blo + n]) if need_chi0 else None,
-                    A.ptr(m_probe_update), 1.0 / num_batch, n, S, pw, det,
-                    inv_scale, st), "general inverse rows + gradients")
-        elif fused:
-            # inverse column pass + both gradients + mode 0 of chi, one
-            # pixel-major kernel (chi itself never exists in memory)
-            p2 = (A.ptr(far if split_kept else mid),
-                  A.ptr(patches[blo:blo + n]), A.ptr(probe), A.ptr(ep),
-                  A.ptr(w_c), C, Sm, A.ptr(objproj) if recover_psi else None,
-                  A.ptr(chi0[blo:blo + n]) if need_chi0 else None,
-                  A.ptr(m_probe_update), 1.0 / num_batch, n, S, det, inv_scale)
-            if steps_in_pass2:
-                check(lib.tike_ifft2_pass2_gradients_scaled(*p2, A.ptr(steps),
-                                                            st),
-                      "inverse pass 2 + gradients (x poisson steps)")
-            else:
-                check(lib.tike_ifft2_pass2_gradients(*p2, st),
-                      "inverse pass 2 + gradients")
-        else:
-            # one pass over chi: probe gradient, object projection, patches
-            check(
-                lib.tike_lstsq_gradients(
-                    A.ptr(chi), A.ptr(scan[clo:chi_hi]), A.ptr(psi),
-                    A.ptr(probe), A.ptr(ep), A.ptr(w_c), C, Sm,
-                    None,  # on the fly: L2-resident
-                    None if patches is None else A.ptr(patches[blo:blo + n]),
-                    A.ptr(m_probe_update),
-                    A.ptr(objproj) if recover_psi else None, n, S, pw, H, W,
-                    st), "probe gradient + object projection")
+                lib.tike_varying_probe(A.ptr(probe), A.ptr(ep), A.ptr(k.w), C,
+                                       Sm, A.ptr(k.uq), n, S, pw, c.st),
+                "varying probe")
+        plan.forward(c, k)
+        plan.gradients(c, k)
+        stored_chi0 = plan.fused or plan.general
         if position_terms:
-            chi_m, chi_modes = ((chi0[blo:blo + n], 1) if fused or general
-                                else (chi, S))
+            chi_m, chi_modes = ((k.chi0, 1) if stored_chi0 else (buf.chi, S))
             check(
                 lib.tike_position_sums(
-                    A.ptr(patches[blo:blo + n]), A.ptr(chi_m), chi_modes,
-                    A.ptr(probe),
-                    A.ptr(ep), A.ptr(w_c), C, Sm, taps.ctypes.data, taps_r,
+                    A.ptr(k.patches), A.ptr(chi_m), chi_modes, A.ptr(probe),
+                    A.ptr(ep), A.ptr(k.w), C, Sm, taps.ctypes.data, taps_r,
                     A.ptr(position_terms[0][clo:chi_hi]),
-                    A.ptr(position_terms[1][clo:chi_hi]), n, S, pw, st),
+                    A.ptr(position_terms[1][clo:chi_hi]), n, S, pw, c.st),
                 "position shift sums")
         if chi_hi == hi and early:
             # the probe gradient is complete: its slice of the flat buffer
@@ -786,12 +503,11 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
             probe_sum = comm.Allreduce_start(grads[n_obj:])
         if recover_psi:
             check(
-                lib.tike_scatter_patches(A.ptr(objproj),
-                                         A.ptr(scan[clo:chi_hi]),
-                                         A.ptr(obj_acc), n, pw, H, W, st),
+                lib.tike_scatter_patches(A.ptr(buf.objproj), A.ptr(k.scan),
+                                         A.ptr(obj_acc), n, pw, H, W, c.st),
                 "object scatter")
-        if not single_chunk and not fused and not general:
-            chi0[blo:blo + n] = chi[:n, 0, 0]
+        if not buf.single_chunk and not stored_chi0:
+            buf.chi0[rows] = buf.chi[:n, 0, 0]
 
     # complete the sums over positions across ranks.  Which collectives are
     # issued, and in which order, depends on rank-invariant facts only
@@ -807,14 +523,13 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         else:
             comm.Allreduce(grads)
     count = global_count(comm, op, lo, hi)
-    if recover_probe and not fused and not general:
-        m_probe_update = m_probe_update / num_batch  # (fused: in the kernel)
-    return dict(chi0=chi_ws if single_chunk else chi0[:B],
-                chi_modes=S if single_chunk else 1, w_old=w_old,
-                patches=None if patches is None
-                else patches[:B], object_acc=obj_acc,
-                m_probe_update=m_probe_update, costs=costs[:B], count=count,
-                local_count=B)
+    if recover_probe and not (plan.fused or plan.general):
+        m_probe_update = m_probe_update / num_batch  # (else: in the kernel)
+    return dict(chi0=buf.chi if buf.single_chunk else buf.chi0[:B],
+                chi_modes=S if buf.single_chunk else 1, w_old=w_old,
+                patches=None if buf.patches is None else buf.patches[:B],
+                object_acc=obj_acc, m_probe_update=m_probe_update,
+                costs=buf.costs[:B], count=count, local_count=B)
 
 
 def object_upd_sum(g):

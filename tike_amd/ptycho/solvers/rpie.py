@@ -18,11 +18,11 @@ max(preconditioner)`` alone (:271-280); position correction is commented out
 (:163-176, 521-563).
 """
 import logging
-import os
 
 import numpy as np
 import torch
 
+from ... import _tuning
 from ... import _arrays as A
 from ... import linalg
 from ... import opt
@@ -198,15 +198,15 @@ composition of the general operators, which remains the path of every other
 configuration."""
 
 
-SLICE_STEP_FUSED = os.environ.get("TIKE_MS_SLICE_STEP", "1") == "1"
+SLICE_STEP_FUSED = _tuning.multislice_slice_step
 """The last pass of a Fresnel step and the first pass of the next slice's
 transform in one launch (`tike_slice_step`)."""
 
-FIRST_SLICE_STORED_PATCHES = os.environ.get("TIKE_MS_FIRST_STORED", "1") == "1"
+FIRST_SLICE_STORED_PATCHES = _tuning.multislice_first_stored
 """The numerators of the first slice by `tike_ifft2_pass2_gradients` on the
 patches pass 1 stored (shared probe only)."""
 
-STEP_BACK_IN_FREQUENCY = os.environ.get("TIKE_MS_STEP_BACK", "1") == "1"
+STEP_BACK_IN_FREQUENCY = _tuning.multislice_step_back
 """The steps back through the slices of the fused multislice path as extra
 outputs of the last slice's gradient pass (see _gradients_multislice_fused)."""
 
