@@ -36,6 +36,7 @@ struct MixPlan {
   int nst;  // number of stages
   int ls;   // LDS line stride in elements (padded)
   int radix[TK_MIX_MAX_STAGES];
+  int step[TK_MIX_MAX_STAGES];  // n / (product of the radices up to and incl. the stage)
 };
 
 // LDS position of element i of a line: one slot of padding per 16 elements, so
@@ -92,6 +93,11 @@ static inline bool mix_make_plan(int n, MixPlan* p) {
         p->radix[j] = t;
       }
   if (p->nst == 0) p->radix[p->nst++] = 1;  // n == 1
+  // (no integer division in the kernels: gfx950 has none in hardware)
+  for (int i = 0, ns = 1; i < p->nst; ++i) {
+    ns *= p->radix[i];
+    p->step[i] = n / ns;
+  }
   return true;
 }
 
@@ -126,8 +132,8 @@ struct Dft<1, INV> {
 template <int R, bool INV>
 __device__ __forceinline__ void mix_stage(const cf* __restrict__ a, cf* __restrict__ b,
                                           const cf* __restrict__ tw, int n, int ls, int Ns,
-                                          int nlines) {
-  const int nb = n / R, step = n / (Ns * R);
+                                          int step, int nlines) {
+  const int nb = n / R;  // (R is a constant: a multiply and a shift)
   const float rcp_nb = 1.0f / (float)nb, rcp_ns = 1.0f / (float)Ns;
   const int total = nlines * nb;
   for (int t = threadIdx.x; t < total; t += blockDim.x) {
@@ -147,21 +153,21 @@ __device__ __forceinline__ cf* mix_stages(cf* a, cf* b, const cf* __restrict__ t
   for (int s = 0; s < p.nst; ++s) {
     const int R = p.radix[s];
     switch (R) {
-      case 2: mix_stage<2, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 3: mix_stage<3, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 4: mix_stage<4, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 5: mix_stage<5, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 6: mix_stage<6, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 7: mix_stage<7, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 8: mix_stage<8, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 10: mix_stage<10, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 11: mix_stage<11, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 12: mix_stage<12, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 13: mix_stage<13, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 16: mix_stage<16, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 20: mix_stage<20, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      case 24: mix_stage<24, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
-      default: mix_stage<1, INV>(a, b, tw, p.n, p.ls, Ns, nlines); break;
+      case 2: mix_stage<2, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 3: mix_stage<3, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 4: mix_stage<4, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 5: mix_stage<5, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 6: mix_stage<6, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 7: mix_stage<7, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 8: mix_stage<8, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 10: mix_stage<10, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 11: mix_stage<11, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 12: mix_stage<12, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 13: mix_stage<13, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 16: mix_stage<16, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 20: mix_stage<20, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      case 24: mix_stage<24, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
+      default: mix_stage<1, INV>(a, b, tw, p.n, p.ls, Ns, p.step[s], nlines); break;
     }
     __syncthreads();
     cf* t = a;

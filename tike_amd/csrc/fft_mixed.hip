@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void mix_pass_kernel(const cf* in, cf* out, Mi
   };
   auto bases = [&](long grp, long* lbase) {
     if (COLS && threadIdx.x < L) {
-      const long g = grp * L + threadIdx.x, tile = g / n;
+      // (32-bit: ntile * n < 2^31 is checked by the launcher)
+      const long g = grp * L + threadIdx.x, tile = (unsigned)g / (unsigned)n;
       lbase[threadIdx.x] = tile * (long)n * n + (g - tile * n);
     }
   };
@@ -358,7 +359,7 @@ int tk_fft2_general(const cf* in, cf* out, long ntile, int n, int inverse, float
                     int l_rows, int l_cols, hipStream_t stream) {
   TK_CHECK_ARG(in && out && n >= 1 && ntile >= 0);
   if (ntile == 0) return TK_OK;
-  if (ntile * (long)n >= (1L << 40)) return TK_ERR_ARG;
+  if (ntile * (long)n >= (1L << 31)) return TK_ERR_ARG;
   const MixTables* t = tk_mix_tables(n);
   if (!t) return TK_ERR_UNSUPPORTED;
   if (t->bluestein)

@@ -51,28 +51,27 @@ __device__ __forceinline__ const cf* gen_probe_row(const TkProbe& probe, long n,
 __global__ __launch_bounds__(GEN_NT) void gen_fwd_rows_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ hand1, cf* __restrict__ patches, MixPlan p, const cf* __restrict__ twg,
-    int nscan, int S, int pw, int det, int H, int W, int RG) {
+    int nscan, int S, int pw, int det, int H, int W) {
+  // work item = (position n, probe row y): the S lines of that row
   extern __shared__ __align__(16) unsigned char lds_raw[];
   cf* twl = reinterpret_cast<cf*>(lds_raw);
   cf* bufa = twl + det;
-  cf* bufb = bufa + S * RG * p.ls;
-  cf* prow = bufb + S * RG * p.ls;  // RG rows of the patch
+  cf* bufb = bufa + S * p.ls;
+  cf* prow = bufb + S * p.ls;  // the row of the patch
   for (int k = threadIdx.x; k < det; k += GEN_NT) twl[k] = twg[k];
   const int pad = (det - pw) / 2;
   const long total = (long)H * W;
-  const int ngrp = (pw + RG - 1) / RG;
-  const long nitem = (long)nscan * ngrp;
+  const unsigned nitem = (unsigned)nscan * (unsigned)pw;
   const bool plain = probe.weights == nullptr;  // an explicit array, no eigen probes
-  for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
-    const long n = item / ngrp;
-    const int y0 = (int)(item - n * ngrp) * RG;
-    const int nr = pw - y0 < RG ? pw - y0 : RG;
+  for (unsigned item = blockIdx.x; item < nitem; item += gridDim.x) {
+    const unsigned n = item / (unsigned)pw;
+    const int y0 = (int)(item - n * (unsigned)pw);
     const TkCorner c = tk_corner(scan, n);
-    // ---- the nr patch rows, once for all modes
-    for (int r = 0; r < nr; ++r) {
-      const int y = c.sy + y0 + r;
+    // ---- the patch row, once for all modes
+    {
+      const int y = c.sy + y0;
       const bool row_ok = y >= 0 && y < H;
-      cf* out = patches ? patches + (n * pw + y0 + r) * (long)pw : nullptr;
+      cf* out = patches ? patches + ((long)n * pw + y0) * pw : nullptr;
       for (int px = threadIdx.x; px < pw; px += GEN_NT) {
         const int x = c.sx + px;
         const bool ok = row_ok && x >= 0 && x < W;
@@ -80,43 +79,36 @@ __global__ __launch_bounds__(GEN_NT) void gen_fwd_rows_kernel(
         // behind a condition is a branch around the load)
         const cf g = tk_gather(psi, ok ? (long)y * W + x : 0L, W, total, c);
         const cf v = ok ? g : mk(0.f, 0.f);
-        prow[r * pw + px] = v;
+        prow[px] = v;
         if (out) out[px] = v;
       }
     }
     __syncthreads();
-    // ---- lines (s, r): patch row x probe, zero-padded to det; the probe
-    // values of four lines are requested together
-    const int nl = S * nr;
+    // ---- line s: patch row x probe row, zero-padded to det; the probe
+    // values of four modes are requested together
     for (int e = threadIdx.x; e < det; e += GEN_NT) {
       const int px = e - pad;
       const bool in = px >= 0 && px < pw;
       const int pe = mix_pad(e);
-      for (int l0 = 0; l0 < nl; l0 += 4) {
+      const cf o = prow[in ? px : 0];
+      for (int s0 = 0; s0 < S; s0 += 4) {
         cf w[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int line = l0 + u < nl ? l0 + u : nl - 1;
-          const int sm = line / nr, r = line - sm * nr;
-          w[u] = plain ? gen_probe_row(probe, n, sm, y0 + r)[in ? px : 0]
-                       : probe.at(n, sm, in ? (long)(y0 + r) * pw + px : 0L);
+          const int sm = s0 + u < S ? s0 + u : S - 1;
+          w[u] = plain ? gen_probe_row(probe, n, sm, y0)[in ? px : 0]
+                       : probe.at(n, sm, in ? (long)y0 * pw + px : 0L);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int line = l0 + u;
-          if (line < nl) {
-            const int r = line % nr;
-            bufa[line * p.ls + pe] = in ? prow[r * pw + px] * w[u] : mk(0.f, 0.f);
-          }
-        }
+        for (int u = 0; u < 4; ++u)
+          if (s0 + u < S) bufa[(s0 + u) * p.ls + pe] = in ? o * w[u] : mk(0.f, 0.f);
       }
     }
     __syncthreads();
-    cf* res = mix_stages<false>(bufa, bufb, twl, p, nl);
-    for (int line = 0; line < nl; ++line) {
-      const int sm = line / nr, r = line - sm * nr;
-      cf* dst = hand1 + ((n * S + sm) * pw + y0 + r) * (long)det;
-      const cf* src = res + line * p.ls;
+    cf* res = mix_stages<false>(bufa, bufb, twl, p, S);
+    for (int sm = 0; sm < S; ++sm) {
+      cf* dst = hand1 + (((long)n * S + sm) * pw + y0) * det;
+      const cf* src = res + sm * p.ls;
       for (int e = threadIdx.x; e < det; e += GEN_NT) dst[e] = src[mix_pad(e)];
     }
     __syncthreads();
@@ -141,9 +133,9 @@ __global__ __launch_bounds__(GEN_NT) void gen_cols_gradient_kernel(
   const int ngrp = (det + L - 1) / L;
   const long nitem = (long)nscan * ngrp;
   const float rcp_pad = 1.0f / (float)(det - pw > 0 ? det - pw : 1);
-  for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
-    const long n = item / ngrp;
-    const int grp = (int)(item - n * ngrp);
+  for (unsigned item = blockIdx.x; item < (unsigned)nitem; item += gridDim.x) {
+    const long n = item / (unsigned)ngrp;
+    const int grp = (int)(item - (unsigned)n * (unsigned)ngrp);
     const int x0 = grp * L;
     const int nc = det - x0 < L ? det - x0 : L;
     // columns x0 .. x0 + nc of mode s into buffer a: rows of the probe window
@@ -266,11 +258,11 @@ __global__ __launch_bounds__(GEN_NT) void gen_inv_rows_gradients_kernel(
   const int D = 1 << logD;  // >= det
   const int mode_stride = pw * det;  // elements between the rows y of two modes
   const int slots = S << logD;       // (mode, e) slots of one position
-  for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
+  for (unsigned item = blockIdx.x; item < (unsigned)nitem; item += gridDim.x) {
     // (rows fastest: the workgroups of one chunk run together and share the
     // chunk's probe / patch lines in L2)
-    const int y = (int)(item % pw);
-    const long c = item / pw;
+    const long c = item / (unsigned)pw;
+    const int y = (int)(item - (unsigned)c * (unsigned)pw);
     const long n0 = c * chunk, n1 = n0 + chunk < nscan ? n0 + chunk : nscan;
     if (grad)
       for (int idx = threadIdx.x; idx < S * pw; idx += GEN_NT) acc[idx] = mk(0.f, 0.f);
@@ -389,7 +381,7 @@ __global__ __launch_bounds__(NT) void gen_cols_resident_kernel(
     const cf* __restrict__ hand1, const float* __restrict__ data,
     const unsigned char* __restrict__ mask, const TkCostSink costs, cf* __restrict__ hand2,
     MixPlan p, const cf* __restrict__ twg, int nscan, int S, int pw, int det, int L, int logL,
-    float fwd_scale, float unmeasured_scaling, float inv_nmeasured) {
+    int logQ, float fwd_scale, float unmeasured_scaling, float inv_nmeasured) {
   constexpr int PF = 8192 / NT, DV = 4096 / NT;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   cf* twl = reinterpret_cast<cf*>(lds_raw);
@@ -400,48 +392,56 @@ __global__ __launch_bounds__(NT) void gen_cols_resident_kernel(
   const int pad = (det - pw) / 2;
   const int ngrp = (det + L - 1) / L;
   const long nitem = (long)nscan * ngrp;
-  const int nl = S * L, tot = pw * nl;
-  const float rcp_pw = 1.0f / (float)pw;
+  const int nl = S * L;
   const float rcp_pad = 1.0f / (float)(det - pw > 0 ? det - pw : 1);
   // element idx of an item: column l of row r of mode s -> (line, r, offset in
   // hand1 / hand2 or -1 for the columns a short last group does not have)
-  // (idx is made opaque at every use: (line, r) of an element do not depend on
-  // the item, so the compiler would hoist them -- for every prefetch slot --
-  // out of the item loop and keep them alive across the butterflies: 256
-  // VGPRs and 344 B/lane of scratch instead of 110 and none)
-  auto where = [&](long n, int x0, int idx, int& line, int& r) -> long {
+  // element slot idx of an item -> (mode s, row r, column l): the (row,
+  // column) pairs of a mode are padded to Q = 2^logQ slots, so the decode is
+  // shifts and masks (a float-reciprocal division and 64-bit offsets per
+  // element cost a quarter of the kernel's vector instructions).  Returns the
+  // 32-bit offset from the item's base in hand1 / hand2, or -1 for a slot
+  // without an element.  (idx is made opaque at every use: (line, r) of a
+  // slot do not depend on the item, and hoisted out of the item loop -- for
+  // every prefetch slot -- they would stay alive across the butterflies: 256
+  // VGPRs and 344 B/lane of scratch instead of 194 and none.)
+  const int Q = 1 << logQ, mode_stride = pw * det;
+  auto where = [&](int x0, int idx, int& line, int& r) -> int {
     asm volatile("" : "+v"(idx));
-    const int l = idx & (L - 1), q = idx >> logL;
-    const int s = mix_div(q, rcp_pw);
-    r = q - s * pw;
+    const int s = idx >> logQ, q2 = idx & (Q - 1);
+    const int l = q2 & (L - 1);
+    r = q2 >> logL;
     line = s * L + l;
-    return idx < tot && x0 + l < det ? ((n * S + s) * pw + r) * (long)det + x0 + l : -1L;
+    return s < S && r < pw && x0 + l < det ? s * mode_stride + r * det + l : -1;
   };
+  const int slots = S << logQ;
   cf pre[PF];
-  auto request = [&](long item) {
-    const long n = item / ngrp;
-    const int x0 = (int)(item - n * ngrp) * L;
+  auto request = [&](unsigned item) {
+    const long n = item / (unsigned)ngrp;
+    const int x0 = (int)(item - (unsigned)n * (unsigned)ngrp) * L;
+    const cf* src = hand1 + n * S * (long)mode_stride + x0;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       int line, r;
-      const long off = where(n, x0, threadIdx.x + u * NT, line, r);
-      pre[u] = hand1[off >= 0 ? off : 0];
+      const int off = where(x0, threadIdx.x + u * NT, line, r);
+      pre[u] = src[off >= 0 ? off : 0];
     }
   };
   if (blockIdx.x < nitem) request(blockIdx.x);
-  for (long item = blockIdx.x; item < nitem; item += gridDim.x) {
-    const long n = item / ngrp;
-    const int grp = (int)(item - n * ngrp), x0 = grp * L;
+  for (unsigned item = blockIdx.x; item < (unsigned)nitem; item += gridDim.x) {
+    const long n = item / (unsigned)ngrp;
+    const int grp = (int)(item - (unsigned)n * (unsigned)ngrp), x0 = grp * L;
 #pragma unroll
     for (int u = 0; u < PF; ++u) asm volatile("" : "+v"(pre[u].x));
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int idx = threadIdx.x + u * NT;
       int line, r;
-      const long off = where(n, x0, idx, line, r);
+      const int off = where(x0, idx, line, r);
       // (columns the group does not have: zeros, so that the arithmetic on
       // their lines stays finite)
-      if (idx < tot) bufa[line * p.ls + mix_pad(pad + r)] = off >= 0 ? pre[u] : mk(0.f, 0.f);
+      if (idx < slots && r < pw)
+        bufa[line * p.ls + mix_pad(pad + r)] = off >= 0 ? pre[u] : mk(0.f, 0.f);
     }
     for (int idx = threadIdx.x; idx < nl * (det - pw); idx += NT) {
       const int line = mix_div(idx, rcp_pad), q = idx - line * (det - pw);
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NT) void gen_cols_resident_kernel(
       const bool m = (measured >> j) & 1u;
       cf* q = res + l * p.ls + mix_pad(k);
       float I = 0.f;
-      for (int s = 0; s < S; ++s) I += norm2(q[(long)s * L * p.ls] * fwd_scale);
+      for (int s = 0; s < S; ++s) I += norm2(q[s * L * p.ls] * fwd_scale);
       float g, term;
       if (MODEL == 0) {
         const float sI = sqrtf(I), sd = sqrtf(dv[j]);
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(NT) void gen_cols_resident_kernel(
       }
       cost += m ? term : 0.f;
       const float gg = (m ? g : unmeasured_scaling - 1.0f) * fwd_scale;
-      for (int s = 0; s < S; ++s) q[(long)s * L * p.ls] = q[(long)s * L * p.ls] * gg;
+      for (int s = 0; s < S; ++s) q[s * L * p.ls] = q[s * L * p.ls] * gg;
     }
     if (costs.costs) {
       cost = gen_block_sum(cost, red);
@@ -494,10 +494,11 @@ __global__ __launch_bounds__(NT) void gen_cols_resident_kernel(
     __syncthreads();
     if (hand2) {
       const cf* back = mix_stages<true>(res, res == bufa ? bufb : bufa, twl, p, nl);
-      for (int idx = threadIdx.x; idx < tot; idx += NT) {
+      cf* dst = hand2 + n * S * (long)mode_stride + x0;
+      for (int idx = threadIdx.x; idx < slots; idx += NT) {
         int line, r;
-        const long off = where(n, x0, idx, line, r);
-        if (off >= 0) hand2[off] = back[line * p.ls + mix_pad(pad + r)];
+        const int off = where(x0, idx, line, r);
+        if (off >= 0) dst[off] = back[line * p.ls + mix_pad(pad + r)];
       }
     }
     __syncthreads();
@@ -508,8 +509,10 @@ __global__ __launch_bounds__(NT) void gen_cols_resident_kernel(
 static int gen_cols_resident(const MixPlan& p, int S, int pw) {
   for (int L = 8; L >= 2; L /= 2) {
     const size_t need = sizeof(cf) * ((size_t)p.n + 2 * (size_t)p.ls * S * L);
-    if (need <= gen_lds_limit() && (long)p.n * L <= 4096 && (long)pw * S * L <= 8192)
-      return L;
+    // (the prefetch registers take S x Q slots, Q = pow2 >= pw * L)
+    long Q = 1;
+    while (Q < (long)pw * L) Q *= 2;
+    if (need <= gen_lds_limit() && (long)p.n * L <= 4096 && Q * S <= 8192) return L;
   }
   return 0;
 }
@@ -526,16 +529,11 @@ static int log2_floor(int v) {
   return l;
 }
 
-// Row groups of K1 (rows per work item) and column groups of K2 for a shape,
-// chosen for three workgroups per CU where the lines allow it; 0: no fit.
-static int gen_rows_per_item(const MixPlan& p, int S, int pw) {
-  const size_t tw = sizeof(cf) * (size_t)p.n;
-  for (int rg = 8; rg >= 1; rg /= 2) {
-    const size_t need = tw + 2 * sizeof(cf) * (size_t)p.ls * S * rg + sizeof(cf) * (size_t)rg * pw;
-    if (need <= (rg > 1 ? 50 * 1024 : gen_lds_limit())) return rg;
-  }
-  return 0;
+// LDS of K1: twiddles, the S lines of a probe row twice, the patch row
+static size_t gen_k1_lds(const MixPlan& p, int S, int pw) {
+  return sizeof(cf) * ((size_t)p.n + 2 * (size_t)p.ls * S + (size_t)pw);
 }
+// column groups of the two-sweep K2 for a shape (0: no fit)
 static int gen_cols_per_item(const MixPlan& p) {
   const size_t tw = sizeof(cf) * (size_t)p.n;
   for (int L = 8; L >= 1; L /= 2) {
@@ -552,7 +550,7 @@ extern "C" int tike_gen_supported(int S, int pw, int det) {
   if (S < 1 || pw < 1 || det < pw || det > TK_MIX_MAX_N) return 0;
   MixPlan p;
   if (!mix_make_plan(det, &p)) return 0;  // (Bluestein sizes: the unfused path)
-  return gen_rows_per_item(p, S, pw) > 0 && gen_cols_per_item(p) > 0 &&
+  return gen_k1_lds(p, S, pw) <= gen_lds_limit() && gen_cols_per_item(p) > 0 &&
                  gen_k3_lds(p, S, pw) <= gen_lds_limit()
              ? 1
              : 0;
@@ -582,17 +580,16 @@ extern "C" int tike_gen_fwd_rows(const void* psi, const float* scan, const void*
   if (!tike_gen_supported(S, pw, det)) return TK_ERR_UNSUPPORTED;
   const MixTables* t = tk_mix_tables(det);
   if (!t || t->bluestein) return TK_ERR_UNSUPPORTED;
-  const int RG = gen_rows_per_item(t->plan, S, pw);
   const TkProbe P = tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
                                   eigen_modes, S, pw, unique);
-  const size_t lds = sizeof(cf) * ((size_t)det + 2 * (size_t)t->plan.ls * S * RG +
-                                   (size_t)RG * pw);
+  const size_t lds = gen_k1_lds(t->plan, S, pw);
   int rc = gen_lds_attr(gen_fwd_rows_kernel, lds);
   if (rc) return rc;
-  const long nitem = (long)nscan * ((pw + RG - 1) / RG);
+  const long nitem = (long)nscan * pw;
+  if (nitem >= (1L << 31)) return TK_ERR_ARG;
   hipLaunchKernelGGL(gen_fwd_rows_kernel, dim3(tk_grid(nitem, 8)), dim3(GEN_NT), lds, stream,
                      (const cf*)psi, scan, P, (cf*)hand1, (cf*)patches, t->plan, t->tw, nscan, S,
-                     pw, det, H, W, RG);
+                     pw, det, H, W);
   TK_LAUNCH_CHECK();
   return TK_OK;
 }
@@ -622,24 +619,28 @@ extern "C" int tike_gen_cols_gradient(const void* hand1, const float* data,
          : sizeof(cf) * (size_t)det +
                (2 * sizeof(cf) * (size_t)t->plan.ls + sizeof(float) * (size_t)det) * L;
   const long nitem = (long)nscan * ngrp;
+  if (nitem >= (1L << 31)) return TK_ERR_ARG;
   const float inv = 1.0f / (float)num_measured;
-#define TK_GEN_K2(KERN, NT, PER_CU)                                                             \
+  const int logQ = log2_ceil(pw * L);
+#define COMMA ,
+#define TK_GEN_K2(KERN, NT, PER_CU, EXTRA)                                                             \
   do {                                                                                          \
     rc = gen_lds_attr(KERN, lds);                                                               \
     if (rc) return rc;                                                                          \
     hipLaunchKernelGGL(KERN, dim3(tk_grid(nitem, PER_CU)), dim3(NT), lds, stream,               \
                        (const cf*)hand1, data, measured, sink, (cf*)hand2, t->plan, t->tw,      \
-                       nscan, S, pw, det, L, logL, fwd_scale, unmeasured_scaling, inv);         \
+                       nscan, S, pw, det, L, logL, EXTRA fwd_scale, unmeasured_scaling, inv);   \
   } while (0)
   if (LR && model == 0)
-    TK_GEN_K2((gen_cols_resident_kernel<0, GEN_K2_NT>), GEN_K2_NT, 1);
+    TK_GEN_K2((gen_cols_resident_kernel<0, GEN_K2_NT>), GEN_K2_NT, 1, logQ COMMA);
   else if (LR)
-    TK_GEN_K2((gen_cols_resident_kernel<1, GEN_K2_NT>), GEN_K2_NT, 1);
+    TK_GEN_K2((gen_cols_resident_kernel<1, GEN_K2_NT>), GEN_K2_NT, 1, logQ COMMA);
   else if (model == 0)
-    TK_GEN_K2(gen_cols_gradient_kernel<0>, GEN_NT, 8);
+    TK_GEN_K2(gen_cols_gradient_kernel<0>, GEN_NT, 8, );
   else
-    TK_GEN_K2(gen_cols_gradient_kernel<1>, GEN_NT, 8);
+    TK_GEN_K2(gen_cols_gradient_kernel<1>, GEN_NT, 8, );
 #undef TK_GEN_K2
+#undef COMMA
   TK_LAUNCH_CHECK();
   return tk_cost_finish(sink, nscan, stream);
 }
@@ -673,6 +674,7 @@ extern "C" int tike_gen_inv_rows_gradients(const void* hand2, const void* patche
   if (nchunk < 1) nchunk = 1;
   int chunk = (nscan + nchunk - 1) / nchunk;
   nchunk = (nscan + chunk - 1) / chunk;
+  if ((long)pw * nchunk >= (1L << 31)) return TK_ERR_ARG;
   float* part = nullptr;
   const long nmpu = 2L * S * pw * pw;
   if (m_probe_update && tk_deterministic()) {
