@@ -212,6 +212,14 @@ def test_lstsq_reconstruct_twice_vs_reference(tp, golden, tag):
     g = golden(f"lstsq_recon_{tag}.npz")
     r1, r2 = _reconstruct_like_reference(tp, g, second=True)
     epochs = int(g["epochs"])
+    # float atomics reorder sums: the eigen quantities and the second call
+    # (3 more epochs on top of the first call's round-off) are compared at
+    # 5e-3 / 5e-2.  Under TIKE_DETERMINISTIC=1 (ordered sums; the whole file
+    # re-run by test_fixtures_under_the_deterministic_switch) they meet the
+    # solver tolerance of DESIGN.md section 4, 1e-3 / 1e-2
+    from tike_amd import _lib
+    loose, loose_abs = ((SOLVER_NORMWISE, 1e-2) if _lib.DETERMINISTIC else
+                        (5e-3, 5e-2))
     np.testing.assert_allclose(
         np.array(r1.algorithm_options.costs[:epochs]), g["costs_1"],
         rtol=1e-3)
@@ -220,15 +228,15 @@ def test_lstsq_reconstruct_twice_vs_reference(tp, golden, tag):
     assert_close(r1.probe, g["probe_1"], normwise=SOLVER_NORMWISE,
                  maxabs=1e-2, what="probe after call 1")
     if "eigen_weights" in g:
-        assert_close(r1.eigen_weights, g["eigen_weights_1"], normwise=5e-3,
-                     maxabs=5e-2, what="eigen_weights after call 1")
-        assert_close(r1.eigen_probe, g["eigen_probe_1"], normwise=5e-3,
-                     maxabs=5e-2, what="eigen_probe after call 1")
+        assert_close(r1.eigen_weights, g["eigen_weights_1"], normwise=loose,
+                     maxabs=loose_abs, what="eigen_weights after call 1")
+        assert_close(r1.eigen_probe, g["eigen_probe_1"], normwise=loose,
+                     maxabs=loose_abs, what="eigen_probe after call 1")
     np.testing.assert_allclose(np.array(r2.algorithm_options.costs),
-                               g["costs_2"], rtol=5e-3)
-    assert_close(r2.psi, g["psi_2"], normwise=5e-3, maxabs=5e-2,
+                               g["costs_2"], rtol=loose)
+    assert_close(r2.psi, g["psi_2"], normwise=loose, maxabs=loose_abs,
                  what="psi after call 2")
-    assert_close(r2.probe, g["probe_2"], normwise=5e-3, maxabs=5e-2,
+    assert_close(r2.probe, g["probe_2"], normwise=loose, maxabs=loose_abs,
                  what="probe after call 2")
 
 
@@ -262,6 +270,14 @@ def test_position_correction_vs_reference(tp, golden, tag):
     g = golden(f"lstsq_recon_{tag}.npz")
     r1, r2 = _reconstruct_like_reference(tp, g, second=True)
     epochs = int(g["epochs"])
+    # float atomics reorder sums: the eigen quantities and the second call
+    # (3 more epochs on top of the first call's round-off) are compared at
+    # 5e-3 / 5e-2.  Under TIKE_DETERMINISTIC=1 (ordered sums; the whole file
+    # re-run by test_fixtures_under_the_deterministic_switch) they meet the
+    # solver tolerance of DESIGN.md section 4, 1e-3 / 1e-2
+    from tike_amd import _lib
+    loose, loose_abs = ((SOLVER_NORMWISE, 1e-2) if _lib.DETERMINISTIC else
+                        (5e-3, 5e-2))
     np.testing.assert_allclose(
         np.array(r1.algorithm_options.costs[:epochs]), g["costs_1"],
         rtol=2e-3)
@@ -1014,10 +1030,15 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
     assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
                  maxabs=1e-2, what="probe")
     if eigen:
-        assert_close(got.eigen_probe, state["eigen_probe"], normwise=5e-3,
-                     maxabs=5e-2, what="eigen_probe")
-        assert_close(got.eigen_weights, state["eigen_weights"], normwise=5e-3,
-                     maxabs=5e-2, what="eigen_weights")
+        # (5e-3 with float atomics; the solver tolerance under the
+        # deterministic switch, test_fixtures_under_the_deterministic_switch)
+        from tike_amd import _lib
+        tol = dict(normwise=SOLVER_NORMWISE, maxabs=1e-2) if (
+            _lib.DETERMINISTIC) else dict(normwise=5e-3, maxabs=5e-2)
+        assert_close(got.eigen_probe, state["eigen_probe"],
+                     what="eigen_probe", **tol)
+        assert_close(got.eigen_weights, state["eigen_weights"],
+                     what="eigen_weights", **tol)
     if positions:
         assert np.abs(got.scan - scan).max() > 0.02  # positions did move
         np.testing.assert_allclose(got.scan, state["scan"], atol=5e-3)
@@ -1027,9 +1048,16 @@ def test_bench_c3_one_epoch_vs_oracle(tp):
     """ONE epoch of bench.py's own c3 problem -- its generator (SURVEY 8(d):
     ramp modes, shuffled raster), its eigen-probe set-up, its update rule, its
     presharded Reconstruction -- at 200 positions against the oracle's epoch.
-    (Over MANY epochs product and oracle part on these inputs: the ramp modes
-    have a Gram matrix conditioned 1 : 7e-7, profiles/r04_bench_convergence.md;
-    the first epoch is what can be, and is, pinned.)"""
+    (From the second epoch on, product and oracle can part by several per cent
+    of the cost on these inputs WITH eigen probes -- and so does the oracle
+    from its own state perturbed by 4e-6: `orthogonalize_eig` takes LAPACK's
+    eigenvectors, whose phase convention makes the last component real, and
+    for the dominant mode of the ramp modes that component is 8e-7 of the
+    vector (tests/test_oracle_sensitivity_cpu.py,
+    profiles/r06_oracle_sensitivity.txt; tools/eigen_diag.py: with the
+    oracle's own simulated patterns the two agree to 1e-3 for three epochs,
+    with the product's they flip in the second).  The first epoch is what can
+    be, and is, pinned -- eigen probe included.)"""
     import sys
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1067,8 +1095,36 @@ def test_bench_c3_one_epoch_vs_oracle(tp):
     assert_close(got.psi, state["psi"], normwise=1e-3, maxabs=1e-2, what="psi")
     assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
                  maxabs=1e-2, what="probe")
-    assert_close(got.eigen_weights, state["eigen_weights"], normwise=5e-3,
-                 maxabs=5e-2, what="eigen_weights")
+    from tike_amd import _lib
+    tol = dict(normwise=SOLVER_NORMWISE, maxabs=1e-2) if _lib.DETERMINISTIC else (
+        dict(normwise=5e-3, maxabs=5e-2))
+    assert_close(got.eigen_weights, state["eigen_weights"],
+                 what="eigen_weights", **tol)
+    assert_close(got.eigen_probe, state["eigen_probe"], what="eigen_probe",
+                 **tol)
+
+
+def test_fixtures_under_the_deterministic_switch():
+    """The reference-run fixtures and the oracle comparisons at the headline
+    shapes once more in a process with TIKE_DETERMINISTIC=1, where the eigen
+    quantities and the second ReconstructTwice call are held to the solver
+    tolerance 1e-3 (with float atomics: 5e-3) -- the tolerances are
+    parametrised on the switch, not loosened."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, TIKE_DETERMINISTIC="1")
+    env.pop("TIKE_CHUNK_POSITIONS", None)
+    out = subprocess.run(
+        [sys.executable, "-m", "pytest", os.path.join(here,
+                                                      "test_solvers_gpu.py"),
+         "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+         "reconstruct_twice_vs_reference or headline_shapes_vs_oracle or "
+         "bench_c3_one_epoch"],
+        capture_output=True, text=True, env=env, timeout=1500)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout
 
 
 @pytest.mark.parametrize("det,S,N,eigen", [(256, 8, 9, True), (256, 4, 7, True),
