@@ -136,7 +136,15 @@ __device__ __forceinline__ void mix_stage(const cf* __restrict__ a, cf* __restri
   const int nb = n / R;  // (R is a constant: a multiply and a shift)
   const float rcp_nb = 1.0f / (float)nb, rcp_ns = 1.0f / (float)Ns;
   const int total = nlines * nb;
-  for (int t = threadIdx.x; t < total; t += blockDim.x) {
+  // few butterflies per stage (4 lines x 16 of radix 24) fill only the first
+  // wave(s) of a workgroup: with several 256-thread workgroups per CU, start
+  // at a wave that depends on the workgroup and on the stage (2-D transform
+  // at 192^2 +11 %, 384^2 +6 %; the one-workgroup-per-CU column kernel of
+  // general.hip loses by it and keeps the plain order)
+  const int first = blockDim.x == 256
+                        ? (threadIdx.x + 64 * ((blockIdx.x + Ns) & 3)) & 255
+                        : threadIdx.x;
+  for (int t = first; t < total; t += blockDim.x) {
     const int line = mix_div(t, rcp_nb), jj = t - line * nb;
     mix_butterfly<R, INV>(a + line * ls, b + line * ls, tw, nb, Ns, step, rcp_ns, jj);
   }
