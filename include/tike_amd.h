@@ -59,8 +59,13 @@ int tike_abi_version(void);
  * iterates.  scratch: caller-owned DEVICE memory of `bytes` bytes that the
  * library may use from then on (one user at a time: launches on one stream);
  * 256 MiB serve a 256 x 256 x 8-mode minibatch; an entry that needs more
- * returns TIKE_ERR_ARG.  Not covered: cgrad's line-search sums, the poisson
- * step lengths. */
+ * returns TIKE_ERR_ARG.  Covered since round 6: the sums of cgrad's direction
+ * and of its all-steps-at-once line search (tike_cgrad_direction,
+ * tike_cgrad_line_search_linear).  The per-mode poisson step lengths formed
+ * from the forward hand-off (tike_poisson_steps_handoff,
+ * tike_poisson_steps_grad_ifft2_pass1) keep their atomics: under the switch
+ * the Python layer routes the poisson model through the stored-far-plane
+ * entries (tike_poisson_steps: one workgroup per pattern, no atomics). */
 int tike_set_deterministic(int on, void* scratch, long bytes);
 
 /* Create the per-device constant tables (FFT twiddles).  Allocates; call once

@@ -85,6 +85,48 @@ def main():
     out["multislice"] = digest(r.psi, r.probe,
                                np.array(r.algorithm_options.costs))
     out["multislice_cost"] = [float(c[0]) for c in r.algorithm_options.costs]
+    # (round 6) the conjugate-gradient solver -- its direction sums and the
+    # all-steps-at-once line search -- at 256^2 (hand-off cost pass) and at
+    # 128^2 (stored far planes), object then probe per minibatch
+    for det_c in (256, 128):
+        S, N = 1, 20
+        scan, psi_true, probe0, _, _, data = _headline_problem(
+            tp, det_c, S, N, seed=21 + det_c, eigen=False)
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+            scan=scan.copy(),
+            algorithm_options=tp.CgradOptions(num_batch=2, num_iter=2,
+                                              cg_iter=3),
+            probe_options=tp.ProbeOptions(), object_options=tp.ObjectOptions())
+        with tp.Reconstruction(data, params, order=np.arange(N),
+                               batches=np.array_split(np.arange(N), 2)) as ctx:
+            ctx.iterate(2)
+            r = ctx.get_result()
+        out[f"cgrad{det_c}"] = digest(r.psi, r.probe,
+                                      np.array(r.algorithm_options.costs))
+        out[f"cgrad{det_c}_cost"] = [float(np.ravel(c)[0])
+                                     for c in r.algorithm_options.costs]
+    # ... and the Poisson model with per-mode step lengths (under the switch
+    # the plan takes the stored-far-plane entries: no atomics)
+    det, S, N = 256, 8, 16
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=31, eigen=False)
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=np.full_like(psi_true, 0.5), scan=scan.copy(),
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
+                                          batch_method="wobbly_center"),
+        probe_options=tp.ProbeOptions(force_orthogonality=True),
+        object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool),
+            noise_model="poisson"))
+    tike_amd.random.randomizer_np = np.random.default_rng(4)
+    with tp.Reconstruction(data, params, order=np.arange(N),
+                           batches=np.array_split(np.arange(N), 2)) as ctx:
+        ctx.iterate(2)
+        r = ctx.get_result()
+    out["poisson"] = digest(r.psi, r.probe, np.array(r.algorithm_options.costs))
+    out["poisson_cost"] = [float(c[0]) for c in r.algorithm_options.costs]
     print("RESULT " + json.dumps(out))
 
 

@@ -2192,5 +2192,11 @@ def test_deterministic_mode_gives_bit_identical_runs():
                                rtol=1e-4)
     np.testing.assert_allclose(a["headline_psi_norm"],
                                free["headline_psi_norm"], rtol=1e-5)
+    # round 6: cgrad (direction sums, all-steps-at-once line search; 256^2 and
+    # 128^2) and the Poisson model with per-mode step lengths
+    for key in ("cgrad256", "cgrad128", "poisson"):
+        assert a[key] == b[key], key
+        np.testing.assert_allclose(a[key + "_cost"], free[key + "_cost"],
+                                   rtol=2e-3)
     assert max(a["compact_err2"]) < 1e-3, a["compact_err2"]
     assert a["compact_cost2"] < 1e-3, a["compact_cost2"]

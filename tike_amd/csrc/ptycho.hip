@@ -1130,7 +1130,10 @@ extern "C" int tike_cgrad_direction(const float* update_planar, const void* upda
   hipError_t e = hipMemsetAsync(sums, 0, 4 * sizeof(double), stream);
   if (e != hipSuccess) return (int)e;
   const dim3 grid(tk_grid((n + 255) / 256, 4)), block(256);
-  hipLaunchKernelGGL(cg_sums_kernel, grid, block, 0, stream, update_planar,
+  // deterministic mode: ONE summing workgroup (its tree is fixed; the double
+  // atomics of several workgroups arrive in any order)
+  hipLaunchKernelGGL(cg_sums_kernel, tk_deterministic() ? dim3(1) : grid, block, 0, stream,
+                     update_planar,
                      (const cf*)update_complex, (const cf*)gradient, (const cf*)direction, n,
                      first, first ? costs : nullptr, ncost, sums);
   hipLaunchKernelGGL(cg_direction_kernel, grid, block, 0, stream, update_planar,
@@ -1240,10 +1243,15 @@ __device__ __forceinline__ void tk_ksteps_costs(const float (&I0)[RB], const flo
 
 // per-thread sums -> one atomic each into costs_k[row * stride + n]; acc[0] is
 // row 0 (FIRST only), acc[1..K] are rows row1 .. row1 + K - 1
+// (deterministic mode: `part` != nullptr receives the contribution of slot
+// `slot` of `nslots` per (row, pattern) -- part[(slot * TK_LS_ROWS + row) *
+// stride + n] -- and ls_costs_finish_kernel adds the slots in order)
 template <int K, bool FIRST>
 __device__ __forceinline__ void tk_ksteps_emit(float (&acc)[K + 1], float (*red)[K + 1],
                                                float* __restrict__ costs_k, long stride, long n,
-                                               int row1, float inv_nmeasured) {
+                                               int row1, float inv_nmeasured,
+                                               float* __restrict__ part = nullptr,
+                                               int slot = 0) {
 #pragma unroll
   for (int k = FIRST ? 0 : 1; k <= K; ++k) acc[k] = tk_wave_sum(acc[k]);
   __syncthreads();  // the previous item's sums have been read
@@ -1255,8 +1263,11 @@ __device__ __forceinline__ void tk_ksteps_emit(float (&acc)[K + 1], float (*red)
   const int k = threadIdx.x;
   if (k <= K && (FIRST || k > 0)) {
     const int row = k == 0 ? 0 : row1 + k - 1;
-    unsafeAtomicAdd(&costs_k[row * stride + n],
-                    (red[0][k] + red[1][k] + red[2][k] + red[3][k]) * inv_nmeasured);
+    const float v = (red[0][k] + red[1][k] + red[2][k] + red[3][k]) * inv_nmeasured;
+    if (part != nullptr)
+      part[((long)slot * TK_LS_ROWS + row) * stride + n] = v;
+    else
+      unsafeAtomicAdd(&costs_k[row * stride + n], v);
   }
 }
 
@@ -1266,7 +1277,8 @@ template <int N, class DT, bool FIRST>
 __global__ __launch_bounds__(256, 2) void ls_ksteps_colpass_kernel(
     const cf* __restrict__ col_a, const cf* __restrict__ col_b, const DT* __restrict__ data,
     float* __restrict__ costs_k, long stride, long nitem, int S, float scale,
-    float inv_nmeasured, int row1, const double* __restrict__ state) {
+    float inv_nmeasured, int row1, const double* __restrict__ state,
+    float* __restrict__ part) {
   constexpr int RB = N / 16, NH = N / 256, K = TK_LS_STEPS;
   __shared__ float red[4][K + 1];
   if (!FIRST && state[2] != 0.0) return;  // an earlier pass has accepted a step
@@ -1303,7 +1315,27 @@ __global__ __launch_bounds__(256, 2) void ls_ksteps_colpass_kernel(
 #pragma unroll
     for (int k = 0; k <= K; ++k) acc[k] = 0.f;
     tk_ksteps_costs<K, RB, FIRST>(I0, C, I1, raw, step0, acc);
-    tk_ksteps_emit<K, FIRST>(acc, red, costs_k, stride, n, row1, inv_nmeasured);
+    tk_ksteps_emit<K, FIRST>(acc, red, costs_k, stride, n, row1, inv_nmeasured, part,
+                             k1 * NH + hb);
+  }
+}
+
+// deterministic mode: costs_k[row][n] = sum over the slots, in slot order
+__global__ __launch_bounds__(256) void ls_costs_finish_kernel(float* __restrict__ costs_k,
+                                                              const float* __restrict__ part,
+                                                              long stride, int n0, int n1,
+                                                              int row_first, int row1,
+                                                              int nslots) {
+  constexpr int K = TK_LS_STEPS;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)(K + 1) * (n1 - n0);
+       i += gridDim.x * 256L) {
+    const int k = (int)(i / (n1 - n0));
+    const long n = n0 + i % (n1 - n0);
+    if (k == 0 && !row_first) continue;
+    const int row = k == 0 ? 0 : row1 + k - 1;
+    float s = 0.f;
+    for (int c = 0; c < nslots; ++c) s += part[((long)c * TK_LS_ROWS + row) * stride + n];
+    costs_k[row * stride + n] = s;
   }
 }
 
@@ -1312,7 +1344,7 @@ template <bool FIRST>
 __global__ __launch_bounds__(256) void ls_ksteps_farplane_kernel(
     const cf* __restrict__ far_a, const cf* __restrict__ far_b, const float* __restrict__ data,
     float* __restrict__ costs_k, long stride, int S, long npix, float inv_nmeasured, int row1,
-    const double* __restrict__ state) {
+    const double* __restrict__ state, float* __restrict__ part) {
   constexpr int K = TK_LS_STEPS;
   __shared__ float red[4][K + 1];
   if (!FIRST && state[2] != 0.0) return;
@@ -1336,7 +1368,8 @@ __global__ __launch_bounds__(256) void ls_ksteps_farplane_kernel(
     }
     tk_ksteps_costs<K, 1, FIRST>(I0, C, I1, raw, step0, acc);
   }
-  tk_ksteps_emit<K, FIRST>(acc, red, costs_k, stride, n, row1, inv_nmeasured);
+  tk_ksteps_emit<K, FIRST>(acc, red, costs_k, stride, n, row1, inv_nmeasured, part,
+                           (int)blockIdx.x);
 }
 
 // One workgroup: the means of a pass's cost rows, then the backtracking
@@ -1491,6 +1524,15 @@ extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const 
         costs_k, 0, sizeof(float) * ((size_t)TK_LS_ROWS * nscan + 1), stream);
     if (e != hipSuccess) return (int)e;
   }
+  // deterministic mode: every (row, pattern) cost has `nslots` contributors --
+  // their values go to the caller's scratch buffer and are added in slot order
+  const int nslots = det == 128 ? (int)(((long)det * det + TK_FG_PIX - 1) / TK_FG_PIX)
+                                : 16 * (det / 256);
+  float* part = nullptr;
+  if (tk_deterministic()) {
+    part = tk_det_scratch(sizeof(float) * (size_t)nslots * TK_LS_ROWS * nscan);
+    if (part == nullptr) return TK_ERR_ARG;  // scratch buffer too small
+  }
   const bool reuse = a_valid && nscan <= chunk;  // the gradient pass left F(x) in far_a
   const bool resident = nscan <= chunk;          // one chunk: both hand-offs stay put
   const size_t dsz = data_u16 ? 2 : 4;
@@ -1532,11 +1574,15 @@ extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const 
         if (pass == 0)
           hipLaunchKernelGGL(ls_ksteps_farplane_kernel<true>, grid, dim3(256), 0, stream,
                              (const cf*)far_a, (const cf*)far_b, dchunk, costs_k + lo,
-                             (long)nscan, S, npix, inv, row1, state);
+                             (long)nscan, S, npix, inv, row1, state, part ? part + lo : part);
         else
           hipLaunchKernelGGL(ls_ksteps_farplane_kernel<false>, grid, dim3(256), 0, stream,
                              (const cf*)far_a, (const cf*)far_b, dchunk, costs_k + lo,
-                             (long)nscan, S, npix, inv, row1, state);
+                             (long)nscan, S, npix, inv, row1, state, part ? part + lo : part);
+        if (part)
+          hipLaunchKernelGGL(ls_costs_finish_kernel, dim3(tk_grid((long)(m * 9 + 255) / 256, 8)),
+                             dim3(256), 0, stream, costs_k, part, (long)nscan, lo, lo + m,
+                             (int)(pass == 0), row1, nslots);
         continue;
       }
       if (form && !(reuse && pass == 0)) {
@@ -1555,7 +1601,7 @@ extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const 
 #define TK_LSK(N, DT, FIRST)                                                                  \
   hipLaunchKernelGGL((ls_ksteps_colpass_kernel<N, DT, FIRST>), grid, block, 0, stream,           \
                      (const cf*)far_a, (const cf*)far_b, (const DT*)dchunk, costs_k + lo,        \
-                     (long)nscan, nitem, S, fwd_scale, inv, row1, state)
+                     (long)nscan, nitem, S, fwd_scale, inv, row1, state, part ? part + lo : part)
 #define TK_LSK_N(N, DT)      \
   do {                       \
     if (pass == 0)           \
@@ -1573,6 +1619,10 @@ extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const 
         TK_LSK_N(512, float);
 #undef TK_LSK_N
 #undef TK_LSK
+      if (part)
+        hipLaunchKernelGGL(ls_costs_finish_kernel, dim3(tk_grid((long)(m * 9 + 255) / 256, 8)),
+                           dim3(256), 0, stream, costs_k, part, (long)nscan, lo, lo + m,
+                           (int)(pass == 0), row1, nslots);
     }
     if (stage == 0)
       hipLaunchKernelGGL(ls_pick_kernel, dim3(1), dim3(256), 0, stream, costs_k, (long)nscan,

@@ -143,7 +143,9 @@ class GradientPlan:
         from . import lstsq as L
         eo = exitwave_options
         unmeasured = float(eo.unmeasured_pixels_scaling)
-        key = (S, pw, det, eo.noise_model, eo.step_length_usemodes,
+        from ... import _lib
+        key = (_lib.DETERMINISTIC, S, pw, det, eo.noise_model,
+               eo.step_length_usemodes,
                mask_u8 is not None, unmeasured == 1.0,
                tuple(L.POSITION_MAJOR_SIZES), tuple(L.NO_FARPLANE_SIZES),
                tuple(L.SPLIT_FORWARD_SIZES), tuple(L.ONE_LAUNCH_GRADIENT_SIZES),
@@ -174,10 +176,13 @@ class GradientPlan:
         # steps of 'all_modes' need |F_s|^2: from the forward hand-off with the
         # fused pass 2, from a stored far plane otherwise); 512^2 only together
         # with the fused pass 2
+        # (deterministic mode: the hand-off kernels of the per-mode steps sum
+        # with float atomics; the stored-far-plane entry does not)
+        from ... import _lib
+        handoff_steps = L.POISSON_FROM_HANDOFF and not _lib.DETERMINISTIC
         no_farplane = (pos_major
                        and (det in L.NO_FARPLANE_SIZES or (det == 512 and fused))
-                       and not (all_modes
-                                and not (fused and L.POISSON_FROM_HANDOFF)))
+                       and not (all_modes and not (fused and handoff_steps)))
         split_kept = (pos_major and fused and not no_farplane
                       and det in L.SPLIT_FORWARD_SIZES)
         one_launch = (no_farplane and fused and not poisson
