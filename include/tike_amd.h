@@ -573,6 +573,52 @@ int tike_gen_inv_rows_gradients(const void* hand2, const void* patches, const vo
                                 float probe_update_scale, int nscan, int S, int pw, int det,
                                 float inv_scale, void* stream);
 
+/* ---- the same chunk body for detector sizes det = p * M, p in {3, 5}, M a
+ * power of two in 32 .. 512 (96, 160, 192, 320, 384, 640, 768, 1536 ...) by the
+ * prime-factor decomposition: p and M are coprime, so the det x det transform
+ * is p x p sub-tiles of M x M through the power-of-two register engine plus a
+ * pointwise p x p DFT across the sub-tiles, no twiddles between them
+ * (csrc/pfa.hip).  tike_pfa_supported(S, pw, det) = 1 where these entries run.
+ *   subtiles (nscan, S, p, p, M, M) c64: tile row y and column x live in
+ *   sub-tile (y qM mod p, x qM mod p) at element (y qp mod M, x qp mod M),
+ *   qM = M^-1 mod p, qp = p^-1 mod M; the far plane in sub-tile (k1y, k1x) at
+ *   (k2y, k2x) is frequency (M qM k1 + p qp k2) mod det.
+ * A chunk: tike_pfa_fwd_gather -> tike_pfa_fft2(forward) ->
+ * tike_pfa_combine_gradient -> tike_pfa_fft2(inverse) -> tike_pfa_inv_products
+ * -> tike_scatter_patches; probe arguments as in tike_gen_fwd_rows. */
+int tike_pfa_supported(int S, int pw, int det);
+
+/* convolution.py:58-101: subtiles = pad(patch_n(psi) * probe_n[s]) in the
+ * sub-tile layout; patches (nscan, pw, pw) = patch_n(psi) if not NULL. */
+int tike_pfa_fwd_gather(const void* psi, const float* scan, const void* probe,
+                        int probe_per_scan, const void* unique, const void* eigen_probe,
+                        const float* eigen_weights, int num_eigen, int eigen_modes,
+                        void* subtiles, void* patches, int nscan, int S, int pw, int det, int H,
+                        int W, void* stream);
+
+/* propagation.py:43-73, the power-of-two part: the M x M transform of every
+ * sub-tile of ntile tiles (unscaled); out must not alias in. */
+int tike_pfa_fft2(const void* in, void* out, long ntile, int det, int inverse, void* stream);
+
+/* The p x p DFT across the sub-tiles completes the far plane F (x fwd_scale);
+ * objective.py:11-124 + lstsq.py:444-502 on it (costs, gradient factor, as
+ * tike_gen_cols_gradient); apply_gradient: F x factor goes back through the
+ * inverse p x p DFT, in place (input of tike_pfa_fft2(inverse)). */
+int tike_pfa_combine_gradient(void* subtiles, const float* data, const unsigned char* measured,
+                              float* costs, int nscan, int S, int det, float fwd_scale, int model,
+                              float unmeasured_scaling, long num_measured, int apply_gradient,
+                              void* stream);
+
+/* convolution.py:103-154 + lstsq.py:504-539 on chi = inv_scale * (inverse
+ * transform, cropped), read through the sub-tile map: outputs as
+ * tike_gen_inv_rows_gradients. */
+int tike_pfa_inv_products(const void* subtiles, const void* patches, const void* probe,
+                          int probe_per_scan, const void* unique, const void* eigen_probe,
+                          const float* eigen_weights, int num_eigen, int eigen_modes,
+                          void* objproj, void* chi0, void* m_probe_update,
+                          float probe_update_scale, int nscan, int S, int pw, int det,
+                          float inv_scale, void* stream);
+
 /* ---- the stages of a multislice object, fused (operators/cupy/multislice.py:
  * 69-92,144-194 = Convolution + FresnelSpectProp slice by slice;
  * fresnelspectprop.py:52-113; ptycho/solvers/rpie.py:367-495).  A Fresnel

@@ -1148,8 +1148,10 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
     (45, 31, 2, 13, True),     # 3 * 3 * 5, odd window, odd padding
     (64, 64, 16, 6, True),     # a power of two the fused kernels do not serve
     (1024, 1024, 1, 2, False), (640, 512, 2, 3, False),
+    (768, 768, 2, 2, False), (192, 192, 9, 4, True), (320, 300, 2, 5, True),
 ])
-def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen):
+@pytest.mark.parametrize("engine", ["pfa", "lds"])
+def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine):
     """The three shape-general launches (csrc/general.hip: tike_gen_fwd_rows ->
     tike_gen_cols_gradient -> tike_gen_inv_rows_gradients) on shapes the fused
     power-of-two kernels refuse -- probe window < detector, 12 and 16 modes,
@@ -1160,12 +1162,19 @@ def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen):
     from tike_amd.ptycho.solvers import lstsq as L
     assert not L.fused_gradients(S, pw, det)
     assert L.general_gradients(S, pw, det)
-    saved = L.GENERAL_FUSED
+    # engine: the prime-factor launches (csrc/pfa.hip: detector sizes 3 x 2^k
+    # and 5 x 2^k on the power-of-two register engine) or the LDS line engine
+    # (csrc/general.hip) -- the same shapes through both where both serve
+    if engine == "pfa" and not L.pfa_gradients(S, pw, det):
+        pytest.skip("no prime-factor decomposition of this detector size")
+    saved = L.GENERAL_FUSED, L.PFA_ROUTE
     L.GENERAL_FUSED = "always"  # also where position-major kernels exist
+    L.PFA_ROUTE = engine == "pfa"
     try:
         _minibatch_vs_oracle(tp, det, S, N, eigen, pw=pw)
+        from tike_amd.operators import Ptycho  # the plan really took the route
     finally:
-        L.GENERAL_FUSED = saved
+        L.GENERAL_FUSED, L.PFA_ROUTE = saved
 
 
 def test_general_shape_launches_equal_the_unfused_kernels(tp):

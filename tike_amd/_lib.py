@@ -53,6 +53,14 @@ _PROTOTYPES = {
     "tike_fft2": [_p, _p, _l, _i, _i, _f, _p],
     "tike_fft2_supported": [_i],
     "tike_fft2_general": [_p, _p, _l, _i, _i, _f, _i, _i, _p],
+    "tike_pfa_supported": [_i, _i, _i],
+    "tike_pfa_fwd_gather": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i,
+                            _i, _i, _i, _p],
+    "tike_pfa_fft2": [_p, _p, _l, _i, _i, _p],
+    "tike_pfa_combine_gradient": [_p, _p, _p, _p, _i, _i, _i, _f, _i, _f, _l, _i,
+                                  _p],
+    "tike_pfa_inv_products": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _p, _f,
+                              _i, _i, _i, _i, _f, _p],
     "tike_gen_supported": [_i, _i, _i],
     "tike_gen_fwd_rows": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i,
                           _i, _i, _i, _p],

@@ -1,0 +1,542 @@
+// Detector sizes det = p * M, p in {3, 5}, M a power of two with a register
+// engine (32 .. 512) -- 96, 160, 192, 320, 384, 640, 768 ... -- by the
+// prime-factor (Good-Thomas) decomposition: p and M are coprime, so with
+//   input index   n = (M n1 + p n2) mod det          (n1 < p, n2 < M)
+//   output index  k = (M qM k1 + p qp k2) mod det     (qM = M^-1 mod p,
+//                                                      qp = p^-1 mod M)
+// the length-det DFT is a p-point DFT over n1 of M-point DFTs over n2 WITHOUT
+// twiddles between them.  In two dimensions a det x det tile is p x p
+// sub-tiles of M x M: every sub-tile goes through the power-of-two register
+// engine (tk_fft2, 2.4-3x the per-byte rate of the LDS line engine of
+// fft_mixed.h), and the p x p combination is pointwise across the sub-tiles.
+// The inverse takes its input in the forward's OUTPUT layout (the maps are
+// symmetric), so nothing is permuted between the two transforms.
+//
+// The chunk body of _get_nearplane_gradients (reference
+// ptycho/solvers/lstsq.py:422-579) on this decomposition -- three streaming
+// kernels around two calls of the power-of-two transform:
+//   tike_pfa_fwd_gather        patch x probe, zero-padded, written sub-tile
+//                              by sub-tile (row y, column x of the tile go to
+//                              sub-tile (y qM mod p, x qM mod p), element
+//                              (y qp mod M, x qp mod M))
+//   tk_fft2 (M, forward)       nscan * S * p^2 tiles
+//   tike_pfa_combine_gradient  per (k2y, k2x): p x p DFT over the sub-tiles ->
+//                              far plane F; intensity over the modes, cost,
+//                              gradient factor (two sweeps over the modes);
+//                              F x factor; inverse p x p DFT; in place
+//   tk_fft2 (M, inverse)
+//   tike_pfa_inv_products      chi read back through the same map: objproj,
+//                              chi0, probe gradient (accumulated over a chunk
+//                              of positions in LDS, one atomic per pixel, mode
+//                              and chunk)
+#include "internal.h"
+#include "tike_amd.h"
+
+struct PfaGeom {
+  int p, M, logM, det, qM, qp;  // qM = M^-1 mod p, qp = p^-1 mod M
+};
+
+static bool pfa_geom(int det, PfaGeom* g) {
+  for (int p : {3, 5}) {
+    if (det % p) continue;
+    const int M = det / p;
+    if (M < 32 || M > 512 || (M & (M - 1))) continue;
+    g->p = p;
+    g->M = M;
+    g->det = det;
+    g->logM = 0;
+    while ((1 << g->logM) < M) ++g->logM;
+    g->qM = g->qp = 0;
+    for (int q = 1; q < p; ++q)
+      if ((M * q) % p == 1) g->qM = q;
+    for (int q = 1; q < M; ++q)
+      if ((p * q) % M == 1) g->qp = q;
+    return g->qM && g->qp;
+  }
+  return false;
+}
+
+// position of tile coordinate v (row or column) on the input side: sub-tile
+// index n1 and element index n2
+template <int P>
+__device__ __forceinline__ void pfa_split(const PfaGeom& g, int v, int& n1, int& n2) {
+  n1 = (v * g.qM) % P;
+  n2 = (v * g.qp) & (g.M - 1);
+}
+
+// ---- the probe of row y, hoisted: the shared probe rows P_s[y][:] (S x pw)
+// and the eigen rows E_c,s[y][:] (C x Sm x pw) are position independent -- a
+// work item that walks a chunk of positions loads them into LDS ONCE and a
+// position contributes scalar weights only (probe.py:272-303; per position
+// they cost as many L2 reads as the far plane itself).  Not for probes given
+// one array per position (`pos_stride`, `unique`): those are read per use.
+__device__ __forceinline__ bool pfa_hoistable(const TkProbe& p) {
+  return p.pos_stride == 0 && p.unique == nullptr;
+}
+__device__ __forceinline__ int pfa_eigen_rows(const TkProbe& p) {
+  return p.weights != nullptr && p.eigen != nullptr ? p.C * p.Sm : 0;
+}
+// every thread of the workgroup; the caller barriers before the first use
+__device__ __forceinline__ void pfa_probe_rows(const TkProbe& p, int y, cf* prw, cf* erw) {
+  const long pp = (long)p.pw * p.pw;
+  for (int s = 0; s < p.S; ++s)
+    for (int x = threadIdx.x; x < p.pw; x += 256)
+      prw[s * p.pw + x] = p.probe[s * pp + (long)y * p.pw + x];
+  const int ne = pfa_eigen_rows(p);
+  for (int k = 0; k < ne; ++k)
+    for (int x = threadIdx.x; x < p.pw; x += 256)
+      erw[k * p.pw + x] = p.eigen[k * pp + (long)y * p.pw + x];
+}
+__device__ __forceinline__ cf pfa_probe_at(const TkProbe& p, const cf* prw, const cf* erw,
+                                           const float* wn, int s, int x) {
+  cf v = prw[s * p.pw + x];
+  if (wn != nullptr) {
+    v = v * wn[s];
+    if (p.eigen != nullptr && s < p.Sm)
+      for (int c = 0; c < p.C; ++c) {
+        const cf e = erw[(c * p.Sm + s) * p.pw + x];
+        const float wc = wn[(c + 1) * p.S + s];
+        v.x += wc * e.x;
+        v.y += wc * e.y;
+      }
+  }
+  return v;
+}
+
+// ------------------------------------------------------------- forward gather
+// work item = (tile row y, chunk of positions): the probe rows once (above),
+// then per position -- phase 1, lanes along x: the patch row (-> patches) into
+// LDS; phase 2, lanes along the sub-tile layout (sub-tile n1x, element n2x):
+// patch x probe read from LDS at x = (M n1x + p n2x) mod det, written as
+// contiguous M-element segments.  A (nscan, S, p, p, M, M).
+template <int P>
+__global__ __launch_bounds__(256) void pfa_fwd_gather_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    cf* __restrict__ A, cf* __restrict__ patches, PfaGeom g, int nscan, int S, int pw, int H,
+    int W, int chunk) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  cf* orow = reinterpret_cast<cf*>(lds_raw);  // pw: the patch row
+  cf* prw = orow + pw;                        // S x pw
+  cf* erw = prw + S * pw;                     // C x Sm x pw
+  const int det = g.det, pad = (det - pw) / 2, M = g.M;
+  const long total = (long)H * W;
+  const long MM = (long)M * M, tile = (long)det * det;
+  const bool hoist = pfa_hoistable(probe);
+  const int nchunk = (nscan + chunk - 1) / chunk;
+  const unsigned nitem = (unsigned)det * (unsigned)nchunk;
+  for (unsigned item = blockIdx.x; item < nitem; item += gridDim.x) {
+    const long c = item / (unsigned)det;
+    const int y = (int)(item - (unsigned)c * (unsigned)det);
+    const long n0 = c * chunk, n1 = n0 + chunk < nscan ? n0 + chunk : nscan;
+    const int py = y - pad;
+    const bool row_in = py >= 0 && py < pw;
+    int n1y, n2y;
+    pfa_split<P>(g, y, n1y, n2y);
+    const long rowoff = ((long)n1y * P * M + n2y) * M;
+    if (!row_in) {  // a row of the zero padding (uniform): zeros for every position
+      for (long n = n0; n < n1; ++n)
+        for (int sm = 0; sm < S; ++sm) {
+          cf* dst = A + (n * S + sm) * tile + rowoff;
+          for (int t = threadIdx.x; t < det; t += 256)
+            dst[(long)(t >> g.logM) * MM + (t & (M - 1))] = mk(0.f, 0.f);
+        }
+      continue;
+    }
+    if (hoist) pfa_probe_rows(probe, py, prw, erw);
+    for (long n = n0; n < n1; ++n) {
+      const TkCorner cn = tk_corner(scan, n);
+      const int iy = cn.sy + py;
+      const bool row_ok = iy >= 0 && iy < H;
+      for (int px = threadIdx.x; px < pw; px += 256) {
+        const int ix = cn.sx + px;
+        const bool ok = row_ok && ix >= 0 && ix < W;
+        // (outside: pixel 0 requested and selected away, no branch around loads)
+        const cf gth = tk_gather(psi, ok ? (long)iy * W + ix : 0L, W, total, cn);
+        const cf o = ok ? gth : mk(0.f, 0.f);
+        if (patches) patches[(n * pw + py) * pw + px] = o;
+        orow[px] = o;
+      }
+      __syncthreads();
+      const float* wn =
+          probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
+      cf* out = A + n * S * tile + rowoff;
+      // sub-tile order: slot t = n1x * M + n2x (segments of M contiguous elements)
+      for (int t = threadIdx.x; t < det; t += 256) {
+        const int n1x = t >> g.logM, n2x = t & (M - 1);
+        int x = M * n1x + P * n2x;  // < 2 det
+        x -= x >= det ? det : 0;
+        const int px = x - pad;
+        const bool in = px >= 0 && px < pw;
+        const int pxc = in ? px : 0;
+        cf* dst = out + (long)n1x * MM + n2x;
+        const cf o = orow[pxc];
+        for (int sm = 0; sm < S; ++sm) {
+          const cf w = hoist ? pfa_probe_at(probe, prw, erw, wn, sm, pxc)
+                             : probe.at(n, sm, (long)py * pw + pxc);
+          dst[(long)sm * tile] = in ? o * w : mk(0.f, 0.f);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------ p x p combine + gradient
+// 1-D DFT over the sub-tile index, in place on p values
+template <int P, bool INV>
+__device__ __forceinline__ void pfa_dft2(cf (&v)[P][P]) {
+#pragma unroll
+  for (int a = 0; a < P; ++a) Dft<P, INV>::run(v[a]);  // along x
+#pragma unroll
+  for (int b = 0; b < P; ++b) {
+    cf t[P];
+#pragma unroll
+    for (int a = 0; a < P; ++a) t[a] = v[a][b];
+    Dft<P, INV>::run(t);
+#pragma unroll
+    for (int a = 0; a < P; ++a) v[a][b] = t[a];
+  }
+}
+
+// thread = one (k2y, k2x) of one position: the P x P sub-tile values of a mode
+// in registers.  B (nscan, S, p, p, M, M), in place.
+template <int P, int MODEL>
+__global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
+    cf* __restrict__ B, const float* __restrict__ data, const unsigned char* __restrict__ mask,
+    const TkCostSink costs, PfaGeom g, int nscan, int S, float fwd_scale,
+    float unmeasured_scaling, float inv_nmeasured, int grad) {
+  __shared__ float red[4];
+  const int M = g.M, det = g.det;
+  const long MM = (long)M * M, tile = (long)det * det;
+  const int blocks_per = (int)(MM / 256);  // M >= 32: a multiple of 256 pixels
+  const unsigned nitem = (unsigned)nscan * (unsigned)blocks_per;
+  const float s2 = fwd_scale * fwd_scale;
+  for (unsigned item = blockIdx.x; item < nitem; item += gridDim.x) {
+    const unsigned n = item / (unsigned)blocks_per;
+    const int blk = (int)(item - n * (unsigned)blocks_per);
+    const int e = blk * 256 + threadIdx.x;  // k2y * M + k2x
+    const int k2y = e >> g.logM, k2x = e & (M - 1);
+    cf* base = B + (long)n * S * tile + e;
+    // counts and mask bits of the P x P pixels this thread owns, requested
+    // with everything else (NaN at unmeasured pixels is selected away)
+    float d[P][P];
+    bool ms[P][P];
+    // frequency of sub-tile index k1 and element k2: (M qM k1 + p qp k2) mod
+    // det = M (qM k1 mod p) + p (qp k2 mod M), minus det if that overflows (no
+    // integer division by a run-time value)
+    const int fy = P * ((g.qp * k2y) & (M - 1)), fx = P * ((g.qp * k2x) & (M - 1));
+#pragma unroll
+    for (int a = 0; a < P; ++a) {
+      int ky = M * ((g.qM * a) % P) + fy;
+      ky -= ky >= det ? det : 0;
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        int kx = M * ((g.qM * b) % P) + fx;
+        kx -= kx >= det ? det : 0;
+        const long pix = (long)ky * det + kx;
+        d[a][b] = data[(long)n * tile + pix];
+        ms[a][b] = mask ? mask[pix] != 0 : true;
+      }
+    }
+    float I[P][P];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+      for (int b = 0; b < P; ++b) I[a][b] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      cf v[P][P];
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) v[a][b] = base[s * tile + (a * P + b) * MM];
+      pfa_dft2<P, false>(v);
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) I[a][b] += norm2(v[a][b]) * s2;
+    }
+    float cost = 0.f;
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+      for (int b = 0; b < P; ++b) {
+        float gg, term;
+        if (MODEL == 0) {
+          const float sI = sqrtf(I[a][b]), sd = sqrtf(d[a][b]);
+          const float diff = sI - sd;
+          term = diff * diff;
+          gg = -(1.0f - sd / (sI + 1e-9f));
+        } else {
+          term = I[a][b] - d[a][b] * logf(I[a][b] + 1e-9f);
+          gg = -(1.0f - d[a][b] / (I[a][b] + 1e-9f));
+        }
+        cost += ms[a][b] ? term : 0.f;
+        I[a][b] = (ms[a][b] ? gg : unmeasured_scaling - 1.0f) * fwd_scale;
+      }
+    if (costs.costs) {
+      cost = tk_block_sum256(cost, red);
+      if (threadIdx.x == 0) tk_cost_add(costs, n, blk, cost * inv_nmeasured);
+    }
+    if (!grad) continue;
+    // second sweep: F x factor, back through the p x p DFT (the far plane of
+    // a mode is formed twice; its second read comes from L2)
+    for (int s = 0; s < S; ++s) {
+      cf v[P][P];
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) v[a][b] = base[s * tile + (a * P + b) * MM];
+      pfa_dft2<P, false>(v);
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) v[a][b] = v[a][b] * I[a][b];
+      pfa_dft2<P, true>(v);
+#pragma unroll
+      for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) base[s * tile + (a * P + b) * MM] = v[a][b];
+    }
+  }
+}
+
+// ------------------------------------------------ inverse: crop + products
+// work item = (probe row y, chunk of positions); lanes along x.  C is the
+// inverse transform's output in the sub-tile layout; chi = inv_scale * C at
+// the mapped place of (pad + y, pad + x), read straight through the map (64
+// lanes touch ~24 cache lines of the three M-element segments of the row;
+// staging the row through LDS -- contiguous reads, two barriers per position
+// -- was slower: 0.87 vs 0.66 ms per 200 positions x 4 modes at 384^2).
+template <int P>
+__global__ __launch_bounds__(256) void pfa_inv_products_kernel(
+    const cf* __restrict__ C, const cf* __restrict__ patches, const TkProbe probe,
+    cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, float mpu_scale,
+    float* __restrict__ part, PfaGeom g, int nscan, int S, int pw, int chunk, float inv_scale) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  cf* acc = reinterpret_cast<cf*>(lds_raw);  // S x pw
+  cf* prw = acc + S * pw;                    // S x pw
+  cf* erw = prw + S * pw;                    // C x Sm x pw
+  const int det = g.det, pad = (det - pw) / 2, M = g.M;
+  const long MM = (long)M * M, tile = (long)det * det;
+  const int nchunk = (nscan + chunk - 1) / chunk;
+  const unsigned nitem = (unsigned)pw * (unsigned)nchunk;
+  const bool grad = mpu != nullptr || part != nullptr;
+  const bool hoist = pfa_hoistable(probe);
+  for (unsigned item = blockIdx.x; item < nitem; item += gridDim.x) {
+    const long c = item / (unsigned)pw;
+    const int y = (int)(item - (unsigned)c * (unsigned)pw);
+    const long n0 = c * chunk, n1 = n0 + chunk < nscan ? n0 + chunk : nscan;
+    int n1y, n2y;
+    pfa_split<P>(g, pad + y, n1y, n2y);
+    const long rowoff = ((long)n1y * P * M + n2y) * M;
+    if (grad)
+      for (int idx = threadIdx.x; idx < S * pw; idx += 256) acc[idx] = mk(0.f, 0.f);
+    if (hoist) pfa_probe_rows(probe, y, prw, erw);
+    __syncthreads();  // (zeroed / loaded by slot, used by column)
+    for (long n = n0; n < n1; ++n) {
+      const float* wn =
+          probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
+      const cf* src = C + n * S * tile + rowoff;
+      const long rowpix = ((long)n * pw + y) * pw;
+      for (int x = threadIdx.x; x < pw; x += 256) {
+        int n1x, n2x;
+        pfa_split<P>(g, pad + x, n1x, n2x);
+        const cf* q = src + (long)n1x * MM + n2x;
+        const cf O = conjf(patches[rowpix + x]);
+        const long pix = (long)y * pw + x;
+        cf op = mk(0.f, 0.f);
+        for (int s0 = 0; s0 < S; s0 += 4) {
+          cf v[4], w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int sm = s0 + u < S ? s0 + u : S - 1;
+            v[u] = q[(long)sm * tile];
+            w[u] = hoist ? pfa_probe_at(probe, prw, erw, wn, sm, x) : probe.at(n, sm, pix);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int sm = s0 + u;
+            if (sm < S) {
+              const cf chi = v[u] * inv_scale;
+              op = op + conjf(w[u]) * chi;
+              if (grad) acc[sm * pw + x] = acc[sm * pw + x] + O * chi;
+              if (sm == 0 && chi0) chi0[rowpix + x] = chi;
+            }
+          }
+        }
+        if (objproj) objproj[rowpix + x] = op;
+      }
+    }
+    if (grad) {
+      for (int sm = 0; sm < S; ++sm) {
+        const long o = 2 * (((long)sm * pw + y) * pw);
+        float* dst = part ? part + c * 2L * S * pw * pw + o : mpu + o;
+        for (int x = threadIdx.x; x < pw; x += 256) {
+          const cf v = acc[sm * pw + x] * mpu_scale;
+          if (part) {
+            dst[2 * x] = v.x;
+            dst[2 * x + 1] = v.y;
+          } else {
+            unsafeAtomicAdd(dst + 2 * x, v.x);
+            unsafeAtomicAdd(dst + 2 * x + 1, v.y);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ entries
+// dynamic LDS of the gather (`rows` = 1: the patch row) and of the products
+// (`rows` = S: the accumulators): + the hoisted probe and eigen rows
+static size_t pfa_lds(const TkProbe& p, int rows) {
+  const int ne = p.weights != nullptr && p.eigen != nullptr ? p.C * p.Sm : 0;
+  return sizeof(cf) * (size_t)p.pw * (size_t)(rows + p.S + ne);
+}
+
+extern "C" int tike_pfa_supported(int S, int pw, int det) {
+  PfaGeom g;
+  if (S < 1 || pw < 1 || det < pw || !pfa_geom(det, &g)) return 0;
+  // (LDS of the products: accumulators + probe rows + up to 2 S eigen rows)
+  return sizeof(cf) * (size_t)(4 * S) * pw <= 150 * 1024 ? 1 : 0;
+}
+
+extern "C" int tike_pfa_fwd_gather(const void* psi, const float* scan, const void* probe,
+                                   int probe_per_scan, const void* unique,
+                                   const void* eigen_probe, const float* eigen_weights,
+                                   int num_eigen, int eigen_modes, void* subtiles,
+                                   void* patches, int nscan, int S, int pw, int det, int H, int W,
+                                   void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
+  PfaGeom g;
+  if (!tike_pfa_supported(S, pw, det) || !pfa_geom(det, &g)) return TK_ERR_UNSUPPORTED;
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(psi && scan && probe && subtiles);
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw, unique);
+  // (tile row, chunk of positions) work items, about eight per CU
+  int nchunk = (2048 + det - 1) / det;
+  if (nchunk > (nscan + 7) / 8) nchunk = (nscan + 7) / 8;
+  if (nchunk < 1) nchunk = 1;
+  const int chunk = (nscan + nchunk - 1) / nchunk;
+  nchunk = (nscan + chunk - 1) / chunk;
+  const dim3 grid(tk_grid((long)det * nchunk, 16)), block(256);
+  const size_t lds = pfa_lds(P, 1);
+  if (lds > 150 * 1024) return TK_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024) {
+    hipError_t e3 = hipFuncSetAttribute((const void*)pfa_fwd_gather_kernel<3>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e5 = hipFuncSetAttribute((const void*)pfa_fwd_gather_kernel<5>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e3 != hipSuccess || e5 != hipSuccess) return (int)(e3 != hipSuccess ? e3 : e5);
+  }
+  if (g.p == 3)
+    hipLaunchKernelGGL(pfa_fwd_gather_kernel<3>, grid, block, lds, stream, (const cf*)psi, scan,
+                       P, (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, chunk);
+  else
+    hipLaunchKernelGGL(pfa_fwd_gather_kernel<5>, grid, block, lds, stream, (const cf*)psi, scan,
+                       P, (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, chunk);
+  TK_LAUNCH_CHECK();
+  return TK_OK;
+}
+
+extern "C" int tike_pfa_fft2(const void* in, void* out, long ntile, int det, int inverse,
+                             void* stream_) {
+  TK_ENTER();
+  PfaGeom g;
+  if (!pfa_geom(det, &g)) return TK_ERR_UNSUPPORTED;
+  TK_CHECK_ARG(in != out);
+  return tk_fft2((const cf*)in, (cf*)out, ntile * g.p * g.p, g.M, inverse, 1.0f,
+                 (hipStream_t)stream_);
+}
+
+extern "C" int tike_pfa_combine_gradient(void* subtiles, const float* data,
+                                         const unsigned char* measured, float* costs,
+                                         int nscan, int S, int det, float fwd_scale, int model,
+                                         float unmeasured_scaling, long num_measured,
+                                         int apply_gradient, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && (model == 0 || model == 1) && num_measured > 0);
+  PfaGeom g;
+  if (!pfa_geom(det, &g)) return TK_ERR_UNSUPPORTED;
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(subtiles && data);
+  const int blocks_per = g.M * g.M / 256;
+  if ((long)nscan * blocks_per >= (1L << 31)) return TK_ERR_ARG;
+  TkCostSink sink;
+  int rc = tk_cost_sink(costs, nscan, blocks_per, stream, &sink);
+  if (rc) return rc;
+  const dim3 grid(tk_grid((long)nscan * blocks_per, 16)), block(256);
+  const float inv = 1.0f / (float)num_measured;
+#define TK_PFA_CG(PP, MM)                                                                    \
+  hipLaunchKernelGGL((pfa_combine_gradient_kernel<PP, MM>), grid, block, 0, stream,             \
+                     (cf*)subtiles, data, measured, sink, g, nscan, S, fwd_scale,               \
+                     unmeasured_scaling, inv, apply_gradient)
+  if (g.p == 3 && model == 0) TK_PFA_CG(3, 0);
+  if (g.p == 3 && model == 1) TK_PFA_CG(3, 1);
+  if (g.p == 5 && model == 0) TK_PFA_CG(5, 0);
+  if (g.p == 5 && model == 1) TK_PFA_CG(5, 1);
+#undef TK_PFA_CG
+  TK_LAUNCH_CHECK();
+  return tk_cost_finish(sink, nscan, stream);
+}
+
+extern "C" int tike_pfa_inv_products(const void* subtiles, const void* patches,
+                                     const void* probe, int probe_per_scan, const void* unique,
+                                     const void* eigen_probe, const float* eigen_weights,
+                                     int num_eigen, int eigen_modes, void* objproj, void* chi0,
+                                     void* m_probe_update, float probe_update_scale, int nscan,
+                                     int S, int pw, int det, float inv_scale, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw);
+  TK_CHECK_ARG(!(eigen_weights && probe_per_scan));
+  PfaGeom g;
+  if (!tike_pfa_supported(S, pw, det) || !pfa_geom(det, &g)) return TK_ERR_UNSUPPORTED;
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(subtiles && patches && probe);
+  const TkProbe P = tk_make_probe(probe, probe_per_scan, eigen_probe, eigen_weights, num_eigen,
+                                  eigen_modes, S, pw, unique);
+  int nchunk = (int)((2048 + pw - 1) / pw);
+  if (nchunk > (nscan + 7) / 8) nchunk = (nscan + 7) / 8;
+  if (nchunk < 1) nchunk = 1;
+  int chunk = (nscan + nchunk - 1) / nchunk;
+  nchunk = (nscan + chunk - 1) / chunk;
+  float* part = nullptr;
+  const long nmpu = 2L * S * pw * pw;
+  if (m_probe_update && tk_deterministic()) {
+    part = tk_det_scratch(sizeof(float) * (size_t)nmpu * nchunk);
+    if (!part) {  // scratch too small: one chunk, one contributor per address
+      nchunk = 1;
+      chunk = nscan;
+      part = tk_det_scratch(sizeof(float) * (size_t)nmpu);
+      if (!part) return TK_ERR_ARG;
+    }
+  }
+  const size_t lds = pfa_lds(P, S);
+  if (lds > 150 * 1024) return TK_ERR_UNSUPPORTED;
+  if (lds > 48 * 1024) {
+    hipError_t e3 = hipFuncSetAttribute((const void*)pfa_inv_products_kernel<3>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e5 = hipFuncSetAttribute((const void*)pfa_inv_products_kernel<5>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e3 != hipSuccess || e5 != hipSuccess) return (int)(e3 != hipSuccess ? e3 : e5);
+  }
+  const dim3 grid(tk_grid((long)pw * nchunk, 16)), block(256);
+  if (g.p == 3)
+    hipLaunchKernelGGL(pfa_inv_products_kernel<3>, grid, block, lds, stream, (const cf*)subtiles,
+                       (const cf*)patches, P, (cf*)objproj, (cf*)chi0, (float*)m_probe_update,
+                       probe_update_scale, part, g, nscan, S, pw, chunk, inv_scale);
+  else
+    hipLaunchKernelGGL(pfa_inv_products_kernel<5>, grid, block, lds, stream, (const cf*)subtiles,
+                       (const cf*)patches, P, (cf*)objproj, (cf*)chi0, (float*)m_probe_update,
+                       probe_update_scale, part, g, nscan, S, pw, chunk, inv_scale);
+  TK_LAUNCH_CHECK();
+  if (part) return tk_ordered_sum((float*)m_probe_update, part, nmpu, nchunk, true, stream);
+  return TK_OK;
+}

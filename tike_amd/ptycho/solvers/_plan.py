@@ -19,6 +19,9 @@ Routes:
   pos_major    128^2, or 256^2 / 512^2 with a probe window narrower than the
                detector or more modes than the fused pass 2 takes: forward +
                intensity in one position-major kernel, scaled inverse
+  pfa          detector sizes p x 2^k, p in {3, 5} (96 ... 1536), gaussian
+               model: p x p sub-tiles through the power-of-two register engine
+               (csrc/pfa.hip)
   general      every other shape with a mixed-radix plan, gaussian model: the
                three launches of csrc/general.hip
   unfused      what is left (Bluestein sizes, poisson on general shapes): the
@@ -92,6 +95,11 @@ def algorithmic_bytes(name, n, S, det, pw, C, depth=1):
         "tike_gen_fwd_rows": n * (Tw + 2 * P + 8) + (S + C) * P,
         "tike_gen_cols_gradient": n * (2 * Tw + D),
         "tike_gen_inv_rows_gradients": n * (Tw + 3 * P) + S * P,
+        # ---- the prime-factor route: whole tiles in the sub-tile layout
+        "tike_pfa_fwd_gather": n * (T + 2 * P + 8) + (S + C) * P,
+        "tike_pfa_fft2": n * 2 * T,
+        "tike_pfa_combine_gradient": n * (2 * T + D),
+        "tike_pfa_inv_products": n * (T + 3 * P) + S * P,
         # ---- the stages of a multislice object (no patches stored there)
         "tike_fwd_pass1:no_patches": n * (T + P + 8) + (S + C) * P,
         # the probe incident on a slice behind the first: one wave per position in
@@ -124,7 +132,8 @@ class GradientPlan:
     masked: bool
     route: str
     fused: bool           # pass 2 + gradients in one kernel (chi never stored)
-    general: bool
+    general: bool         # chi never stored, patches + chi0 stored (general, pfa)
+    pfa: bool
     pos_major: bool
     no_farplane: bool
     split_kept: bool
@@ -150,7 +159,7 @@ class GradientPlan:
                tuple(L.POSITION_MAJOR_SIZES), tuple(L.NO_FARPLANE_SIZES),
                tuple(L.SPLIT_FORWARD_SIZES), tuple(L.ONE_LAUNCH_GRADIENT_SIZES),
                L.POISSON_FROM_HANDOFF, L.POISSON_STEPS_IN_PASS2,
-               L.GENERAL_FUSED, L.CHUNK_POSITIONS_OVERRIDE)
+               L.GENERAL_FUSED, L.PFA_ROUTE, L.CHUNK_POSITIONS_OVERRIDE)
         cache = op.__dict__.setdefault("_tike_amd_plans", {})
         if key not in cache:
             cache[key] = GradientPlan._build(S, pw, det, eo, mask_u8, unmeasured,
@@ -170,6 +179,9 @@ class GradientPlan:
         general = (not fused
                    and (not pos_major or L.GENERAL_FUSED == "always")
                    and not poisson and L.general_gradients(S, pw, det))
+        # ... and among them the sizes p x 2^k, p in {3, 5}, the prime-factor
+        # launches (power-of-two register engine on p x p sub-tiles)
+        pfa = general and L.pfa_gradients(S, pw, det)
         if general:
             pos_major = False
         # detector sizes with the far-plane-free pipeline (the per-mode poisson
@@ -194,12 +206,16 @@ class GradientPlan:
         steps_in_pass2 = (no_farplane and all_modes and fused and det == 256
                           and (mask_u8 is None or unmeasured == 1.0)
                           and L.POISSON_STEPS_IN_PASS2)
-        route = ("general" if general else "no_farplane" if no_farplane else
+        route = ("pfa" if pfa else "general" if general else
+                 "no_farplane" if no_farplane else
                  "split_kept" if split_kept else "pos_major" if pos_major else
                  "unfused")
         launches = {
             "general": ("tike_gen_fwd_rows", "tike_gen_cols_gradient",
                         "tike_gen_inv_rows_gradients"),
+            "pfa": ("tike_pfa_fwd_gather", "tike_pfa_fft2",
+                    "tike_pfa_combine_gradient", "tike_pfa_fft2",
+                    "tike_pfa_inv_products"),
             "no_farplane": ("tike_fwd_pass1",) + (
                 ("tike_poisson_steps_grad_ifft2_pass1",) if steps_in_pass2 else
                 ("tike_poisson_steps_handoff", "tike_grad_ifft2_pass1")
@@ -224,7 +240,8 @@ class GradientPlan:
         return GradientPlan(
             det=det, pw=pw, S=S, model=MODELS[eo.noise_model], poisson=poisson,
             dominant=dominant, all_modes=all_modes, masked=mask_u8 is not None,
-            route=route, fused=fused, general=general, pos_major=pos_major,
+            route=route, fused=fused, general=general, pfa=pfa,
+            pos_major=pos_major,
             no_farplane=no_farplane, split_kept=split_kept,
             one_launch=one_launch, steps_in_pass2=steps_in_pass2,
             chunk=L.chunk_positions(S, det, pos_major or general),
@@ -252,9 +269,10 @@ class GradientPlan:
         b.objproj = ws.get("objproj", (n, pw, pw), c64, dev)
         if varying and not self.general:
             b.unique = ws.get("unique", (n, varying, pw, pw), c64, dev)
-        # (general: the two hand-offs hold the pw rows of the probe window only)
-        b.far = ws.get("far", (n, 1, S, pw if self.general else det, det), c64,
-                       dev)
+        # (general: the two hand-offs hold the pw rows of the probe window only;
+        # pfa: whole tiles, sub-tile by sub-tile)
+        b.far = ws.get("far", (n, 1, S, pw if self.general and not self.pfa
+                               else det, det), c64, dev)
         # the inverse transform is out of place (far -> mid); chi is the
         # cropped result and aliases mid when the probe fills the detector
         b.mid = ws.get("mid", tuple(b.far.shape), c64, dev)
@@ -276,6 +294,29 @@ class GradientPlan:
         model, costs, far-plane gradient factor, the inverse's first half (or
         the whole inverse + crop where chi is stored)."""
         getattr(self, "_forward_" + self.route)(c, k)
+
+    def _forward_pfa(self, c, k):
+        # gather into p x p sub-tiles -> power-of-two transform of every
+        # sub-tile -> p x p combine, cost, gradient factor, inverse combine ->
+        # inverse transform; the products in gradients()
+        b = c.buf
+        check(
+            lib.tike_pfa_fwd_gather(
+                A.ptr(c.psi), A.ptr(k.scan), A.ptr(c.probe), 0, None,
+                A.ptr(c.ep), A.ptr(k.w), c.C, c.Sm, A.ptr(b.far),
+                A.ptr(k.patches), k.n, self.S, self.pw, self.det, c.H, c.W,
+                c.st), "prime-factor gather")
+        check(lib.tike_pfa_fft2(A.ptr(b.far), A.ptr(b.mid), k.n * self.S,
+                                self.det, 0, c.st), "sub-tile transforms")
+        check(
+            lib.tike_pfa_combine_gradient(
+                A.ptr(b.mid), A.ptr(k.data_f32()), A.ptr(c.mask_u8),
+                A.ptr(k.costs), k.n, self.S, self.det, c.fwd_scale, self.model,
+                c.unmeasured, c.nmeasured, 1, c.st),
+            "p x p combine + gradient")
+        check(lib.tike_pfa_fft2(A.ptr(b.mid), A.ptr(b.far), k.n * self.S,
+                                self.det, 1, c.st),
+              "inverse sub-tile transforms")
 
     def _forward_general(self, c, k):
         # K1 rows (patch x probe, zero padding made in LDS) -> K2 columns
@@ -474,7 +515,14 @@ class GradientPlan:
         n, st = k.n, c.st
         objproj = A.ptr(b.objproj) if c.recover_psi else None
         chi0 = A.ptr(k.chi0) if c.need_chi0 and k.chi0 is not None else None
-        if self.general:
+        if self.pfa:
+            check(
+                lib.tike_pfa_inv_products(
+                    A.ptr(b.far), A.ptr(k.patches), A.ptr(c.probe), 0, None,
+                    A.ptr(c.ep), A.ptr(k.w), c.C, c.Sm, objproj, chi0,
+                    A.ptr(c.m_probe_update), 1.0 / c.num_batch, n, S, pw, det,
+                    c.inv_scale, st), "prime-factor inverse products")
+        elif self.general:
             check(
                 lib.tike_gen_inv_rows_gradients(
                     A.ptr(b.mid), A.ptr(k.patches), A.ptr(c.probe), 0, None,

@@ -97,6 +97,18 @@ launches of csrc/general.hip (tike_gen_*; gaussian model) instead of the
 unfused round-1 kernels; tests set this to False to compare the two."""
 
 
+PFA_ROUTE = True
+"""Detector sizes 3 x 2^k and 5 x 2^k (96 ... 1536) without position-major
+kernels take the prime-factor launches of csrc/pfa.hip (tike_pfa_*): the
+power-of-two register engine on p x p sub-tiles; tests set this to False to
+compare with the LDS line engine of csrc/general.hip."""
+
+
+def pfa_gradients(S, pw, det):
+    """True where the prime-factor launches serve (csrc/pfa.hip)."""
+    return bool(PFA_ROUTE and lib.tike_pfa_supported(S, pw, det))
+
+
 def general_gradients(S, pw, det):
     """True where the shape-general fused launches serve (csrc/general.hip):
     the detector size has a mixed-radix plan and the S lines of a row fit
