@@ -969,6 +969,10 @@ def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0, margin=8,
     ("c3", 256, 8, 20, 2),  # BASELINE configs[2]: 8 modes + eigen probe, far-plane-free
     ("c3-4modes", 256, 4, 12, 2),
     ("c5", 512, 4, 8, 2),   # BASELINE configs[4]: 512^2, 4 modes, position correction
+    # round 6, off-grid detector sizes through the whole solver: 192 = 3 x 64
+    # (prime-factor launches), 100 = 10 x 10 (LDS line engine), eigen probes
+    ("off-grid pfa", 192, 3, 12, 2),
+    ("off-grid lds", 100, 2, 10, 2),
 ])
 def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
                                          spatial_sort, batch_method):
@@ -978,8 +982,12 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
     object-update rules."""
     import tike_amd.random
     from oracle import solvers as osol
-    eigen = tag.startswith("c3")
+    eigen = tag.startswith(("c3", "off-grid"))
     positions = tag == "c5"
+    if tag.startswith("off-grid"):
+        from tike_amd.ptycho.solvers import lstsq as L
+        assert L.pfa_gradients(S, det, det) == (tag == "off-grid pfa")
+        assert L.general_gradients(S, det, det)
     # (position correction under the per-minibatch rule moves the corner
     # positions further: more room around the scan, or check_allowed_positions
     # -- the reference's rule -- stops the run)
@@ -1610,7 +1618,9 @@ def test_rpie_reconstruct_twice_vs_reference(tp, golden, tag):
                                    rtol=5e-3, atol=5e-3)
 
 
-@pytest.mark.parametrize("det,S,N,eigen", [(256, 8, 12, True), (128, 2, 10, False)])
+@pytest.mark.parametrize("det,S,N,eigen", [(256, 8, 12, True), (128, 2, 10, False),
+                                           # off-grid: prime-factor launches
+                                           (160, 3, 9, True)])
 def test_rpie_epochs_vs_oracle(tp, det, S, N, eigen):
     """rpie on the fused-kernel sizes (256^2 with 8 modes and eigen-probe
     weights: the far-plane-free pipeline) against the CPU oracle."""
