@@ -200,7 +200,10 @@ __device__ __forceinline__ void pfa_dft2(cf (&v)[P][P]) {
 
 // thread = one (k2y, k2x) of one position: the P x P sub-tile values of a mode
 // in registers.  B (nscan, S, p, p, M, M), in place.
-template <int P, int MODEL>
+// SMAX > 0: at most SMAX modes, all of them kept in registers between the
+// intensity and the factor (one read of the sub-tiles); SMAX = 0: any number of
+// modes, formed twice (the second read comes from L2).
+template <int P, int MODEL, int SMAX = 0>
 __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
     cf* __restrict__ B, const float* __restrict__ data, const unsigned char* __restrict__ mask,
     const TkCostSink costs, PfaGeom g, int nscan, int S, float fwd_scale,
@@ -243,17 +246,35 @@ __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
     for (int a = 0; a < P; ++a)
 #pragma unroll
       for (int b = 0; b < P; ++b) I[a][b] = 0.f;
-    for (int s = 0; s < S; ++s) {
-      cf v[P][P];
+    cf keep[SMAX > 0 ? SMAX : 1][P][P];
+    if (SMAX > 0) {
 #pragma unroll
-      for (int a = 0; a < P; ++a)
+      for (int s = 0; s < SMAX; ++s) {
+        if (s < S) {  // uniform
 #pragma unroll
-        for (int b = 0; b < P; ++b) v[a][b] = base[s * tile + (a * P + b) * MM];
-      pfa_dft2<P, false>(v);
+          for (int a = 0; a < P; ++a)
 #pragma unroll
-      for (int a = 0; a < P; ++a)
+            for (int b = 0; b < P; ++b) keep[s][a][b] = base[s * tile + (a * P + b) * MM];
+          pfa_dft2<P, false>(keep[s]);
 #pragma unroll
-        for (int b = 0; b < P; ++b) I[a][b] += norm2(v[a][b]) * s2;
+          for (int a = 0; a < P; ++a)
+#pragma unroll
+            for (int b = 0; b < P; ++b) I[a][b] += norm2(keep[s][a][b]) * s2;
+        }
+      }
+    } else {
+      for (int s = 0; s < S; ++s) {
+        cf v[P][P];
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+#pragma unroll
+          for (int b = 0; b < P; ++b) v[a][b] = base[s * tile + (a * P + b) * MM];
+        pfa_dft2<P, false>(v);
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+#pragma unroll
+          for (int b = 0; b < P; ++b) I[a][b] += norm2(v[a][b]) * s2;
+      }
     }
     float cost = 0.f;
 #pragma unroll
@@ -280,6 +301,23 @@ __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
     if (!grad) continue;
     // second sweep: F x factor, back through the p x p DFT (the far plane of
     // a mode is formed twice; its second read comes from L2)
+    if (SMAX > 0) {
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) {
+        if (s < S) {
+#pragma unroll
+          for (int a = 0; a < P; ++a)
+#pragma unroll
+            for (int b = 0; b < P; ++b) keep[s][a][b] = keep[s][a][b] * I[a][b];
+          pfa_dft2<P, true>(keep[s]);
+#pragma unroll
+          for (int a = 0; a < P; ++a)
+#pragma unroll
+            for (int b = 0; b < P; ++b) base[s * tile + (a * P + b) * MM] = keep[s][a][b];
+        }
+      }
+      continue;
+    }
     for (int s = 0; s < S; ++s) {
       cf v[P][P];
 #pragma unroll
@@ -473,14 +511,18 @@ extern "C" int tike_pfa_combine_gradient(void* subtiles, const float* data,
   if (rc) return rc;
   const dim3 grid(tk_grid((long)nscan * blocks_per, 16)), block(256);
   const float inv = 1.0f / (float)num_measured;
-#define TK_PFA_CG(PP, MM)                                                                    \
-  hipLaunchKernelGGL((pfa_combine_gradient_kernel<PP, MM>), grid, block, 0, stream,             \
+#define TK_PFA_CG(PP, MM, SM)                                                                \
+  hipLaunchKernelGGL((pfa_combine_gradient_kernel<PP, MM, SM>), grid, block, 0, stream,         \
                      (cf*)subtiles, data, measured, sink, g, nscan, S, fwd_scale,               \
                      unmeasured_scaling, inv, apply_gradient)
-  if (g.p == 3 && model == 0) TK_PFA_CG(3, 0);
-  if (g.p == 3 && model == 1) TK_PFA_CG(3, 1);
-  if (g.p == 5 && model == 0) TK_PFA_CG(5, 0);
-  if (g.p == 5 && model == 1) TK_PFA_CG(5, 1);
+  // (3 x 3 sub-tiles of up to 4 modes fit the registers: one read)
+  const bool resident = g.p == 3 && S <= 4 && apply_gradient;
+  if (resident && model == 0) TK_PFA_CG(3, 0, 4);
+  if (resident && model == 1) TK_PFA_CG(3, 1, 4);
+  if (!resident && g.p == 3 && model == 0) TK_PFA_CG(3, 0, 0);
+  if (!resident && g.p == 3 && model == 1) TK_PFA_CG(3, 1, 0);
+  if (g.p == 5 && model == 0) TK_PFA_CG(5, 0, 0);
+  if (g.p == 5 && model == 1) TK_PFA_CG(5, 1, 0);
 #undef TK_PFA_CG
   TK_LAUNCH_CHECK();
   return tk_cost_finish(sink, nscan, stream);
