@@ -535,7 +535,8 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
 
 PROBE_WIDTH = {"c3pad": 128}  # probe window narrower than the detector
 
-LEG_EPOCHS = {"c1": 20, "c2": 3, "c5": 3, "c3poisson": 3, "c3rpie": 3, "c3rpie2": 3}
+LEG_EPOCHS = {"c1": 20, "c2": 3, "c5": 3, "c3poisson": 3, "c3rpie": 3, "c3rpie2": 3,
+              "c3pad": 3, "c3m12": 3, "c384": 3}
 # untimed epochs in front (cgrad: at least two -- its line searches learn their
 # slot counts; c1's epochs are 3 ms: ten of them bring the clocks of a GPU
 # that idled during the set-up back up, profiles/r04_leg_probe.txt)
@@ -993,6 +994,15 @@ def main():
         # model, rpie, rpie on a two-slice object
         secondary += [guarded(w, epoch_leg, w, tp, A, torch)
                       for w in ("c3poisson", "c3rpie", "c3rpie2")]
+        # ... and the off-grid shapes (round 6): a probe window of half the
+        # detector, 12 modes, a 384^2 detector -- each with its rate per
+        # far-plane byte beside c3's
+        for w in ("c3pad", "c3m12", "c384"):
+            leg = guarded(w, epoch_leg, w, tp, A, torch)
+            if "value" in leg:
+                leg["farplane_GBs"] = (8 * leg["modes"] * leg["detector"]**2 *
+                                       leg["value"] / 1e9)
+            secondary.append(leg)
 
     if rank == 0:
         summ = timers.summary()  # the timed steps

@@ -26,6 +26,10 @@ KERNELS = {
     "void ptycho_fwd_pos_kernel<256, true>": "tike_ptycho_fwd_intensity",
     "void ptycho_fwd_pos_kernel<512": "tike_ptycho_fwd_intensity",
     "void fwd_pass1_kernel": "tike_fwd_pass1",
+    "void pfa_fwd_gather_kernel": "tike_pfa_fwd_gather",
+    "void pfa_combine_gradient_kernel": "tike_pfa_combine_gradient",
+    "void pfa_inv_products_kernel": "tike_pfa_inv_products",
+    "void fft2_v2_kernel": "tike_pfa_fft2",
     "gen_fwd_rows_kernel": "tike_gen_fwd_rows",
     "void gen_cols_resident_kernel": "tike_gen_cols_gradient",
     "void gen_cols_gradient_kernel": "tike_gen_cols_gradient",
