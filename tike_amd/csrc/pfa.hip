@@ -103,6 +103,39 @@ __device__ __forceinline__ cf pfa_probe_at(const TkProbe& p, const cf* prw, cons
   return v;
 }
 
+// tk_gather (common.h) in two halves: the four taps requested now, weighted
+// later -- a load issued behind a store waits for it (one in-order counter), so
+// a kernel that walks positions requests the taps of position n + 1 BEFORE it
+// stores the products of position n.
+struct PfaTaps {
+  cf a, b, d, e;
+  bool t1, t2, t3;  // taps inside the allocation
+};
+__device__ __forceinline__ PfaTaps pfa_taps(const cf* __restrict__ img, long ii, int W,
+                                            long total) {
+  const long last = total - 1;
+  PfaTaps t;
+  t.t1 = ii + 1 <= last;
+  t.t2 = ii + W <= last;
+  t.t3 = ii + W + 1 <= last;
+  t.a = img[ii];
+  t.b = img[t.t1 ? ii + 1 : last];
+  t.d = img[t.t2 ? ii + W : last];
+  t.e = img[t.t3 ? ii + W + 1 : last];
+  return t;
+}
+__device__ __forceinline__ cf pfa_taps_value(const PfaTaps& t, const TkCorner& c) {
+  const float w1 = t.t1 ? c.w01 : 0.0f, w2 = t.t2 ? c.w10 : 0.0f, w3 = t.t3 ? c.w11 : 0.0f;
+  cf r = mk(t.a.x * c.w00, t.a.y * c.w00);
+  r.x += t.b.x * w1;
+  r.y += t.b.y * w1;
+  r.x += t.d.x * w2;
+  r.y += t.d.y * w2;
+  r.x += t.e.x * w3;
+  r.y += t.e.y * w3;
+  return r;
+}
+
 // ------------------------------------------------------------- forward gather
 // work item = (tile row y, chunk of positions): the probe rows once (above),
 // then per position -- phase 1, lanes along x: the patch row (-> patches) into
@@ -143,20 +176,51 @@ __global__ __launch_bounds__(256) void pfa_fwd_gather_kernel(
       continue;
     }
     if (hoist) pfa_probe_rows(probe, py, prw, erw);
+    // the taps of the first two pixels of a thread (pw <= 512: all of them)
+    // travel one position ahead
+    PfaTaps nt[2];
+    bool nok[2];
+    auto request = [&](long n) {
+      const TkCorner cn = tk_corner(scan, n);
+      const int iy = cn.sy + py;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int px = threadIdx.x + j * 256;
+        const int ix = cn.sx + px;
+        nok[j] = px < pw && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        // (outside: pixel 0 requested and selected away, no branch around loads)
+        nt[j] = pfa_taps(psi, nok[j] ? (long)iy * W + ix : 0L, W, total);
+      }
+    };
+    request(n0);
     for (long n = n0; n < n1; ++n) {
       const TkCorner cn = tk_corner(scan, n);
       const int iy = cn.sy + py;
       const bool row_ok = iy >= 0 && iy < H;
-      for (int px = threadIdx.x; px < pw; px += 256) {
+      cf held[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int px = threadIdx.x + j * 256;
+        held[j] = nok[j] ? pfa_taps_value(nt[j], cn) : mk(0.f, 0.f);
+        if (px < pw) orow[px] = held[j];
+      }
+      for (int px = threadIdx.x + 512; px < pw; px += 256) {  // (windows wider than 512)
         const int ix = cn.sx + px;
         const bool ok = row_ok && ix >= 0 && ix < W;
-        // (outside: pixel 0 requested and selected away, no branch around loads)
         const cf gth = tk_gather(psi, ok ? (long)iy * W + ix : 0L, W, total, cn);
         const cf o = ok ? gth : mk(0.f, 0.f);
         if (patches) patches[(n * pw + py) * pw + px] = o;
         orow[px] = o;
       }
       __syncthreads();
+      if (n + 1 < n1) request(n + 1);  // in flight before the stores below
+      if (patches) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int px = threadIdx.x + j * 256;
+          if (px < pw) patches[(n * pw + py) * pw + px] = held[j];
+        }
+      }
       const float* wn =
           probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
       cf* out = A + n * S * tile + rowoff;
@@ -371,38 +435,86 @@ __global__ __launch_bounds__(256) void pfa_inv_products_kernel(
       for (int idx = threadIdx.x; idx < S * pw; idx += 256) acc[idx] = mk(0.f, 0.f);
     if (hoist) pfa_probe_rows(probe, y, prw, erw);
     __syncthreads();  // (zeroed / loaded by slot, used by column)
-    for (long n = n0; n < n1; ++n) {
-      const float* wn =
-          probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
-      const cf* src = C + n * S * tile + rowoff;
+    // the work of pixel x of position n on values already in registers
+    auto consume = [&](long n, const float* wn, int x, const cf* v4, int s0, cf O, cf& op) {
       const long rowpix = ((long)n * pw + y) * pw;
-      for (int x = threadIdx.x; x < pw; x += 256) {
-        int n1x, n2x;
-        pfa_split<P>(g, pad + x, n1x, n2x);
-        const cf* q = src + (long)n1x * MM + n2x;
-        const cf O = conjf(patches[rowpix + x]);
-        const long pix = (long)y * pw + x;
-        cf op = mk(0.f, 0.f);
-        for (int s0 = 0; s0 < S; s0 += 4) {
-          cf v[4], w[4];
+      const long pix = (long)y * pw + x;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int sm = s0 + u < S ? s0 + u : S - 1;
-            v[u] = q[(long)sm * tile];
-            w[u] = hoist ? pfa_probe_at(probe, prw, erw, wn, sm, x) : probe.at(n, sm, pix);
-          }
+      for (int u = 0; u < 4; ++u) {
+        const int sm = s0 + u;
+        if (sm < S) {
+          const cf w = hoist ? pfa_probe_at(probe, prw, erw, wn, sm, x) : probe.at(n, sm, pix);
+          const cf chi = v4[u] * inv_scale;
+          op = op + conjf(w) * chi;
+          if (grad) acc[sm * pw + x] = acc[sm * pw + x] + O * chi;
+          if (sm == 0 && chi0) chi0[rowpix + x] = chi;
+        }
+      }
+    };
+    if (S <= 4 && pw <= 512) {
+      // at most four modes, two pixels per thread: the values of position
+      // n + 1 are requested BEFORE the stores of position n (a load issued
+      // behind a store waits for it)
+      cf nv[2][4], nO[2];
+      auto request = [&](long n) {
+        const cf* src = C + n * S * tile + rowoff;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int sm = s0 + u;
-            if (sm < S) {
-              const cf chi = v[u] * inv_scale;
-              op = op + conjf(w[u]) * chi;
-              if (grad) acc[sm * pw + x] = acc[sm * pw + x] + O * chi;
-              if (sm == 0 && chi0) chi0[rowpix + x] = chi;
-            }
+        for (int j = 0; j < 2; ++j) {
+          const int x = threadIdx.x + j * 256, xc = x < pw ? x : 0;
+          int n1x, n2x;
+          pfa_split<P>(g, pad + xc, n1x, n2x);
+          const cf* q = src + (long)n1x * MM + n2x;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) nv[j][u] = q[(long)(u < S ? u : S - 1) * tile];
+          nO[j] = patches[((long)n * pw + y) * pw + xc];
+        }
+      };
+      request(n0);
+      for (long n = n0; n < n1; ++n) {
+        const float* wn =
+            probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
+        cf cv[2][4], cO[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          cO[j] = conjf(nO[j]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) cv[j][u] = nv[j][u];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          asm volatile("" : "+v"(cv[j][0].x), "+v"(cv[j][1].x), "+v"(cv[j][2].x),
+                       "+v"(cv[j][3].x));
+        if (n + 1 < n1) request(n + 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int x = threadIdx.x + j * 256;
+          if (x < pw) {
+            cf op = mk(0.f, 0.f);
+            consume(n, wn, x, cv[j], 0, cO[j], op);
+            if (objproj) objproj[((long)n * pw + y) * pw + x] = op;
           }
         }
-        if (objproj) objproj[rowpix + x] = op;
+      }
+    } else {
+      for (long n = n0; n < n1; ++n) {
+        const float* wn =
+            probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
+        const cf* src = C + n * S * tile + rowoff;
+        const long rowpix = ((long)n * pw + y) * pw;
+        for (int x = threadIdx.x; x < pw; x += 256) {
+          int n1x, n2x;
+          pfa_split<P>(g, pad + x, n1x, n2x);
+          const cf* q = src + (long)n1x * MM + n2x;
+          const cf O = conjf(patches[rowpix + x]);
+          cf op = mk(0.f, 0.f);
+          for (int s0 = 0; s0 < S; s0 += 4) {
+            cf v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = q[(long)(s0 + u < S ? s0 + u : S - 1) * tile];
+            consume(n, wn, x, v, s0, O, op);
+          }
+          if (objproj) objproj[rowpix + x] = op;
+        }
       }
     }
     if (grad) {
@@ -509,7 +621,9 @@ extern "C" int tike_pfa_combine_gradient(void* subtiles, const float* data,
   TkCostSink sink;
   int rc = tk_cost_sink(costs, nscan, blocks_per, stream, &sink);
   if (rc) return rc;
-  const dim3 grid(tk_grid((long)nscan * blocks_per, 16)), block(256);
+  // one work item per workgroup: the loads of a second item would queue
+  // behind the stores of the first (one in-order counter)
+  const dim3 grid((unsigned)((long)nscan * blocks_per)), block(256);
   const float inv = 1.0f / (float)num_measured;
 #define TK_PFA_CG(PP, MM, SM)                                                                \
   hipLaunchKernelGGL((pfa_combine_gradient_kernel<PP, MM, SM>), grid, block, 0, stream,         \
