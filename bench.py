@@ -440,6 +440,9 @@ EPOCH_DEFAULTS = {
     "c3pad": (256, 8, 10000, 10),
     "c3m12": (256, 12, 10000, 10),
     "c384": (384, 4, 10000, 10),
+    # powers of two WITHOUT position-major kernels (not in the default run)
+    "c64": (64, 8, 10000, 10),
+    "c1024": (1024, 2, 1000, 10),
 }
 # The minibatches are contiguous chunks of the ONCE-SHUFFLED scan (SURVEY
 # 8(d)): each spans the whole field of view, like the batches the reference's

@@ -970,9 +970,12 @@ def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0, margin=8,
     ("c3-4modes", 256, 4, 12, 2),
     ("c5", 512, 4, 8, 2),   # BASELINE configs[4]: 512^2, 4 modes, position correction
     # round 6, off-grid detector sizes through the whole solver: 192 = 3 x 64
-    # (prime-factor launches), 100 = 10 x 10 (LDS line engine), eigen probes
+    # (prime-factor launches), 300 = 20 x 15 (LDS line engine), 100 (below
+    # GENERAL_MIN_DETECTOR: the unfused kernels on the new transforms), all
+    # with eigen probes
     ("off-grid pfa", 192, 3, 12, 2),
-    ("off-grid lds", 100, 2, 10, 2),
+    ("off-grid lds", 300, 2, 8, 2),
+    ("off-grid unfused", 100, 2, 10, 2),
 ])
 def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
                                          spatial_sort, batch_method):
@@ -988,6 +991,9 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
         from tike_amd.ptycho.solvers import lstsq as L
         assert L.pfa_gradients(S, det, det) == (tag == "off-grid pfa")
         assert L.general_gradients(S, det, det)
+        # (the prime-factor launches take their sizes whatever the side)
+        assert (det < L.GENERAL_MIN_DETECTOR and not L.pfa_gradients(
+            S, det, det)) == (tag == "off-grid unfused")
     # (position correction under the per-minibatch rule moves the corner
     # positions further: more room around the scan, or check_allowed_positions
     # -- the reference's rule -- stops the run)

@@ -159,7 +159,8 @@ class GradientPlan:
                tuple(L.POSITION_MAJOR_SIZES), tuple(L.NO_FARPLANE_SIZES),
                tuple(L.SPLIT_FORWARD_SIZES), tuple(L.ONE_LAUNCH_GRADIENT_SIZES),
                L.POISSON_FROM_HANDOFF, L.POISSON_STEPS_IN_PASS2,
-               L.GENERAL_FUSED, L.PFA_ROUTE, L.CHUNK_POSITIONS_OVERRIDE)
+               L.GENERAL_FUSED, L.PFA_ROUTE, L.GENERAL_MIN_DETECTOR,
+               L.CHUNK_POSITIONS_OVERRIDE)
         cache = op.__dict__.setdefault("_tike_amd_plans", {})
         if key not in cache:
             cache[key] = GradientPlan._build(S, pw, det, eo, mask_u8, unmeasured,
@@ -180,8 +181,17 @@ class GradientPlan:
                    and (not pos_major or L.GENERAL_FUSED == "always")
                    and not poisson and L.general_gradients(S, pw, det))
         # ... and among them the sizes p x 2^k, p in {3, 5}, the prime-factor
-        # launches (power-of-two register engine on p x p sub-tiles)
+        # launches (power-of-two register engine on p x p sub-tiles): faster
+        # than everything else wherever they apply (96^2 ... 768^2: +15 ... +56 %
+        # over the unfused kernels, profiles/r06_experiments.md section 6)
         pfa = general and L.pfa_gradients(S, pw, det)
+        # the LDS line engine pays per work item: below ~256 pixels a side the
+        # unfused kernels on the new transforms are faster (45^2: 1360 vs 824 k
+        # patterns/s, 64^2: 1117 vs 614 k, 100^2: 559 vs 372 k; 320^2 equal;
+        # 384^2 +17 %, 768^2 +16 %, 1024^2 +10 % for the general launches)
+        if (general and not pfa and det < L.GENERAL_MIN_DETECTOR
+                and L.GENERAL_FUSED != "always"):
+            general = False
         if general:
             pos_major = False
         # detector sizes with the far-plane-free pipeline (the per-mode poisson

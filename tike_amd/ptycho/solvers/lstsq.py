@@ -97,6 +97,11 @@ launches of csrc/general.hip (tike_gen_*; gaussian model) instead of the
 unfused round-1 kernels; tests set this to False to compare the two."""
 
 
+GENERAL_MIN_DETECTOR = 256
+"""Detector sizes below this (and without a prime-factor decomposition) keep
+the unfused kernels: measured faster there than the LDS line engine's three
+launches (`_plan.py`)."""
+
 PFA_ROUTE = True
 """Detector sizes 3 x 2^k and 5 x 2^k (96 ... 1536) without position-major
 kernels take the prime-factor launches of csrc/pfa.hip (tike_pfa_*): the

@@ -19,6 +19,14 @@ import tike_amd.ptycho as tp  # noqa: E402
 if os.environ.get("OFFGRID_GENERAL") == "0":  # the unfused round-1 kernels
     from tike_amd.ptycho.solvers import lstsq as _L
     _L.GENERAL_FUSED = False
+import re
+for name in sys.argv[2:]:  # gDETxS: any detector size / mode count, no eigen probe
+    m = re.fullmatch(r"g(\d+)x(\d+)", name)
+    if m:
+        bench.EPOCH_DEFAULTS[name] = (int(m.group(1)), int(m.group(2)), 10000, 10)
+if os.environ.get("OFFGRID_PFA") == "0":  # the LDS line engine instead
+    from tike_amd.ptycho.solvers import lstsq as _L2
+    _L2.PFA_ROUTE = False
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 for w in sys.argv[2:] or ["c3", "c3pad", "c3m12", "c384"]:
     leg = bench.epoch_leg(w, tp, A, torch, positions=N, epochs=3)
