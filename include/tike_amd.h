@@ -573,8 +573,9 @@ int tike_gen_inv_rows_gradients(const void* hand2, const void* patches, const vo
                                 float probe_update_scale, int nscan, int S, int pw, int det,
                                 float inv_scale, void* stream);
 
-/* ---- the same chunk body for detector sizes det = p * M, p in {3, 5}, M a
- * power of two in 32 .. 512 (96, 160, 192, 320, 384, 640, 768, 1536 ...) by the
+/* ---- the same chunk body for detector sizes det = p * M, p in {3, 5, 7}, M a
+ * power of two in 32 .. 512 (96, 160, 192, 224, 320, 384, 448, 640, 768, 896,
+ * 1536 ...) by the
  * prime-factor decomposition: p and M are coprime, so the det x det transform
  * is p x p sub-tiles of M x M through the power-of-two register engine plus a
  * pointwise p x p DFT across the sub-tiles, no twiddles between them

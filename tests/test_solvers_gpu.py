@@ -1163,6 +1163,7 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
     (64, 64, 16, 6, True),     # a power of two the fused kernels do not serve
     (1024, 1024, 1, 2, False), (640, 512, 2, 3, False),
     (768, 768, 2, 2, False), (192, 192, 9, 4, True), (320, 300, 2, 5, True),
+    (448, 448, 2, 3, True), (224, 200, 3, 4, False),  # 7 x 2^k
 ])
 @pytest.mark.parametrize("engine", ["pfa", "lds"])
 def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine):

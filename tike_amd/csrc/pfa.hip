@@ -1,5 +1,5 @@
-// Detector sizes det = p * M, p in {3, 5}, M a power of two with a register
-// engine (32 .. 512) -- 96, 160, 192, 320, 384, 640, 768 ... -- by the
+// Detector sizes det = p * M, p in {3, 5, 7}, M a power of two with a register
+// engine (32 .. 512) -- 96, 160, 192, 224, 320, 384, 448, 640, 768, 896 ... -- by the
 // prime-factor (Good-Thomas) decomposition: p and M are coprime, so with
 //   input index   n = (M n1 + p n2) mod det          (n1 < p, n2 < M)
 //   output index  k = (M qM k1 + p qp k2) mod det     (qM = M^-1 mod p,
@@ -37,7 +37,7 @@ struct PfaGeom {
 };
 
 static bool pfa_geom(int det, PfaGeom* g) {
-  for (int p : {3, 5}) {
+  for (int p : {3, 5, 7}) {
     if (det % p) continue;
     const int M = det / p;
     if (M < 32 || M > 512 || (M & (M - 1))) continue;
@@ -582,13 +582,19 @@ extern "C" int tike_pfa_fwd_gather(const void* psi, const float* scan, const voi
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipError_t e5 = hipFuncSetAttribute((const void*)pfa_fwd_gather_kernel<5>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e3 != hipSuccess || e5 != hipSuccess) return (int)(e3 != hipSuccess ? e3 : e5);
+    hipError_t e7 = hipFuncSetAttribute((const void*)pfa_fwd_gather_kernel<7>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e3 != hipSuccess || e5 != hipSuccess || e7 != hipSuccess)
+      return (int)(e3 != hipSuccess ? e3 : e5 != hipSuccess ? e5 : e7);
   }
   if (g.p == 3)
     hipLaunchKernelGGL(pfa_fwd_gather_kernel<3>, grid, block, lds, stream, (const cf*)psi, scan,
                        P, (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, chunk);
-  else
+  else if (g.p == 5)
     hipLaunchKernelGGL(pfa_fwd_gather_kernel<5>, grid, block, lds, stream, (const cf*)psi, scan,
+                       P, (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, chunk);
+  else
+    hipLaunchKernelGGL(pfa_fwd_gather_kernel<7>, grid, block, lds, stream, (const cf*)psi, scan,
                        P, (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, chunk);
   TK_LAUNCH_CHECK();
   return TK_OK;
@@ -637,6 +643,8 @@ extern "C" int tike_pfa_combine_gradient(void* subtiles, const float* data,
   if (!resident && g.p == 3 && model == 1) TK_PFA_CG(3, 1, 0);
   if (g.p == 5 && model == 0) TK_PFA_CG(5, 0, 0);
   if (g.p == 5 && model == 1) TK_PFA_CG(5, 1, 0);
+  if (g.p == 7 && model == 0) TK_PFA_CG(7, 0, 0);
+  if (g.p == 7 && model == 1) TK_PFA_CG(7, 1, 0);
 #undef TK_PFA_CG
   TK_LAUNCH_CHECK();
   return tk_cost_finish(sink, nscan, stream);
@@ -681,15 +689,22 @@ extern "C" int tike_pfa_inv_products(const void* subtiles, const void* patches,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipError_t e5 = hipFuncSetAttribute((const void*)pfa_inv_products_kernel<5>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e3 != hipSuccess || e5 != hipSuccess) return (int)(e3 != hipSuccess ? e3 : e5);
+    hipError_t e7 = hipFuncSetAttribute((const void*)pfa_inv_products_kernel<7>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e3 != hipSuccess || e5 != hipSuccess || e7 != hipSuccess)
+      return (int)(e3 != hipSuccess ? e3 : e5 != hipSuccess ? e5 : e7);
   }
   const dim3 grid(tk_grid((long)pw * nchunk, 16)), block(256);
   if (g.p == 3)
     hipLaunchKernelGGL(pfa_inv_products_kernel<3>, grid, block, lds, stream, (const cf*)subtiles,
                        (const cf*)patches, P, (cf*)objproj, (cf*)chi0, (float*)m_probe_update,
                        probe_update_scale, part, g, nscan, S, pw, chunk, inv_scale);
-  else
+  else if (g.p == 5)
     hipLaunchKernelGGL(pfa_inv_products_kernel<5>, grid, block, lds, stream, (const cf*)subtiles,
+                       (const cf*)patches, P, (cf*)objproj, (cf*)chi0, (float*)m_probe_update,
+                       probe_update_scale, part, g, nscan, S, pw, chunk, inv_scale);
+  else
+    hipLaunchKernelGGL(pfa_inv_products_kernel<7>, grid, block, lds, stream, (const cf*)subtiles,
                        (const cf*)patches, P, (cf*)objproj, (cf*)chi0, (float*)m_probe_update,
                        probe_update_scale, part, g, nscan, S, pw, chunk, inv_scale);
   TK_LAUNCH_CHECK();

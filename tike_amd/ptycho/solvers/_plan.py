@@ -19,7 +19,7 @@ Routes:
   pos_major    128^2, or 256^2 / 512^2 with a probe window narrower than the
                detector or more modes than the fused pass 2 takes: forward +
                intensity in one position-major kernel, scaled inverse
-  pfa          detector sizes p x 2^k, p in {3, 5} (96 ... 1536), gaussian
+  pfa          detector sizes p x 2^k, p in {3, 5, 7} (96 ... 3584), gaussian
                model: p x p sub-tiles through the power-of-two register engine
                (csrc/pfa.hip)
   general      every other shape with a mixed-radix plan, gaussian model: the
@@ -180,7 +180,7 @@ class GradientPlan:
         general = (not fused
                    and (not pos_major or L.GENERAL_FUSED == "always")
                    and not poisson and L.general_gradients(S, pw, det))
-        # ... and among them the sizes p x 2^k, p in {3, 5}, the prime-factor
+        # ... and among them the sizes p x 2^k, p in {3, 5, 7}, the prime-factor
         # launches (power-of-two register engine on p x p sub-tiles): faster
         # than everything else wherever they apply (96^2 ... 768^2: +15 ... +56 %
         # over the unfused kernels, profiles/r06_experiments.md section 6)
