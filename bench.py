@@ -434,6 +434,11 @@ EPOCH_DEFAULTS = {
     "c3rpie": (256, 8, 10000, 10),
     # ... and by rpie on a two-slice object (row f3, multislice part)
     "c3rpie2": (256, 8, 10000, 10),
+    # ... at the other two tile sizes of the fused multislice chain, and under
+    # the Poisson model (round 6; `--workload` legs, c5rpie2 in the default run)
+    "c5rpie2": (512, 4, 4000, 10),
+    "c128rpie2": (128, 8, 10000, 10),
+    "c3rpie2poisson": (256, 8, 10000, 10),
     # off-grid shapes (round 6; not BASELINE configurations): what the
     # reference's cuFFT path serves at one speed and the fused pow-2 kernels
     # do not -- a probe window of half the detector, 12 modes, a 384^2 crop
@@ -456,7 +461,11 @@ EPOCH_DEFAULTS = {
 BATCH_RULE = os.environ.get("TIKE_BENCH_BATCH_RULE", "wobbly_center")
 SOLVER_LABEL = {"c1": "cgrad (cg_iter=4)", "c2": "cgrad (cg_iter=4)",
                 "c3poisson": "lstsq_grad (poisson, all_modes)",
-                "c3rpie": "rpie", "c3rpie2": "rpie, two-slice object"}
+                "c3rpie": "rpie", "c3rpie2": "rpie, two-slice object",
+                "c5rpie2": "rpie, two-slice object",
+                "c128rpie2": "rpie, two-slice object",
+                "c3rpie2poisson": "rpie, two-slice object (poisson)"}
+MULTISLICE = ("c3rpie2", "c5rpie2", "c128rpie2", "c3rpie2poisson")
 
 
 def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
@@ -484,7 +493,7 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
     C = 0
     # (the two-slice workload runs without eigen probes, like the reference's
     # multislice test and tools/soak_multislice.py)
-    if workload.startswith("c3") and workload != "c3rpie2":
+    if workload.startswith("c3") and workload not in MULTISLICE:
         import tike_amd.random
         tike_amd.random.randomizer_np = np.random.default_rng(4321)
         eigen_probe, eigen_weights = tp.init_varying_probe(
@@ -493,7 +502,7 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
     data = tp.simulate(det, p["probe"], p["scan"], p["psi"])
     psi0 = np.full_like(p["psi"], 0.5 + 0j)
     multislice = {}
-    if workload == "c3rpie2":
+    if workload in MULTISLICE:
         # two slices, the one behind starts transparent; 0.1 nm, 2 um field
         # of view, 1 um between the slices (tools/soak_multislice.py)
         psi0 = np.concatenate([psi0, np.ones_like(psi0)])
@@ -508,12 +517,14 @@ def epoch_problem(workload, positions, world, rank, tp, A, data_on_host=False):
                            if workload in ("c1", "c2") else
                            tp.RpieOptions(num_batch=num_batch,
                                           batch_method=BATCH_RULE)
-                           if workload in ("c3rpie", "c3rpie2") else
+                           if workload == "c3rpie" or workload in MULTISLICE
+                           else
                            tp.LstsqOptions(num_batch=num_batch,
                                            batch_method=BATCH_RULE)),
         exitwave_options=tp.ExitWaveOptions(
             measured_pixels=np.ones((det, det), dtype=bool),
-            noise_model="poisson") if workload == "c3poisson" else
+            noise_model="poisson")
+        if workload in ("c3poisson", "c3rpie2poisson") else
         # (the default mask has the probe's shape, options.py:168: a probe
         # window narrower than the detector must bring its own)
         tp.ExitWaveOptions(measured_pixels=np.ones((det, det), dtype=bool))
@@ -572,7 +583,7 @@ def epoch_leg(workload, tp, A, torch, positions=0, epochs=None):
                num_batch=built["num_batch"],
                position_correction=workload == "c5", epochs=epochs,
                ms_per_epoch=dt / epochs * 1e3, value=rate, unit="patterns/s")
-    if workload != "c3rpie2":  # (SURVEY 8(d)'s bounds are a single slice's)
+    if workload not in MULTISLICE:  # (SURVEY 8(d)'s bounds: a single slice's)
         leg.update(iteration_hbm_frac=b_iter * rate / 1e9 / HBM_PEAK_GBS,
                    iteration_fp32_frac=f_iter * rate / 1e12 / FP32_PEAK_TFLOPS)
     return leg
@@ -763,12 +774,12 @@ def main():
     from tike_amd.ptycho.solvers.lstsq import chunk_positions
 
     timers = KernelTimers(lib, [n for n in _PROTOTYPES if n != "tike_init"])
-    timers.label_cost_only = a.workload in ("c1", "c2", "c3rpie2")
-    if a.workload == "c3rpie2":
+    timers.label_cost_only = a.workload in ("c1", "c2") + MULTISLICE
+    if a.workload in MULTISLICE:
         global MULTISLICE_DEPTH
         MULTISLICE_DEPTH = 2
         timers.cost_only_suffix = ":no_patches"
-        timers.modes = EPOCH_DEFAULTS["c3rpie2"][1]
+        timers.modes = EPOCH_DEFAULTS[a.workload][1]
     counts = dict(epoch=0, steps=0, in_minibatch=False)
     cpu = None
     cpu_job = None
@@ -996,7 +1007,7 @@ def main():
         # ... and SURVEY 8 rows f2 / f3 at the headline shapes: the Poisson
         # model, rpie, rpie on a two-slice object
         secondary += [guarded(w, epoch_leg, w, tp, A, torch)
-                      for w in ("c3poisson", "c3rpie", "c3rpie2")]
+                      for w in ("c3poisson", "c3rpie", "c3rpie2", "c5rpie2")]
         # ... and the off-grid shapes (round 6): a probe window of half the
         # detector, 12 modes, a 384^2 detector -- each with its rate per
         # far-plane byte beside c3's

@@ -197,7 +197,8 @@ int tike_ptycho_fwd_gradient_scale(const void* psi, const float* scan, const voi
                                    int H, int W, float scale, int model, float unmeasured_scaling,
                                    long num_measured, void* stream);
 
-/* ---- the same, split in two launches (det = 256 or 512).  tike_fwd_pass1: bilinear
+/* ---- the same, split in two launches (det = 256 or 512; tike_fwd_pass1 also
+ * det = 128, for the multislice chain below).  tike_fwd_pass1: bilinear
  * gather * probe -> row transforms -> radix-16 column stage; scratch
  * (nscan,S,det,det) receives the UNSCALED input of the column pass of every
  * tile, patches (nscan,pw,pw, may be NULL) the object patches O_n.  The varying
@@ -641,7 +642,7 @@ int tike_fft2_pass2_inplace(void* tiles, long ntile, int det, int inverse, float
 
 /* The last pass of a Fresnel step fused with the first pass of the next
  * slice's transform (operators/cupy/multislice.py:86-91, then :79-85 of the
- * slice behind; det = 256, probe window = detector): wave (nscan,S,det,det)
+ * slice behind; probe window = detector): wave (nscan,S,det,det)
  * in = tike_fresnel_colpass's output, out = the probe incident on the slice
  * (x scale), in place; farplane1 (nscan,S,det,det) != wave receives pass 1 of
  * FFT2(wave x patch_n(psi)) -- the input of the column pass kernels
@@ -661,8 +662,8 @@ int tike_fft2_pass2_intensity(void* tiles, float* amplitude, long nscan, int S, 
 /* forward column pass -> x propagator (conj when `adjoint`) x scale -> inverse
  * pass 1 (fresnelspectprop.py:86-113): colin = output of a FORWARD pass 1,
  * work = input of an INVERSE pass 2; propagator (det,det) c64 in FFT order
- * (fresnelspectprop.py:115-137).  det = 256 (TIKE_ERR_UNSUPPORTED otherwise:
- * use tike_fresnel_spect_prop). */
+ * (fresnelspectprop.py:115-137).  det in {128, 256, 512} (TIKE_ERR_UNSUPPORTED
+ * otherwise: use tike_fresnel_spect_prop). */
 int tike_fresnel_colpass(const void* colin, const void* propagator, int adjoint, void* work,
                          long ntile, int det, float scale, void* stream);
 

@@ -446,16 +446,17 @@ def test_ptycho_adj_positions_outside_take_the_general_kernels(ops, oracle):
     assert_close(probe_adj, o_probe, what="probe_adj")
 
 
+@pytest.mark.parametrize("n", [256, 128, 512])
 @pytest.mark.parametrize("adjoint", [False, True])
-def test_fresnel_step_in_three_launches_vs_oracle(oracle, adjoint):
+def test_fresnel_step_in_three_launches_vs_oracle(oracle, adjoint, n):
     """tike_fft2_pass1 -> tike_fresnel_colpass -> tike_fft2_pass2_inplace ==
     FresnelSpectProp.fwd / .adj (fresnelspectprop.py:52-113) of the oracle,
-    for few tiles (k1 split over workgroups) and for many."""
+    for few tiles (k1 split over workgroups) and for many; 128^2 and 512^2
+    (round 6): two column stages per 16-row group / two groups per stage."""
     import torch
     import tike_amd._arrays as A
     from tike_amd._lib import check, lib
     rng = np.random.default_rng(4)
-    n = 256
     H = oracle.fresnel_spectrum_propagator((n, n), (2e-6, 2e-6), 1e-6, 1e-10)
     st = A.stream_ptr()
     for ntile in (3, 40):
@@ -470,9 +471,10 @@ def test_fresnel_step_in_three_launches_vs_oracle(oracle, adjoint):
         assert_close(b.cpu().numpy(), want, what=f"fresnel, {ntile} tiles")
 
 
+@pytest.mark.parametrize("det", [256, 128, 512])
 @pytest.mark.parametrize("S,N,inside", [(8, 5, True), (1, 33, True),
                                         (3, 6, False)])
-def test_slice_step_vs_its_two_launches(oracle, S, N, inside):
+def test_slice_step_vs_its_two_launches(oracle, S, N, inside, det):
     """tike_slice_step == tike_fft2_pass2_inplace (the probe incident on the
     slice) followed by tike_fwd_pass1 with those per-position probes
     (multislice.py:86-91, :79-85), and both against NumPy; positions whose
@@ -481,7 +483,7 @@ def test_slice_step_vs_its_two_launches(oracle, S, N, inside):
     import tike_amd._arrays as A
     from tike_amd._lib import check, lib
     rng = np.random.default_rng(S + N)
-    det, HW = 256, 300
+    HW = det + 44
     scan = (rng.random((N, 2)) * 40 + 1.5).astype(np.float32)
     if not inside:
         scan[1] = (-3.25, 10.5)

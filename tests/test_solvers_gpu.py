@@ -1764,6 +1764,105 @@ def test_rpie_multislice_fused_vs_oracle(tp, depth, S, N, eigen, u16, step_back)
                  maxabs=1e-2, what="probe")
 
 
+@pytest.mark.parametrize("det,depth,S,N,model,slice_step,u16", [
+    (128, 2, 3, 10, "gaussian", True, False),
+    (128, 3, 1, 9, "gaussian", False, True),
+    (128, 2, 8, 7, "gaussian", True, False),
+    (512, 2, 2, 6, "gaussian", True, False),
+    (512, 3, 1, 5, "gaussian", False, False),
+    (512, 2, 5, 4, "gaussian", True, True),
+    (256, 2, 4, 8, "poisson", True, False),
+    (256, 3, 1, 7, "poisson", False, True),
+    (128, 2, 2, 8, "poisson", True, False),
+    (512, 2, 1, 5, "poisson", True, False),
+])
+def test_rpie_multislice_fused_sizes_and_models(tp, det, depth, S, N, model,
+                                                slice_step, u16):
+    """Round 6: the fused multislice chain at 128^2 and 512^2
+    (`tike_fresnel_colpass`, `tike_slice_step` and `tike_fwd_pass1` at those
+    sizes; `tike_ifft2_pass2_products` with the numerators at 512^2) and under
+    the Poisson model at all three (the last slice with its far field stored,
+    `rpie._stored_farplane_gradient`): two rpie epochs against the CPU oracle
+    (rpie.py:367-495, multislice.py:69-92, fresnelspectprop.py:52-113,
+    exitwave.py:122-234) and against the slice-by-slice composition of the
+    general operators."""
+    import importlib
+    from oracle import operators as oops
+    from oracle import solvers as osol
+    from tike_amd import _lib
+    R = importlib.import_module("tike_amd.ptycho.solvers.rpie")
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=7 * depth + S + det, eigen=False)
+    phys = dict(wavelength=1e-10, fov=(2e-6, 2e-6), distance=1e-6)
+    psi0 = np.repeat(np.full_like(psi_true, 0.5), depth, axis=0)
+    psi0[1:] = 1.0
+    if u16 or model == "poisson":
+        data = np.round(data * (20000.0 / data.max()))
+        data = data.astype(np.uint16 if u16 else np.float32)
+    batches = np.array_split(np.arange(N), 2)
+    seen = []
+    real = R._gradients_multislice_fused
+
+    def spy(*a, **k):
+        seen.append(1)
+        return real(*a, **k)
+
+    def run(fused):
+        R.FUSED_MULTISLICE = fused
+        R.SLICE_STEP_FUSED = slice_step
+        R._gradients_multislice_fused = spy
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
+            algorithm_options=tp.RpieOptions(num_batch=2, num_iter=2,
+                                             batch_method="compact",
+                                             alpha=1.0),
+            probe_options=tp.ProbeOptions(
+                force_orthogonality=True, probe_wavelength=phys["wavelength"],
+                probe_FOV_lengths=phys["fov"]),
+            object_options=tp.ObjectOptions(
+                multislice_propagation_distance=phys["distance"]),
+            exitwave_options=tp.ExitWaveOptions(
+                measured_pixels=np.ones((det, det), dtype=bool),
+                noise_model=model))
+        try:
+            with tp.Reconstruction(data, params, order=np.arange(N),
+                                   batches=batches) as ctx:
+                ctx.iterate(2)
+                return ctx.get_result()
+        finally:
+            R.FUSED_MULTISLICE = True
+            R.SLICE_STEP_FUSED = True
+            R._gradients_multislice_fused = real
+
+    got = run(True)
+    assert len(seen) == 4, "the fused chain ran for every minibatch"
+    slow = run(False)
+    assert len(seen) == 4
+    np.testing.assert_allclose(np.array(got.algorithm_options.costs),
+                               np.array(slow.algorithm_options.costs),
+                               rtol=2e-4)
+    assert_close(got.psi, slow.psi, normwise=3e-4, maxabs=3e-3,
+                 what="psi vs slice by slice")
+    assert_close(got.probe, slow.probe, normwise=3e-4, maxabs=3e-3,
+                 what="probe vs slice by slice")
+    propagator = oops.fresnel_spectrum_propagator(
+        (det, det), phys["fov"], phys["distance"], phys["wavelength"])
+    fdata = data.astype(np.float32)
+    state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
+                 costs=[], eigen_probe=None, eigen_weights=None)
+    state = osol.rescale_probe(state, fdata, det, propagator=propagator)
+    state = osol.iterate(state, fdata, batches, 2, detector_shape=det,
+                         solver="rpie", alpha=1.0, batch_method="compact",
+                         force_orthogonality=True, propagator=propagator,
+                         noise_model=model)
+    np.testing.assert_allclose(np.array(got.algorithm_options.costs),
+                               np.array(state["costs"]), rtol=1e-3)
+    assert_close(got.psi, state["psi"], normwise=SOLVER_NORMWISE, maxabs=1e-2,
+                 what="psi")
+    assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe")
+
+
 @pytest.mark.parametrize("det,S,model", [(256, 2, "gaussian"),
                                          (64, 1, "gaussian"),
                                          (256, 3, "poisson")])

@@ -86,7 +86,7 @@ __device__ __forceinline__ float tk_lane_up(float v) {
 // chunk instead of idling as a second mode-wave (no sum over modes: the waves
 // stay independent).
 template <int N, int MW, int MPW, bool PER_POS, int OUT, int PW = 1>
-__global__ __launch_bounds__(256, (N == 512 || MW > 1 || OUT > 0) ? 2 : 3)
+__global__ __launch_bounds__(256, (N == 512 && OUT > 0) ? 1 : (N == 512 || MW > 1 || OUT > 0) ? 2 : 3)
 void ifft2_pass2_adjoint_kernel(
     cf* work, const cf* __restrict__ psi, const float* __restrict__ scan,
     const cf* __restrict__ probe, cf* __restrict__ objproj, float* __restrict__ pnum,
@@ -404,22 +404,13 @@ int tk_ifft2_pass2_products(cf* work, const cf* psi, const float* scan, const cf
     else                             \
       A(N, 4, 2);                    \
   } while (0)
-  // (512^2: only Ptycho.adj -- with the numerator's accumulators beside a
-  // radix-32 butterfly the kernel would spill 70 registers)
-#define TK_ADJ512(N, MW_, MPW_)             \
-  do {                                      \
-    if (probe_per_scan)                     \
-      TK_ADJ_O(N, MW_, MPW_, true, 0);      \
-    else                                    \
-      TK_ADJ_O(N, MW_, MPW_, false, 0);     \
-  } while (0)
-  if (det == 512 && out != 0) return TK_ERR_UNSUPPORTED;
+  // (512^2 with the numerator's accumulators beside a radix-32 butterfly: one
+  // workgroup of 256 per SIMD pair -- at two it would spill 70 registers)
   switch (det) {
     case 128: TK_ADJ_N(128, TK_ADJ); break;
     case 256: TK_ADJ_N(256, TK_ADJ); break;
-    default: TK_ADJ_N(512, TK_ADJ512); break;
+    default: TK_ADJ_N(512, TK_ADJ); break;
   }
-#undef TK_ADJ512
 #undef TK_ADJ_N
 #undef TK_ADJ
 #undef TK_ADJ_O

@@ -198,8 +198,8 @@ __device__ __forceinline__ void fft2_pass2(const cf* __restrict__ mid, int k1, S
   for (int k2 = 0; k2 < G2::RB; ++k2) store(k1 + 16 * k2, t, u[k2]);
 }
 
-// Column-first counterpart of fft2_pass1 (N = 256: RB = 16 rows of T = 16
-// threads): every thread t holds a[ya], ya < 16 -- column t of 16 rows whose
+// Column-first counterpart of fft2_pass1 (16 rows of T = N / 16 threads, the
+// N threads of the workgroup): every thread t holds a[ya], ya < 16 -- column t of 16 rows whose
 // COLUMN stage is already done -- and the rows still need their length-N
 // transform.  The values are transposed through LDS into the row layout
 // (16 threads per row, element e = j + i*T), transformed with the in-wave
@@ -209,7 +209,6 @@ template <int N, bool INV, bool STREAM = false, class Tw>
 __device__ __forceinline__ void fft2_rows_from_columns(cf* __restrict__ lds, const Tw& tw, int line,
                                                        int j, cf (&a)[16], cf* __restrict__ rows) {
   using G2 = Fft2Geom<N>;
-  static_assert(G2::RB == 16, "one pass: 16 rows x 16 threads");
   const int t = threadIdx.x;
 #pragma unroll
   for (int ya = 0; ya < 16; ++ya) lds[ya * G2::LS + tk_pad16(t)] = a[ya];

@@ -527,7 +527,7 @@ extern "C" int tike_ptycho_fwd_gradient_scale(
 // forward operator's sub-batched column pass); the solver's minibatch-sized
 // hand-off does not fit and keeps the non-temporal stores.
 template <int N, bool FULL, bool KEEP = false>
-__global__ __launch_bounds__(N, N == 256 ? 3 : 2) void fwd_pass1_kernel(
+__global__ __launch_bounds__(N, N == 512 ? 2 : 3) void fwd_pass1_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
     cf* __restrict__ scratch, cf* __restrict__ patches, int nscan, int S, int pw, int H, int W,
     const cf* __restrict__ twtab, const int* __restrict__ skip) {
@@ -719,14 +719,14 @@ static int tk_fwd_pass1(const void* psi, const float* scan, const void* probe,
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(psi && scan && probe && scratch);
   TK_CHECK_ARG(!(eigen_weights && eigen_modes > 0 && !unique_probe && !eigen_probe));
-  if (det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
+  if (det != 128 && det != 256 && det != 512) return TK_ERR_UNSUPPORTED;
   const cf* tw = tk_twiddles();
   if (!tw) return (int)hipErrorNotInitialized;
   const TkProbe P = tk_make_probe(probe, probe_per_scan, unique_probe ? nullptr : eigen_probe,
                                   eigen_weights, num_eigen, eigen_modes, S, pw, unique_probe);
 #define TK_F1K(N, FULL, KEEP)                                                                   \
   hipLaunchKernelGGL((fwd_pass1_kernel<N, FULL, KEEP>),                                        \
-                     dim3(tk_grid((long)nscan * (N / 16), N == 256 ? 8 : 1)),                  \
+                     dim3(tk_grid((long)nscan * (N / 16), N == 512 ? 1 : (N == 256 ? 8 : 16))), \
                      dim3(N), 0, stream, (const cf*)psi, scan, P, (cf*)scratch, (cf*)patches,   \
                      nscan, S, pw, H, W, tw, skip)
 #define TK_F1(N, FULL)      \
@@ -736,7 +736,11 @@ static int tk_fwd_pass1(const void* psi, const float* scan, const void* probe,
     else                    \
       TK_F1K(N, FULL, false); \
   } while (0)
-  if (det == 256 && pw == det)
+  if (det == 128 && pw == det)  // (a multislice object: tike_slice_step's partner)
+    TK_F1(128, true);
+  else if (det == 128)
+    TK_F1(128, false);
+  else if (det == 256 && pw == det)
     TK_F1(256, true);
   else if (det == 256)
     TK_F1(256, false);

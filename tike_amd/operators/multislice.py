@@ -19,8 +19,10 @@ from .propagation import ZeroPropagation
 
 def fused_slices(probe_shape, detector_shape, S):
     """Shapes whose slice-to-slice step runs on the two-pass kernels
-    (`next_incident_probe`): 256^2 tiles, probe window = detector, <= 8 modes."""
-    return probe_shape == detector_shape == 256 and S <= 8
+    (`next_incident_probe`): 128^2, 256^2 or 512^2 tiles, probe window =
+    detector, <= 8 modes."""
+    return (probe_shape == detector_shape and detector_shape in (128, 256, 512)
+            and S <= 8)
 
 
 def next_incident_probe(psi_slice, scan, beam, scratch, out, propagator,

@@ -191,9 +191,9 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
 
 
 FUSED_MULTISLICE = True
-"""256^2 tiles with probe window = detector, at most 8 modes, the gaussian
-model and the object being recovered: a multislice minibatch runs on the
-two-pass kernels (`_gradients_multislice_fused`).  False: the slice-by-slice
+"""128^2, 256^2 or 512^2 tiles with probe window = detector, at most 8 modes
+and the object being recovered: a multislice minibatch runs on the two-pass
+kernels (`_gradients_multislice_fused`).  False: the slice-by-slice
 composition of the general operators, which remains the path of every other
 configuration."""
 
@@ -214,7 +214,6 @@ outputs of the last slice's gradient pass (see _gradients_multislice_fused)."""
 def _fused_multislice_shapes(op, S, pw, exitwave_options, recover_psi, data):
     return (FUSED_MULTISLICE and recover_psi
             and fused_slices(pw, op.detector_shape, S)
-            and exitwave_options.noise_model == "gaussian"
             and isinstance(data, torch.Tensor))
 
 
@@ -240,7 +239,15 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
     finishes it and forms both numerators of the slice (object: through the
     grouped scatter).  STEP_BACK_IN_FREQUENCY = False runs the step as the
     reference writes it (`tike_fft2_pass1` -> `tike_fresnel_colpass` with the
-    conjugated propagator)."""
+    conjugated propagator).
+
+    That one-launch last slice exists at 256^2 (512^2: without the steps back)
+    for the gaussian model.  The Poisson model (its step lengths need the whole
+    far field of a position first, exitwave.py:122-234) and 128^2 tiles store
+    the far field instead: `tike_fft2_pass2_inplace` -> [`tike_intensity` ->
+    `tike_poisson_steps`] -> `tike_farplane_gradient` [-> `tike_scale_modes`]
+    -> `tike_fft2_pass1` (inverse), two more trips of the last slice's waves
+    through memory, and the steps back as the reference writes them."""
     dev = psi.device
     B = hi - lo
     D = psi.shape[0]
@@ -252,6 +259,11 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
     nmeasured, mask_u8 = L.mask_info(exitwave_options, det)
     unmeasured = float(exitwave_options.unmeasured_pixels_scaling)
     ws = L._workspace(op)
+    poisson = exitwave_options.noise_model == "poisson"
+    # the last slice's far field in one launch, never stored
+    one_launch = not poisson and det in (256, 512)
+    step_back_in_frequency = (STEP_BACK_IN_FREQUENCY and one_launch
+                              and det == 256)
     costs = torch.empty(max(B, 1), dtype=torch.float32, device=dev)
     chi0 = torch.empty((max(B, 1), pw, pw), dtype=torch.complex64, device=dev)
     patches0 = (torch.empty_like(chi0) if eigen_weights is not None else None)
@@ -272,7 +284,7 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
              max(64, budget // (2 * D * S * det * det * 8)))
     nmax = max(1, min(chunk, B))
     far = ws.get("ms_far", (nmax, S, det, det), torch.complex64, dev)
-    nback = D if STEP_BACK_IN_FREQUENCY else 1
+    nback = D if step_back_in_frequency else 1
     mids = ws.get("ms_mid", (nback, nmax, S, det, det), torch.complex64, dev)
     beams = ws.get("ms_beams", (max(D - 1, 1), nmax, S, pw, pw),
                    torch.complex64, dev)
@@ -337,16 +349,23 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
         # (the outputs of a chunk packed: (nback, n, S, det, det))
         midv = mids.view(-1)[:nback * n * S * det * det].view(
             nback, n, S, det, det)
-        check(
-            lib.tike_fwd_grad_ifft2_pass1_slices(
-                A.ptr(far), A.ptr(data[clo:chi_hi]), u16, A.ptr(mask_u8),
-                A.ptr(costs[blo:blo + n]), A.ptr(midv), n, S, det, fwd_scale,
-                0, unmeasured, nmeasured, A.ptr(prop), nback, st),
-            "far field + gradient + inverse pass 1 (every slice)")
+        if one_launch:
+            check(
+                lib.tike_fwd_grad_ifft2_pass1_slices(
+                    A.ptr(far), A.ptr(data[clo:chi_hi]), u16, A.ptr(mask_u8),
+                    A.ptr(costs[blo:blo + n]), A.ptr(midv), n, S, det,
+                    fwd_scale, 0, unmeasured, nmeasured, A.ptr(prop), nback,
+                    st),
+                "far field + gradient + inverse pass 1 (every slice)")
+        else:
+            _stored_farplane_gradient(
+                far[:n], midv[0], data, clo, chi_hi, mask_u8,
+                costs[blo:blo + n], fwd_scale, unmeasured, nmeasured,
+                exitwave_options)
         mid = midv[0]
         for tt in range(D - 1, -1, -1):
             beam, per = incident[tt]
-            if STEP_BACK_IN_FREQUENCY:
+            if step_back_in_frequency:
                 mid = midv[D - 1 - tt]
             if tt == 0 and first_stored:
                 check(
@@ -365,14 +384,14 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
                     A.ptr(mid), A.ptr(psi[tt]), A.ptr(sc), A.ptr(beam), per,
                     A.ptr(objproj), A.ptr(pacc[tt]), 1.0,
                     A.ptr(chi0[blo:blo + n]) if tt == 0 else None,
-                    int(tt > 0 and not STEP_BACK_IN_FREQUENCY), n, S, det, H,
+                    int(tt > 0 and not step_back_in_frequency), n, S, det, H,
                     W, inv_scale, st),
                 "inverse pass 2 + numerators")
             check(
                 lib.tike_scatter_patches(A.ptr(objproj), A.ptr(sc),
                                          A.ptr(acc[tt]), n, pw, H, W, st),
                 "object numerator")
-            if tt == 0 or STEP_BACK_IN_FREQUENCY:
+            if tt == 0 or step_back_in_frequency:
                 continue
             check(lib.tike_fft2_pass1(A.ptr(mid), A.ptr(far), n * S, det, 0,
                                       st), "Fresnel step back: pass 1")
@@ -388,6 +407,46 @@ def _gradients_multislice_fused(data, psi, scan, probe, eigen_probe,
     psi_num += torch.complex(acc[:, 0], acc[:, 1]) / S
     probe_num[:, 0, 0] = pacc
     return costs[:B], chi0[:B], None if patches0 is None else patches0[:B]
+
+
+def _stored_farplane_gradient(far, mid, data, lo, hi, mask_u8, costs,
+                              fwd_scale, unmeasured, nmeasured,
+                              exitwave_options):
+    """The last slice with its far field stored: `far` (n, S, det, det), the
+    hand-off of `tike_fwd_pass1`, becomes the far field, then its gradient
+    (rpie.py:420-442; the Poisson model's per-mode step lengths,
+    exitwave.py:122-234), and `mid` receives the first pass of the inverse
+    transform."""
+    n, S, det = far.shape[0], far.shape[1], far.shape[-1]
+    st = A.stream_ptr()
+    poisson = exitwave_options.noise_model == "poisson"
+    dchunk = A.data_f32(data, lo, hi)
+    check(lib.tike_fft2_pass2_inplace(A.ptr(far), n * S, det, 0, fwd_scale, st),
+          "last slice: far field")
+    if poisson:
+        inten = torch.empty((n, det, det), dtype=torch.float32,
+                            device=far.device)
+        steps = torch.empty((n, S), dtype=torch.float32, device=far.device)
+        check(lib.tike_intensity(A.ptr(far), A.ptr(inten), n, S, det * det,
+                                 st), "intensity")
+        check(
+            lib.tike_poisson_steps(
+                A.ptr(far), A.ptr(inten), A.ptr(dchunk), A.ptr(mask_u8),
+                A.ptr(steps), n, S, det,
+                float(exitwave_options.step_length_start),
+                float(exitwave_options.step_length_weight),
+                int(exitwave_options.step_length_usemodes == "dominant_mode"),
+                st), "poisson step lengths")
+    check(
+        lib.tike_farplane_gradient(
+            A.ptr(far), A.ptr(dchunk), A.ptr(mask_u8), None, A.ptr(costs), n,
+            S, det, L._MODELS[exitwave_options.noise_model], 1, unmeasured,
+            nmeasured, st), "farplane gradient")
+    if poisson:
+        check(lib.tike_scale_modes(A.ptr(far), A.ptr(steps), A.ptr(mask_u8),
+                                   n * S, det, st), "poisson step scaling")
+    check(lib.tike_fft2_pass1(A.ptr(far), A.ptr(mid), n * S, det, 1, st),
+          "last slice: inverse pass 1")
 
 
 def _gradients_multislice(data, psi, scan, probe, eigen_probe, eigen_weights,
