@@ -374,6 +374,11 @@ def test_cgrad_with_probe_vs_reference_composition(tp, golden):
 @pytest.mark.parametrize("det,pw,S,N", [(256, 256, 1, 6), (256, 192, 2, 5),
                                         (128, 128, 1, 8), (512, 512, 2, 3),
                                         (64, 48, 2, 9),
+                                        # round 6: sizes off the power-of-two
+                                        # grid (prime-factor / mixed-radix /
+                                        # Bluestein transforms under cgrad)
+                                        (96, 96, 2, 6), (100, 80, 1, 7),
+                                        (384, 384, 1, 3), (127, 127, 1, 4),
                                         (128, 128, 1, 256)])  # BASELINE configs[0]
 def test_cgrad_vs_oracle(tp, det, pw, S, N):
     """cgrad (object then probe, 2 CG iterations each) against the oracle's
