@@ -707,6 +707,237 @@ __global__ __launch_bounds__(N, N == 512 ? 2 : 3) void fwd_pass1_kernel(
   }
 }
 
+// ---- pass 1 at 512^2, one WAVE per row (round 6) ----------------
+// fwd_pass1_kernel<512> holds 16 elements per thread (32 threads per row, one
+// 512-thread workgroup per CU at 204-244 VGPRs, two waves per SIMD) and moves
+// its bytes at 4.1 TB/s where the 256^2 form reaches 5.4.  Here a thread holds
+// EIGHT elements (e = lane + 64 i): a row is one wave, 512 = 8 x 8 x 8 in three
+// radix-8 stages with two exchanges inside the wave through the row's LDS
+// slot; 1024 threads per workgroup = the 16 rows of a group, and in the column
+// phase TWO threads share a column (the radix-16 over y2 as one
+// decimation-in-frequency step and a radix-8 each: even / odd k1).
+// <= 128 VGPRs: four waves per SIMD.  LDS: 16 rows x 545 + 1024 twiddles.
+struct TkRow8 {
+  static constexpr int N = 512, T = 64, LS = N + N / 16 + 1;
+  // twiddles of stages 1 and 2: tab[((s - 1) * 8 + r) * 64 + lane]
+  static constexpr int TW_ELEMS = 2 * 8 * 64;
+  static __device__ __forceinline__ void fill(cf* tab, const cf* __restrict__ g_tw) {
+    for (int idx = threadIdx.x; idx < TW_ELEMS; idx += blockDim.x) {
+      const int l = idx & 63, r = (idx >> 6) & 7, st = (idx >> 9) + 1;
+      const int Ns = st == 1 ? 8 : 64;
+      tab[idx] = g_tw[N + (l & (Ns - 1)) * r * (N / (Ns * 8))];
+    }
+  }
+  // v[i] = element lane + 64 i of the row, in and out (natural order)
+  template <bool INV>
+  static __device__ __forceinline__ void run(cf (&v)[8], cf* __restrict__ lbase, int l,
+                                             const cf* __restrict__ tab) {
+#pragma unroll
+    for (int st = 0; st < 3; ++st) {
+      const int Ns = st == 0 ? 1 : (st == 1 ? 8 : 64);
+      if (st > 0) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = mul_tw<INV>(v[r], tab[((st - 1) * 8 + r) * 64 + l]);
+      }
+      Dft<8, INV>::run(v);
+      if (st < 2) {
+        const int k = l & (Ns - 1);
+        const int j0 = (l - k) * 8 + k;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) lbase[tk_pad16(j0 + r * Ns)] = v[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = lbase[tk_pad16(l + 64 * i)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+};
+
+template <bool FULL, bool KEEP>
+__global__ __launch_bounds__(1024, 1) void fwd_pass1_512w_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    cf* __restrict__ scratch, cf* __restrict__ patches, int nscan, int S, int pw, int H, int W,
+    const cf* __restrict__ twtab, const int* __restrict__ skip) {
+  constexpr int N = 512, RB = 32, LS = TkRow8::LS;
+  constexpr unsigned EB = 64 * sizeof(cf);  // bytes between a thread's elements
+  if (skip != nullptr && *skip != 0) return;
+  // two sets of 16 rows: mode s + 1 writes its rows while the columns of mode s
+  // are still being read -- ONE barrier per mode (the only workgroup of its CU
+  // has nobody to hide a second one behind)
+  __shared__ cf lds[2 * 16 * LS + TkRow8::TW_ELEMS];
+  cf* twl = lds + 2 * 16 * LS;
+  TkRow8::fill(twl, twtab);
+  __syncthreads();
+  const int pad = FULL ? 0 : (N - pw) / 2;
+  const long total = (long)H * W;
+  const long PP = (long)pw * pw;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int l = threadIdx.x & 63;
+  asm volatile("" : "+v"(l));
+  const int col = threadIdx.x & 511;
+  const int q = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9));  // even / odd k1
+  auto at = [](const cf* base, unsigned byte_off) -> const cf* {
+    return reinterpret_cast<const cf*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  for (long item = blockIdx.x; item < (long)nscan * RB; item += gridDim.x) {
+    const long n = item / RB;
+    const int r = (int)(item % RB);
+    const TkCorner c = tk_corner(scan, n);
+    cf* __restrict__ dst0 = scratch + n * S * (long)N * N;
+    const float* __restrict__ wn =
+        probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
+    const bool interior = FULL && c.sy >= 0 && c.sx >= 0 && c.sy + pw < H && c.sx + pw < W &&
+                          total < (1L << 28);
+    // this wave's row: y = r + 32 w, elements e = l + 64 i
+    const int py = r + RB * w - pad;
+    const int pyc = py < 0 ? 0 : (py >= pw ? pw - 1 : py);
+    const unsigned pbo = (unsigned)(pyc * pw + l) * (unsigned)sizeof(cf);
+    cf pv[8];
+    if (interior) {
+      const unsigned g0 = (unsigned)((c.sy + py) * W + c.sx + l) * (unsigned)sizeof(cf);
+      const unsigned g1 = g0 + (unsigned)W * (unsigned)sizeof(cf);
+      typedef float tk_v4f __attribute__((ext_vector_type(4)));
+      auto ld4 = [](const cf* base, unsigned byte_off) {
+        tk_v4f v;
+        __builtin_memcpy(&v, reinterpret_cast<const char*>(base) + byte_off, sizeof(v));
+        return v;
+      };
+      tk_v4f u[8], lo[8];  // upper row (a, b), lower row (d, e)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        u[i] = ld4(psi, g0 + EB * i);
+        lo[i] = ld4(psi, g1 + EB * i);
+      }
+      asm volatile(""
+                   : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]),
+                     "+v"(u[6]), "+v"(u[7]), "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]),
+                     "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        cf o = mk(u[i].x * c.w00, u[i].y * c.w00);
+        o.x += u[i].z * c.w01;
+        o.y += u[i].w * c.w01;
+        o.x += lo[i].x * c.w10;
+        o.y += lo[i].y * c.w10;
+        o.x += lo[i].z * c.w11;
+        o.y += lo[i].w * c.w11;
+        pv[i] = o;
+      }
+    } else {
+      const int y = c.sy + py;
+      const bool row_ok = py >= 0 && py < pw && y >= 0 && y < H;
+      const int yc = c.sy + pyc < 0 ? 0 : (c.sy + pyc >= H ? H - 1 : c.sy + pyc);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int px = l + 64 * i - pad;
+        const int x = c.sx + px;
+        const bool ok = row_ok && px >= 0 && px < pw && x >= 0 && x < W;
+        const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+        const int xc = c.sx + pxc < 0 ? 0 : (c.sx + pxc >= W ? W - 1 : c.sx + pxc);
+        const cf o = tk_gather(psi, (long)yc * W + xc, W, total, c);
+        pv[i] = ok ? o : mk(0.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);  // rare path: one element in flight
+      }
+    }
+    if (patches != nullptr && py >= 0 && py < pw) {
+      cf* __restrict__ On = patches + n * PP;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int px = l + 64 * i - pad;
+        if (FULL)
+          tk_st_stream(const_cast<cf*>(at(On, pbo + EB * i)), pv[i]);
+        else if (px >= 0 && px < pw)
+          tk_st_stream(On + (long)py * pw + px, pv[i]);
+      }
+    }
+    auto pix = [&](const cf* base, int i) {
+      if (FULL) return *at(base, pbo + EB * i);
+      const int px = l + 64 * i - pad;
+      const int pxc = px < 0 ? 0 : (px >= pw ? pw - 1 : px);
+      return base[pyc * pw + pxc];
+    };
+    // probe of (position, mode) (probe.py:272-303, as fwd_pass1_kernel).
+    // (Requested one mode ahead, before the transforms of the mode in hand: 12
+    // bytes of scratch per lane and 2.76 instead of 2.62 ms per 1000 x 4.)
+    auto load_probe = [&](int s, cf (&pn)[8]) {
+      const cf* __restrict__ Pn = probe.probe + n * probe.pos_stride + s * PP;
+      float w0 = 1.0f;
+      int nE = 0;
+      if (wn != nullptr) {
+        if (probe.unique != nullptr && s < probe.Sm) {
+          Pn = probe.unique + (n * probe.Sm + s) * PP;
+        } else {
+          w0 = wn[s];
+          if (probe.eigen != nullptr && s < probe.Sm) nE = probe.C;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pn[i] = pix(Pn, i) * w0;
+      for (int k = 0; k < nE; ++k) {  // uniform, rare (modes owning eigen probes)
+        const cf* __restrict__ E = probe.eigen + ((long)k * probe.Sm + s) * PP;
+        const float wk = wn[(k + 1) * probe.S + s];
+        cf e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = pix(E, i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          pn[i].x += wk * e[i].x;
+          pn[i].y += wk * e[i].y;
+        }
+      }
+    };
+    for (int s = 0; s < S; ++s) {
+      cf v[8];
+      load_probe(s, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = pv[i] * v[i];
+      cf* const set = lds + (s & 1) * 16 * LS;
+      cf* lbase = set + w * LS;
+      TkRow8::run<false>(v, lbase, l, twl);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lbase[tk_pad16(l + 64 * i)] = v[i];
+      __syncthreads();
+      // column `col` of the 16 rows: the radix-16 over y2 split between TWO
+      // threads by one decimation-in-frequency step -- q = 0 the even k1 (radix-8
+      // of x[n] + x[n + 8]), q = 1 the odd ones (radix-8 of (x[n] - x[n + 8])
+      // w_16^n): all 1024 threads work, eight values each
+      cf t[8];
+      {
+        constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f;
+        constexpr float H2 = 0.70710678118654752f;
+        const cf w16[8] = {mk(1.f, 0.f),  mk(C1, -S1),  mk(H2, -H2),  mk(S1, -C1),
+                           mk(0.f, -1.f), mk(-S1, -C1), mk(-H2, -H2), mk(-C1, -S1)};
+#pragma unroll
+        for (int y2 = 0; y2 < 8; ++y2) {
+          const cf a = set[y2 * LS + tk_pad16(col)];
+          const cf b = set[(y2 + 8) * LS + tk_pad16(col)];
+          t[y2] = q == 0 ? a + b : (a - b) * w16[y2];
+        }
+      }
+      Dft<8, false>::run(t);
+      cf* __restrict__ mid = dst0 + s * (long)N * N + (long)(16 * r) * N + col;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int k1 = 2 * m + q;
+        cf o = t[m];
+        o = mul_tw<false>(o, twtab[N + r * k1]);  // uniform -> scalar load (k1 = 0: 1)
+        if (KEEP)
+          mid[k1 * N] = o;
+        else
+          tk_st_stream(mid + k1 * N, o);
+      }
+    }
+    // (the next item starts at set 0 again: after an odd number of modes that
+    // is the set just read)
+    if (S & 1) __syncthreads();
+  }
+}
+
 // unique_probe: the varying probe of the first eigen_modes modes from
 // tike_varying_probe, or NULL with eigen_probe given: formed on the fly.
 static int tk_fwd_pass1(const void* psi, const float* scan, const void* probe,
@@ -744,10 +975,23 @@ static int tk_fwd_pass1(const void* psi, const float* scan, const void* probe,
     TK_F1(256, true);
   else if (det == 256)
     TK_F1(256, false);
-  else if (pw == det)
-    TK_F1(512, true);
-  else
-    TK_F1(512, false);
+  else {
+    // 512^2: one wave per row, 1024 threads (fwd_pass1_kernel<512>: 2.77 ms per
+    // 1000 positions x 4 modes; this one 2.61)
+#define TK_F1W(FULL, KEEP)                                                                      \
+  hipLaunchKernelGGL((fwd_pass1_512w_kernel<FULL, KEEP>), dim3(tk_grid((long)nscan * 32, 1)),   \
+                     dim3(1024), 0, stream, (const cf*)psi, scan, P, (cf*)scratch,              \
+                     (cf*)patches, nscan, S, pw, H, W, tw, skip)
+    if (pw == det && keep)
+      TK_F1W(true, true);
+    else if (pw == det)
+      TK_F1W(true, false);
+    else if (keep)
+      TK_F1W(false, true);
+    else
+      TK_F1W(false, false);
+#undef TK_F1W
+  }
 #undef TK_F1
 #undef TK_F1K
   TK_LAUNCH_CHECK();
