@@ -303,6 +303,20 @@ int tike_ifft2_pass2_gradients_scaled(const void* work, const void* patches, con
                                       void* m_probe_update, float mpu_scale, int nscan, int S,
                                       int det, float inv_scale, const float* mode_scale,
                                       void* stream);
+/* ... for MORE modes than one launch holds in registers (9 .. 16 at 128^2 /
+ * 256^2; the reference's cuFFT path, lstsq.py:504-539, takes any number): the
+ * modes [mode0, mode0 + nmodes) of an S-mode problem, 3 <= nmodes <= 8 --
+ * their probe gradients, mode 0 of chi when mode0 == 0, and their share of
+ * objproj = sum_s conj(P_n,s) chi_n,s stored (accumulate == 0) or added to what
+ * the launch of the modes in front left there.  Arguments as
+ * tike_ifft2_pass2_gradients with S the mode count of the problem; the
+ * eigen probes must all belong to the modes of the first group. */
+int tike_ifft2_pass2_gradients_modes(const void* work, const void* patches, const void* probe,
+                                     const void* eigen_probe, const float* eigen_weights,
+                                     int num_eigen, int eigen_modes, void* objproj, void* chi0,
+                                     void* m_probe_update, float mpu_scale, int nscan, int S,
+                                     int det, float inv_scale, int mode0, int nmodes,
+                                     int accumulate, void* stream);
 
 /* ---- far-plane gradient factor from the intensity (objective.py:31-44,97-109;
  * lstsq.py:491-502): gscale[n][p] = -(1 - sqrt(d)/(sqrt(I)+1e-9)) (gaussian) or

@@ -1171,7 +1171,8 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
     (448, 448, 2, 3, True), (224, 200, 3, 4, False),  # 7 x 2^k
 ])
 @pytest.mark.parametrize("engine", ["pfa", "lds"])
-def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine):
+def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine,
+                                          monkeypatch):
     """The three shape-general launches (csrc/general.hip: tike_gen_fwd_rows ->
     tike_gen_cols_gradient -> tike_gen_inv_rows_gradients) on shapes the fused
     power-of-two kernels refuse -- probe window < detector, 12 and 16 modes,
@@ -1182,6 +1183,7 @@ def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine):
     from tike_amd.ptycho.solvers import lstsq as L
     assert not L.fused_gradients(S, pw, det)
     assert L.general_gradients(S, pw, det)
+    monkeypatch.setattr(L, "MODE_GROUPS", False)  # (9 ... 16 modes: not in groups here)
     # engine: the prime-factor launches (csrc/pfa.hip: detector sizes 3 x 2^k
     # and 5 x 2^k on the power-of-two register engine) or the LDS line engine
     # (csrc/general.hip) -- the same shapes through both where both serve
@@ -1195,6 +1197,38 @@ def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine):
         from tike_amd.operators import Ptycho  # the plan really took the route
     finally:
         L.GENERAL_FUSED, L.PFA_ROUTE = saved
+
+
+@pytest.mark.parametrize("det,S,N,eigen", [(256, 12, 7, True),   # bench c3m12
+                                           (256, 9, 6, False), (256, 16, 5, True),
+                                           (128, 10, 9, True), (128, 13, 6, False)])
+def test_mode_groups_vs_oracle(tp, det, S, N, eigen):
+    """9 ... 16 modes at 128^2 / 256^2 on the far-plane-free kernels with the
+    inverse's second pass in two groups of modes
+    (`tike_ifft2_pass2_gradients_modes`: the second group adds its share of the
+    object projection to the first's): the oracle's minibatch
+    (ptycho/solvers/lstsq.py:422-579), and the plan really took that route."""
+    from tike_amd.ptycho.solvers import lstsq as L
+    from tike_amd.ptycho.solvers._plan import GradientPlan
+    assert not L.fused_gradients(S, det, det)
+    groups = L.mode_groups(S, det, det, 1)
+    assert len(groups) == 2 and sum(c for _, c in groups) == S
+    assert all(3 <= c <= 8 for _, c in groups)
+    calls = []
+    real = GradientPlan.gradients
+
+    def spy(self, c, k):
+        calls.append((self.route, self.groups))
+        return real(self, c, k)
+
+    GradientPlan.gradients = spy
+    try:
+        _minibatch_vs_oracle(tp, det, S, N, eigen)
+    finally:
+        GradientPlan.gradients = real
+    assert calls and all(g == groups for _, g in calls)
+    assert all(r == ("no_farplane" if det == 256 else "pos_major")
+               for r, _ in calls)
 
 
 def test_general_shape_launches_equal_the_unfused_kernels(tp):

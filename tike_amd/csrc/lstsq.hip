@@ -734,12 +734,19 @@ struct TkModeProbe {  // probe of one (position, mode): uniform values
 
 // EIG: eigen probes are applied on the fly (their loops cost the 512^2
 // instantiation 19 spilled registers when compiled in and never taken).
-template <int N, int MW, int MPW, bool HAVE_PROJ, bool EIG = true>
+// GRP (round 6: more modes than one launch holds in registers -- 9 .. 16 at
+// 256^2): the launch serves S consecutive modes of a problem with Stot modes
+// per position (`mid`, `probe`, the weights and `mpu` arrive offset to the
+// first of them; tiles and mode_scale are Stot apart) and, `accumulate`, adds
+// its projection to what the launch of the group in front left in objproj.
+template <int N, int MW, int MPW, bool HAVE_PROJ, bool EIG = true, bool GRP = false>
 __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
     const cf* __restrict__ mid, const cf* __restrict__ patches, const TkProbe probe,
     cf* __restrict__ objproj, cf* __restrict__ chi0, float* __restrict__ mpu, float mpu_scale,
     int nscan, int S, float inv_scale, int chunk, float* __restrict__ mpu_part,
-    const float* __restrict__ mode_scale) {
+    const float* __restrict__ mode_scale, int Stot_ = 0, int accumulate_ = 0) {
+  const int Stot = GRP ? Stot_ : S;
+  const bool accumulate = GRP && accumulate_ != 0;
   constexpr int RB = N / 16;
   constexpr int CW = 4 / MW;            // column-waves per workgroup
   constexpr int NCB = N / (64 * CW);    // column blocks
@@ -825,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
     for (int m = 0; m < MPW; ++m) {
       const int s = mw + MW * m;
       if (s < S) {  // wave-uniform
-        const cf* __restrict__ src = mid + ((long)n * S + s) * P + slice0;
+        const cf* __restrict__ src = mid + ((long)n * Stot + s) * P + slice0;
         cf u[RB];
 #pragma unroll
         for (int k = 0; k < RB; ++k) u[k] = tk_ld_stream(tk_at(src + k * ROW, lo));
@@ -836,7 +843,7 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
         const float w0 = vary ? wn[s] : 1.0f;
         // (poisson step lengths that became known after pass 1 was written:
         // a uniform factor per position and mode)
-        const float sc = mode_scale ? inv_scale * mode_scale[(long)n * S + s] : inv_scale;
+        const float sc = mode_scale ? inv_scale * mode_scale[(long)n * Stot + s] : inv_scale;
         Dft<RB, true>::run(u);
         if (HOIST) {
 #pragma unroll
@@ -921,6 +928,7 @@ __global__ __launch_bounds__(256, 2) void ifft2_pass2_gradients_kernel(
         cf sum = slots[yb * 64];
 #pragma unroll
         for (int k = 1; k < MW; ++k) sum = sum + slots[(k * RB + yb) * 64];
+        if (accumulate) sum = sum + *tk_at(objproj + (long)n * P + slice0 + yb * ROW, lo);
         tk_st_stream(tk_at(objproj + (long)n * P + slice0 + yb * ROW, lo), sum);
       }
       if (NBUF == 1) __syncthreads();  // the single slot set is rewritten next
@@ -962,13 +970,17 @@ static int launch_pass2_gradients(const void* work, const void* patches, const v
                                   int num_eigen, int eigen_modes, void* objproj, void* chi0,
                                   void* m_probe_update, float mpu_scale, int nscan, int S,
                                   int det, float inv_scale, const float* mode_scale,
-                                  hipStream_t stream) {
+                                  hipStream_t stream, int Stot = 0, int accumulate = 0) {
   TK_CHECK_ARG(nscan >= 0 && S >= 1 && det >= 1);
   if (nscan == 0) return TK_OK;
   TK_CHECK_ARG(work && patches && (probe || !objproj));
   if (S > 8 || (det != 128 && det != 256 && det != 512)) return TK_ERR_UNSUPPORTED;
+  // a group of S modes out of Stot (tike_ifft2_pass2_gradients_modes): the
+  // weights are Stot apart, as the tiles
+  const bool grp = Stot != 0;
+  if (grp && (S < 3 || !objproj)) return TK_ERR_UNSUPPORTED;  // (the mode-sum path)
   const TkProbe pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
-                                   S, det);
+                                   grp ? Stot : S, det);
   // mode-waves x column-waves of a workgroup and modes per wave
   int MW = S >= 3 ? 4 : S;
   if (det == 128 && MW == 1) MW = 2;  // a 128-wide tile has only two 64-column waves
@@ -1002,7 +1014,19 @@ static int launch_pass2_gradients(const void* work, const void* patches, const v
   if (eig_lds > 32 * 1024) return TK_ERR_UNSUPPORTED;
 #define TK_P2G(N, MW_, MPW_)                                                                 \
   do {                                                                                       \
-    if (objproj && eig_lds > 0)                                                              \
+    if (grp && eig_lds > 0)                                                                  \
+      hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true, true, true>),     \
+                         grid, block, eig_lds,                                               \
+                         stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
+                         (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
+                         chunk, mpu_part, mode_scale, Stot, accumulate);                     \
+    else if (grp)                                                                            \
+      hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true, false, true>),    \
+                         grid, block, 0,                                                     \
+                         stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
+                         (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
+                         chunk, mpu_part, mode_scale, Stot, accumulate);                     \
+    else if (objproj && eig_lds > 0)                                                         \
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true>), grid, block,    \
                          eig_lds,                                                            \
                          stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
@@ -1071,6 +1095,35 @@ extern "C" int tike_ifft2_pass2_gradients_scaled(const void* work, const void* p
   return launch_pass2_gradients(work, patches, probe, eigen_probe, eigen_weights, num_eigen,
                                 eigen_modes, objproj, chi0, m_probe_update, mpu_scale, nscan, S,
                                 det, inv_scale, mode_scale, (hipStream_t)stream);
+}
+
+// Modes [mode0, mode0 + nmodes) of an S-mode problem (3 <= nmodes <= 8): what
+// tike_ifft2_pass2_gradients does for those modes alone -- their probe
+// gradients, mode 0 of chi when mode0 == 0 -- with their share of objproj
+// stored (accumulate == 0: the first group) or added to what is there.  The
+// caller walks the groups in order; eigen probes must all belong to the modes
+// of the first group (eigen_modes <= its nmodes).
+extern "C" int tike_ifft2_pass2_gradients_modes(const void* work, const void* patches,
+                                                const void* probe, const void* eigen_probe,
+                                                const float* eigen_weights, int num_eigen,
+                                                int eigen_modes, void* objproj, void* chi0,
+                                                void* m_probe_update, float mpu_scale,
+                                                int nscan, int S, int det, float inv_scale,
+                                                int mode0, int nmodes, int accumulate,
+                                                void* stream) {
+  TK_ENTER();
+  TK_CHECK_ARG(S >= 1 && det >= 1 && mode0 >= 0 && nmodes >= 1 && mode0 + nmodes <= S);
+  TK_CHECK_ARG(nscan == 0 || (work && probe && objproj));
+  const long P = (long)det * det;
+  const bool first = mode0 == 0;
+  if (first ? eigen_modes > nmodes : false) return TK_ERR_UNSUPPORTED;
+  return launch_pass2_gradients(
+      (const cf*)work + mode0 * P, patches, (const cf*)probe + mode0 * P,
+      first ? eigen_probe : nullptr, eigen_weights ? eigen_weights + mode0 : nullptr,
+      first ? num_eigen : (eigen_weights ? num_eigen : 0), first ? eigen_modes : 0, objproj,
+      first ? chi0 : nullptr,
+      m_probe_update ? (void*)((float*)m_probe_update + 2 * mode0 * P) : nullptr, mpu_scale,
+      nscan, nmodes, det, inv_scale, nullptr, (hipStream_t)stream, S, accumulate);
 }
 
 // The probe preconditioner with RW vertically adjacent pixels per thread: the

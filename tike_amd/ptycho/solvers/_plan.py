@@ -79,6 +79,9 @@ def algorithmic_bytes(name, n, S, det, pw, C, depth=1):
         # inverse pass 2 + both gradients: intermediate + patches in,
         # objproj + chi0 out (+ the probe gradient, probe-sized)
         "tike_ifft2_pass2_gradients": n * (T + 3 * P) + S * P,
+        # (one of the two launches of a problem with 9 ... 16 modes: about
+        # half the modes each, the patches read and objproj written by both)
+        "tike_ifft2_pass2_gradients_modes": n * (T // 2 + 3 * P) + S // 2 * P,
         # the five far-plane-free stages in one call (cgrad's gradient pass:
         # no chi0 stored)
         "tike_lstsq_chunk_gradients":
@@ -141,12 +144,13 @@ class GradientPlan:
     steps_in_pass2: bool  # poisson steps applied by pass 2
     chunk: int
     launches: tuple       # the C-ABI entries of one chunk, in order
+    groups: tuple = ()    # more modes than one pass-2 launch holds: (first, count)s
 
     def bytes(self, entry, n, C=0):
         return algorithmic_bytes(entry, n, self.S, self.det, self.pw, C)
 
     @staticmethod
-    def for_(op, S, pw, det, exitwave_options, mask_u8):
+    def for_(op, S, pw, det, exitwave_options, mask_u8, eigen_modes=0):
         """The plan of this shape on this operator (cached on it, keyed also on
         the module switches tests and A/B runs flip)."""
         from . import lstsq as L
@@ -160,20 +164,28 @@ class GradientPlan:
                tuple(L.SPLIT_FORWARD_SIZES), tuple(L.ONE_LAUNCH_GRADIENT_SIZES),
                L.POISSON_FROM_HANDOFF, L.POISSON_STEPS_IN_PASS2,
                L.GENERAL_FUSED, L.PFA_ROUTE, L.GENERAL_MIN_DETECTOR,
-               L.CHUNK_POSITIONS_OVERRIDE)
+               L.CHUNK_POSITIONS_OVERRIDE,
+               L.mode_groups(S, pw, det, eigen_modes))
         cache = op.__dict__.setdefault("_tike_amd_plans", {})
         if key not in cache:
             cache[key] = GradientPlan._build(S, pw, det, eo, mask_u8, unmeasured,
-                                             L)
+                                             L, eigen_modes)
         return cache[key]
 
     @staticmethod
-    def _build(S, pw, det, eo, mask_u8, unmeasured, L):
+    def _build(S, pw, det, eo, mask_u8, unmeasured, L, eigen_modes=0):
         poisson = eo.noise_model == "poisson"
         dominant = int(poisson and eo.step_length_usemodes == "dominant_mode")
         all_modes = poisson and not dominant
         pos_major = det in L.POSITION_MAJOR_SIZES
         fused = L.fused_gradients(S, pw, det)
+        # 9 ... 16 modes (gaussian): the same far-plane-free kernels -- pass 1
+        # and the two-sweep gradient launch take any number of modes -- with
+        # the inverse's second pass in two groups of modes
+        # (c3m12: 80 -> see profiles/r06_experiments.md section 10)
+        groups = () if fused or poisson else L.mode_groups(S, pw, det,
+                                                           eigen_modes)
+        fused = fused or bool(groups)
         # (detector sizes with position-major kernels -- 128, 256, 512 -- keep
         # those for pw < det or many modes: measured faster, c3pad 160 vs 88 k
         # patterns/s, c3m12 69 vs 41 k, profiles/r06_experiments.md)
@@ -255,7 +267,10 @@ class GradientPlan:
             no_farplane=no_farplane, split_kept=split_kept,
             one_launch=one_launch, steps_in_pass2=steps_in_pass2,
             chunk=L.chunk_positions(S, det, pos_major or general),
-            launches=launches)
+            launches=tuple("tike_ifft2_pass2_gradients_modes"
+                           if groups and e == "tike_ifft2_pass2_gradients" else e
+                           for e in launches),
+            groups=groups)
 
     # -------------------------------------------------------- workspaces
     def buffers(self, ws, B, dev, *, varying, want_patches):
@@ -546,7 +561,12 @@ class GradientPlan:
                   A.ptr(c.probe), A.ptr(c.ep), A.ptr(k.w), c.C, c.Sm, objproj,
                   chi0, A.ptr(c.m_probe_update), 1.0 / c.num_batch, n, S, det,
                   c.inv_scale)
-            if self.steps_in_pass2:
+            if self.groups:
+                for first, count in self.groups:
+                    check(lib.tike_ifft2_pass2_gradients_modes(
+                        *p2, first, count, int(first > 0), st),
+                        "inverse pass 2 + gradients (a group of modes)")
+            elif self.steps_in_pass2:
                 check(lib.tike_ifft2_pass2_gradients_scaled(
                     *p2, A.ptr(b.steps), st),
                     "inverse pass 2 + gradients (x poisson steps)")

@@ -109,6 +109,23 @@ power-of-two register engine on p x p sub-tiles; tests set this to False to
 compare with the LDS line engine of csrc/general.hip."""
 
 
+MODE_GROUPS = True
+"""9 ... 16 modes at 128^2 / 256^2 (probe window = detector, gaussian model)
+run the far-plane-free kernels with the inverse's second pass in two groups
+of modes (tike_ifft2_pass2_gradients_modes); False: the position-major
+kernels with a stored far plane, as until round 6."""
+
+
+def mode_groups(S, pw, det, eigen_modes=0):
+    """[(first mode, count), ...] for `tike_ifft2_pass2_gradients_modes`, or
+    () where the shape is not served in groups: each group is what one launch
+    holds in registers (3 ... 8 modes), the eigen probes belong to the first."""
+    if not (MODE_GROUPS and pw == det and det in (128, 256) and 8 < S <= 16):
+        return ()
+    first = (S + 1) // 2
+    return ((0, first), (first, S - first)) if eigen_modes <= first else ()
+
+
 def pfa_gradients(S, pw, det):
     """True where the prime-factor launches serve (csrc/pfa.hip)."""
     return bool(PFA_ROUTE and lib.tike_pfa_supported(S, pw, det))
@@ -441,13 +458,14 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
         raise ValueError(
             f"unknown noise model {exitwave_options.noise_model!r}")
     nmeasured, mask_u8 = mask_info(exitwave_options, det)
-    plan = GradientPlan.for_(op, S, pw, det, exitwave_options, mask_u8)
     fwd_scale, inv_scale = fft_scales(det, op.norm)
 
     # the weights this gradient uses; every consumer (forward, gradients, step
     # statistics) runs before _update_nearplane changes them in place
     w_old = None if eigen_weights is None else eigen_weights[lo:hi]
     ep, _, C, Sm = _eigen_args(eigen_probe, w_old)
+    plan = GradientPlan.for_(op, S, pw, det, exitwave_options, mask_u8,
+                             eigen_modes=Sm)
 
     # planar (real plane, imaginary plane) float32 accumulator of the object
     # gradient: the shape float atomics run fastest on; recombined below
