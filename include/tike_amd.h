@@ -303,9 +303,10 @@ int tike_ifft2_pass2_gradients_scaled(const void* work, const void* patches, con
                                       void* m_probe_update, float mpu_scale, int nscan, int S,
                                       int det, float inv_scale, const float* mode_scale,
                                       void* stream);
-/* ... for MORE modes than one launch holds in registers (9 .. 16 at 128^2 /
- * 256^2; the reference's cuFFT path, lstsq.py:504-539, takes any number): the
- * modes [mode0, mode0 + nmodes) of an S-mode problem, 3 <= nmodes <= 8 --
+/* ... for MORE modes than one launch holds in registers (more than 8 at 128^2 /
+ * 256^2, more than 4 at 512^2; the reference's cuFFT path, lstsq.py:504-539,
+ * takes any number): the modes [mode0, mode0 + nmodes) of an S-mode problem,
+ * 2 <= nmodes <= 8 (512^2: 4 without register spills) --
  * their probe gradients, mode 0 of chi when mode0 == 0, and their share of
  * objproj = sum_s conj(P_n,s) chi_n,s stored (accumulate == 0) or added to what
  * the launch of the modes in front left there.  Arguments as

@@ -1201,7 +1201,10 @@ def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine,
 
 @pytest.mark.parametrize("det,S,N,eigen", [(256, 12, 7, True),   # bench c3m12
                                            (256, 9, 6, False), (256, 16, 5, True),
-                                           (128, 10, 9, True), (128, 13, 6, False)])
+                                           (128, 10, 9, True), (128, 13, 6, False),
+                                           (256, 19, 4, True),   # three groups
+                                           (512, 5, 4, True), (512, 8, 3, False),
+                                           (512, 11, 2, False)])
 def test_mode_groups_vs_oracle(tp, det, S, N, eigen):
     """9 ... 16 modes at 128^2 / 256^2 on the far-plane-free kernels with the
     inverse's second pass in two groups of modes
@@ -1212,8 +1215,9 @@ def test_mode_groups_vs_oracle(tp, det, S, N, eigen):
     from tike_amd.ptycho.solvers._plan import GradientPlan
     assert not L.fused_gradients(S, det, det)
     groups = L.mode_groups(S, det, det, 1)
-    assert len(groups) == 2 and sum(c for _, c in groups) == S
-    assert all(3 <= c <= 8 for _, c in groups)
+    cap = 4 if det == 512 else 8
+    assert len(groups) == -(-S // cap) and sum(c for _, c in groups) == S
+    assert all(2 <= c <= cap for _, c in groups)
     calls = []
     real = GradientPlan.gradients
 
@@ -1227,7 +1231,7 @@ def test_mode_groups_vs_oracle(tp, det, S, N, eigen):
     finally:
         GradientPlan.gradients = real
     assert calls and all(g == groups for _, g in calls)
-    assert all(r == ("no_farplane" if det == 256 else "pos_major")
+    assert all(r == ("pos_major" if det == 128 else "no_farplane")
                for r, _ in calls)
 
 

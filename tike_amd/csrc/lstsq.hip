@@ -978,7 +978,7 @@ static int launch_pass2_gradients(const void* work, const void* patches, const v
   // a group of S modes out of Stot (tike_ifft2_pass2_gradients_modes): the
   // weights are Stot apart, as the tiles
   const bool grp = Stot != 0;
-  if (grp && (S < 3 || !objproj)) return TK_ERR_UNSUPPORTED;  // (the mode-sum path)
+  if (grp && (S < 2 || !objproj)) return TK_ERR_UNSUPPORTED;  // (the mode-sum path)
   const TkProbe pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
                                    grp ? Stot : S, det);
   // mode-waves x column-waves of a workgroup and modes per wave
@@ -1097,7 +1097,7 @@ extern "C" int tike_ifft2_pass2_gradients_scaled(const void* work, const void* p
                                 det, inv_scale, mode_scale, (hipStream_t)stream);
 }
 
-// Modes [mode0, mode0 + nmodes) of an S-mode problem (3 <= nmodes <= 8): what
+// Modes [mode0, mode0 + nmodes) of an S-mode problem (2 <= nmodes <= 8): what
 // tike_ifft2_pass2_gradients does for those modes alone -- their probe
 // gradients, mode 0 of chi when mode0 == 0 -- with their share of objproj
 // stored (accumulate == 0: the first group) or added to what is there.  The

@@ -79,9 +79,9 @@ def algorithmic_bytes(name, n, S, det, pw, C, depth=1):
         # inverse pass 2 + both gradients: intermediate + patches in,
         # objproj + chi0 out (+ the probe gradient, probe-sized)
         "tike_ifft2_pass2_gradients": n * (T + 3 * P) + S * P,
-        # (one of the two launches of a problem with 9 ... 16 modes: about
-        # half the modes each, the patches read and objproj written by both)
-        "tike_ifft2_pass2_gradients_modes": n * (T // 2 + 3 * P) + S // 2 * P,
+        # (the launches of all mode groups of a chunk together; the patches are
+        # read and objproj rewritten by each of them: + 2 P per further group)
+        "tike_ifft2_pass2_gradients_modes": n * (T + 3 * P) + S * P,  # (all groups)
         # the five far-plane-free stages in one call (cgrad's gradient pass:
         # no chi0 stored)
         "tike_lstsq_chunk_gradients":

@@ -110,20 +110,29 @@ compare with the LDS line engine of csrc/general.hip."""
 
 
 MODE_GROUPS = True
-"""9 ... 16 modes at 128^2 / 256^2 (probe window = detector, gaussian model)
-run the far-plane-free kernels with the inverse's second pass in two groups
-of modes (tike_ifft2_pass2_gradients_modes); False: the position-major
-kernels with a stored far plane, as until round 6."""
+"""More modes than one launch of the inverse's second pass holds in registers
+(9 ... 32 at 128^2 / 256^2, 5 ... 16 at 512^2; probe window = detector,
+gaussian model) run the far-plane-free kernels with that pass in groups of
+modes (tike_ifft2_pass2_gradients_modes); False: the position-major kernels
+with a stored far plane, as until round 6."""
 
 
 def mode_groups(S, pw, det, eigen_modes=0):
-    """[(first mode, count), ...] for `tike_ifft2_pass2_gradients_modes`, or
-    () where the shape is not served in groups: each group is what one launch
-    holds in registers (3 ... 8 modes), the eigen probes belong to the first."""
-    if not (MODE_GROUPS and pw == det and det in (128, 256) and 8 < S <= 16):
+    """((first mode, count), ...) for `tike_ifft2_pass2_gradients_modes`, or
+    () where the shape is not served in groups: every group is what one launch
+    holds in registers (<= 8 modes, <= 4 at 512^2), balanced, at least two
+    modes each; the eigen probes belong to the first."""
+    cap = 4 if det == 512 else 8
+    if not (MODE_GROUPS and pw == det and det in POSITION_MAJOR_SIZES
+            and cap < S <= 4 * cap):
         return ()
-    first = (S + 1) // 2
-    return ((0, first), (first, S - first)) if eigen_modes <= first else ()
+    k = -(-S // cap)
+    base, extra = divmod(S, k)
+    sizes = [base + (i < extra) for i in range(k)]
+    if min(sizes) < 2 or eigen_modes > sizes[0]:
+        return ()
+    firsts = [sum(sizes[:i]) for i in range(k)]
+    return tuple(zip(firsts, sizes))
 
 
 def pfa_gradients(S, pw, det):

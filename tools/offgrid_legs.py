@@ -24,6 +24,9 @@ for name in sys.argv[2:]:  # gDETxS: any detector size / mode count, no eigen pr
     m = re.fullmatch(r"g(\d+)x(\d+)", name)
     if m:
         bench.EPOCH_DEFAULTS[name] = (int(m.group(1)), int(m.group(2)), 10000, 10)
+if os.environ.get("OFFGRID_GROUPS") == "0":  # > 8 modes: the stored far plane
+    from tike_amd.ptycho.solvers import lstsq as _L3
+    _L3.MODE_GROUPS = False
 if os.environ.get("OFFGRID_PFA") == "0":  # the LDS line engine instead
     from tike_amd.ptycho.solvers import lstsq as _L2
     _L2.PFA_ROUTE = False
