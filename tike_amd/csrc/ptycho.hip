@@ -3031,12 +3031,14 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
         // (unmeasured_pixels_scaling = 1, the only value this path serves)
         const bool meas = !MK || ((bits >> k2) & 1u);
         const float dv = meas ? (float)raw[k2] : -1.0f;
-        cost += meas ? I[k2] - dv * logf(I[k2] + 1e-9f) : 0.f;
+        // (the costs come out of the FIRST sweep's launch: sixteen logarithms
+        // beside 128 registers of F are what the second one spilled for)
+        if (STEPS == 1) cost += meas ? I[k2] - dv * logf(I[k2] + 1e-9f) : 0.f;
         dvp[k2 * 512 + threadIdx.x] = dv;
         if (STEPS == 2) ivp[k2 * 512 + threadIdx.x] = I[k2];
       }
     }
-    if (costs.costs && h == 0) {
+    if (STEPS != 2 && costs.costs && h == 0) {
       cost = tk_wave_sum(cost);
       if ((threadIdx.x & 63) == 0)
         tk_cost_add(costs, n, k1 * 4 + (int)(threadIdx.x >> 6), cost * inv_nmeasured);
@@ -3060,6 +3062,10 @@ __global__ __launch_bounds__(512, 1) void fwd_grad_ifft2_pass1_resident_kernel(
           // of F)
           const bool meas = !MK || dv >= 0.f;
           const float xi = 1.0f - dv * __builtin_amdgcn_rcpf(ie + 1e-9f);
+          // (|F|^2 formed AGAIN here: kept from the intensity loop -- the same
+          // expression -- sixteen values per mode lived across the exchange,
+          // in scratch: 108-140 bytes per lane until round 6)
+          if (STEPS == 2) asm volatile("" : "+v"(F[m][k2].x), "+v"(F[m][k2].y));
           const float av = norm2(F[m][k2]) * s2;
           const float xam1 = xi * al - 1.0f;
           const float tn =
