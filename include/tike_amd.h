@@ -617,6 +617,22 @@ int tike_pfa_fwd_gather(const void* psi, const float* scan, const void* probe,
  * sub-tile of ntile tiles (unscaled); out must not alias in. */
 int tike_pfa_fft2(const void* in, void* out, long ntile, int det, int inverse, void* stream);
 
+/* tike_pfa_fwd_gather + the forward tike_pfa_fft2 in ONE launch where the
+ * sub-tiles are 128 x 128 (det = 384, 640, 896; a shared probe with or without
+ * eigen probes): a sub-tile is gathered, multiplied by the probe and
+ * transformed inside the LDS of a CU and written once (the forward operator's
+ * 128^2 kernel with the prime-factor map in front; lstsq.py:441-452 +
+ * propagation.py:43-57).  subtiles (nscan,S,p,p,128,128) receives what the two
+ * launches leave in their output; probe_scratch ((S + num_eigen x
+ * eigen_modes) det^2 c64) is rewritten by every call (the probe and the eigen
+ * probes in the sub-tile layout).  tike_pfa_fwd_subtiles_supported: 1 where it
+ * serves, no device work. */
+int tike_pfa_fwd_subtiles_supported(int S, int pw, int det);
+int tike_pfa_fwd_subtiles(const void* psi, const float* scan, const void* probe,
+                          const void* eigen_probe, const float* eigen_weights, int num_eigen,
+                          int eigen_modes, void* probe_scratch, void* subtiles, void* patches,
+                          int nscan, int S, int pw, int det, int H, int W, void* stream);
+
 /* The p x p DFT across the sub-tiles completes the far plane F (x fwd_scale);
  * objective.py:11-124 + lstsq.py:444-502 on it (costs, gradient factor, as
  * tike_gen_cols_gradient); apply_gradient: F x factor goes back through the

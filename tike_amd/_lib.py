@@ -56,6 +56,9 @@ _PROTOTYPES = {
     "tike_pfa_supported": [_i, _i, _i],
     "tike_pfa_fwd_gather": [_p, _p, _p, _i, _p, _p, _p, _i, _i, _p, _p, _i, _i, _i,
                             _i, _i, _i, _p],
+    "tike_pfa_fwd_subtiles_supported": [_i, _i, _i],
+    "tike_pfa_fwd_subtiles": [_p, _p, _p, _p, _p, _i, _i, _p, _p, _p, _i, _i,
+                              _i, _i, _i, _i, _p],
     "tike_pfa_fft2": [_p, _p, _l, _i, _i, _p],
     "tike_pfa_combine_gradient": [_p, _p, _p, _p, _i, _i, _i, _f, _i, _f, _l, _i,
                                   _p],

@@ -227,3 +227,20 @@ __device__ __forceinline__ void fft2_rows_from_columns(cf* __restrict__ lds, con
   }
   __syncthreads();
 }
+
+// ---- a whole 128 x 128 tile in LDS (fwd128_lds_kernel of ptycho.hip, the
+// prime-factor sub-tile kernel of pfa.hip)
+constexpr int TK_L128_LS = 136;
+// Column offset of row `row` inside the LDS tile (element (row, col) lives at
+// row * LS + ((col + swizzle(row)) & 127)), chosen so that BOTH transforms run
+// on the tile without bank conflicts, dword bank = 16 row + 2 col' (mod 64):
+//   rows     a 32-lane group = 4 consecutive rows x 8 lanes j: the rows share
+//            the swizzle, 16 row covers the four 16-bank quarters;
+//   columns  lanes j read rows j + 8 i (bit 2 of the row separates j from
+//            j + 4: + 8 banks) and exchange through rows 16 j + r (bits 4..6 of
+//            the row = j: + 8 j banks); 4 neighbouring columns fill the 8
+//            banks in between.
+__device__ __forceinline__ int tk_l128_swizzle(int row) {
+  return 4 * (((row >> 2) & 1) + ((row >> 4) & 7));
+}
+

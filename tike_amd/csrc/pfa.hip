@@ -29,6 +29,7 @@
 //                              chi0, probe gradient (accumulated over a chunk
 //                              of positions in LDS, one atomic per pixel, mode
 //                              and chunk)
+#include "fft_engine2.h"
 #include "internal.h"
 #include "tike_amd.h"
 
@@ -241,6 +242,185 @@ __global__ __launch_bounds__(256) void pfa_fwd_gather_kernel(
         }
       }
       __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------- M = 128: gather + sub-tile transform
+// A 128 x 128 sub-tile is 128 KiB: it fits the LDS of a CU, so the gather and
+// the whole 2-D transform of a sub-tile are ONE kernel whose only HBM traffic
+// is the transformed sub-tile, written once from registers (the forward
+// operator's fwd128_lds_kernel with the prime-factor map in front: 384 = 3 x
+// 128, 640, 896).  tike_pfa_fwd_gather + tk_fft2 move W + R + W of the far
+// plane for the same result.
+// Work item = (position, sub-tile (n1y, n1x)); 1024 threads: thread (line, j)
+// owns elements n2x = j + 8 i of sub-tile row n2y = line, i.e. pixel
+//   y = (M n1y + p line) mod det,  x = (M n1x + p (j + 8 i)) mod det
+// of the zero-padded tile; the patch values are gathered once and shared by
+// the modes.  The probe is read from `psub`, the shared probe (and the eigen
+// probes) PERMUTED into the sub-tile layout once per launch
+// (pfa_permute_probe_kernel): consecutive lanes, consecutive addresses --
+// straight from the probe they would be p pixels apart.
+template <int P>
+__global__ __launch_bounds__(256) void pfa_permute_probe_kernel(const cf* __restrict__ src,
+                                                                cf* __restrict__ dst, PfaGeom g,
+                                                                int nimg, int pw) {
+  const int det = g.det, M = g.M, pad = (det - pw) / 2;
+  const long tile = (long)det * det;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < nimg * tile; i += gridDim.x * 256L) {
+    const long img = i / tile;
+    const int e = (int)(i - img * tile);
+    // e = ((n1y P + n1x) M + n2y) M + n2x
+    const int n2x = e & (M - 1), n2y = (e >> g.logM) & (M - 1);
+    const int st = e >> (2 * g.logM), n1x = st % P, n1y = st / P;
+    int y = M * n1y + P * n2y, x = M * n1x + P * n2x;
+    y -= y >= det ? det : 0;
+    x -= x >= det ? det : 0;
+    const int py = y - pad, px = x - pad;
+    const bool in = py >= 0 && py < pw && px >= 0 && px < pw;
+    dst[i] = in ? src[img * (long)pw * pw + (long)py * pw + px] : mk(0.f, 0.f);
+  }
+}
+
+template <int P>
+__global__ __launch_bounds__(1024, 4) void pfa_fwd128_kernel(
+    const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,
+    const cf* __restrict__ psub, cf* __restrict__ B, cf* __restrict__ patches, PfaGeom g,
+    int nscan, int S, int pw, int H, int W, const cf* __restrict__ twtab) {
+  constexpr int N = 128, T = 8, LS = TK_L128_LS, det = P * N;
+  __shared__ cf lds[N * LS + FftTwLds<N>::ELEMS];
+  cf* twl = lds + N * LS;
+  FftTwLds<N>::fill(twl, twtab);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  int line = tid / T, j = tid % T;
+  asm volatile("" : "+v"(line), "+v"(j));
+  const FftTwLds<N> tw{twl, j};
+  __builtin_assume(j >= 0 && j < T && line >= 0 && line < N);
+  const long MM = (long)N * N, tile = (long)det * det;
+  const long total = (long)H * W;
+  const int pad = (det - pw) / 2;
+  const int nE = probe.weights != nullptr && probe.eigen != nullptr ? probe.C : 0;
+  auto at = [](const cf* base, unsigned byte_off) -> const cf* {
+    return reinterpret_cast<const cf*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
+  const unsigned pbo = (unsigned)(line * N + j) * (unsigned)sizeof(cf);
+  for (long item = blockIdx.x; item < (long)nscan * (P * P); item += gridDim.x) {
+    const long n = item / (P * P);
+    const int st = (int)(item - n * (P * P));  // n1y P + n1x
+    const int n1y = st / P, n1x = st - n1y * P;
+    const TkCorner c = tk_corner(scan, n);
+    int y = N * n1y + P * line;
+    y -= y >= det ? det : 0;
+    const int py = y - pad;
+    const bool row_in = py >= 0 && py < pw;
+    const int x0 = N * n1x + P * j;  // + 8 P i, minus det once past the edge
+    const bool interior = pad == 0 && c.sy >= 0 && c.sx >= 0 && c.sy + pw < H &&
+                          c.sx + pw < W && total < (1L << 28);
+    cf pv[16];
+    if (interior) {
+      // the two taps of a row are adjacent complex values: one 16-byte load
+      typedef float tk_v4f __attribute__((ext_vector_type(4)));
+      auto ld4 = [](const cf* base, unsigned byte_off) {
+        tk_v4f v;
+        __builtin_memcpy(&v, reinterpret_cast<const char*>(base) + byte_off, sizeof(v));
+        return v;
+      };
+      const unsigned g0 = (unsigned)((c.sy + y) * W + c.sx) * (unsigned)sizeof(cf);
+      const unsigned g1 = g0 + (unsigned)W * (unsigned)sizeof(cf);
+#pragma unroll
+      for (int h = 0; h < 16; h += 4) {
+        tk_v4f u[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int x = x0 + 8 * P * (h + i);
+          x -= x >= det ? det : 0;
+          u[i] = ld4(psi, g0 + (unsigned)x * 8u);
+          l[i] = ld4(psi, g1 + (unsigned)x * 8u);
+        }
+        asm volatile(""
+                     : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(l[0]), "+v"(l[1]),
+                       "+v"(l[2]), "+v"(l[3]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          cf o = mk(u[i].x * c.w00, u[i].y * c.w00);
+          o.x += u[i].z * c.w01;
+          o.y += u[i].w * c.w01;
+          o.x += l[i].x * c.w10;
+          o.y += l[i].y * c.w10;
+          o.x += l[i].z * c.w11;
+          o.y += l[i].w * c.w11;
+          pv[h + i] = o;
+        }
+      }
+    } else {
+      const int iy = c.sy + py;
+      const bool row_ok = row_in && iy >= 0 && iy < H;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int x = x0 + 8 * P * i;
+        x -= x >= det ? det : 0;
+        const int px = x - pad, ix = c.sx + px;
+        const bool ok = row_ok && px >= 0 && px < pw && ix >= 0 && ix < W;
+        const cf o = tk_gather(psi, ok ? (long)iy * W + ix : 0L, W, total, c);
+        pv[i] = ok ? o : mk(0.f, 0.f);
+        __builtin_amdgcn_sched_barrier(0);  // rare path: one element in flight
+      }
+    }
+    if (patches != nullptr && row_in) {
+      cf* __restrict__ On = patches + ((long)n * pw + py) * pw;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        int x = x0 + 8 * P * i;
+        x -= x >= det ? det : 0;
+        const int px = x - pad;
+        if (px >= 0 && px < pw) On[px] = pv[i];
+      }
+    }
+    const float* __restrict__ wn =
+        probe.weights ? probe.weights + n * (long)(probe.C + 1) * probe.S : nullptr;
+    cf* __restrict__ out = B + (long)n * S * tile + (long)st * MM;
+    for (int s = 0; s < S; ++s) {
+      // probe of (position, mode) in the sub-tile layout (zero outside the window)
+      const cf* __restrict__ Pn = psub + (long)s * tile + (long)st * MM;
+      const float w0 = wn != nullptr ? wn[s] : 1.0f;
+      cf v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = *at(Pn, pbo + 64 * i) * w0;
+      if (s < probe.Sm) {
+        for (int k = 0; k < nE; ++k) {  // uniform, rare (modes owning eigen probes)
+          const cf* __restrict__ E =
+              psub + ((long)probe.S + (long)k * probe.Sm + s) * tile + (long)st * MM;
+          const float wk = wn[(k + 1) * probe.S + s];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const cf e = *at(E, pbo + 64 * i);
+            v[i].x += wk * e.x;
+            v[i].y += wk * e.y;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = pv[i] * v[i];
+      cf* lbase = lds + line * LS;
+      FftStageWave<N, false, 0>::run(v, lbase, j, tw);
+      const int rsw = tk_l128_swizzle(line);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lbase[(j + i * T + rsw) & (N - 1)] = v[i];
+      __syncthreads();
+      const int col = line;
+      auto cat = [&](int e) { return e * LS + ((col + tk_l128_swizzle(e)) & (N - 1)); };
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = lds[cat(j + i * T)];
+      FftStageWave<N, false, 0>::run_at(v, lds, j, tw, cat);
+      // (stored straight from the column layout: eight 64-byte pieces of eight
+      // rows per wave and instruction.  Back through the tile and out row by
+      // row, 512 contiguous bytes per instruction, was SLOWER: 3.22 vs 2.79 ms
+      // per 1000 positions x 4 modes -- the kernel is bound by its LDS traffic)
+      cf* __restrict__ dst = out + (long)s * tile + col;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tk_st_stream(dst + (long)(j + i * T) * N, v[i]);
+      __syncthreads();  // the next mode's rows overwrite the tile
     }
   }
 }
@@ -608,6 +788,58 @@ extern "C" int tike_pfa_fft2(const void* in, void* out, long ntile, int det, int
   TK_CHECK_ARG(in != out);
   return tk_fft2((const cf*)in, (cf*)out, ntile * g.p * g.p, g.M, inverse, 1.0f,
                  (hipStream_t)stream_);
+}
+
+// gather + forward sub-tile transforms in one launch (M = 128: det = 384, 640,
+// 896; a shared probe): subtiles receives what tike_pfa_fwd_gather followed by
+// tike_pfa_fft2 leaves there.  probe_scratch ((S + C Sm) det^2 c64): the probe
+// and the eigen probes in the sub-tile layout, rewritten by every call.
+extern "C" int tike_pfa_fwd_subtiles_supported(int S, int pw, int det) {
+  PfaGeom g;
+  return tike_pfa_supported(S, pw, det) && pfa_geom(det, &g) && g.M == 128 ? 1 : 0;
+}
+
+extern "C" int tike_pfa_fwd_subtiles(const void* psi, const float* scan, const void* probe,
+                                     const void* eigen_probe, const float* eigen_weights,
+                                     int num_eigen, int eigen_modes, void* probe_scratch,
+                                     void* subtiles, void* patches, int nscan, int S, int pw,
+                                     int det, int H, int W, void* stream_) {
+  TK_ENTER();
+  hipStream_t stream = (hipStream_t)stream_;
+  TK_CHECK_ARG(nscan >= 0 && S >= 1 && pw >= 1 && det >= pw && H >= 1 && W >= 1);
+  PfaGeom g;
+  if (!tike_pfa_fwd_subtiles_supported(S, pw, det) || !pfa_geom(det, &g))
+    return TK_ERR_UNSUPPORTED;
+  if (nscan == 0) return TK_OK;
+  TK_CHECK_ARG(psi && scan && probe && probe_scratch && subtiles);
+  const cf* tw = tk_twiddles();
+  if (!tw) return (int)hipErrorNotInitialized;
+  const TkProbe Pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
+                                   S, pw, nullptr);
+  const int ne = eigen_weights && eigen_probe ? num_eigen * eigen_modes : 0;
+  const long tile = (long)det * det;
+  cf* psub = (cf*)probe_scratch;
+#define TK_PFW(P_)                                                                             \
+  do {                                                                                         \
+    hipLaunchKernelGGL(pfa_permute_probe_kernel<P_>, dim3(tk_grid((S * tile + 255) / 256, 8)), \
+                       dim3(256), 0, stream, (const cf*)probe, psub, g, S, pw);                \
+    if (ne > 0)                                                                                \
+      hipLaunchKernelGGL(pfa_permute_probe_kernel<P_>,                                         \
+                         dim3(tk_grid((ne * tile + 255) / 256, 8)), dim3(256), 0, stream,      \
+                         (const cf*)eigen_probe, psub + S * tile, g, ne, pw);                  \
+    hipLaunchKernelGGL(pfa_fwd128_kernel<P_>, dim3(tk_grid((long)nscan * P_ * P_, 1)),         \
+                       dim3(1024), 0, stream, (const cf*)psi, scan, Pr, (const cf*)psub,       \
+                       (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, tw);                \
+  } while (0)
+  if (g.p == 3)
+    TK_PFW(3);
+  else if (g.p == 5)
+    TK_PFW(5);
+  else
+    TK_PFW(7);
+#undef TK_PFW
+  TK_LAUNCH_CHECK();
+  return TK_OK;
 }
 
 extern "C" int tike_pfa_combine_gradient(void* subtiles, const float* data,

@@ -1914,20 +1914,7 @@ extern "C" int tike_cgrad_line_search_linear(int variable, const void* x, const 
 // LDS row stride: 136 elements = 272 dwords = 16 (mod 64 banks), so the four
 // rows a 32-lane read group touches (8 lanes x 16 dwords each) tile the 64
 // banks exactly; 136 also holds the padded row (127 + 127/16 = 134).
-constexpr int TK_L128_LS = 136;
-// Column offset of row `row` inside the LDS tile (element (row, col) lives at
-// row * LS + ((col + swizzle(row)) & 127)), chosen so that BOTH transforms run
-// on the tile without bank conflicts, dword bank = 16 row + 2 col' (mod 64):
-//   rows     a 32-lane group = 4 consecutive rows x 8 lanes j: the rows share
-//            the swizzle, 16 row covers the four 16-bank quarters;
-//   columns  lanes j read rows j + 8 i (bit 2 of the row separates j from
-//            j + 4: + 8 banks) and exchange through rows 16 j + r (bits 4..6 of
-//            the row = j: + 8 j banks); 4 neighbouring columns fill the 8
-//            banks in between.
-__device__ __forceinline__ int tk_l128_swizzle(int row) {
-  return 4 * (((row >> 2) & 1) + ((row >> 4) & 7));
-}
-
+// (TK_L128_LS, tk_l128_swizzle: fft_engine2.h -- csrc/pfa.hip runs the same tile)
 template <bool WITH_I>
 __global__ __launch_bounds__(1024, 4) void fwd128_lds_kernel(
     const cf* __restrict__ psi, const float* __restrict__ scan, const TkProbe probe,

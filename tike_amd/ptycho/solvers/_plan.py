@@ -325,14 +325,29 @@ class GradientPlan:
         # sub-tile -> p x p combine, cost, gradient factor, inverse combine ->
         # inverse transform; the products in gradients()
         b = c.buf
-        check(
-            lib.tike_pfa_fwd_gather(
-                A.ptr(c.psi), A.ptr(k.scan), A.ptr(c.probe), 0, None,
-                A.ptr(c.ep), A.ptr(k.w), c.C, c.Sm, A.ptr(b.far),
-                A.ptr(k.patches), k.n, self.S, self.pw, self.det, c.H, c.W,
-                c.st), "prime-factor gather")
-        check(lib.tike_pfa_fft2(A.ptr(b.far), A.ptr(b.mid), k.n * self.S,
-                                self.det, 0, c.st), "sub-tile transforms")
+        from . import lstsq as L
+        if L.PFA_SUBTILES_IN_LDS and lib.tike_pfa_fwd_subtiles_supported(
+                self.S, self.pw, self.det):
+            # 128^2 sub-tiles (384, 640, 896): gathered and transformed inside
+            # LDS, written once
+            psub = L._workspace(c.op).get(
+                "pfa_probe", (self.S + c.C * c.Sm, self.det, self.det),
+                torch.complex64, c.psi.device)
+            check(
+                lib.tike_pfa_fwd_subtiles(
+                    A.ptr(c.psi), A.ptr(k.scan), A.ptr(c.probe), A.ptr(c.ep),
+                    A.ptr(k.w), c.C, c.Sm, A.ptr(psub), A.ptr(b.mid),
+                    A.ptr(k.patches), k.n, self.S, self.pw, self.det, c.H,
+                    c.W, c.st), "prime-factor gather + sub-tile transforms")
+        else:
+            check(
+                lib.tike_pfa_fwd_gather(
+                    A.ptr(c.psi), A.ptr(k.scan), A.ptr(c.probe), 0, None,
+                    A.ptr(c.ep), A.ptr(k.w), c.C, c.Sm, A.ptr(b.far),
+                    A.ptr(k.patches), k.n, self.S, self.pw, self.det, c.H,
+                    c.W, c.st), "prime-factor gather")
+            check(lib.tike_pfa_fft2(A.ptr(b.far), A.ptr(b.mid), k.n * self.S,
+                                    self.det, 0, c.st), "sub-tile transforms")
         check(
             lib.tike_pfa_combine_gradient(
                 A.ptr(b.mid), A.ptr(k.data_f32()), A.ptr(c.mask_u8),

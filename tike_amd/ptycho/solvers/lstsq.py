@@ -135,6 +135,12 @@ def mode_groups(S, pw, det, eigen_modes=0):
     return tuple(zip(firsts, sizes))
 
 
+PFA_SUBTILES_IN_LDS = True
+"""Prime-factor sizes with 128^2 sub-tiles (384, 640, 896): gather and forward
+sub-tile transform in one launch, the sub-tile inside LDS
+(tike_pfa_fwd_subtiles); False: tike_pfa_fwd_gather + tike_pfa_fft2."""
+
+
 def pfa_gradients(S, pw, det):
     """True where the prime-factor launches serve (csrc/pfa.hip)."""
     return bool(PFA_ROUTE and lib.tike_pfa_supported(S, pw, det))
