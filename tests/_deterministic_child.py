@@ -127,6 +127,57 @@ def main():
         r = ctx.get_result()
     out["poisson"] = digest(r.psi, r.probe, np.array(r.algorithm_options.costs))
     out["poisson_cost"] = [float(c[0]) for c in r.algorithm_options.costs]
+    # (round 6, late) the routes added this round: 10 modes at 128^2 (pass 2 in
+    # two groups of modes), a 192^2 detector (prime-factor launches), a 100^2
+    # one (unfused kernels on the mixed-radix transforms)
+    for key, det_r, S_r, N_r in (("groups", 128, 10, 14), ("pfa", 192, 3, 12),
+                                 ("offgrid", 100, 2, 12)):
+        scan, psi_true, probe0, ep, ew, data = _headline_problem(
+            tp, det_r, S_r, N_r, seed=41 + det_r, eigen=True)
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=np.full_like(psi_true, 0.5),
+            scan=scan.copy(), eigen_probe=ep.copy(), eigen_weights=ew.copy(),
+            algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
+                                              batch_method="wobbly_center"),
+            probe_options=tp.ProbeOptions(force_orthogonality=True),
+            object_options=tp.ObjectOptions(),
+            exitwave_options=tp.ExitWaveOptions(
+                measured_pixels=np.ones((det_r, det_r), dtype=bool)))
+        tike_amd.random.randomizer_np = np.random.default_rng(6)
+        with tp.Reconstruction(data, params, order=np.arange(N_r),
+                               batches=np.array_split(np.arange(N_r), 2)) as ctx:
+            ctx.iterate(2)
+            r = ctx.get_result()
+        out[key] = digest(r.psi, r.probe, r.eigen_probe, r.eigen_weights,
+                          np.array(r.algorithm_options.costs))
+        out[key + "_cost"] = [float(c[0]) for c in r.algorithm_options.costs]
+    # ... and a two-slice object at 128^2 under the Poisson model (the fused
+    # chain with the last slice's far field stored)
+    det_m, S, N = 128, 2, 14
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det_m, S, N, seed=9, eigen=False)
+    data = np.round(data * (20000.0 / data.max())).astype(np.float32)
+    psi0 = np.repeat(np.full_like(psi_true, 0.5), 2, axis=0)
+    psi0[1:] = 1.0
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=psi0, scan=scan.copy(),
+        algorithm_options=tp.RpieOptions(num_batch=2, num_iter=2,
+                                         batch_method="compact", alpha=1.0),
+        probe_options=tp.ProbeOptions(
+            force_orthogonality=True, probe_wavelength=1e-10,
+            probe_FOV_lengths=(2e-6, 2e-6)),
+        object_options=tp.ObjectOptions(multislice_propagation_distance=1e-6),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det_m, det_m), dtype=bool),
+            noise_model="poisson"))
+    with tp.Reconstruction(data, params, order=np.arange(N),
+                           batches=np.array_split(np.arange(N), 2)) as ctx:
+        ctx.iterate(2)
+        r = ctx.get_result()
+    out["multislice128p"] = digest(r.psi, r.probe,
+                                   np.array(r.algorithm_options.costs))
+    out["multislice128p_cost"] = [float(c[0])
+                                  for c in r.algorithm_options.costs]
     print("RESULT " + json.dumps(out))
 
 

@@ -2362,7 +2362,8 @@ def test_deterministic_mode_gives_bit_identical_runs():
                                free["headline_psi_norm"], rtol=1e-5)
     # round 6: cgrad (direction sums, all-steps-at-once line search; 256^2 and
     # 128^2) and the Poisson model with per-mode step lengths
-    for key in ("cgrad256", "cgrad128", "poisson"):
+    for key in ("cgrad256", "cgrad128", "poisson", "groups", "pfa", "offgrid",
+                "multislice128p"):
         assert a[key] == b[key], key
         np.testing.assert_allclose(a[key + "_cost"], free[key + "_cost"],
                                    rtol=2e-3)
