@@ -310,8 +310,9 @@ int tike_ifft2_pass2_gradients_scaled(const void* work, const void* patches, con
  * their probe gradients, mode 0 of chi when mode0 == 0, and their share of
  * objproj = sum_s conj(P_n,s) chi_n,s stored (accumulate == 0) or added to what
  * the launch of the modes in front left there.  Arguments as
- * tike_ifft2_pass2_gradients with S the mode count of the problem; the
- * eigen probes must all belong to the modes of the first group. */
+ * tike_ifft2_pass2_gradients with S the mode count of the problem (objproj
+ * NULL: the probe gradients and chi0 only); the eigen probes must all belong to
+ * the modes of the first group. */
 int tike_ifft2_pass2_gradients_modes(const void* work, const void* patches, const void* probe,
                                      const void* eigen_probe, const float* eigen_weights,
                                      int num_eigen, int eigen_modes, void* objproj, void* chi0,

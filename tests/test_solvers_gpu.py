@@ -1169,6 +1169,7 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
     (1024, 1024, 1, 2, False), (640, 512, 2, 3, False),
     (768, 768, 2, 2, False), (192, 192, 9, 4, True), (320, 300, 2, 5, True),
     (448, 448, 2, 3, True), (224, 200, 3, 4, False),  # 7 x 2^k
+    (896, 896, 1, 2, False),   # 7 x 128: sub-tiles gathered and transformed in LDS
 ])
 @pytest.mark.parametrize("engine", ["pfa", "lds"])
 def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine,
@@ -1233,6 +1234,44 @@ def test_mode_groups_vs_oracle(tp, det, S, N, eigen):
     assert calls and all(g == groups for _, g in calls)
     assert all(r == ("pos_major" if det == 128 else "no_farplane")
                for r, _ in calls)
+
+
+@pytest.mark.parametrize("det,S,N", [(256, 10, 8), (128, 12, 9), (256, 6, 8)])
+def test_probe_only_reconstruction_vs_oracle(tp, det, S, N):
+    """`object_options=None` (the object is not recovered, lstsq.py:383-420
+    with recover_psi False): no object projection is formed -- with more
+    than 8 modes the groups of `tike_ifft2_pass2_gradients_modes` run without
+    it -- two epochs against the oracle."""
+    from oracle import solvers as osol
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=det + S, eigen=False)
+    batches = np.array_split(np.arange(N), 2)
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=psi_true.copy(), scan=scan.copy(),
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
+                                          batch_method="compact"),
+        # (no orthogonalisation: with the object at its true value the modes'
+        # powers come close and the eigenbasis of `orthogonalize_eig` is then
+        # a matter of rounding -- product and oracle pick different ones)
+        probe_options=tp.ProbeOptions(force_orthogonality=False),
+        object_options=None,
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    with tp.Reconstruction(data, params, order=np.arange(N),
+                           batches=batches) as ctx:
+        ctx.iterate(2)
+        got = ctx.get_result()
+    state = dict(psi=psi_true.copy(), probe=probe0.copy(), scan=scan.copy(),
+                 costs=[], eigen_probe=None, eigen_weights=None)
+    state = osol.rescale_probe(state, data, det)
+    state = osol.iterate(state, data, batches, 2, detector_shape=det,
+                         batch_method="compact", force_orthogonality=False,
+                         recover_psi=False)
+    np.testing.assert_allclose(np.array(got.algorithm_options.costs),
+                               np.array(state["costs"]), rtol=1e-3)
+    np.testing.assert_array_equal(got.psi, psi_true)
+    assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe")
 
 
 def test_general_shape_launches_equal_the_unfused_kernels(tp):

@@ -978,7 +978,8 @@ static int launch_pass2_gradients(const void* work, const void* patches, const v
   // a group of S modes out of Stot (tike_ifft2_pass2_gradients_modes): the
   // weights are Stot apart, as the tiles
   const bool grp = Stot != 0;
-  if (grp && (S < 2 || !objproj)) return TK_ERR_UNSUPPORTED;  // (the mode-sum path)
+  // (with objproj: through the mode-sum path, which needs two mode-waves)
+  if (grp && objproj && S < 2) return TK_ERR_UNSUPPORTED;
   const TkProbe pr = tk_make_probe(probe, 0, eigen_probe, eigen_weights, num_eigen, eigen_modes,
                                    grp ? Stot : S, det);
   // mode-waves x column-waves of a workgroup and modes per wave
@@ -1014,7 +1015,13 @@ static int launch_pass2_gradients(const void* work, const void* patches, const v
   if (eig_lds > 32 * 1024) return TK_ERR_UNSUPPORTED;
 #define TK_P2G(N, MW_, MPW_)                                                                 \
   do {                                                                                       \
-    if (grp && eig_lds > 0)                                                                  \
+    if (grp && !objproj)                                                                     \
+      hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, false, true, true>),    \
+                         grid, block, 0,                                                     \
+                         stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
+                         (cf*)chi0, (float*)m_probe_update, mpu_scale, nscan, S, inv_scale,  \
+                         chunk, mpu_part, mode_scale, Stot, accumulate);                     \
+    else if (grp && eig_lds > 0)                                                             \
       hipLaunchKernelGGL((ifft2_pass2_gradients_kernel<N, MW_, MPW_, true, true, true>),     \
                          grid, block, eig_lds,                                               \
                          stream, (const cf*)work, (const cf*)patches, pr, (cf*)objproj,      \
@@ -1113,12 +1120,12 @@ extern "C" int tike_ifft2_pass2_gradients_modes(const void* work, const void* pa
                                                 void* stream) {
   TK_ENTER();
   TK_CHECK_ARG(S >= 1 && det >= 1 && mode0 >= 0 && nmodes >= 1 && mode0 + nmodes <= S);
-  TK_CHECK_ARG(nscan == 0 || (work && probe && objproj));
+  TK_CHECK_ARG(nscan == 0 || (work && (probe || !objproj)));
   const long P = (long)det * det;
   const bool first = mode0 == 0;
   if (first ? eigen_modes > nmodes : false) return TK_ERR_UNSUPPORTED;
   return launch_pass2_gradients(
-      (const cf*)work + mode0 * P, patches, (const cf*)probe + mode0 * P,
+      (const cf*)work + mode0 * P, patches, probe ? (const cf*)probe + mode0 * P : nullptr,
       first ? eigen_probe : nullptr, eigen_weights ? eigen_weights + mode0 : nullptr,
       first ? num_eigen : (eigen_weights ? num_eigen : 0), first ? eigen_modes : 0, objproj,
       first ? chi0 : nullptr,
