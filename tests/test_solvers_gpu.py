@@ -1149,7 +1149,14 @@ def test_fixtures_under_the_deterministic_switch():
 @pytest.mark.parametrize("det,S,N,eigen", [(256, 8, 9, True), (256, 4, 7, True),
                                            (512, 4, 5, False),
                                            (128, 8, 11, True),
-                                           (256, 5, 6, False)])
+                                           (256, 5, 6, False),
+                                           # one / two modes WITH eigen probes:
+                                           # their LDS slices need spare
+                                           # mode-waves at 512^2 (raised
+                                           # "unsupported size" until round 6,
+                                           # found by tools/fuzz_routes.py)
+                                           (512, 1, 4, True), (512, 2, 4, True),
+                                           (256, 1, 6, True), (128, 1, 7, True)])
 def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
     """One minibatch through the HIP kernels at the headline shapes (every
     specialisation on the number of modes the bench runs: S = 8 at 256^2,

@@ -985,6 +985,15 @@ static int launch_pass2_gradients(const void* work, const void* patches, const v
   // mode-waves x column-waves of a workgroup and modes per wave
   int MW = S >= 3 ? 4 : S;
   if (det == 128 && MW == 1) MW = 2;  // a 128-wide tile has only two 64-column waves
+  // eigen probes applied on the fly keep conj(E) of the workgroup's slice in LDS
+  // (32 KiB at most: two workgroups per CU): a slice of 4 / MW column-waves --
+  // with one or two modes at 512^2 (or several eigen probes) more mode-waves,
+  // the spare ones idle, make it narrow enough
+  auto eig_bytes = [&](int mw) {
+    return sizeof(cf) * (size_t)num_eigen * eigen_modes * (det / 16) * 64 * (4 / mw);
+  };
+  if (objproj && eigen_weights && eigen_probe)
+    while (MW < 4 && eig_bytes(MW) > 32 * 1024) MW *= 2;
   const int MPW = S > 4 ? 2 : 1;
   const int nslice = 16 * (det / (64 * (4 / MW)));
   // enough (slice, chunk) workgroups to fill the chip about twice -- and
@@ -1010,8 +1019,7 @@ static int launch_pass2_gradients(const void* work, const void* patches, const v
   }
   // LDS for the eigen-probe slices (only when they are applied on the fly)
   size_t eig_lds = 0;
-  if (objproj && eigen_weights && eigen_probe)
-    eig_lds = sizeof(cf) * (size_t)num_eigen * eigen_modes * (det / 16) * 64 * (4 / MW);
+  if (objproj && eigen_weights && eigen_probe) eig_lds = eig_bytes(MW);
   if (eig_lds > 32 * 1024) return TK_ERR_UNSUPPORTED;
 #define TK_P2G(N, MW_, MPW_)                                                                 \
   do {                                                                                       \

@@ -1,0 +1,169 @@
+"""Random shapes and option combinations through lstsq_grad twice: on the
+routes `GradientPlan` picks and with every round-6 route switched off (the
+unfused kernels / the stored far plane) -- costs and iterates must agree.
+Catches routing and edge-case bugs without the oracle's run time.
+
+    gpurun -- python tools/fuzz_routes.py [cases=40] [seed=0]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+
+import tike_amd.ptycho as tp  # noqa: E402
+import tike_amd.random  # noqa: E402
+from test_solvers_gpu import _headline_problem  # noqa: E402
+from tike_amd.ptycho.solvers import lstsq as L  # noqa: E402
+from tike_amd.ptycho.solvers._plan import GradientPlan  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+SIZES = (45, 64, 96, 100, 128, 160, 192, 224, 256, 300, 320, 384, 448, 512, 640)
+
+
+def rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+routes = []
+real = GradientPlan.gradients
+
+
+def spy(self, c, k):
+    routes.append(self.route + ("+groups" if self.groups else ""))
+    return real(self, c, k)
+
+
+GradientPlan.gradients = spy
+bad = 0
+for case in range(cases):
+    det = int(rng.choice(SIZES))
+    pw = det if rng.random() < 0.6 else int(det - 2 * rng.integers(1, max(2, det // 6)))
+    S = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 14]))
+    if det >= 384:
+        S = min(S, 5 if det < 512 else 9)
+    N = int(rng.integers(4, 11))
+    eigen = bool(rng.random() < 0.5)
+    masked = bool(rng.random() < 0.3)
+    model = "poisson" if rng.random() < 0.2 else "gaussian"
+    u16 = bool(rng.random() < 0.25)
+    recover_psi = bool(rng.random() < 0.85)
+    scan, psi_true, probe0, ep, ew, data = _headline_problem(
+        tp, det, S, N, seed=1000 + case, eigen=eigen, pw=pw)
+    data = np.round(data * (20000.0 / data.max()))
+    data = data.astype(np.uint16 if u16 else np.float32)
+    mask = (rng.random((det, det)) > 0.1) if masked else np.ones((det, det), bool)
+    tag = (f"det {det} pw {pw} S {S} N {N} eigen {int(eigen)} mask {int(masked)} "
+           f"{model} u16 {int(u16)} psi {int(recover_psi)}")
+
+    def run():
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=(np.full_like(psi_true, 0.5)
+                                      if recover_psi else psi_true.copy()),
+            scan=scan.copy(),
+            eigen_probe=None if ep is None else ep.copy(),
+            eigen_weights=None if ew is None else ew.copy(),
+            algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
+                                              batch_method="compact"),
+            probe_options=tp.ProbeOptions(force_orthogonality=False),
+            object_options=tp.ObjectOptions() if recover_psi else None,
+            exitwave_options=tp.ExitWaveOptions(measured_pixels=mask,
+                                                noise_model=model))
+        tike_amd.random.randomizer_np = np.random.default_rng(5)
+        with tp.Reconstruction(data, params, order=np.arange(N),
+                               batches=np.array_split(np.arange(N), 2)) as ctx:
+            ctx.iterate(2)
+            return ctx.get_result()
+
+    del routes[:]
+    try:
+        a = run()
+        ra = sorted(set(routes))
+        saved = (L.GENERAL_FUSED, L.PFA_ROUTE, L.MODE_GROUPS,
+                 L.PFA_SUBTILES_IN_LDS)
+        L.GENERAL_FUSED, L.PFA_ROUTE, L.MODE_GROUPS = False, False, False
+        L.PFA_SUBTILES_IN_LDS = False
+        del routes[:]
+        try:
+            b = run()
+        finally:
+            (L.GENERAL_FUSED, L.PFA_ROUTE, L.MODE_GROUPS,
+             L.PFA_SUBTILES_IN_LDS) = saved
+        rb = sorted(set(routes))
+        ca = np.array(a.algorithm_options.costs).ravel()
+        cb = np.array(b.algorithm_options.costs).ravel()
+        dc = float(np.max(np.abs(ca / cb - 1)))
+        dp, dq = rel(a.psi, b.psi), rel(a.probe, b.probe)
+        ok = dc < 1e-3 and dp < 1e-3 and dq < 2e-3
+        print(f"{'ok ' if ok else 'BAD'} {tag}: {ra} vs {rb}  cost {dc:.1e} "
+              f"psi {dp:.1e} probe {dq:.1e}", flush=True)
+        bad += not ok
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print(f"ERR {tag}: {type(e).__name__}: {str(e)[:200]}", flush=True)
+print(f"lstsq_grad: {cases - bad} of {cases} agree", flush=True)
+
+# ---- rpie on multislice objects: the fused chain against the slice-by-slice
+# composition of the general operators
+import importlib  # noqa: E402
+
+R = importlib.import_module("tike_amd.ptycho.solvers.rpie")
+mcases = max(4, cases // 4)
+mbad = 0
+for case in range(mcases):
+    det = int(rng.choice((128, 256, 512)))
+    S = int(rng.integers(1, 9 if det < 512 else 5))
+    depth = int(rng.integers(2, 4))
+    N = int(rng.integers(4, 9))
+    model = "poisson" if rng.random() < 0.3 else "gaussian"
+    u16 = bool(rng.random() < 0.25)
+    step = bool(rng.random() < 0.7)
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=5000 + case, eigen=False)
+    data = np.round(data * (20000.0 / data.max()))
+    data = data.astype(np.uint16 if u16 else np.float32)
+    psi0 = np.repeat(np.full_like(psi_true, 0.5), depth, axis=0)
+    psi0[1:] = 1.0
+    tag = (f"multislice det {det} S {S} depth {depth} N {N} {model} "
+           f"u16 {int(u16)} slice_step {int(step)}")
+
+    def mrun(fused):
+        R.FUSED_MULTISLICE, R.SLICE_STEP_FUSED = fused, step
+        params = tp.PtychoParameters(
+            probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
+            algorithm_options=tp.RpieOptions(num_batch=2, num_iter=2,
+                                             batch_method="compact", alpha=1.0),
+            probe_options=tp.ProbeOptions(
+                force_orthogonality=False, probe_wavelength=1e-10,
+                probe_FOV_lengths=(2e-6, 2e-6)),
+            object_options=tp.ObjectOptions(
+                multislice_propagation_distance=1e-6),
+            exitwave_options=tp.ExitWaveOptions(
+                measured_pixels=np.ones((det, det), dtype=bool),
+                noise_model=model))
+        try:
+            with tp.Reconstruction(data, params, order=np.arange(N),
+                                   batches=np.array_split(np.arange(N), 2)) as ctx:
+                ctx.iterate(2)
+                return ctx.get_result()
+        finally:
+            R.FUSED_MULTISLICE = R.SLICE_STEP_FUSED = True
+
+    try:
+        a, b = mrun(True), mrun(False)
+        ca = np.array(a.algorithm_options.costs).ravel()
+        cb = np.array(b.algorithm_options.costs).ravel()
+        dc = float(np.max(np.abs(ca / cb - 1)))
+        dp, dq = rel(a.psi, b.psi), rel(a.probe, b.probe)
+        ok = dc < 1e-3 and dp < 1e-3 and dq < 2e-3
+        print(f"{'ok ' if ok else 'BAD'} {tag}: cost {dc:.1e} psi {dp:.1e} "
+              f"probe {dq:.1e}", flush=True)
+        mbad += not ok
+    except Exception as e:  # noqa: BLE001
+        mbad += 1
+        print(f"ERR {tag}: {type(e).__name__}: {str(e)[:200]}", flush=True)
+print(f"multislice rpie: {mcases - mbad} of {mcases} agree")
+sys.exit(1 if bad or mbad else 0)
