@@ -303,6 +303,13 @@ int tike_ifft2_pass2_gradients_scaled(const void* work, const void* patches, con
                                       void* m_probe_update, float mpu_scale, int nscan, int S,
                                       int det, float inv_scale, const float* mode_scale,
                                       void* stream);
+/* 1 where the eigen probes of a problem fit the LDS slices
+ * tike_ifft2_pass2_gradients[_scaled|_modes] keep of them (num_eigen x
+ * eigen_modes x det / 16 rows x 64 columns of complex64 in 32 KiB: 8 probe-mode
+ * pairs at 128^2, 4 at 256^2, 2 at 512^2); 0: those entries return
+ * TIKE_ERR_UNSUPPORTED and the caller keeps chi (tike_ifft2_crop* +
+ * tike_lstsq_gradients, probe.py:272-303 on the fly).  No device work. */
+int tike_ifft2_pass2_eigen_fits(int det, int num_eigen, int eigen_modes);
 /* ... for MORE modes than one launch holds in registers (more than 8 at 128^2 /
  * 256^2, more than 4 at 512^2; the reference's cuFFT path, lstsq.py:504-539,
  * takes any number): the modes [mode0, mode0 + nmodes) of an S-mode problem,

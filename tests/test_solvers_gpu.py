@@ -952,12 +952,18 @@ def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0, margin=8,
                       for m in range(S)])[None, None].astype(np.complex64)
     ep = ew = None
     if eigen:
+        # (eigen = (probes incl. the shared one, modes owning eigen probes),
+        # True: (2, 1) -- one eigen probe on the first mode)
+        K, Mm = eigen if isinstance(eigen, tuple) else (2, 1)
         np.random.seed(seed)
         tike_amd.random.randomizer_np = np.random.default_rng(seed + 1)
-        ep, ew = tp.init_varying_probe(scan, probe, num_eigen_probes=2,
-                                       probes_with_modes=1)
+        ep, ew = tp.init_varying_probe(scan, probe, num_eigen_probes=K,
+                                       probes_with_modes=Mm)
         # weights large enough for the eigen probe to matter in the forward
         ew[:, 1, 0] = 0.05 * rng.standard_normal(N).astype(np.float32)
+        if (K, Mm) != (2, 1):
+            ew[:, 1:, :Mm] = 0.05 * rng.standard_normal(
+                ew[:, 1:, :Mm].shape).astype(np.float32)
     data = tp.simulate(det, probe, scan, psi_true, eigen_probe=ep,
                        eigen_weights=ew)
     probe0 = (probe * (1 + 0.05 * rng.standard_normal(probe.shape))).astype(
@@ -1241,6 +1247,55 @@ def test_mode_groups_vs_oracle(tp, det, S, N, eigen):
     assert calls and all(g == groups for _, g in calls)
     assert all(r == ("pos_major" if det == 128 else "no_farplane")
                for r, _ in calls)
+
+
+@pytest.mark.parametrize("det,S,N,eigen", [
+    (256, 4, 8, (3, 2)),    # 2 eigen probes x 2 modes: 4 slices fit pass 2's LDS
+    (256, 6, 6, (3, 3)),    # 6 do not: chi is stored (found by tools/fuzz_routes.py:
+    (512, 3, 4, (3, 3)),    # "unsupported size" until round 6)
+    (128, 8, 8, (3, 3)),
+    (256, 12, 6, (3, 2)),   # ... with the modes in two groups
+    (192, 3, 8, (3, 2)), (300, 2, 6, (3, 2))])  # prime-factor / LDS line engine
+def test_several_eigen_probes_vs_oracle(tp, det, S, N, eigen):
+    """More than one eigen probe, on more than one mode (probe.py:272-476,
+    lstsq.py:297-364): two epochs against the oracle on every route."""
+    import tike_amd.random
+    from oracle import solvers as osol
+    scan, psi_true, probe0, ep, ew, data = _headline_problem(
+        tp, det, S, N, seed=det + S, eigen=eigen)
+    assert ep.shape[-4] == eigen[0] - 1 and ep.shape[-3] == eigen[1]
+    psi0 = np.full_like(psi_true, 0.5)
+    batches = np.array_split(np.arange(N), 2)
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
+        eigen_probe=ep.copy(), eigen_weights=ew.copy(),
+        algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
+                                          batch_method="compact"),
+        probe_options=tp.ProbeOptions(force_orthogonality=False),
+        object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    tike_amd.random.randomizer_np = np.random.default_rng(11)
+    with tp.Reconstruction(data, params, order=np.arange(N),
+                           batches=batches) as ctx:
+        ctx.iterate(2)
+        got = ctx.get_result()
+    state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
+                 costs=[], eigen_probe=ep.copy(), eigen_weights=ew.copy())
+    state = osol.rescale_probe(state, data, det)
+    state = osol.iterate(state, data, batches, 2, detector_shape=det,
+                         batch_method="compact", force_orthogonality=False,
+                         rng=np.random.default_rng(11))
+    np.testing.assert_allclose(np.array(got.algorithm_options.costs),
+                               np.array(state["costs"]), rtol=1e-3)
+    assert_close(got.psi, state["psi"], normwise=SOLVER_NORMWISE, maxabs=1e-2,
+                 what="psi")
+    assert_close(got.probe, state["probe"], normwise=SOLVER_NORMWISE,
+                 maxabs=1e-2, what="probe")
+    assert_close(got.eigen_probe, state["eigen_probe"], normwise=5e-3,
+                 maxabs=5e-2, what="eigen probes")
+    np.testing.assert_allclose(got.eigen_weights, state["eigen_weights"],
+                               rtol=5e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize("det,S,N", [(256, 10, 8), (128, 12, 9), (256, 6, 8)])

@@ -113,6 +113,7 @@ _PROTOTYPES = {
                                    _i, _i, _i, _f, _p],
     "tike_ifft2_pass2_gradients_scaled": [_p, _p, _p, _p, _p, _i, _i, _p, _p,
                                           _p, _f, _i, _i, _i, _f, _p, _p],
+    "tike_ifft2_pass2_eigen_fits": [_i, _i, _i],
     "tike_ifft2_pass2_gradients_modes": [_p, _p, _p, _p, _p, _i, _i, _p, _p,
                                          _p, _f, _i, _i, _i, _f, _i, _i, _i, _p],
     "tike_poisson_steps_grad_ifft2_pass1": [_p, _p, _i, _p, _p, _p, _p, _p, _i,

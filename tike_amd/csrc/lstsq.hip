@@ -1112,6 +1112,14 @@ extern "C" int tike_ifft2_pass2_gradients_scaled(const void* work, const void* p
                                 det, inv_scale, mode_scale, (hipStream_t)stream);
 }
 
+// 1 where the eigen probes' LDS slices of tike_ifft2_pass2_gradients fit (32 KiB
+// per workgroup at the widest mode-wave split); 0: the caller keeps chi
+// (tike_ifft2_crop* + tike_lstsq_gradients).  No device work.
+extern "C" int tike_ifft2_pass2_eigen_fits(int det, int num_eigen, int eigen_modes) {
+  if (det < 16 || num_eigen < 0 || eigen_modes < 0) return 0;
+  return sizeof(cf) * (size_t)num_eigen * eigen_modes * (det / 16) * 64 <= 32 * 1024 ? 1 : 0;
+}
+
 // Modes [mode0, mode0 + nmodes) of an S-mode problem (2 <= nmodes <= 8): what
 // tike_ifft2_pass2_gradients does for those modes alone -- their probe
 // gradients, mode 0 of chi when mode0 == 0 -- with their share of objproj

@@ -150,7 +150,8 @@ class GradientPlan:
         return algorithmic_bytes(entry, n, self.S, self.det, self.pw, C)
 
     @staticmethod
-    def for_(op, S, pw, det, exitwave_options, mask_u8, eigen_modes=0):
+    def for_(op, S, pw, det, exitwave_options, mask_u8, eigen_modes=0,
+             num_eigen=0):
         """The plan of this shape on this operator (cached on it, keyed also on
         the module switches tests and A/B runs flip)."""
         from . import lstsq as L
@@ -165,15 +166,18 @@ class GradientPlan:
                L.POISSON_FROM_HANDOFF, L.POISSON_STEPS_IN_PASS2,
                L.GENERAL_FUSED, L.PFA_ROUTE, L.GENERAL_MIN_DETECTOR,
                L.CHUNK_POSITIONS_OVERRIDE,
-               L.mode_groups(S, pw, det, eigen_modes))
+               L.mode_groups(S, pw, det, eigen_modes),
+               bool(lib.tike_ifft2_pass2_eigen_fits(det, num_eigen,
+                                                    eigen_modes)))
         cache = op.__dict__.setdefault("_tike_amd_plans", {})
         if key not in cache:
             cache[key] = GradientPlan._build(S, pw, det, eo, mask_u8, unmeasured,
-                                             L, eigen_modes)
+                                             L, eigen_modes, key[-1])
         return cache[key]
 
     @staticmethod
-    def _build(S, pw, det, eo, mask_u8, unmeasured, L, eigen_modes=0):
+    def _build(S, pw, det, eo, mask_u8, unmeasured, L, eigen_modes=0,
+               eigen_fits=True):
         poisson = eo.noise_model == "poisson"
         dominant = int(poisson and eo.step_length_usemodes == "dominant_mode")
         all_modes = poisson and not dominant
@@ -185,7 +189,10 @@ class GradientPlan:
         # (c3m12: 80 -> see profiles/r06_experiments.md section 10)
         groups = () if fused or poisson else L.mode_groups(S, pw, det,
                                                            eigen_modes)
-        fused = fused or bool(groups)
+        # (many eigen probes x modes owning them: their slices do not fit the
+        # LDS of the fused pass 2 -- chi is stored then)
+        fused = (fused or bool(groups)) and eigen_fits
+        groups = groups if fused else ()
         # (detector sizes with position-major kernels -- 128, 256, 512 -- keep
         # those for pw < det or many modes: measured faster, c3pad 160 vs 88 k
         # patterns/s, c3m12 69 vs 41 k, profiles/r06_experiments.md)

@@ -480,7 +480,7 @@ def _get_nearplane_gradients(data, psi, scan, probe, eigen_probe,
     w_old = None if eigen_weights is None else eigen_weights[lo:hi]
     ep, _, C, Sm = _eigen_args(eigen_probe, w_old)
     plan = GradientPlan.for_(op, S, pw, det, exitwave_options, mask_u8,
-                             eigen_modes=Sm)
+                             eigen_modes=Sm, num_eigen=C)
 
     # planar (real plane, imaginary plane) float32 accumulator of the object
     # gradient: the shape float atomics run fastest on; recombined below

@@ -53,11 +53,27 @@ for case in range(cases):
     recover_psi = bool(rng.random() < 0.85)
     scan, psi_true, probe0, ep, ew, data = _headline_problem(
         tp, det, S, N, seed=1000 + case, eigen=eigen, pw=pw)
+    shape = ""
+    if eigen and rng.random() < 0.4:
+        # more eigen probes / more modes owning them than the tests' one of each
+        K, Mm = int(rng.integers(2, 4)), int(rng.integers(1, min(S, 3) + 1))
+        np.random.seed(case)
+        tike_amd.random.randomizer_np = np.random.default_rng(case)
+        ep, ew = tp.init_varying_probe(scan, probe0, num_eigen_probes=K,
+                                       probes_with_modes=Mm)
+        ew[:, 1:, :Mm] = 0.05 * rng.standard_normal(
+            ew[:, 1:, :Mm].shape).astype(np.float32)
+        shape = f" eigen probes {K - 1} x {Mm} modes"
+    positions = bool(rng.random() < 0.2)  # (only with the object recovered, below)
+    nb = int(rng.choice((1, 2, 3)))
+    method = "compact" if rng.random() < 0.6 else "wobbly_center"
     data = np.round(data * (20000.0 / data.max()))
     data = data.astype(np.uint16 if u16 else np.float32)
     mask = (rng.random((det, det)) > 0.1) if masked else np.ones((det, det), bool)
-    tag = (f"det {det} pw {pw} S {S} N {N} eigen {int(eigen)} mask {int(masked)} "
-           f"{model} u16 {int(u16)} psi {int(recover_psi)}")
+    positions = positions and recover_psi
+    tag = (f"det {det} pw {pw} S {S} N {N} eigen {int(eigen)}{shape} mask "
+           f"{int(masked)} {model} u16 {int(u16)} psi {int(recover_psi)} "
+           f"positions {int(positions)} batches {nb} {method}")
 
     def run():
         params = tp.PtychoParameters(
@@ -66,15 +82,18 @@ for case in range(cases):
             scan=scan.copy(),
             eigen_probe=None if ep is None else ep.copy(),
             eigen_weights=None if ew is None else ew.copy(),
-            algorithm_options=tp.LstsqOptions(num_batch=2, num_iter=2,
-                                              batch_method="compact"),
+            algorithm_options=tp.LstsqOptions(num_batch=nb, num_iter=2,
+                                              batch_method=method),
             probe_options=tp.ProbeOptions(force_orthogonality=False),
             object_options=tp.ObjectOptions() if recover_psi else None,
+            position_options=tp.PositionOptions(
+                scan.copy(), use_adaptive_moment=True,
+                update_magnitude_limit=1.0) if positions else None,
             exitwave_options=tp.ExitWaveOptions(measured_pixels=mask,
                                                 noise_model=model))
         tike_amd.random.randomizer_np = np.random.default_rng(5)
         with tp.Reconstruction(data, params, order=np.arange(N),
-                               batches=np.array_split(np.arange(N), 2)) as ctx:
+                               batches=np.array_split(np.arange(N), nb)) as ctx:
             ctx.iterate(2)
             return ctx.get_result()
 
