@@ -71,9 +71,21 @@ for case in range(cases):
     data = data.astype(np.uint16 if u16 else np.float32)
     mask = (rng.random((det, det)) > 0.1) if masked else np.ones((det, det), bool)
     positions = positions and recover_psi
+    solver = str(rng.choice(("lstsq", "lstsq", "rpie", "cgrad")))
+    if solver == "cgrad":  # (gaussian, no eigen probes, whole-pattern data)
+        ep = ew = None
+        eigen, shape, model, positions, recover_psi = False, "", "gaussian", False, True
+        mask = np.ones((det, det), bool)
+        masked = False
+        S = min(S, 3)
+        probe0 = probe0[..., :S, :, :]
+        data = tp.simulate(det, probe0, scan, psi_true)
+        data = np.round(data * (20000.0 / data.max())).astype(np.float32)
+    if solver == "rpie":
+        positions = False
     tag = (f"det {det} pw {pw} S {S} N {N} eigen {int(eigen)}{shape} mask "
            f"{int(masked)} {model} u16 {int(u16)} psi {int(recover_psi)} "
-           f"positions {int(positions)} batches {nb} {method}")
+           f"positions {int(positions)} batches {nb} {method} {solver}")
 
     def run():
         params = tp.PtychoParameters(
@@ -82,8 +94,12 @@ for case in range(cases):
             scan=scan.copy(),
             eigen_probe=None if ep is None else ep.copy(),
             eigen_weights=None if ew is None else ew.copy(),
-            algorithm_options=tp.LstsqOptions(num_batch=nb, num_iter=2,
-                                              batch_method=method),
+            algorithm_options=(
+                tp.RpieOptions(num_batch=nb, num_iter=2, batch_method=method,
+                               alpha=0.5) if solver == "rpie" else
+                tp.CgradOptions(num_batch=nb, num_iter=2, cg_iter=2)
+                if solver == "cgrad" else
+                tp.LstsqOptions(num_batch=nb, num_iter=2, batch_method=method)),
             probe_options=tp.ProbeOptions(force_orthogonality=False),
             object_options=tp.ObjectOptions() if recover_psi else None,
             position_options=tp.PositionOptions(
