@@ -1183,6 +1183,8 @@ def test_lstsq_minibatch_kernels_vs_oracle(tp, det, S, N, eigen):
     (768, 768, 2, 2, False), (192, 192, 9, 4, True), (320, 300, 2, 5, True),
     (448, 448, 2, 3, True), (224, 200, 3, 4, False),  # 7 x 2^k
     (896, 896, 1, 2, False),   # 7 x 128: sub-tiles gathered and transformed in LDS
+    (1536, 1536, 1, 2, False),  # 3 x 512 sub-tiles
+    (2048, 1500, 2, 2, False),  # the largest transform size
 ])
 @pytest.mark.parametrize("engine", ["pfa", "lds"])
 def test_general_shape_launches_vs_oracle(tp, det, pw, S, N, eigen, engine,
@@ -1396,7 +1398,8 @@ def _minibatch_vs_oracle(tp, det, S, N, eigen, pw=None):
     # sqrt(log2 n) in I (product and oracle alike, tools/debug/fft_bias.py) is
     # 1e-5 ... 1e-4 of such a cost and grows with the line length -- 1.5e-4 at
     # 640, 5.5e-4 at 1024 (gradients, chi and step lengths agree to 2e-5 there)
-    cost_rtol = COST_RTOL if det <= 512 else 1e-3
+    # ... 1.8e-3 at 1536, 3e-3 at 1792, 4.5e-3 at 2048
+    cost_rtol = COST_RTOL if det <= 512 else 1e-3 if det <= 1024 else 6e-3
     import tike_amd._arrays as A
     from tike_amd.communicators import Comm
     from tike_amd.operators import Ptycho
