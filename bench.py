@@ -438,6 +438,8 @@ EPOCH_DEFAULTS = {
     # the Poisson model (round 6; `--workload` legs, c5rpie2 in the default run)
     "c5rpie2": (512, 4, 4000, 10),
     "c128rpie2": (128, 8, 10000, 10),
+    # (a rate leg: rpie + Poisson on this problem stops converging after ~10
+    # epochs on every route, profiles/r06_experiments.md section 7)
     "c3rpie2poisson": (256, 8, 10000, 10),
     # off-grid shapes (round 6; not BASELINE configurations): what the
     # reference's cuFFT path serves at one speed and the fused pow-2 kernels

@@ -13,7 +13,7 @@ import tike_amd._arrays as A  # noqa: E402
 import tike_amd.ptycho as tp  # noqa: E402
 
 epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-for workload in ("c3", "c2", "c5", "c1", "c3poisson"):
+for workload in (sys.argv[2:] or ("c3", "c2", "c5", "c1", "c3poisson")):
     built = bench.epoch_problem(workload, 0, 1, 0, tp, A)
     ctx, N = built["ctx"], built["N"]
     try:
