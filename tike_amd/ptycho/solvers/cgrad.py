@@ -52,6 +52,19 @@ class _CostPlan:
         chunk = chunk_positions(S, det, self.split)
         self.far = ws.get("far", (min(chunk, max(N, 1)), 1, S, det, det),
                           torch.complex64, dev)
+        # detector sizes p x 2^k (round 6): the prime-factor launches of the
+        # gradient pipeline with nothing but the costs stored -- sub-tile
+        # transforms + the p x p combine, no far plane in natural order
+        from . import lstsq as L
+        self.pfa = (not self.split and L.PFA_ROUTE and L.GENERAL_FUSED
+                    and L.pfa_gradients(S, pw, det))
+        self.pfa_lds = bool(self.pfa and L.PFA_SUBTILES_IN_LDS
+                            and lib.tike_pfa_fwd_subtiles_supported(S, pw, det))
+        if self.pfa_lds:
+            self.aux = ws.get("pfa_probe", (S, det, det), torch.complex64, dev)
+        elif self.pfa:
+            self.aux = ws.get("mid", tuple(self.far.shape), torch.complex64,
+                              dev)
         self.costs = ws.get("costs", (max(N, 1),), torch.float32, dev)[:N]
         self.fwd_scale = fft_scales(det, op.norm)[0]
         self.dims = (S, pw, det, H, W)
@@ -84,6 +97,26 @@ class _CostPlan:
                         pfar, d.data_ptr(), self.u16, None, None, None,
                         cost.data_ptr(), None, n, S, det, self.fwd_scale, 0,
                         1.0, det * det, st), "cgrad forward pass 2 + cost")
+            elif self.pfa:
+                if self.pfa_lds:
+                    check(
+                        lib.tike_pfa_fwd_subtiles(
+                            ppsi, sc.data_ptr(), pprobe, None, None, 0, 0,
+                            A.ptr(self.aux), pfar, None, n, S, pw, det, H, W,
+                            st), "cgrad forward (sub-tiles in LDS)")
+                else:
+                    check(
+                        lib.tike_pfa_fwd_gather(
+                            ppsi, sc.data_ptr(), pprobe, 0, None, None, None,
+                            0, 0, A.ptr(self.aux), None, n, S, pw, det, H, W,
+                            st), "cgrad forward (prime-factor gather)")
+                    check(lib.tike_pfa_fft2(A.ptr(self.aux), pfar, n * S, det,
+                                            0, st), "cgrad sub-tile transforms")
+                check(
+                    lib.tike_pfa_combine_gradient(
+                        pfar, d.data_ptr(), None, cost.data_ptr(), n, S, det,
+                        self.fwd_scale, 0, 1.0, det * det, 0, st),
+                    "cgrad cost (p x p combine)")
             else:
                 check(
                     lib.tike_ptycho_fwd(ppsi, sc.data_ptr(), pprobe, 0, None,
