@@ -599,7 +599,8 @@ int tike_gen_inv_rows_gradients(const void* hand2, const void* patches, const vo
 
 /* ---- the same chunk body for detector sizes det = p * M, p in {3, 5, 7}, M a
  * power of two in 32 .. 512 (96, 160, 192, 224, 320, 384, 448, 640, 768, 896,
- * 1536 ...) by the
+ * 1536 ...) -- and for 1024 = 4 x 256 and 2048 = 4 x 512, where the step is a
+ * Cooley-Tukey one (twiddles w_det^(n1 k2) applied by the combine entry) -- by the
  * prime-factor decomposition: p and M are coprime, so the det x det transform
  * is p x p sub-tiles of M x M through the power-of-two register engine plus a
  * pointwise p x p DFT across the sub-tiles, no twiddles between them

@@ -22,8 +22,8 @@ const cf* tk_twiddles() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lock(g_tw_mutex);
   if (g_tw_dev[dev]) return g_tw_dev[dev];
-  static cf host[2048];
-  for (int n = 32; n <= 1024; n *= 2)
+  static cf host[4096];  // w_n^k at [n + k], n = 32 ... 2048
+  for (int n = 32; n <= 2048; n *= 2)
     for (int k = 0; k < n; ++k) {
       const double a = -2.0 * M_PI * (double)k / (double)n;
       host[n + k] = mk((float)std::cos(a), (float)std::sin(a));

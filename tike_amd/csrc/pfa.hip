@@ -1,3 +1,5 @@
+// (Round 6, late: the same kernels also serve 1024 = 4 x 256 and 2048 = 4 x 512
+// by one Cooley-Tukey step -- see pfa_ct below.)
 // Detector sizes det = p * M, p in {3, 5, 7}, M a power of two with a register
 // engine (32 .. 512) -- 96, 160, 192, 224, 320, 384, 448, 640, 768, 896 ... -- by the
 // prime-factor (Good-Thomas) decomposition: p and M are coprime, so with
@@ -37,7 +39,25 @@ struct PfaGeom {
   int p, M, logM, det, qM, qp;  // qM = M^-1 mod p, qp = p^-1 mod M
 };
 
+// ... and, with the same kernels, powers of two beyond the fused kernels (1024
+// = 4 x 256, 2048 = 4 x 512; 1024 as 2 x 512 was slower: 14.0 vs 15.5 k
+// patterns/s at 2 modes) by one Cooley-Tukey step instead of the
+// prime-factor one: input index n = n1 + p n2, output index k = k2 + M k1, and
+// the twiddle w_det^(n1 k2) between the M-point and the p-point transforms
+// (applied by the combine kernel, conjugated on the way back).  P in {2, 4}
+// selects these maps at compile time (pfa_ct<P>).
+template <int P>
+constexpr bool pfa_ct = (P == 2 || P == 4);
+
 static bool pfa_geom(int det, PfaGeom* g) {
+  if (det == 1024 || det == 2048) {
+    g->p = 4;
+    g->M = det / 4;
+    g->det = det;
+    g->logM = det == 1024 ? 8 : 9;
+    g->qM = g->qp = 1;  // (unused)
+    return true;
+  }
   for (int p : {3, 5, 7}) {
     if (det % p) continue;
     const int M = det / p;
@@ -61,8 +81,31 @@ static bool pfa_geom(int det, PfaGeom* g) {
 // index n1 and element index n2
 template <int P>
 __device__ __forceinline__ void pfa_split(const PfaGeom& g, int v, int& n1, int& n2) {
-  n1 = (v * g.qM) % P;
-  n2 = (v * g.qp) & (g.M - 1);
+  if (pfa_ct<P>) {
+    n1 = v & (P - 1);
+    n2 = v / P;
+  } else {
+    n1 = (v * g.qM) % P;
+    n2 = (v * g.qp) & (g.M - 1);
+  }
+}
+// ... and back: tile coordinate of (sub-tile n1, element n2)
+template <int P>
+__device__ __forceinline__ int pfa_coord(const PfaGeom& g, int n1, int n2) {
+  if (pfa_ct<P>) return n1 + P * n2;
+  int v = g.M * n1 + P * n2;  // < 2 det
+  v -= v >= g.det ? g.det : 0;
+  return v;
+}
+// frequency of (sub-tile index k1, element k2) on the output side: (M qM k1 +
+// p qp k2) mod det = M (qM k1 mod p) + p (qp k2 mod M), minus det if that
+// overflows (no integer division by a run-time value)
+template <int P>
+__device__ __forceinline__ int pfa_freq(const PfaGeom& g, int k1, int k2) {
+  if (pfa_ct<P>) return k2 + g.M * k1;
+  int k = g.M * ((g.qM * k1) % P) + P * ((g.qp * k2) & (g.M - 1));
+  k -= k >= g.det ? g.det : 0;
+  return k;
 }
 
 // ---- the probe of row y, hoisted: the shared probe rows P_s[y][:] (S x pw)
@@ -228,8 +271,7 @@ __global__ __launch_bounds__(256) void pfa_fwd_gather_kernel(
       // sub-tile order: slot t = n1x * M + n2x (segments of M contiguous elements)
       for (int t = threadIdx.x; t < det; t += 256) {
         const int n1x = t >> g.logM, n2x = t & (M - 1);
-        int x = M * n1x + P * n2x;  // < 2 det
-        x -= x >= det ? det : 0;
+        const int x = pfa_coord<P>(g, n1x, n2x);
         const int px = x - pad;
         const bool in = px >= 0 && px < pw;
         const int pxc = in ? px : 0;
@@ -451,7 +493,8 @@ template <int P, int MODEL, int SMAX = 0>
 __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
     cf* __restrict__ B, const float* __restrict__ data, const unsigned char* __restrict__ mask,
     const TkCostSink costs, PfaGeom g, int nscan, int S, float fwd_scale,
-    float unmeasured_scaling, float inv_nmeasured, int grad) {
+    float unmeasured_scaling, float inv_nmeasured, int grad,
+    const cf* __restrict__ twdet) {
   __shared__ float red[4];
   const int M = g.M, det = g.det;
   const long MM = (long)M * M, tile = (long)det * det;
@@ -468,23 +511,38 @@ __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
     // with everything else (NaN at unmeasured pixels is selected away)
     float d[P][P];
     bool ms[P][P];
-    // frequency of sub-tile index k1 and element k2: (M qM k1 + p qp k2) mod
-    // det = M (qM k1 mod p) + p (qp k2 mod M), minus det if that overflows (no
-    // integer division by a run-time value)
-    const int fy = P * ((g.qp * k2y) & (M - 1)), fx = P * ((g.qp * k2x) & (M - 1));
 #pragma unroll
     for (int a = 0; a < P; ++a) {
-      int ky = M * ((g.qM * a) % P) + fy;
-      ky -= ky >= det ? det : 0;
+      const int ky = pfa_freq<P>(g, a, k2y);
 #pragma unroll
       for (int b = 0; b < P; ++b) {
-        int kx = M * ((g.qM * b) % P) + fx;
-        kx -= kx >= det ? det : 0;
+        const int kx = pfa_freq<P>(g, b, k2x);
         const long pix = (long)ky * det + kx;
         d[a][b] = data[(long)n * tile + pix];
         ms[a][b] = mask ? mask[pix] != 0 : true;
       }
     }
+    // Cooley-Tukey step (P = 2, 4): w_det^(n1y k2y + n1x k2x) on the sub-tile
+    // (n1y, n1x) in front of the p x p DFT, its conjugate behind the inverse
+    cf wy[pfa_ct<P> ? P : 1], wx[pfa_ct<P> ? P : 1];
+    if (pfa_ct<P>) {
+#pragma unroll
+      for (int a = 0; a < P; ++a) {
+        wy[a] = twdet[a * k2y];
+        wx[a] = twdet[a * k2x];
+      }
+    }
+    auto twiddle = [&](cf (&v)[P][P], auto inv) {
+      if (pfa_ct<P>) {
+#pragma unroll
+        for (int a = 0; a < P; ++a)
+#pragma unroll
+          for (int b = 0; b < P; ++b) {
+            const cf w = wy[a] * wx[b];
+            v[a][b] = v[a][b] * (decltype(inv)::value ? conjf(w) : w);
+          }
+      }
+    };
     float I[P][P];
 #pragma unroll
     for (int a = 0; a < P; ++a)
@@ -499,6 +557,7 @@ __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
           for (int a = 0; a < P; ++a)
 #pragma unroll
             for (int b = 0; b < P; ++b) keep[s][a][b] = base[s * tile + (a * P + b) * MM];
+          twiddle(keep[s], std::false_type{});
           pfa_dft2<P, false>(keep[s]);
 #pragma unroll
           for (int a = 0; a < P; ++a)
@@ -513,6 +572,7 @@ __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
         for (int a = 0; a < P; ++a)
 #pragma unroll
           for (int b = 0; b < P; ++b) v[a][b] = base[s * tile + (a * P + b) * MM];
+        twiddle(v, std::false_type{});
         pfa_dft2<P, false>(v);
 #pragma unroll
         for (int a = 0; a < P; ++a)
@@ -554,6 +614,7 @@ __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
 #pragma unroll
             for (int b = 0; b < P; ++b) keep[s][a][b] = keep[s][a][b] * I[a][b];
           pfa_dft2<P, true>(keep[s]);
+          twiddle(keep[s], std::true_type{});
 #pragma unroll
           for (int a = 0; a < P; ++a)
 #pragma unroll
@@ -568,12 +629,14 @@ __global__ __launch_bounds__(256) void pfa_combine_gradient_kernel(
       for (int a = 0; a < P; ++a)
 #pragma unroll
         for (int b = 0; b < P; ++b) v[a][b] = base[s * tile + (a * P + b) * MM];
+      twiddle(v, std::false_type{});
       pfa_dft2<P, false>(v);
 #pragma unroll
       for (int a = 0; a < P; ++a)
 #pragma unroll
         for (int b = 0; b < P; ++b) v[a][b] = v[a][b] * I[a][b];
       pfa_dft2<P, true>(v);
+      twiddle(v, std::true_type{});
 #pragma unroll
       for (int a = 0; a < P; ++a)
 #pragma unroll
@@ -764,10 +827,22 @@ extern "C" int tike_pfa_fwd_gather(const void* psi, const float* scan, const voi
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipError_t e7 = hipFuncSetAttribute((const void*)pfa_fwd_gather_kernel<7>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e7 == hipSuccess)
+      e7 = hipFuncSetAttribute((const void*)pfa_fwd_gather_kernel<2>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e7 == hipSuccess)
+      e7 = hipFuncSetAttribute((const void*)pfa_fwd_gather_kernel<4>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e3 != hipSuccess || e5 != hipSuccess || e7 != hipSuccess)
       return (int)(e3 != hipSuccess ? e3 : e5 != hipSuccess ? e5 : e7);
   }
-  if (g.p == 3)
+  if (g.p == 2)
+    hipLaunchKernelGGL(pfa_fwd_gather_kernel<2>, grid, block, lds, stream, (const cf*)psi, scan,
+                       P, (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, chunk);
+  else if (g.p == 4)
+    hipLaunchKernelGGL(pfa_fwd_gather_kernel<4>, grid, block, lds, stream, (const cf*)psi, scan,
+                       P, (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, chunk);
+  else if (g.p == 3)
     hipLaunchKernelGGL(pfa_fwd_gather_kernel<3>, grid, block, lds, stream, (const cf*)psi, scan,
                        P, (cf*)subtiles, (cf*)patches, g, nscan, S, pw, H, W, chunk);
   else if (g.p == 5)
@@ -863,10 +938,17 @@ extern "C" int tike_pfa_combine_gradient(void* subtiles, const float* data,
   // behind the stores of the first (one in-order counter)
   const dim3 grid((unsigned)((long)nscan * blocks_per)), block(256);
   const float inv = 1.0f / (float)num_measured;
+  // (the Cooley-Tukey sizes: w_det^m, m < det)
+  const cf* twdet = nullptr;
+  if (g.p == 2 || g.p == 4) {
+    const cf* tw = tk_twiddles();
+    if (!tw) return (int)hipErrorNotInitialized;
+    twdet = tw + det;
+  }
 #define TK_PFA_CG(PP, MM, SM)                                                                \
   hipLaunchKernelGGL((pfa_combine_gradient_kernel<PP, MM, SM>), grid, block, 0, stream,         \
                      (cf*)subtiles, data, measured, sink, g, nscan, S, fwd_scale,               \
-                     unmeasured_scaling, inv, apply_gradient)
+                     unmeasured_scaling, inv, apply_gradient, twdet)
   // (3 x 3 sub-tiles of up to 4 modes fit the registers: one read)
   const bool resident = g.p == 3 && S <= 4 && apply_gradient;
   if (resident && model == 0) TK_PFA_CG(3, 0, 4);
@@ -877,6 +959,10 @@ extern "C" int tike_pfa_combine_gradient(void* subtiles, const float* data,
   if (g.p == 5 && model == 1) TK_PFA_CG(5, 1, 0);
   if (g.p == 7 && model == 0) TK_PFA_CG(7, 0, 0);
   if (g.p == 7 && model == 1) TK_PFA_CG(7, 1, 0);
+  if (g.p == 2 && model == 0) TK_PFA_CG(2, 0, 0);
+  if (g.p == 2 && model == 1) TK_PFA_CG(2, 1, 0);
+  if (g.p == 4 && model == 0) TK_PFA_CG(4, 0, 0);
+  if (g.p == 4 && model == 1) TK_PFA_CG(4, 1, 0);
 #undef TK_PFA_CG
   TK_LAUNCH_CHECK();
   return tk_cost_finish(sink, nscan, stream);
@@ -923,11 +1009,25 @@ extern "C" int tike_pfa_inv_products(const void* subtiles, const void* patches,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipError_t e7 = hipFuncSetAttribute((const void*)pfa_inv_products_kernel<7>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e7 == hipSuccess)
+      e7 = hipFuncSetAttribute((const void*)pfa_inv_products_kernel<2>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e7 == hipSuccess)
+      e7 = hipFuncSetAttribute((const void*)pfa_inv_products_kernel<4>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e3 != hipSuccess || e5 != hipSuccess || e7 != hipSuccess)
       return (int)(e3 != hipSuccess ? e3 : e5 != hipSuccess ? e5 : e7);
   }
   const dim3 grid(tk_grid((long)pw * nchunk, 16)), block(256);
-  if (g.p == 3)
+  if (g.p == 2)
+    hipLaunchKernelGGL(pfa_inv_products_kernel<2>, grid, block, lds, stream, (const cf*)subtiles,
+                       (const cf*)patches, P, (cf*)objproj, (cf*)chi0, (float*)m_probe_update,
+                       probe_update_scale, part, g, nscan, S, pw, chunk, inv_scale);
+  else if (g.p == 4)
+    hipLaunchKernelGGL(pfa_inv_products_kernel<4>, grid, block, lds, stream, (const cf*)subtiles,
+                       (const cf*)patches, P, (cf*)objproj, (cf*)chi0, (float*)m_probe_update,
+                       probe_update_scale, part, g, nscan, S, pw, chunk, inv_scale);
+  else if (g.p == 3)
     hipLaunchKernelGGL(pfa_inv_products_kernel<3>, grid, block, lds, stream, (const cf*)subtiles,
                        (const cf*)patches, P, (cf*)objproj, (cf*)chi0, (float*)m_probe_update,
                        probe_update_scale, part, g, nscan, S, pw, chunk, inv_scale);

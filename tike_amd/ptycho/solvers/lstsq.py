@@ -103,7 +103,7 @@ the unfused kernels: measured faster there than the LDS line engine's three
 launches (`_plan.py`)."""
 
 PFA_ROUTE = True
-"""Detector sizes 3 x 2^k, 5 x 2^k and 7 x 2^k (96 ... 3584) without position-major
+"""Detector sizes 3 x 2^k, 5 x 2^k and 7 x 2^k (96 ... 3584), and 1024 / 2048, without position-major
 kernels take the prime-factor launches of csrc/pfa.hip (tike_pfa_*): the
 power-of-two register engine on p x p sub-tiles; tests set this to False to
 compare with the LDS line engine of csrc/general.hip."""
