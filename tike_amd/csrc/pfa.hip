@@ -50,6 +50,8 @@ template <int P>
 constexpr bool pfa_ct = (P == 2 || P == 4);
 
 static bool pfa_geom(int det, PfaGeom* g) {
+  // (64 = 2 x 32 the same way: 813 k patterns/s at 8 modes against 1117 k on the
+  // unfused kernels -- not taken)
   if (det == 1024 || det == 2048) {
     g->p = 4;
     g->M = det / 4;
