@@ -21,7 +21,8 @@ from tike_amd.ptycho.solvers._plan import GradientPlan  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-SIZES = (45, 64, 96, 100, 128, 160, 192, 224, 256, 300, 320, 384, 448, 512, 640)
+SIZES = (45, 64, 96, 100, 128, 160, 192, 224, 256, 300, 320, 384, 448, 512, 640,
+         768, 1024)
 
 
 def rel(a, b):
@@ -46,6 +47,8 @@ for case in range(cases):
     if det >= 384:
         S = min(S, 5 if det < 512 else 9)
     N = int(rng.integers(4, 11))
+    if det >= 768:
+        S, N = min(S, 3), min(N, 5)
     eigen = bool(rng.random() < 0.5)
     masked = bool(rng.random() < 0.3)
     model = "poisson" if rng.random() < 0.2 else "gaussian"
