@@ -449,6 +449,7 @@ EPOCH_DEFAULTS = {
     "c384": (384, 4, 10000, 10),
     # powers of two WITHOUT position-major kernels (not in the default run)
     "c64": (64, 8, 10000, 10),
+    "c128": (128, 8, 10000, 10),
     "c1024": (1024, 2, 1000, 10),
 }
 # The minibatches are contiguous chunks of the ONCE-SHUFFLED scan (SURVEY
