@@ -379,6 +379,7 @@ def test_cgrad_with_probe_vs_reference_composition(tp, golden):
                                         # Bluestein transforms under cgrad)
                                         (96, 96, 2, 6), (100, 80, 1, 7),
                                         (192, 160, 2, 5), (640, 640, 1, 2),
+                                        (300, 300, 2, 4), (400, 320, 1, 4),
                                         (384, 384, 1, 3), (127, 127, 1, 4),
                                         (128, 128, 1, 256)])  # BASELINE configs[0]
 def test_cgrad_vs_oracle(tp, det, pw, S, N):
