@@ -991,7 +991,8 @@ def _headline_problem(tp, det, S, N, seed, eigen, pitch=7.0, margin=8,
     ("off-grid unfused", 100, 2, 10, 2),
 ])
 def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
-                                         spatial_sort, batch_method):
+                                         spatial_sort, batch_method,
+                                         monkeypatch):
     """The code path bench.py times (c3: 256^2, S = 8, one eigen probe,
     several minibatches; c5: 512^2, S = 4, position correction with ADAM and
     affine regularisation): two epochs against the CPU oracle, under both
@@ -1002,11 +1003,17 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
     positions = tag == "c5"
     if tag.startswith("off-grid"):
         from tike_amd.ptycho.solvers import lstsq as L
+        from tike_amd.ptycho.solvers._plan import GradientPlan
         assert L.pfa_gradients(S, det, det) == (tag == "off-grid pfa")
         assert L.general_gradients(S, det, det)
-        # (the prime-factor launches take their sizes whatever the side)
-        assert (det < L.GENERAL_MIN_DETECTOR and not L.pfa_gradients(
-            S, det, det)) == (tag == "off-grid unfused")
+        # (the LDS line engine is no longer anybody's default route: this case
+        # asks for it from 256 pixels a side, round 6's first rule)
+        monkeypatch.setattr(L, "GENERAL_MIN_DETECTOR", 256)
+        seen = []
+        real = GradientPlan.gradients
+        monkeypatch.setattr(GradientPlan, "gradients",
+                            lambda self, c, k: (seen.append(self.route),
+                                                real(self, c, k))[1])
     # (position correction under the per-minibatch rule moves the corner
     # positions further: more room around the scan, or check_allowed_positions
     # -- the reference's rule -- stops the run)
@@ -1038,6 +1045,9 @@ def test_lstsq_headline_shapes_vs_oracle(tp, tag, det, S, N, num_batch,
                            spatial_sort=spatial_sort) as ctx:
         ctx.iterate(2)
         got = ctx.get_result()
+    if tag.startswith("off-grid"):
+        assert set(seen) == {dict(pfa="pfa", lds="general",
+                                  unfused="unfused")[tag.split()[-1]]}
     state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
                  costs=[], eigen_probe=None if ep is None else ep.copy(),
                  eigen_weights=None if ew is None else ew.copy())

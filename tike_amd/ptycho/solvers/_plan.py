@@ -207,7 +207,9 @@ class GradientPlan:
         # the LDS line engine pays per work item: below ~256 pixels a side the
         # unfused kernels on the new transforms are faster (45^2: 1360 vs 824 k
         # patterns/s, 64^2: 1117 vs 614 k, 100^2: 559 vs 372 k; 320^2 equal;
-        # 384^2 +17 %, 768^2 +16 %, 1024^2 +10 % for the general launches)
+        # 384^2 +17 %, 768^2 +16 %, 1024^2 +10 % for the general launches) --
+        # and since those three sizes moved to the prime-factor kernels it is
+        # nobody's default (lstsq.GENERAL_MIN_DETECTOR)
         if (general and not pfa and det < L.GENERAL_MIN_DETECTOR
                 and L.GENERAL_FUSED != "always"):
             general = False

@@ -97,10 +97,16 @@ launches of csrc/general.hip (tike_gen_*; gaussian model) instead of the
 unfused round-1 kernels; tests set this to False to compare the two."""
 
 
-GENERAL_MIN_DETECTOR = 256
+GENERAL_MIN_DETECTOR = 1 << 30
 """Detector sizes below this (and without a prime-factor decomposition) keep
-the unfused kernels: measured faster there than the LDS line engine's three
-launches (`_plan.py`)."""
+the unfused kernels.  Late in round 6 that is every size: with 384, 768 and
+1024 -- the sizes where the LDS line engine's three launches were 10 ... 17 %
+ahead -- on the prime-factor kernels, what is left to it loses to the unfused
+kernels on the mixed-radix transforms or ties with them (300^2 x 1 ... 8 modes
+-43 ... -6 %, 400^2 +-0, 500^2 x 4 +7 %, 600^2 x 2 -12 %, 720^2 x 4 -15 %, 1000^2
+x 1 ... 4 -3 ... -25 %; with an eigen probe -14 ... +7 %:
+profiles/r06_experiments.md section 17).  The launches stay in the tree and
+in the tests (`GENERAL_FUSED = "always"`); 256 restores round 6's first rule."""
 
 PFA_ROUTE = True
 """Detector sizes 3 x 2^k, 5 x 2^k and 7 x 2^k (96 ... 3584), and 1024 / 2048, without position-major

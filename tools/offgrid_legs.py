@@ -21,7 +21,8 @@ if os.environ.get("OFFGRID_GENERAL") == "0":  # the unfused round-1 kernels
     _L.GENERAL_FUSED = False
 import re
 for name in sys.argv[2:]:  # gDETxS: any detector size / mode count, no eigen probe
-    m = re.fullmatch(r"g(\d+)x(\d+)", name)
+    # (c3gDETxS: the same with the eigen probe of the c3 workloads)
+    m = re.fullmatch(r"(?:c3)?g(\d+)x(\d+)", name)
     if m:
         bench.EPOCH_DEFAULTS[name] = (int(m.group(1)), int(m.group(2)), 10000, 10)
 if os.environ.get("OFFGRID_GROUPS") == "0":  # > 8 modes: the stored far plane
