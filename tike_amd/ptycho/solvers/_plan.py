@@ -204,6 +204,12 @@ class GradientPlan:
         # than everything else wherever they apply (96^2 ... 768^2: +15 ... +56 %
         # over the unfused kernels, profiles/r06_experiments.md section 6)
         pfa = general and L.pfa_gradients(S, pw, det)
+        # (... except ONE mode below 256 pixels a side, where the unfused
+        # kernels are 3-5 % ahead: 96^2 916 vs 949 k patterns/s, 160^2 534 vs
+        # 560 k, 192^2 453 vs 469 k; two modes: 96^2 829 vs 794 k, 224^2 246 vs
+        # 219 k; one mode from 320^2: +5 ... +36 %)
+        if (pfa and S == 1 and det < 256 and L.GENERAL_FUSED != "always"):
+            pfa = general = False
         # the LDS line engine pays per work item: below ~256 pixels a side the
         # unfused kernels on the new transforms are faster (45^2: 1360 vs 824 k
         # patterns/s, 64^2: 1117 vs 614 k, 100^2: 559 vs 372 k; 320^2 equal;
