@@ -21,7 +21,7 @@ from tike_amd.ptycho.solvers._plan import GradientPlan  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-SIZES = (45, 64, 96, 100, 128, 160, 192, 224, 256, 300, 320, 384, 448, 512, 640,
+SIZES = (45, 64, 96, 100, 127, 128, 160, 192, 200, 224, 256, 300, 320, 384, 448, 512, 640,
          768, 1024)
 
 
