@@ -134,5 +134,69 @@ for case in range(cases):
         bad += 1
         print(f"ERR {tag}: {type(e).__name__}: {str(e)[:240]}", flush=True)
 print(f"lstsq_grad vs oracle: {cases - bad} of {cases} agree ({illcond} of them on a "
-      f"problem the oracle itself does not reproduce under a 1e-6 change of the probe)")
-sys.exit(1 if bad else 0)
+      f"problem the oracle itself does not reproduce under a 1e-6 change of the probe)",
+      flush=True)
+GradientPlan.gradients = real
+
+# ---- rpie: single-slice and multislice objects (2 ... 3 slices; the fused chain
+# at 128^2 / 256^2, slice by slice elsewhere), both noise models
+from oracle import operators as oops  # noqa: E402
+
+rcases = max(4, cases // 3)
+rbad = 0
+for case in range(rcases):
+    depth = int(rng.choice((1, 1, 2, 3)))
+    det = int(rng.choice((64, 96, 128, 256) if depth > 1 else SIZES))
+    S = int(rng.integers(1, 7))
+    N = int(rng.integers(4, 9))
+    model = "poisson" if rng.random() < 0.3 else "gaussian"
+    alpha = float(rng.choice((0.05, 0.5, 1.0)))
+    nb = int(rng.choice((1, 2)))
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=7000 + case, eigen=False)
+    data = np.round(data * (20000.0 / data.max())).astype(np.float32)
+    psi0 = np.repeat(np.full_like(psi_true, 0.5), depth, axis=0)
+    psi0[1:] = 1.0
+    phys = dict(wavelength=1e-10, fov=(2e-6, 2e-6), distance=1e-6)
+    tag = f"rpie det {det} S {S} N {N} slices {depth} {model} alpha {alpha} batches {nb}"
+    batches = np.array_split(np.arange(N), nb)
+    ms = dict(probe_wavelength=phys["wavelength"],
+              probe_FOV_lengths=phys["fov"]) if depth > 1 else {}
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
+        algorithm_options=tp.RpieOptions(num_batch=nb, num_iter=2,
+                                         batch_method="compact", alpha=alpha),
+        probe_options=tp.ProbeOptions(force_orthogonality=False, **ms),
+        object_options=tp.ObjectOptions(
+            **(dict(multislice_propagation_distance=phys["distance"])
+               if depth > 1 else {})),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool), noise_model=model))
+    try:
+        with tp.Reconstruction(data, params, order=np.arange(N),
+                               batches=batches) as ctx:
+            ctx.iterate(2)
+            got = ctx.get_result()
+        propagator = (oops.fresnel_spectrum_propagator(
+            (det, det), phys["fov"], phys["distance"], phys["wavelength"])
+            if depth > 1 else None)
+        state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
+                     costs=[], eigen_probe=None, eigen_weights=None)
+        kw = dict(propagator=propagator) if depth > 1 else {}
+        state = osol.rescale_probe(state, data, det, **kw)
+        state = osol.iterate(state, data, batches, 2, detector_shape=det,
+                             solver="rpie", alpha=alpha, batch_method="compact",
+                             force_orthogonality=False, noise_model=model, **kw)
+        ca = np.array(got.algorithm_options.costs).ravel()
+        cb = np.array([np.ravel(c)[0] for c in state["costs"]])
+        dc = float(np.max(np.abs(ca / cb - 1)))
+        dp, dq = rel(got.psi, state["psi"]), rel(got.probe, state["probe"])
+        ok = dc < 1e-3 and dp < 1e-3 and dq < 2e-3
+        print(f"{'ok ' if ok else 'BAD'} {tag}: cost {dc:.1e} psi {dp:.1e} probe "
+              f"{dq:.1e}", flush=True)
+        rbad += not ok
+    except Exception as e:  # noqa: BLE001
+        rbad += 1
+        print(f"ERR {tag}: {type(e).__name__}: {str(e)[:240]}", flush=True)
+print(f"rpie vs oracle: {rcases - rbad} of {rcases} agree")
+sys.exit(1 if bad or rbad else 0)
