@@ -198,5 +198,54 @@ for case in range(rcases):
     except Exception as e:  # noqa: BLE001
         rbad += 1
         print(f"ERR {tag}: {type(e).__name__}: {str(e)[:240]}", flush=True)
-print(f"rpie vs oracle: {rcases - rbad} of {rcases} agree")
-sys.exit(1 if bad or rbad else 0)
+print(f"rpie vs oracle: {rcases - rbad} of {rcases} agree", flush=True)
+
+# ---- cgrad (the composition of SURVEY a17: Dai-Yuan directions, backtracking
+# line search; object then probe per minibatch): every accepted / rejected step
+# is a branch, so the FIRST call's cost must agree closely and the iterates
+# after two calls to 2e-3 (the tests' bar), unless a branch flipped
+ccases = max(4, cases // 4)
+cbad = 0
+for case in range(ccases):
+    det = int(rng.choice(SIZES))
+    pw = det if rng.random() < 0.7 else int(det - 2 * rng.integers(1, max(2, det // 6)))
+    S = int(rng.integers(1, 4))
+    N = int(rng.integers(4, 12))
+    cg_iter = int(rng.integers(1, 4))
+    scan, psi_true, probe0, _, _, data = _headline_problem(
+        tp, det, S, N, seed=9000 + case, eigen=False, pw=pw)
+    tag = f"cgrad det {det} pw {pw} S {S} N {N} cg_iter {cg_iter}"
+    psi0 = np.full_like(psi_true, 0.5)
+    batches = [np.arange(N)]
+    params = tp.PtychoParameters(
+        probe=probe0.copy(), psi=psi0.copy(), scan=scan.copy(),
+        algorithm_options=tp.CgradOptions(num_batch=1, cg_iter=cg_iter,
+                                          num_iter=1, batch_method="contiguous"),
+        probe_options=tp.ProbeOptions(init_rescale_from_measurements=False),
+        object_options=tp.ObjectOptions(),
+        exitwave_options=tp.ExitWaveOptions(
+            measured_pixels=np.ones((det, det), dtype=bool)))
+    try:
+        with tp.Reconstruction(data, params, order=np.arange(N),
+                               batches=batches) as ctx:
+            ctx.iterate(2)
+            got = ctx.get_result()
+        state = dict(psi=psi0.copy(), probe=probe0.copy(), scan=scan.copy(),
+                     costs=[])
+        for _ in range(2):
+            state = osol.cgrad(state, data, batches, detector_shape=det,
+                               cg_iter=cg_iter, recover_probe=True)
+        ca = np.array(got.algorithm_options.costs).ravel()
+        cb = np.array([np.ravel(c)[0] for c in state["costs"]])
+        d0 = abs(ca[0] / cb[0] - 1)
+        dc = float(np.max(np.abs(ca / cb - 1)))
+        dp, dq = rel(got.psi, state["psi"]), rel(got.probe, state["probe"])
+        ok = d0 < 1e-4 and dc < 2e-3 and dp < 2e-3 and dq < 2e-3
+        print(f"{'ok ' if ok else 'BAD'} {tag}: first cost {d0:.1e} costs {dc:.1e} "
+              f"psi {dp:.1e} probe {dq:.1e}", flush=True)
+        cbad += not ok
+    except Exception as e:  # noqa: BLE001
+        cbad += 1
+        print(f"ERR {tag}: {type(e).__name__}: {str(e)[:240]}", flush=True)
+print(f"cgrad vs oracle: {ccases - cbad} of {ccases} agree")
+sys.exit(1 if bad or rbad or cbad else 0)
