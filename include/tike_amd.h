@@ -152,7 +152,9 @@ int tike_ptycho_fwd(const void* psi, const float* scan, const void* probe, int p
  * farplane is read only.  probe_adj doubles as the workspace of the two-pass
  * inverse transform (it must not alias farplane).  Caller-owned scratch:
  * objproj_work (nscan,pw,pw) c64, acc_work (2,H,W) f32; nothing is allocated.
- * sub_batch as in tike_ptycho_fwd. */
+ * sub_batch > 0: positions per sub-batch as in tike_ptycho_fwd; 0 or < 0: one
+ * batch, the default (measured faster for the adjoint: 0.391 -> 0.438 of the
+ * roofline at 256^2 x 1 mode). */
 int tike_ptycho_adj(const void* farplane, const void* probe, int probe_per_scan,
                     const float* scan, const void* psi, void* psi_adj, void* probe_adj,
                     void* objproj_work, float* acc_work, int nscan, int S, int pw, int det,

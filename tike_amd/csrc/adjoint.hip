@@ -437,12 +437,14 @@ extern "C" int tike_ptycho_adj(const void* farplane, const void* probe, int prob
     TK_CHECK_ARG(farplane && probe && scan && psi && probe_adj && objproj_work);
     TK_CHECK_ARG(probe_adj != farplane);
     const size_t tile_bytes = sizeof(cf) * (size_t)det * det;
-    // sub-batches of about 256 MiB of far plane: pass 1 leaves its output in
-    // the Infinity Cache (plain stores), pass 2 finds it there and overwrites
-    // it in place; the objproj scratch of a sub-batch is re-used by the next
-    long sub = sub_batch > 0   ? sub_batch
-               : sub_batch < 0 ? nscan
-                               : (256L << 20) / (long)(tile_bytes * S);
+    // sub_batch > 0: sub-batches of that many positions -- pass 1 leaves its
+    // output in the Infinity Cache (plain stores), pass 2 finds it there and
+    // overwrites it in place.  The default (0, as -1) is ONE batch since late
+    // round 6: measured, the launches of a sub-batch cost more than the cache
+    // gives back (256^2 x 1 mode, 4096 positions: 0.391 of the roofline at 256
+    // MiB per sub-batch, 0.419 at 512, 0.428 at 1024, 0.438 in one batch; 256^2
+    // x 8 0.314 -> 0.319, 128^2 x 1 0.373 -> 0.383)
+    long sub = sub_batch > 0 ? sub_batch : nscan;
     if (sub < 1) sub = 1;
     const bool keep = sub < nscan;
     for (long lo = 0; lo < nscan; lo += sub) {

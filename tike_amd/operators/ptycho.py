@@ -22,7 +22,8 @@ from .propagation import Propagation, fft_scales
 def sub_batch_positions(S, det, mib=None):
     """Positions per sub-batch of the two-kernel 256^2 / 512^2 operators: the
     ``sub_batch`` argument of ``tike_ptycho_fwd`` / ``tike_ptycho_adj``
-    (0 = the library's default of 256 MiB of far plane, -1 = one batch).
+    (0 = the library's default -- 256 MiB of far plane for the forward
+    operator, one batch for the adjoint --, -1 = one batch).
     ``TIKE_FWD_SUB_MIB`` (`tike_amd._tuning`) is read on the host side of
     the C ABI, never inside the library."""
     if mib is None:
