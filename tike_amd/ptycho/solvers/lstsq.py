@@ -172,7 +172,12 @@ def chunk_positions(S, det, position_major=False):
     kernels run one workgroup per position (not per tile)."""
     if CHUNK_POSITIONS_OVERRIDE:
         return max(1, int(CHUNK_POSITIONS_OVERRIDE))
-    tiles = max(2048, (1 << 28) // (det * det * 8))  # >= 2048 tiles or 256 MiB
+    # >= 2048 tiles, or 8 GiB of far plane (256 MiB until late round 6: on a
+    # 288 GB part a whole minibatch per launch is affordable and measured
+    # faster wherever the old bound split one -- 100^2 x 4 modes 567 -> 602 k
+    # patterns/s, 100^2 x 8 320 -> 334 k, 200^2 x 8 90.2 -> 92.0 k, 300^2 x 8
+    # 36.4 -> 37.1 k; an 838 + 162 split is the worst case)
+    tiles = max(2048, (1 << 33) // (det * det * 8))
     if position_major:
         return max(1024, tiles // max(S, 1))
     return max(64, tiles // max(S, 1))
